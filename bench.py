@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""Benchmark of the Sopro synthesize hot path on MI355X (BASELINE.json metric: audio-seconds per
+wall-second, plus p50 time-to-first-audio of stream()).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch of synthetic input: 32 utterances x 200 frames
+(BASELINE.json configs[1]) through conditioning -> AR loop (hipGraph replay) -> NAR refinement -> Mimi
+decode, with weights, text ids and the prepared reference voice already resident in HBM when the timed
+region starts.  N > 1 (launched by torch.distributed.run, one rank per GPU) is weak scaling: every rank
+synthesises its own 32 utterances, there is no data-path collective; the timed region is bracketed by a
+barrier + device sync on both sides and the MAX over ranks is reported.
+
+One JSON line is printed by rank 0.  Extra objects on it:
+  roofline     -- the dominant kernel family of the step (by summed HIP-event time on the engine streams),
+                  its algorithmic flops (MFMA bound) or bytes (HBM bound) per launch / its average launch time
+  cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference, validated against the reference
+                  in tests/) timed on this host on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BATCH = 32
+FRAMES = 200          # max_frames = 199 -> 200 AR steps (reference runs max_frames + 1 steps, model.py:242)
+TEXT_LEN = 64
+REF_FRAMES = 150
+VOCAB = 512           # synthetic text table (the real 128k-row table only changes a gather)
+FRAME_SEC = 0.08
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+
+
+class Tok:
+    vocab_size = VOCAB
+
+    def encode(self, text):
+        raise RuntimeError("bench passes token ids directly")
+
+
+def build_engine(device: str):
+    from sopro_amd import SoproTTS
+    from sopro_amd.config import MimiDecoderConfig, SoproTTSConfig
+    from sopro_amd.weights import synth_mimi_weights, synth_sopro_weights
+
+    cfg, mc = SoproTTSConfig(), MimiDecoderConfig()
+    wn = synth_sopro_weights(cfg, VOCAB, 0, suppress_eos=True)  # EOS bias -1e9: fixed-length runs
+    mn = synth_mimi_weights(mc, 0)
+    return SoproTTS.from_weights(cfg, wn, mn, Tok(), device=device), cfg, mc, wn, mn
+
+
+def make_inputs(rank: int):
+    rng = np.random.default_rng(1000 + rank)
+    ids = [torch.from_numpy(rng.integers(0, VOCAB, size=TEXT_LEN)) for _ in range(BATCH)]
+    ref_tq = torch.from_numpy(rng.integers(0, 2048, size=(REF_FRAMES, 32)))
+    return ids, ref_tq
+
+
+def cpu_baseline(cfg, mc, wn, mn, n_utts: int):
+    """The oracle on the host cores, one utterance at a time (the reference has no batched API)."""
+    from oracle import sopro_oracle as O
+
+    w, mw = O.to_torch(wn), O.to_torch(mn)
+    ids, ref_tq = make_inputs(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.inference_mode():
+        ref = O.prepare_reference(ref_tq, w, cfg)
+        O.synthesize(ids[0], ref, w, mw, cfg, mc, max_frames=7, top_p=0.9, temperature=1.05, anti_loop=True)  # warm-up
+        t0 = time.perf_counter()
+        frames = 0
+        for i in range(n_utts):
+            wav = O.synthesize(ids[i], ref, w, mw, cfg, mc, max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True)
+            frames += wav.shape[-1] // 1920
+        dt = time.perf_counter() - t0
+    return {"value": round(frames * FRAME_SEC / dt, 3), "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_utts} utterances x {FRAMES} frames, sequential synthesize() of oracle/sopro_oracle.py (torch fp32 CPU), "
+                      f"{dt:.1f} s wall"}
+
+
+def ar_step_bytes(B: int, S: int) -> float:
+    """weights + cond/embedding rows + ring buffers + K/V, fp32 (w = a = 4 bytes)."""
+    return 10_575_492 * 4 + B * (768 + 32_256 + 2304 * S) * 4
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-utts", type=int, default=6)
+    ap.add_argument("--ttfa-runs", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the Sopro engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+
+    from sopro_amd import hip
+
+    tts, cfg, mc, wn, mn = build_engine(device)
+    ids, ref_tq = make_inputs(rank)
+    ref = tts.prepare_reference(ref_tokens_tq=ref_tq)  # per-voice, outside the timed region (README "precalculate" flow)
+    refs = [ref] * BATCH
+    kw = dict(max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True, text_ids=ids)
+
+    def step(timings=None):
+        out = tts.synthesize_batch([""] * BATCH, refs, timings=timings, **kw)
+        assert all(o.shape[-1] == FRAMES * 1920 for o in out)
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    prof = hip.Profiler()
+    hip.set_profiler(prof)
+    phases = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(phases)
+    fence()
+    dt = time.perf_counter() - t0
+    hip.set_profiler(None)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel family (HIP events recorded on the engine streams during the timed steps)
+    fam = prof.summary()
+    roof = None
+    if fam:
+        name = max(fam, key=lambda k: fam[k]["ms"])
+        f = fam[name]
+        per_launch_ms = f["ms"] / max(1, f["launches"])
+        if name == "ar_step_graph":
+            bytes_step = ar_step_bytes(BATCH, TEXT_LEN)
+            ach = bytes_step / (per_launch_ms * 1e-3) / 1e9
+            roof = {"kernel": "AR frame (hipGraph of 26 launches: skinny_kernel x22, attention x3, ar_sample)", "bound": "hbm",
+                    "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5),
+                    "traffic": None, "launches": f["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
+                    "algorithmic_bytes_per_launch": bytes_step}
+        else:
+            ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None, "launches": f["launches"],
+                    "avg_launch_us": round(per_launch_ms * 1e3, 2),
+                    "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"]))}
+    families = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] // args.steps,
+                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 3) if v["flops"] else None} for k, v in fam.items()}
+
+    # ---- p50 time-to-first-audio of stream(), batch 1 (BASELINE.json configs[2]); outside the timed steps
+    ttfa = None
+    if rank == 0 and args.ttfa_runs > 0:
+        lat = []
+        for i in range(args.ttfa_runs + 3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            it = tts.stream("", ref=ref, max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True, chunk_frames=6,
+                            text_ids=ids[i % BATCH])
+            first = next(it)
+            torch.cuda.synchronize()
+            if i >= 3:
+                lat.append((time.perf_counter() - t1) * 1e3)
+            del it, first
+        ttfa = float(np.percentile(lat, 50))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, mc, wn, mn, args.cpu_utts)
+
+    if rank == 0:
+        audio_sec = world * args.steps * BATCH * FRAMES * FRAME_SEC
+        line = {
+            "metric": "audio_seconds_per_second", "value": round(audio_sec / dt, 2), "unit": "audio-s/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Sopro-135M synthesize, {BATCH} utterances x {FRAMES} frames per GPU (BASELINE configs[1]), "
+                                   f"S={TEXT_LEN} text tokens, {REF_FRAMES}-frame reference voice prepared outside the timed region, "
+                                   "top_p=0.9 T=1.05 anti_loop (reference defaults), synthetic weights with EOS suppressed",
+                       "batch_per_gpu": BATCH, "frames": FRAMES, "parallelism": f"replicas x{world} (utterance sharding, no collective)"},
+            "phase_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phases.items()},
+            "kernel_families": families,
+            "ttfa_ms_p50": None if ttfa is None else round(ttfa, 3),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,212 @@
+/* sopro_hip.h -- C ABI of libsopro_hip.so, the MI355X (gfx950) kernel library behind the
+ * Sopro TTS synthesize/stream hot path.
+ *
+ * The reference (samuel-vitorino/sopro) is pure Python on torch ATen: it has NO native
+ * interface of its own.  Every entry point below therefore replaces an
+ * ATen op *sequence* of the reference; the sequence is cited per function as
+ * `src/sopro/...:lines` (paths relative to the reference checkout) or `HF:modeling_mimi.py`
+ * (the third-party transformers Mimi implementation the reference calls into).
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a hipStream_t passed as void*;
+ *   - every function returns 0 on success and a negative code on failure; the message is
+ *     available from sopro_last_error() (thread-local); nothing throws across the ABI;
+ *   - nothing allocates, frees or synchronises: the caller owns every buffer and every
+ *     launch is enqueued on the caller's stream, so any call sequence can be recorded into
+ *     a hipGraph with sopro_capture_begin/_end and replayed with sopro_graph_launch;
+ *   - all activations are fp32, row-major, channels-last ([rows, channels]); token ids are
+ *     int32; "seg" parameters describe a batch of equally long row segments whose start
+ *     addresses are `seg_stride` elements apart (this is how per-utterance zero padding in
+ *     front of causal convolutions is addressed without copies);
+ *   - weights are fp32 [N, K] row-major (torch nn.Linear layout); convolution weights are
+ *     repacked by the host into that layout (sopro_amd/engine/pack.py).
+ */
+#ifndef SOPRO_HIP_H
+#define SOPRO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOPRO_ABI_VERSION 3
+
+/* ---- error handling / introspection ------------------------------------------------ */
+const char* sopro_last_error(void);
+int sopro_abi_version(void);
+/* device facts: out[0]=CU count, out[1]=LDS bytes per block, out[2]=clock kHz, out[3]=gfx arch number */
+int sopro_device_info(int device, int* out4);
+
+/* ---- hipGraph helpers (new; the reference has no graph capture) ---------------------- */
+int sopro_capture_begin(void* stream);
+int sopro_capture_end(void* stream, void** graph_exec_out);
+int sopro_graph_launch(void* graph_exec, void* stream);
+int sopro_graph_destroy(void* graph_exec);
+
+/* ---- dense contraction ------------------------------------------------------------------ */
+enum { SOPRO_PRO_NONE = 0, SOPRO_PRO_ELU = 1, SOPRO_PRO_ADDVEC = 2 };
+enum { SOPRO_EPI_NONE = 0, SOPRO_EPI_GELU = 1, SOPRO_EPI_GLU = 2, SOPRO_EPI_RES = 3, SOPRO_EPI_TANH = 4,
+       SOPRO_EPI_GLU_DW = 5 /* skinny only */ };
+
+/* C[m, n] = epi( sum_k pro(A[m, k]) * W[n, k] + bias[n] ),  fp32 in / fp32 accumulate on
+ * v_mfma_f32_32x32x2_f32 (bit-equal to an fmaf chain).
+ * Row m lives at A + (m / rows_per_seg) * a_seg_stride + (m % rows_per_seg) * lda; rows may
+ * overlap (lda < K) which turns a causal Conv1d / ConvTranspose1d over channels-last data
+ * into this contraction.  K must be a multiple of 4, all base pointers 16-byte aligned and
+ * lda / a_seg_stride / ldw multiples of 4.
+ *   EPI_GLU : W rows are packed per 64 as [32 value rows | 32 gate rows]; C has N/2 columns,
+ *             C = value * sigmoid(gate)                       (src/sopro/nn/blocks.py:16-23)
+ *   EPI_RES : C = R + scale[n] * (acc + bias)  (scale NULL = 1) (residual adds, LayerScale
+ *             HF:modeling_mimi.py:495-507, tanh(gate) of src/sopro/nn/text.py:131)
+ *   EPI_GELU: erf form (torch nn.GELU default)
+ * Replaces: every nn.Linear / F.linear of src/sopro/nn/{blocks,text,ref,nar,speaker}.py on the
+ * full-sequence paths, HF MimiTransformer projections (HF:modeling_mimi.py:602-726) and,
+ * through overlapping rows, MimiConv1d / MimiConvTranspose1d (HF:modeling_mimi.py:210-405). */
+typedef struct sopro_gemm_args {
+  const float* A; int64_t lda; int64_t a_seg_stride;
+  const float* W; int64_t ldw;
+  const float* bias;
+  float* C; int64_t ldc; int64_t c_seg_stride;
+  const float* R; int64_t ldr; int64_t r_seg_stride;
+  const float* scale;
+  const float* pro_vec; /* PRO_ADDVEC: a + pro_vec[k] */
+  int32_t M, N, K, rows_per_seg;
+  int32_t prologue, epilogue;
+} sopro_gemm_args;
+int sopro_gemm_f32(const sopro_gemm_args* args, void* stream);
+
+/* Batch-of-at-most-a-few-dozen-rows contraction for the autoregressive step
+ * (src/sopro/nn/generator.py:98-130): Y[b, n] = epi( sum_k norm(X)[b, k] * W[n, k] + bias[n] ).
+ * Weights are spread over the chip 16 output columns per workgroup, K split over the 4 waves,
+ * fp32 v_mfma_f32_16x16x4_f32.  norm_w != NULL fuses the RMSNorm of
+ * src/sopro/nn/blocks.py:26-37 in front (each workgroup recomputes the row statistics).
+ *   EPI_GLU_DW (needs N == 2*D, W in the natural torch layout [value rows | gate rows]):
+ *     h = value*sigmoid(gate); ring[(t % L)][b] = h; y = dwconv taps over the ring; Y = X + y
+ *     == SSMLiteBlock.forward_step first half, src/sopro/nn/blocks.py:150-157 and :76-110.
+ *     `step` is a device pointer to the current frame index t. */
+typedef struct sopro_skinny_args {
+  const float* X; int64_t ldx;
+  const float* norm_w; float eps;
+  const float* W; int64_t ldw;
+  const float* bias;
+  float* Y; int64_t ldy;
+  const float* R; int64_t ldr;
+  const float* scale;
+  int32_t B, N, K, epilogue;
+  /* EPI_GLU_DW */
+  float* ring;            /* [L, ring_bcap, D] */
+  const float* dw_w;      /* [ksize, D] (tap-major, oldest tap first) */
+  const float* dw_b;      /* [D] */
+  const int32_t* step;    /* device scalar */
+  int32_t ring_len, ring_bcap, dil, ksize;
+} sopro_skinny_args;
+int sopro_skinny_f32(const sopro_skinny_args* args, void* stream);
+
+/* ---- normalisation / elementwise ------------------------------------------------------- */
+enum { SOPRO_NORM_RMS = 0, SOPRO_NORM_LN = 1 };
+/* out[r, :] = (norm(x[r, :]) * w (+ b)) * mul[seg(r), :] + add[seg(r), :]   (mul/add optional, one
+ * row per segment of rows_per_seg rows).  RMS: src/sopro/nn/blocks.py:26-37 (eps inside rsqrt);
+ * LN: torch nn.LayerNorm (src/sopro/nn/speaker.py:72,83; HF:modeling_mimi.py:739-740).
+ * mul/add express SpeakerFiLM (speaker.py:76-85) and NARStageAdapter (nar.py:25-32). */
+int sopro_norm_f32(const float* x, int64_t ldx, int64_t x_seg_stride /* 0 = dense */, float* out, int64_t ldo, const float* w, const float* b,
+                   const float* mul, const float* add, int32_t rows, int32_t rows_per_seg, int32_t C,
+                   float eps, int32_t kind, void* stream);
+/* a * clamp(rms(x)/rms(a), 0, 10) per row, rms = sqrt(mean(t^2)+1e-6)   (src/sopro/nn/ref.py:12-13,101-102) */
+int sopro_rms_match_f32(const float* a, const float* x, float* out, int32_t rows, int32_t C, void* stream);
+/* out = c0 + c1 * tanh(in)     (FiLM / adapter coefficients, gates) */
+int sopro_tanh_affine_f32(const float* in, float* out, float c0, float c1, int64_t n, void* stream);
+/* out[b, t, :] = rowvec[b, :] + table[pos0 + t, :]   (src/sopro/model.py:200-202) */
+int sopro_add_pos_f32(const float* rowvec, const float* table, float* out, int32_t B, int32_t T, int32_t C,
+                      int32_t pos0, void* stream);
+/* pooled[b, :] = sum_{t < len[b]} x[b, t, :] / (len[b] + 1e-6)   (src/sopro/nn/text.py:40-43) */
+int sopro_masked_mean_f32(const float* x, const int32_t* lens, float* out, int32_t B, int32_t T, int32_t C,
+                          void* stream);
+
+/* attentive statistics pooling: a = softmax_{t<len}(logit[b,t]); out[b] = [sum a h | sqrt(clamp_min(sum a (h-mu)^2, 1e-6))]
+ * (src/sopro/nn/blocks.py:174-188) and F.normalize(x, eps) (src/sopro/nn/speaker.py:60): Token2SV tail. */
+int sopro_stats_pool_f32(const float* h, const float* logit, const int32_t* lens, float* out, int32_t B, int32_t T,
+                         int32_t C, void* stream);
+int sopro_l2norm_f32(const float* x, float* out, int32_t rows, int32_t C, float eps, void* stream);
+
+/* Depthwise Conv1d over time, channels-last [B, T, C]; taps w[j, c] (tap-major), dilation dil,
+ * `left` zero-padded positions on the left (causal: (k-1)*dil, symmetric: ((k-1)*dil)/2), positions
+ * >= lens[b] read as zero (lens NULL = T).  mode 0: y; 1: res + y; 2: gelu(y).
+ * == DepthwiseConv1d.forward, src/sopro/nn/blocks.py:63-74. */
+int sopro_dwconv_f32(const float* x, const float* w, const float* bias, const float* res, float* out,
+                     const int32_t* lens, int32_t B, int32_t T, int32_t C, int32_t ksize, int32_t dil,
+                     int32_t left, int32_t mode, void* stream);
+
+/* out[r, :] = alpha * base[r, :] + beta * sum_i wq[i] * table[off[i] + tok[r, col[i]], :]
+ * (base optional).  Embedding gathers: src/sopro/nn/embeddings.py:54-55,77-112, text.py:31,
+ * speaker.py:43-48, HF:modeling_mimi.py:1070-1081.  tok is int32 [rows, ldt]; col/off int32[nq]; wq float[nq]. */
+int sopro_codebook_sum_f32(const int32_t* tok, int32_t ldt, const int32_t* col, const int32_t* off, const float* wq,
+                           int32_t nq, const float* table, int64_t table_rows, const float* base, float alpha,
+                           float beta, float* out, int64_t ldo, int64_t o_seg_stride, int32_t rows,
+                           int32_t rows_per_seg, int32_t D, void* stream);
+/* out[b, t, :] = table[ids[b, t], :] + pe[t, :]  (0 for t >= lens[b])   src/sopro/nn/text.py:31-33 */
+int sopro_text_embed_f32(const int32_t* ids, const int32_t* lens, const float* table, int64_t table_rows,
+                         const float* pe, float* out, int32_t B, int32_t T, int32_t C, void* stream);
+/* argmax over each row of [rows, N] -> int32 written at out[r * ldo]  (src/sopro/model.py:340-343) */
+int sopro_argmax_rows_f32(const float* x, int64_t ldx, int32_t* out, int64_t ldo, int32_t rows, int32_t N,
+                          void* stream);
+
+/* ---- attention ---------------------------------------------------------------------------- */
+/* softmax(q k^T * scale + mask) v, fp32, heads interleaved in the row ([.., H*dh]).
+ * klens[b] (NULL = Tk) masks keys >= klens[b]; causal != 0 additionally keeps only keys with
+ * q_abs - window < k_abs <= q_abs where q_abs = q_pos0 + tq, k_abs = k_pos0 + tk.
+ * dh in {64, 96, 192}.  Replaces F.scaled_dot_product_attention at src/sopro/nn/text.py:118-126,
+ * src/sopro/nn/ref.py:88-96 and HF:modeling_mimi.py:657-726 (sliding window :882-888). */
+typedef struct sopro_attn_args {
+  const float* Q; int64_t ldq; int64_t q_bstride;
+  const float* K; int64_t ldk; int64_t k_bstride;
+  const float* V; int64_t ldv; int64_t v_bstride;
+  float* O; int64_t ldo; int64_t o_bstride;
+  const int32_t* klens;
+  int32_t B, H, dh, Tq, Tk;
+  int32_t causal, q_pos0, k_pos0, window;
+  float scale;
+} sopro_attn_args;
+int sopro_attention_f32(const sopro_attn_args* args, void* stream);
+/* rotate-half RoPE in place on [rows, H*dh] with host-made tables cos/sin [npos, dh/2]; position of
+ * row r is pos0 + (r % rows_per_seg).  HF:modeling_mimi.py:511-599. */
+int sopro_rope_f32(float* x, int64_t ldx, const float* cos_t, const float* sin_t, int32_t rows,
+                   int32_t rows_per_seg, int32_t pos0, int32_t H, int32_t dh, void* stream);
+
+/* ---- Mimi decoder specials --------------------------------------------------------------- */
+/* depthwise ConvTranspose1d k=4 s=2, causal trim: y[2t+r, c] = x[t,c] w[c,r] + x[t-1,c] w[c,r+2]
+ * (HF:modeling_mimi.py:1208-1216, 350-405).  x [B, T, C] dense; y segments [B][2T, C] at y_seg_stride. */
+int sopro_upsample2_f32(const float* x, const float* w, float* y, int64_t y_seg_stride, int32_t B, int32_t T,
+                        int32_t C, void* stream);
+/* last SEANet layer: wav[b, n] = bias + sum_{j<3} sum_c elu(h[b, n-2+j, c]) w[j, c], C = 64; h has two
+ * zero rows in front of each segment (HF:modeling_mimi.py:957-960). */
+int sopro_final_conv_f32(const float* h, int64_t h_seg_stride, const float* w, float bias, float* wav,
+                         int64_t wav_seg_stride, int32_t B, int32_t T, void* stream);
+
+/* ---- autoregressive driver state ----------------------------------------------------------- */
+/* Device-resident state of ar_stream (src/sopro/model.py:218-305) for up to `bcap` rows. All
+ * pointers are caller-allocated device buffers. */
+typedef struct sopro_ar_state {
+  float* x_cur;            /* [bcap, D] input of the current frame */
+  const float* cond;       /* [B, Tar, D] */
+  const float* emb;        /* cb_embed.emb.weight [Q*V+1, D] */
+  int32_t* hist;           /* [bcap, max_steps] sampled tokens */
+  int32_t* step;           /* scalar: current frame index t */
+  int32_t* arrive;         /* scalar ticket */
+  int32_t* first_eos;      /* [bcap] first t with tok == EOS, -1 if none */
+  int32_t* stop_t;         /* [bcap] first t with tok == EOS and t+1 >= min_gen, -1 if none */
+  int32_t* n_stopped;      /* scalar: rows with stop_t >= 0 */
+  const float* params;     /* [8] top_p, temperature, anti_loop, rec_top_p, rec_temperature, rep_penalty, top_k, min_gen */
+  uint64_t seed;
+  int32_t B, D, Tar, max_steps, V /* 2048, EOS id == V */, bos_row;
+} sopro_ar_state;
+/* zero-step initialisation: step=0, flags reset, x_cur[b] = cond[b,0] + emb[bos_row]  (model.py:266-272) */
+int sopro_ar_init(const sopro_ar_state* st, void* stream);
+/* sample_token (src/sopro/sampling.py:24-93) + anti-loop policy (model.py:274-299) + EOS rule
+ * (model.py:301-305) for every row, then x_cur[b] = cond[b, t+1] + emb[tok] and step += 1. */
+int sopro_ar_sample(const sopro_ar_state* st, const float* logits, int64_t ld_logits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOPRO_HIP_H */

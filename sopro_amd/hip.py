@@ -1,0 +1,368 @@
+"""ctypes binding of ``libsopro_hip.so`` (C ABI declared in ``include/sopro_hip.h``).
+
+The library is the product: there is no torch / CPU fallback behind these wrappers.  If the
+shared object is missing, or a wrapper is handed a tensor that is not a contiguous CUDA(HIP)
+tensor, the call raises.  Every wrapper enqueues on torch's *current* stream so that torch's
+caching allocator and the kernels agree on ordering (wrap a region in
+``torch.cuda.stream(s)`` to move it, e.g. for hipGraph capture).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
+ABI_VERSION = 3
+
+PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
+NORM_RMS, NORM_LN = 0, 1
+
+_p = C.c_void_p
+_i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", _p), ("lda", _i64), ("a_seg_stride", _i64), ("W", _p), ("ldw", _i64), ("bias", _p),
+                ("C", _p), ("ldc", _i64), ("c_seg_stride", _i64), ("R", _p), ("ldr", _i64), ("r_seg_stride", _i64),
+                ("scale", _p), ("pro_vec", _p), ("M", _i32), ("N", _i32), ("K", _i32), ("rows_per_seg", _i32),
+                ("prologue", _i32), ("epilogue", _i32)]
+
+
+class SkinnyArgs(C.Structure):
+    _fields_ = [("X", _p), ("ldx", _i64), ("norm_w", _p), ("eps", _f32), ("W", _p), ("ldw", _i64), ("bias", _p),
+                ("Y", _p), ("ldy", _i64), ("R", _p), ("ldr", _i64), ("scale", _p),
+                ("B", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32),
+                ("ring", _p), ("dw_w", _p), ("dw_b", _p), ("step", _p),
+                ("ring_len", _i32), ("ring_bcap", _i32), ("dil", _i32), ("ksize", _i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("Q", _p), ("ldq", _i64), ("q_bstride", _i64), ("K", _p), ("ldk", _i64), ("k_bstride", _i64),
+                ("V", _p), ("ldv", _i64), ("v_bstride", _i64), ("O", _p), ("ldo", _i64), ("o_bstride", _i64),
+                ("klens", _p), ("B", _i32), ("H", _i32), ("dh", _i32), ("Tq", _i32), ("Tk", _i32),
+                ("causal", _i32), ("q_pos0", _i32), ("k_pos0", _i32), ("window", _i32), ("scale", _f32)]
+
+
+class ArState(C.Structure):
+    _fields_ = [("x_cur", _p), ("cond", _p), ("emb", _p), ("hist", _p), ("step", _p), ("arrive", _p),
+                ("first_eos", _p), ("stop_t", _p), ("n_stopped", _p), ("params", _p), ("seed", C.c_uint64),
+                ("B", _i32), ("D", _i32), ("Tar", _i32), ("max_steps", _i32), ("V", _i32), ("bos_row", _i32)]
+
+
+# every symbol declared in include/sopro_hip.h: name -> (restype, argtypes)
+SYMBOLS = {
+    "sopro_last_error": (C.c_char_p, []),
+    "sopro_abi_version": (C.c_int, []),
+    "sopro_device_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "sopro_capture_begin": (C.c_int, [_p]),
+    "sopro_capture_end": (C.c_int, [_p, C.POINTER(_p)]),
+    "sopro_graph_launch": (C.c_int, [_p, _p]),
+    "sopro_graph_destroy": (C.c_int, [_p]),
+    "sopro_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), _p]),
+    "sopro_skinny_f32": (C.c_int, [C.POINTER(SkinnyArgs), _p]),
+    "sopro_norm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32, _p]),
+    "sopro_rms_match_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
+    "sopro_tanh_affine_f32": (C.c_int, [_p, _p, _f32, _f32, _i64, _p]),
+    "sopro_add_pos_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "sopro_masked_mean_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    "sopro_stats_pool_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "sopro_l2norm_f32": (C.c_int, [_p, _p, _i32, _i32, _f32, _p]),
+    "sopro_dwconv_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "sopro_codebook_sum_f32": (C.c_int, [_p, _i32, _p, _p, _p, _i32, _p, _i64, _p, _f32, _f32, _p, _i64, _i64, _i32, _i32, _i32, _p]),
+    "sopro_text_embed_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
+    "sopro_argmax_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _p]),
+    "sopro_attention_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
+    "sopro_rope_f32": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "sopro_upsample2_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "sopro_final_conv_f32": (C.c_int, [_p, _i64, _p, _f32, _p, _i64, _i32, _i32, _p]),
+    "sopro_ar_init": (C.c_int, [C.POINTER(ArState), _p]),
+    "sopro_ar_sample": (C.c_int, [C.POINTER(ArState), _p, _i64, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class SoproHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared object (once) and type every entry point.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SoproHipError(
+            f"{LIB_PATH} not found: the HIP kernel library is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C sopro_amd/csrc`). There is no CPU / torch fallback for the Sopro hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.sopro_abi_version()
+    if v != ABI_VERSION:
+        raise SoproHipError(f"{LIB_PATH} has ABI version {v}, the Python host expects {ABI_VERSION}: rebuild it")
+    _lib = lib
+    return lib
+
+
+class Profiler:
+    """HIP-event timing of the heavy launches, recorded on the stream each launch is enqueued on
+    (bench.py's roofline leg).  Families: the fp32 GEMM kernel, the attention kernel, AR graph replays."""
+
+    def __init__(self):
+        self.rec = []  # (family, flops, ev0, ev1)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, family: str, flops: float, e0) -> None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(torch.cuda.current_stream())
+        self.rec.append((family, flops, e0, e1))
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        out: dict = {}
+        for fam, fl, e0, e1 in self.rec:
+            d = out.setdefault(fam, {"ms": 0.0, "launches": 0, "flops": 0.0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["launches"] += 1
+            d["flops"] += fl
+        return out
+
+
+_prof: Optional[Profiler] = None
+
+
+def set_profiler(p: Optional[Profiler]) -> None:
+    global _prof
+    _prof = p
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise SoproHipError(f"{what} failed ({rc}): {load().sopro_last_error().decode()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor], dtype: torch.dtype = torch.float32) -> Optional[int]:
+    """Device address of a tensor after checking that it is what the ABI expects."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SoproHipError("tensor is not on a HIP device: the Sopro hot path has no CPU fallback")
+    if t.dtype != dtype:
+        raise SoproHipError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------
+# op wrappers (thin: argument marshalling only)
+# ------------------------------------------------------------------------------------------
+def gemm(A: torch.Tensor, W: torch.Tensor, Cout: torch.Tensor, *, M: int, N: int, K: int, lda: Optional[int] = None,
+         ldc: Optional[int] = None, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
+         prologue: int = PRO_NONE, R: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
+         scale: Optional[torch.Tensor] = None, pro_vec: Optional[torch.Tensor] = None, rows_per_seg: Optional[int] = None,
+         a_seg_stride: int = 0, c_seg_stride: int = 0, r_seg_stride: int = 0, a_off: int = 0, c_off: int = 0,
+         r_off: int = 0, ldw: Optional[int] = None) -> None:
+    """C = epi(pro(A) @ W^T + bias); offsets are in elements from the tensors' first element."""
+    n_out = N // 2 if epilogue == EPI_GLU else N
+    g = GemmArgs()
+    g.A = ptr(A) + 4 * a_off
+    g.lda = K if lda is None else lda
+    g.a_seg_stride = a_seg_stride
+    g.W = ptr(W)
+    g.ldw = K if ldw is None else ldw
+    g.bias = ptr(bias)
+    g.C = ptr(Cout) + 4 * c_off
+    g.ldc = n_out if ldc is None else ldc
+    g.c_seg_stride = c_seg_stride
+    g.R = (ptr(R) + 4 * r_off) if R is not None else None
+    g.ldr = (n_out if ldr is None else ldr)
+    g.r_seg_stride = r_seg_stride
+    g.scale = ptr(scale)
+    g.pro_vec = ptr(pro_vec)
+    g.M, g.N, g.K = M, N, K
+    g.rows_per_seg = M if rows_per_seg is None else rows_per_seg
+    g.prologue, g.epilogue = prologue, epilogue
+    e0 = _prof.begin() if _prof is not None else None
+    _check(load().sopro_gemm_f32(C.byref(g), _stream()), "sopro_gemm_f32")
+    if e0 is not None:
+        _prof.end("gemm_f32_kernel", 2.0 * M * N * K, e0)
+
+
+def skinny(X: torch.Tensor, W: torch.Tensor, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: Optional[int] = None,
+           ldy: Optional[int] = None, norm_w: Optional[torch.Tensor] = None, eps: float = 1e-6,
+           bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE, R: Optional[torch.Tensor] = None,
+           ldr: Optional[int] = None, scale: Optional[torch.Tensor] = None, ring: Optional[torch.Tensor] = None,
+           dw_w: Optional[torch.Tensor] = None, dw_b: Optional[torch.Tensor] = None, step: Optional[torch.Tensor] = None,
+           ring_len: int = 0, ring_bcap: int = 0, dil: int = 1, ksize: int = 1) -> None:
+    a = SkinnyArgs()
+    a.X, a.ldx = ptr(X), (K if ldx is None else ldx)
+    a.norm_w, a.eps = ptr(norm_w), eps
+    a.W, a.ldw = ptr(W), K
+    a.bias = ptr(bias)
+    n_out = N // 2 if epilogue == EPI_GLU_DW else N
+    a.Y, a.ldy = ptr(Y), (n_out if ldy is None else ldy)
+    a.R, a.ldr = ptr(R), (n_out if ldr is None else ldr)
+    a.scale = ptr(scale)
+    a.B, a.N, a.K, a.epilogue = B, N, K, epilogue
+    a.ring, a.dw_w, a.dw_b = ptr(ring), ptr(dw_w), ptr(dw_b)
+    a.step = ptr(step, torch.int32)
+    a.ring_len, a.ring_bcap, a.dil, a.ksize = ring_len, ring_bcap, dil, ksize
+    _check(load().sopro_skinny_f32(C.byref(a), _stream()), "sopro_skinny_f32")
+
+
+def norm(x: torch.Tensor, out: torch.Tensor, w: torch.Tensor, *, rows: int, C_: int, eps: float, kind: int = NORM_RMS,
+         b: Optional[torch.Tensor] = None, mul: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
+         rows_per_seg: Optional[int] = None, ldx: Optional[int] = None, ldo: Optional[int] = None, x_off: int = 0,
+         o_off: int = 0, x_seg_stride: int = 0) -> None:
+    _check(load().sopro_norm_f32(ptr(x) + 4 * x_off, C_ if ldx is None else ldx, x_seg_stride, ptr(out) + 4 * o_off,
+                                 C_ if ldo is None else ldo, ptr(w), ptr(b), ptr(mul), ptr(add), rows,
+                                 rows if rows_per_seg is None else rows_per_seg, C_, eps, kind, _stream()), "sopro_norm_f32")
+
+
+def rms_match(a: torch.Tensor, x: torch.Tensor, out: torch.Tensor, rows: int, C_: int) -> None:
+    _check(load().sopro_rms_match_f32(ptr(a), ptr(x), ptr(out), rows, C_, _stream()), "sopro_rms_match_f32")
+
+
+def tanh_affine(x: torch.Tensor, out: torch.Tensor, c0: float, c1: float, n: int) -> None:
+    _check(load().sopro_tanh_affine_f32(ptr(x), ptr(out), c0, c1, n, _stream()), "sopro_tanh_affine_f32")
+
+
+def add_pos(rowvec: torch.Tensor, table: torch.Tensor, out: torch.Tensor, B: int, T: int, C_: int, pos0: int = 0) -> None:
+    _check(load().sopro_add_pos_f32(ptr(rowvec), ptr(table), ptr(out), B, T, C_, pos0, _stream()), "sopro_add_pos_f32")
+
+
+def masked_mean(x: torch.Tensor, lens: Optional[torch.Tensor], out: torch.Tensor, B: int, T: int, C_: int) -> None:
+    _check(load().sopro_masked_mean_f32(ptr(x), ptr(lens, torch.int32), ptr(out), B, T, C_, _stream()), "sopro_masked_mean_f32")
+
+
+def stats_pool(h: torch.Tensor, logit: torch.Tensor, lens: Optional[torch.Tensor], out: torch.Tensor, B: int, T: int, C_: int) -> None:
+    _check(load().sopro_stats_pool_f32(ptr(h), ptr(logit), ptr(lens, torch.int32), ptr(out), B, T, C_, _stream()), "sopro_stats_pool_f32")
+
+
+def l2norm(x: torch.Tensor, out: torch.Tensor, rows: int, C_: int, eps: float = 1e-6) -> None:
+    _check(load().sopro_l2norm_f32(ptr(x), ptr(out), rows, C_, eps, _stream()), "sopro_l2norm_f32")
+
+
+def dwconv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, B: int, T: int, C_: int,
+           ksize: int, dil: int, left: int, mode: int = 0, res: Optional[torch.Tensor] = None,
+           lens: Optional[torch.Tensor] = None) -> None:
+    _check(load().sopro_dwconv_f32(ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), ptr(lens, torch.int32), B, T, C_, ksize,
+                                   dil, left, mode, _stream()), "sopro_dwconv_f32")
+
+
+def codebook_sum(tok: torch.Tensor, ldt: int, col: torch.Tensor, off: torch.Tensor, wq: torch.Tensor, table: torch.Tensor,
+                 out: torch.Tensor, *, rows: int, D: int, base: Optional[torch.Tensor] = None, alpha: float = 0.0,
+                 beta: float = 1.0, ldo: Optional[int] = None, rows_per_seg: Optional[int] = None, o_seg_stride: int = 0,
+                 o_off: int = 0, tok_off: int = 0) -> None:
+    _check(load().sopro_codebook_sum_f32(ptr(tok, torch.int32) + 4 * tok_off, ldt, ptr(col, torch.int32), ptr(off, torch.int32),
+                                         ptr(wq), int(col.numel()), ptr(table), int(table.shape[0]), ptr(base), alpha, beta,
+                                         ptr(out) + 4 * o_off, D if ldo is None else ldo, o_seg_stride, rows,
+                                         rows if rows_per_seg is None else rows_per_seg, D, _stream()), "sopro_codebook_sum_f32")
+
+
+def text_embed(ids: torch.Tensor, lens: Optional[torch.Tensor], table: torch.Tensor, pe: torch.Tensor, out: torch.Tensor,
+               B: int, T: int, C_: int) -> None:
+    _check(load().sopro_text_embed_f32(ptr(ids, torch.int32), ptr(lens, torch.int32), ptr(table), int(table.shape[0]), ptr(pe),
+                                       ptr(out), B, T, C_, _stream()), "sopro_text_embed_f32")
+
+
+def argmax_rows(x: torch.Tensor, out: torch.Tensor, *, rows: int, N: int, ldx: Optional[int] = None, ldo: int = 1,
+                o_off: int = 0) -> None:
+    _check(load().sopro_argmax_rows_f32(ptr(x), N if ldx is None else ldx, ptr(out, torch.int32) + 4 * o_off, ldo, rows, N,
+                                        _stream()), "sopro_argmax_rows_f32")
+
+
+def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor, *, B: int, H: int, dh: int, Tq: int,
+              Tk: int, ldq: int, ldk: int, ldv: int, ldo: int, q_bstride: int, k_bstride: int, v_bstride: int,
+              o_bstride: int, klens: Optional[torch.Tensor] = None, causal: bool = False, q_pos0: int = 0, k_pos0: int = 0,
+              window: int = 0, scale: Optional[float] = None, q_off: int = 0, k_off: int = 0, v_off: int = 0,
+              o_off: int = 0) -> None:
+    a = AttnArgs()
+    a.Q, a.ldq, a.q_bstride = ptr(Q) + 4 * q_off, ldq, q_bstride
+    a.K, a.ldk, a.k_bstride = ptr(K) + 4 * k_off, ldk, k_bstride
+    a.V, a.ldv, a.v_bstride = ptr(V) + 4 * v_off, ldv, v_bstride
+    a.O, a.ldo, a.o_bstride = ptr(O) + 4 * o_off, ldo, o_bstride
+    a.klens = ptr(klens, torch.int32)
+    a.B, a.H, a.dh, a.Tq, a.Tk = B, H, dh, Tq, Tk
+    a.causal, a.q_pos0, a.k_pos0, a.window = int(causal), q_pos0, k_pos0, window
+    a.scale = float(scale if scale is not None else dh ** -0.5)
+    e0 = _prof.begin() if _prof is not None else None
+    _check(load().sopro_attention_f32(C.byref(a), _stream()), "sopro_attention_f32")
+    if e0 is not None:
+        _prof.end("attention_kernel", 0.0, e0)
+
+
+def rope(x: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, *, rows: int, rows_per_seg: int, pos0: int, H: int,
+         dh: int, ldx: int, x_off: int = 0) -> None:
+    _check(load().sopro_rope_f32(ptr(x) + 4 * x_off, ldx, ptr(cos_t), ptr(sin_t), rows, rows_per_seg, pos0, H, dh, _stream()),
+           "sopro_rope_f32")
+
+
+def upsample2(x: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, B: int, T: int, C_: int, y_seg_stride: int,
+              y_off: int = 0) -> None:
+    _check(load().sopro_upsample2_f32(ptr(x), ptr(w), ptr(y) + 4 * y_off, y_seg_stride, B, T, C_, _stream()), "sopro_upsample2_f32")
+
+
+def final_conv(h: torch.Tensor, w: torch.Tensor, bias: float, wav: torch.Tensor, *, B: int, T: int, h_seg_stride: int,
+               wav_seg_stride: int) -> None:
+    _check(load().sopro_final_conv_f32(ptr(h), h_seg_stride, ptr(w), bias, ptr(wav), wav_seg_stride, B, T, _stream()),
+           "sopro_final_conv_f32")
+
+
+def ar_init(st: ArState) -> None:
+    _check(load().sopro_ar_init(C.byref(st), _stream()), "sopro_ar_init")
+
+
+def ar_sample(st: ArState, logits: torch.Tensor, ld: int) -> None:
+    _check(load().sopro_ar_sample(C.byref(st), ptr(logits), ld, _stream()), "sopro_ar_sample")
+
+
+class Graph:
+    """A recorded launch sequence (hipGraphExec) replayable on any stream."""
+
+    def __init__(self, handle: int):
+        self.handle = handle
+
+    def launch(self) -> None:
+        e0 = _prof.begin() if _prof is not None else None
+        _check(load().sopro_graph_launch(self.handle, _stream()), "sopro_graph_launch")
+        if e0 is not None:
+            _prof.end("ar_step_graph", 0.0, e0)
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.sopro_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def capture_begin() -> None:
+    _check(load().sopro_capture_begin(_stream()), "sopro_capture_begin")
+
+
+def capture_end() -> Graph:
+    out = _p()
+    _check(load().sopro_capture_end(_stream(), C.byref(out)), "sopro_capture_end")
+    return Graph(out.value)
+
+
+def device_info(device: int = 0) -> dict:
+    arr = (C.c_int * 4)()
+    _check(load().sopro_device_info(device, arr), "sopro_device_info")
+    return {"cus": arr[0], "lds_per_block": arr[1], "clock_khz": arr[2], "gfx": arr[3]}

@@ -1,0 +1,614 @@
+"""Generation engine of the Sopro hot path on MI355X: the host-side mirror of the reference's
+``SoproTTSModel`` (reference: src/sopro/model.py:53-401).
+
+Same method names and argument meaning as the reference (``prepare_reference``,
+``prepare_conditioning``, ``ar_stream``, ``nar_refine``, ``generate_tokens``) so that the CLI /
+demo call sites keep working, plus batched forms (``*_batch``) that the reference does not have.
+Every arithmetic step is a HIP kernel from ``libsopro_hip.so`` (see ``sopro_amd/hip.py``); torch is
+used for device memory, index bookkeeping and streams only.  The per-frame autoregressive step is
+recorded once into a hipGraph and replayed.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+from .config import SoproTTSConfig
+from .pack import pack_sopro, sinusoid_table
+
+RMS_EPS = 1e-6  # reference: src/sopro/nn/blocks.py:27
+
+
+@dataclass
+class PreparedReference:
+    """Field-for-field the reference's public type (src/sopro/model.py:45-50)."""
+
+    ref_tokens_btq: torch.Tensor
+    sv_ref: torch.Tensor
+    ref_seq: torch.Tensor
+    ref_kv_caches: List[Dict[str, Optional[torch.Tensor]]]
+
+
+class Workspace:
+    """Named device scratch buffers, reused across calls of the same shape (single stream)."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self._bufs: Dict[Tuple[str, Tuple[int, ...], torch.dtype], torch.Tensor] = {}
+
+    def get(self, name: str, shape: Sequence[int], dtype: torch.dtype = torch.float32, zero: bool = False) -> torch.Tensor:
+        key = (name, tuple(int(s) for s in shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            # buffers whose padding rows must read as zero are zero-filled once; kernels never write the pads
+            t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def clear(self) -> None:
+        self._bufs.clear()
+
+
+def _i32(values, device) -> torch.Tensor:
+    return torch.tensor(list(values), dtype=torch.int32, device=device)
+
+
+class SoproTTSModel:
+    """Weights on the device + the orchestration of the hot path."""
+
+    def __init__(self, cfg: SoproTTSConfig, weights: Dict[str, "np.ndarray"], device: str = "cuda:0", *, seed: int = 0,
+                 use_graph: bool = True):
+        hip.load()  # fail loudly here when the kernel library is missing
+        if not torch.cuda.is_available():
+            raise hip.SoproHipError("no HIP device visible: the Sopro engine has no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.seed = int(seed)
+        self.use_graph = bool(use_graph)
+        self.D = int(cfg.d_model)
+        self.V = int(cfg.codebook_size)
+        self.Q = int(cfg.num_codebooks)
+        packed = pack_sopro(weights, cfg)
+        self.w: Dict[str, torch.Tensor] = {k: v.to(self.device) for k, v in packed.items()}
+        npos = int(cfg.pos_emb_max) + 8  # reference: src/sopro/model.py:62-64
+        self.pe = sinusoid_table(npos, self.D).to(self.device)
+        self.ws = Workspace(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._ar_cache: Dict[Tuple[int, int, int], "_ARPlan"] = {}
+        self._ones: Dict[int, torch.Tensor] = {}
+        sc = cfg.stage_codebooks()
+        self._stage_cbs = [(s, sc[s]) for s in cfg.stage_order()]
+        # per-stage adapter coefficients do not depend on the input: computed lazily on the device
+        self._adapter: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None
+
+    # ------------------------------------------------------------------ helpers
+    def on_stream(self):
+        """Context: run on the engine's stream, ordered after whatever the caller queued so far."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(self.stream)
+
+    def rf_ar(self) -> int:
+        return self.cfg.rf_ar()
+
+    def rf_nar(self) -> int:
+        return self.cfg.rf_nar()
+
+    def _ssm_block_seq(self, x: torch.Tensor, out: torch.Tensor, p: str, *, B: int, T: int, ksize: int, dil: int,
+                       causal: bool, lens: Optional[torch.Tensor]) -> None:
+        """Full-sequence SSMLiteBlock over dense [B*T, D] rows (reference: src/sopro/nn/blocks.py:143-148)."""
+        D, M, w, ws = self.D, B * T, self.w, self.ws
+        nrm = ws.get("ssm.nrm", (M, D))
+        h = ws.get("ssm.h", (M, D))
+        x1 = ws.get("ssm.x1", (M, D))
+        u = ws.get("ssm.u", (M, 4 * D))
+        hip.norm(x, nrm, w[p + ".norm.weight"], rows=M, C_=D, eps=RMS_EPS)
+        hip.gemm(nrm, w[p + ".glu.w"], h, M=M, N=2 * D, K=D, bias=w[p + ".glu.b"], epilogue=hip.EPI_GLU)
+        total = (ksize - 1) * dil
+        left = total if causal else total // 2
+        hip.dwconv(h, w[p + ".dw.w"], w[p + ".dw.b"], x1, B=B, T=T, C_=D, ksize=ksize, dil=dil, left=left, mode=1, res=x, lens=lens)
+        hip.norm(x1, nrm, w[p + ".ff.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
+        hip.gemm(nrm, w[p + ".ff1.w"], u, M=M, N=4 * D, K=D, bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
+        hip.gemm(u, w[p + ".ff2.w"], out, M=M, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=x1)
+
+    # ------------------------------------------------------------------ per-voice preparation
+    @torch.inference_mode()
+    def prepare_reference(self, ref_tokens_tq: torch.Tensor) -> PreparedReference:
+        """reference: src/sopro/model.py:151-170 (Token2SV src/sopro/nn/speaker.py:37-61,
+        reference encoder model.py:133-149, K/V caches src/sopro/nn/ref.py:120-128)."""
+        cfg, w, dev, D = self.cfg, self.w, self.device, self.D
+        if ref_tokens_tq.dim() != 2 or ref_tokens_tq.shape[1] != self.Q:
+            raise ValueError(f"ref_tokens_tq must be [T, {self.Q}], got {tuple(ref_tokens_tq.shape)}")
+        T = int(ref_tokens_tq.shape[0])
+        with self.on_stream():
+            tok64 = ref_tokens_tq.to(dev).long()
+            tok = tok64.to(torch.int32).contiguous()
+            col = _i32(range(self.Q), dev)
+            off = _i32([q * self.V for q in range(self.Q)], dev)
+            # --- Token2SV
+            SD = int(w["token2sv.emb"].shape[1])
+            x = torch.empty(T, SD, device=dev)
+            hip.codebook_sum(tok, self.Q, col, off, w["token2sv.cw"], w["token2sv.emb"], x, rows=T, D=SD)
+            h1 = torch.empty_like(x)
+            h2 = torch.empty_like(x)
+            hip.dwconv(x, w["token2sv.enc.0.w"], w["token2sv.enc.0.b"], h1, B=1, T=T, C_=SD, ksize=7, dil=1, left=3, mode=2)
+            hip.dwconv(h1, w["token2sv.enc.3.w"], w["token2sv.enc.3.b"], h2, B=1, T=T, C_=SD, ksize=7, dil=1, left=3, mode=2)
+            a1 = torch.empty(T, SD, device=dev)
+            hip.gemm(h2, w["token2sv.pool.attn.0.w"], a1, M=T, N=SD, K=SD, bias=w["token2sv.pool.attn.0.b"], epilogue=hip.EPI_TANH)
+            lg = torch.empty(T, 1, device=dev)
+            hip.gemm(a1, w["token2sv.pool.attn.2.w"], lg, M=T, N=1, K=SD, bias=w["token2sv.pool.attn.2.b"])
+            st = torch.empty(1, 2 * SD, device=dev)
+            hip.stats_pool(h2, lg, None, st, 1, T, SD)
+            svd = int(cfg.sv_student_dim)
+            e = torch.empty(1, svd, device=dev)
+            hip.gemm(st, w["token2sv.proj.w"], e, M=1, N=svd, K=2 * SD, bias=w["token2sv.proj.b"])
+            sv = torch.empty(1, svd, device=dev)
+            hip.l2norm(e, sv, 1, svd, 1e-6)
+            # --- reference sequence encoder
+            xa = torch.empty(T, D, device=dev)
+            xb = torch.empty(T, D, device=dev)
+            hip.codebook_sum(tok, self.Q, col, off, w["ref_cw"], w["cb_embed"], xa, rows=T, D=D)
+            for i in range(int(cfg.ref_enc_layers)):
+                self._ssm_block_seq(xa, xb, f"ref_enc_blocks.{i}", B=1, T=T, ksize=7, dil=1, causal=False, lens=None)
+                xa, xb = xb, xa
+            ref_seq = torch.empty(1, T, D, device=dev)
+            hip.norm(xa, ref_seq, w["ref_enc_norm.weight"], rows=T, C_=D, eps=RMS_EPS)
+            # --- K/V of the three reference cross-attention blocks
+            H = int(cfg.ref_xattn_heads)
+            caches: List[Dict[str, Optional[torch.Tensor]]] = []
+            nkv = torch.empty(T, D, device=dev)
+            for i in range(int(cfg.ref_xattn_layers)):
+                p = f"ref_xattn.blocks.{i}"
+                hip.norm(ref_seq, nkv, w[p + ".nkv.weight"], rows=T, C_=D, eps=RMS_EPS)
+                kv = torch.empty(T, 2 * D, device=dev)
+                hip.gemm(nkv, w[p + ".kv.w"], kv, M=T, N=2 * D, K=D)
+                k = kv[:, :D].reshape(1, T, H, D // H).permute(0, 2, 1, 3)  # [1, H, T, dh] view, as the reference stores it
+                v = kv[:, D:].reshape(1, T, H, D // H).permute(0, 2, 1, 3)
+                caches.append({"k": k, "v": v, "key_padding_mask": None})
+        self.stream.synchronize()
+        return PreparedReference(ref_tokens_btq=tok64.unsqueeze(0), sv_ref=sv, ref_seq=ref_seq, ref_kv_caches=caches)
+
+    # ------------------------------------------------------------------ per-utterance conditioning
+    @torch.inference_mode()
+    def prepare_conditioning(self, text_ids_1d: torch.Tensor, ref: PreparedReference, *, max_frames: int,
+                             device: Any = None, style_strength: float = 1.0) -> Dict[str, torch.Tensor]:
+        """reference: src/sopro/model.py:172-216 (one utterance)."""
+        out = self.prepare_conditioning_batch([text_ids_1d], [ref], max_frames=max_frames, style_strength=style_strength)
+        S = int(out["text_lens_host"][0])
+        return {"txt_seq": out["txt_seq"][:, :S], "text_mask": torch.ones(1, S, dtype=torch.bool, device=self.device),
+                "txt_pool": out["txt_pool"], "sv_ref": ref.sv_ref, "cond_ar": out["cond_ar"]}
+
+    @torch.inference_mode()
+    def prepare_conditioning_batch(self, ids_list: Sequence[torch.Tensor], refs: Sequence[PreparedReference], *,
+                                   max_frames: int, style_strength: float = 1.0) -> Dict[str, Any]:
+        """B utterances at once (new): text encoder (src/sopro/nn/text.py:29-44), base = pooled text +
+        frame positions (model.py:200-202), SpeakerFiLM (src/sopro/nn/speaker.py:76-85), three reference
+        cross-attention blocks (src/sopro/nn/ref.py:54-108), cond_norm (model.py:208)."""
+        cfg, w, dev, D = self.cfg, self.w, self.device, self.D
+        B = len(ids_list)
+        if B == 0 or len(refs) != B:
+            raise ValueError("need one reference per utterance")
+        lens_h = [int(x.numel()) for x in ids_list]
+        S = max(lens_h)
+        if S > int(cfg.max_text_len) or min(lens_h) <= 0:
+            raise ValueError(f"text length must be in [1, {cfg.max_text_len}]")
+        Tar = int(max_frames) + 1
+        if Tar > self.pe.shape[0]:
+            raise ValueError("max_frames exceeds the position table")
+        ids = torch.zeros(B, S, dtype=torch.int32)
+        for b, x in enumerate(ids_list):
+            ids[b, : lens_h[b]] = x.detach().to("cpu", torch.int32).view(-1)
+        with self.on_stream():
+            ids = ids.to(dev)
+            lens = _i32(lens_h, dev)
+            ragged = min(lens_h) != S
+            M = B * S
+            xa = torch.empty(M, D, device=dev)
+            xb = torch.empty(M, D, device=dev)
+            hip.text_embed(ids, lens, w["text_enc.embed"], self.pe, xa, B, S, D)
+            for i in range(int(cfg.n_layers_text)):
+                self._ssm_block_seq(xa, xb, f"text_enc.layers.{i}", B=B, T=S, ksize=7, dil=1, causal=False,
+                                    lens=lens if ragged else None)
+                xa, xb = xb, xa
+            txt_seq = torch.empty(B, S, D, device=dev)
+            hip.norm(xa, txt_seq, w["text_enc.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
+            txt_pool = torch.empty(B, D, device=dev)
+            hip.masked_mean(txt_seq, lens, txt_pool, B, S, D)
+            # base + FiLM
+            base = torch.empty(B * Tar, D, device=dev)
+            hip.add_pos(txt_pool, self.pe, base, B, Tar, D, 0)
+            sv = torch.cat([r.sv_ref.to(dev).reshape(1, -1) for r in refs], dim=0).contiguous()
+            svd = int(sv.shape[1])
+            f1 = torch.empty(B, D, device=dev)
+            hip.gemm(sv, w["spk_film.mlp.0.w"], f1, M=B, N=D, K=svd, bias=w["spk_film.mlp.0.b"], epilogue=hip.EPI_GELU)
+            film = torch.empty(B, 2 * D, device=dev)
+            hip.gemm(f1, w["spk_film.mlp.2.w"], film, M=B, N=2 * D, K=D, bias=w["spk_film.mlp.2.b"])
+            gam = film[:, :D].contiguous()
+            bet = film[:, D:].contiguous()
+            mul = torch.empty(B, D, device=dev)
+            add = torch.empty(B, D, device=dev)
+            s = float(style_strength)
+            hip.tanh_affine(gam, mul, 1.0, s, B * D)
+            hip.tanh_affine(bet, add, 0.0, s, B * D)
+            cond = torch.empty(B * Tar, D, device=dev)
+            hip.norm(base, cond, w["spk_film.norm.weight"], rows=B * Tar, C_=D, eps=1e-5, kind=hip.NORM_LN,
+                     b=w["spk_film.norm.bias"], mul=mul, add=add, rows_per_seg=Tar)
+            # reference cross-attention stack
+            H = int(cfg.ref_xattn_heads)
+            dh = D // H
+            tr_h = [int(r.ref_kv_caches[0]["k"].shape[2]) for r in refs]
+            Tr = max(tr_h)
+            klens = _i32(tr_h, dev) if min(tr_h) != Tr else None
+            nq = torch.empty(B * Tar, D, device=dev)
+            q = torch.empty(B * Tar, D, device=dev)
+            a = torch.empty(B * Tar, D, device=dev)
+            am = torch.empty(B * Tar, D, device=dev)
+            Kb = torch.zeros(B, Tr, D, device=dev)
+            Vb = torch.zeros(B, Tr, D, device=dev)
+            for i in range(int(cfg.ref_xattn_layers)):
+                p = f"ref_xattn.blocks.{i}"
+                for b, r in enumerate(refs):
+                    c = r.ref_kv_caches[i]
+                    Kb[b, : tr_h[b]] = c["k"].to(dev).permute(0, 2, 1, 3).reshape(tr_h[b], D)
+                    Vb[b, : tr_h[b]] = c["v"].to(dev).permute(0, 2, 1, 3).reshape(tr_h[b], D)
+                hip.norm(cond, nq, w[p + ".nq.weight"], rows=B * Tar, C_=D, eps=RMS_EPS)
+                hip.gemm(nq, w[p + ".q.w"], q, M=B * Tar, N=D, K=D)
+                hip.attention(q, Kb, Vb, a, B=B, H=H, dh=dh, Tq=Tar, Tk=Tr, ldq=D, ldk=D, ldv=D, ldo=D, q_bstride=Tar * D,
+                              k_bstride=Tr * D, v_bstride=Tr * D, o_bstride=Tar * D, klens=klens)
+                hip.rms_match(a, cond, am, B * Tar, D)
+                hip.gemm(am, w[p + ".o.w"], cond, M=B * Tar, N=D, K=D, epilogue=hip.EPI_RES, R=cond, scale=w[p + ".gate_scale"])
+            cond_ar = torch.empty(B, Tar, D, device=dev)
+            hip.norm(cond, cond_ar, w["cond_norm.weight"], rows=B * Tar, C_=D, eps=RMS_EPS)
+        self.stream.synchronize()
+        return {"txt_seq": txt_seq, "text_lens": lens, "text_lens_host": lens_h, "txt_pool": txt_pool, "sv_ref": sv,
+                "cond_ar": cond_ar}
+
+    # ------------------------------------------------------------------ autoregressive generation
+    def _ar_plan(self, B: int, S_cap: int, Tar: int) -> "_ARPlan":
+        key = (B, S_cap, Tar)
+        plan = self._ar_cache.get(key)
+        if plan is None:
+            if len(self._ar_cache) >= 8:
+                self._ar_cache.clear()
+            plan = _ARPlan(self, B, S_cap, Tar)
+            self._ar_cache[key] = plan
+        return plan
+
+    @torch.inference_mode()
+    def ar_generate_batch(self, cond_ar: torch.Tensor, txt_seq: torch.Tensor, text_lens: Optional[torch.Tensor], *,
+                          max_frames: int, top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True,
+                          min_gen_frames: Optional[int] = None, stop_on_first_eos: bool = False,
+                          poll_every: int = 16) -> Tuple[torch.Tensor, List[int]]:
+        """Run the AR loop for B rows until every row has stopped or max_frames+1 steps were taken
+        (reference loop: src/sopro/model.py:218-305, one row).  Returns (hist [B, steps] int32 on the
+        device, per-row frame counts T_b following generate_tokens' cut at the FIRST EOS, model.py:385-390)."""
+        B, Tar, _ = cond_ar.shape
+        if Tar != int(max_frames) + 1:
+            raise ValueError("cond_ar must have max_frames+1 rows")
+        run = _ARRun(self, cond_ar, txt_seq, text_lens, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
+                     min_gen_frames=min_gen_frames)
+        steps = 0
+        while steps < Tar:
+            n = min(int(poll_every), Tar - steps)
+            run.advance(n)
+            steps += n
+            if run.n_stopped(stop_on_first_eos) >= B:
+                break
+        hist, first_eos = run.history(steps)
+        lens = [int(f) if f >= 0 else steps for f in first_eos]
+        return hist, lens
+
+    @torch.inference_mode()
+    def ar_stream(self, prep: Dict[str, torch.Tensor], *, max_frames: int = 400, top_p: float = 0.9,
+                  temperature: float = 1.05, anti_loop: bool = True, use_prefix: bool = False,
+                  prefix_sec_fixed: Optional[float] = None, use_stop_head: Optional[bool] = None,
+                  stop_patience: Optional[int] = None, stop_threshold: Optional[float] = None,
+                  min_gen_frames: Optional[int] = None, lookahead: int = 1) -> Iterator[Tuple[int, int, bool]]:
+        """Yields (t, token, is_eos) like the reference generator (src/sopro/model.py:218-305).
+        ``lookahead`` frames are generated per host round trip (new; 1 == token-by-token)."""
+        cond = prep["cond_ar"]
+        Tar = int(max_frames) + 1
+        if cond.shape[1] != Tar:
+            raise ValueError("prep['cond_ar'] must have max_frames+1 rows")
+        min_gen = int(min_gen_frames if min_gen_frames is not None else self.cfg.min_gen_frames)
+        run = _ARRun(self, cond, prep["txt_seq"], None, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
+                     min_gen_frames=min_gen)
+        t = 0
+        eos = self.V
+        while t < Tar:
+            n = min(max(1, int(lookahead)), Tar - t)
+            run.advance(n)
+            toks = run.tokens_host(t, t + n)
+            for j in range(n):
+                tok = int(toks[j])
+                is_eos = tok == eos
+                yield t + j, tok, is_eos
+                if is_eos and (t + j + 1) >= min_gen:
+                    return
+            t += n
+
+    # ------------------------------------------------------------------ NAR refinement
+    def _adapter_coeffs(self) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        """(1 + tanh g, tanh b) per stage (reference: src/sopro/nn/nar.py:25-32)."""
+        if self._adapter is None:
+            w, dev, D = self.w, self.device, self.D
+            ns = len(self._stage_cbs)
+            h = torch.empty(ns, 256, device=dev)
+            hip.gemm(w["nar.stage_emb"], w["nar.adapter.mlp.0.w"], h, M=ns, N=256, K=D, bias=w["nar.adapter.mlp.0.b"], epilogue=hip.EPI_GELU)
+            gb = torch.empty(ns, 2 * D, device=dev)
+            hip.gemm(h, w["nar.adapter.mlp.2.w"], gb, M=ns, N=2 * D, K=256, bias=w["nar.adapter.mlp.2.b"])
+            out = []
+            for s in range(ns):
+                g = gb[s, :D].contiguous()
+                b = gb[s, D:].contiguous()
+                mul = torch.empty(D, device=dev)
+                add = torch.empty(D, device=dev)
+                hip.tanh_affine(g, mul, 1.0, 1.0, D)
+                hip.tanh_affine(b, add, 0.0, 1.0, D)
+                out.append((mul, add))
+            self._adapter = out
+        return self._adapter
+
+    @torch.inference_mode()
+    def nar_refine(self, cond_seq: torch.Tensor, tokens_A_1xT: torch.Tensor, lens: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """Codebooks 1..Q-1 from codebook 0: [B, T, D], [B, T] -> [B, T, Q] int64
+        (reference: src/sopro/model.py:307-347 and src/sopro/nn/nar.py:89-116; B = 1 there)."""
+        cfg, w, dev, D, V, Q = self.cfg, self.w, self.device, self.D, self.V, self.Q
+        B, T, _ = cond_seq.shape
+        M = B * T
+        with self.on_stream():
+            cond = cond_seq.to(dev).float().contiguous().view(M, D)
+            toks = torch.zeros(M, Q, dtype=torch.int32, device=dev)
+            toks[:, 0] = tokens_A_1xT.to(dev).reshape(M).to(torch.int32)
+            lens_d = _i32(lens, dev) if lens is not None and min(lens) != T else None
+            adapters = self._adapter_coeffs()
+            pcw = w["nar_prev_cb_weights"]
+            xa = self.ws.get("nar.xa", (M, D))
+            xb = self.ws.get("nar.xb", (M, D))
+            z = self.ws.get("nar.z", (M, int(cfg.nar_head_dim)))
+            logits = self.ws.get("nar.logits", (M, V))
+            known: List[int] = [0]
+            HD = int(cfg.nar_head_dim)
+            for sid, (stage, cbs) in enumerate(self._stage_cbs):
+                # prev = sum_j softmax(w[known])_j * E[cb_j*V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
+                cw = torch.softmax(pcw[torch.tensor(known, device=dev)].float(), dim=0).contiguous()
+                mix = w[f"nar.mix.{stage}"]
+                mix_h = mix.tolist()
+                hip.codebook_sum(toks, Q, _i32(known, dev), _i32([c * V for c in known], dev), cw, w["cb_embed"], xa,
+                                 rows=M, D=D, base=cond, alpha=float(mix_h[0]), beta=float(mix_h[1]))
+                mul, add = adapters[sid]
+                hip.norm(xa, xb, w["nar.adapter.norm.weight"], rows=M, C_=D, eps=RMS_EPS, mul=mul, add=add, rows_per_seg=M)
+                xa, xb = xb, xa
+                for i, dil in enumerate(cfg.nar_dilations):
+                    self._ssm_block_seq(xa, xb, f"nar.blocks.{i}", B=B, T=T, ksize=int(cfg.nar_kernel_size), dil=int(dil),
+                                        causal=False, lens=lens_d)
+                    xa, xb = xb, xa
+                hip.norm(xa, xb, w["nar.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
+                hip.gemm(xb, w["nar.pre.w"], z, M=M, N=HD, K=D, bias=w["nar.pre.b"])
+                hid = w[f"nar.head_id_emb.{stage}"]
+                for j, cb in enumerate(cbs):
+                    hip.gemm(z, w[f"nar.heads.{stage}.{j}.w"], logits, M=M, N=V, K=HD, bias=w[f"nar.heads.{stage}.{j}.b"],
+                             prologue=hip.PRO_ADDVEC, pro_vec=hid[j])
+                    hip.argmax_rows(logits, toks, rows=M, N=V, ldo=Q, o_off=cb)
+                known = known + list(cbs)
+            out = toks.view(B, T, Q).long()
+        self.stream.synchronize()
+        return out
+
+    # ------------------------------------------------------------------ text + reference -> tokens
+    @torch.inference_mode()
+    def generate_tokens(self, text_ids: torch.Tensor, ref: PreparedReference, *, max_frames: int, device: Any = None,
+                        top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True, use_prefix: bool = False,
+                        prefix_sec_fixed: Optional[float] = None, style_strength: float = 1.0,
+                        use_stop_head: Optional[bool] = None, stop_patience: Optional[int] = None,
+                        stop_threshold: Optional[float] = None, min_gen_frames: Optional[int] = None) -> torch.Tensor:
+        """reference: src/sopro/model.py:349-401 -> [T, Q] int64 (``[0, Q]`` when EOS comes first)."""
+        return self.generate_tokens_batch([text_ids], [ref], max_frames=max_frames, top_p=top_p, temperature=temperature,
+                                          anti_loop=anti_loop, style_strength=style_strength, min_gen_frames=min_gen_frames)[0]
+
+    @torch.inference_mode()
+    def generate_tokens_batch(self, ids_list: Sequence[torch.Tensor], refs: Sequence[PreparedReference], *, max_frames: int,
+                              top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True,
+                              style_strength: float = 1.0, min_gen_frames: Optional[int] = None,
+                              timings: Optional[Dict[str, float]] = None) -> List[torch.Tensor]:
+        """B utterances -> list of [T_b, Q] int64 token matrices (new, batched form of generate_tokens)."""
+        ev = _PhaseTimer(self.stream, timings)
+        prep = self.prepare_conditioning_batch(ids_list, refs, max_frames=max_frames, style_strength=style_strength)
+        ev.mark("cond")
+        hist, lens = self.ar_generate_batch(prep["cond_ar"], prep["txt_seq"], prep["text_lens"], max_frames=max_frames,
+                                            top_p=top_p, temperature=temperature, anti_loop=anti_loop,
+                                            min_gen_frames=min_gen_frames)
+        ev.mark("ar")
+        B = len(ids_list)
+        Tm = max(lens)
+        if Tm <= 0:
+            ev.mark("nar")
+            return [torch.zeros(0, self.Q, dtype=torch.long, device=self.device) for _ in range(B)]
+        rvq1 = hist[:, :Tm].clamp(max=self.V - 1)  # rows past their own length are ignored below
+        toks = self.nar_refine(prep["cond_ar"][:, :Tm, :], rvq1, lens=[max(1, n) for n in lens])
+        ev.mark("nar")
+        return [toks[b, : lens[b]] for b in range(B)]
+
+
+class _PhaseTimer:
+    """Optional per-phase wall-clock (device-synchronised) used by bench.py."""
+
+    def __init__(self, stream: torch.cuda.Stream, sink: Optional[Dict[str, float]]):
+        self.sink = sink
+        self.stream = stream
+        if sink is not None:
+            import time
+
+            self._time = time
+            stream.synchronize()
+            self.t0 = time.perf_counter()
+
+    def mark(self, name: str) -> None:
+        if self.sink is None:
+            return
+        self.stream.synchronize()
+        t = self._time.perf_counter()
+        self.sink[name] = self.sink.get(name, 0.0) + (t - self.t0)
+        self.t0 = t
+
+
+class _ARPlan:
+    """Static buffers + the recorded per-frame launch sequence for (B rows, S_cap keys, Tar frames).
+    reference step: src/sopro/nn/generator.py:98-130."""
+
+    def __init__(self, m: SoproTTSModel, B: int, S_cap: int, Tar: int):
+        cfg, dev, D = m.cfg, m.device, m.D
+        self.m, self.B, self.S_cap, self.Tar = m, B, S_cap, Tar
+        self.max_steps = Tar
+        V1 = m.V + 1
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        self.cond = z(B, Tar, D)
+        self.x = [z(B, D) for _ in range(2)]
+        self.u = z(B, 4 * D)
+        self.q = z(B, D)
+        self.att = z(B, D)
+        self.logits = z(B, V1)
+        self.kv = {i: z(B, S_cap, 2 * D) for i in cfg.ar_xattn_layers}
+        self.klens = z(B, dt=torch.int32)
+        k = int(cfg.ar_kernel)
+        self.rings = [z((k - 1) * int(d) + 1, B, D) for d in cfg.ar_dilations]
+        self.hist = z(B, self.max_steps, dt=torch.int32)
+        self.ctr = z(8, dt=torch.int32)  # step, arrive, n_stopped
+        self.first_eos = z(B, dt=torch.int32)
+        self.stop_t = z(B, dt=torch.int32)
+        self.params = z(8)
+        st = hip.ArState()
+        st.x_cur = self.x[0].data_ptr()
+        st.cond = self.cond.data_ptr()
+        st.emb = m.w["cb_embed"].data_ptr()
+        st.hist = self.hist.data_ptr()
+        st.step = self.ctr.data_ptr()
+        st.arrive = self.ctr.data_ptr() + 4
+        st.n_stopped = self.ctr.data_ptr() + 8
+        st.first_eos = self.first_eos.data_ptr()
+        st.stop_t = self.stop_t.data_ptr()
+        st.params = self.params.data_ptr()
+        st.seed = m.seed
+        st.B, st.D, st.Tar, st.max_steps, st.V, st.bos_row = B, D, Tar, self.max_steps, m.V, int(cfg.bos_row)
+        self.state = st
+        self.step_t = self.ctr[0:1]
+        self.graph: Optional[hip.Graph] = None
+        self.nlaunch = 0
+
+    def issue_step(self) -> None:
+        """Enqueue one frame on the current stream (this is what the graph records)."""
+        m, cfg, w, B, D = self.m, self.m.cfg, self.m.w, self.B, self.m.D
+        k = int(cfg.ar_kernel)
+        H = 4  # reference: src/sopro/nn/generator.py:36
+        # two ping-pong residual-stream buffers; X0 is also where the sampler leaves the next frame's input
+        cur, oth = self.x[0], self.x[1]
+        nl = 0
+        for i, dil in enumerate(cfg.ar_dilations):
+            p = f"ar.blocks.{i}"
+            # RMSNorm -> GLU -> ring write -> dilated taps -> +x   (src/sopro/nn/blocks.py:150-157, 76-110)
+            hip.skinny(cur, w[p + ".glu.w"], oth, B=B, N=2 * D, K=D, norm_w=w[p + ".norm.weight"], eps=RMS_EPS, bias=w[p + ".glu.b"],
+                       epilogue=hip.EPI_GLU_DW, ring=self.rings[i], dw_w=w[p + ".dw.w"], dw_b=w[p + ".dw.b"], step=self.step_t,
+                       ring_len=(k - 1) * int(dil) + 1, ring_bcap=B, dil=int(dil), ksize=k)
+            # RMSNorm -> Linear -> GELU ; Linear -> +x (in place: every element is read and written by one thread)
+            hip.skinny(oth, w[p + ".ff1.w"], self.u, B=B, N=4 * D, K=D, norm_w=w[p + ".ff.norm.weight"], eps=RMS_EPS,
+                       bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
+            hip.skinny(self.u, w[p + ".ff2.w"], oth, B=B, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=oth)
+            nl += 3
+            if i in self.kv:
+                pa = f"ar.x_attns.{i}"
+                # cached text cross-attention (src/sopro/nn/text.py:85-132)
+                hip.skinny(oth, w[pa + ".q.w"], self.q, B=B, N=D, K=D, norm_w=w[pa + ".nq.weight"], eps=RMS_EPS)
+                kvb = self.kv[i]
+                hip.attention(self.q, kvb, kvb, self.att, B=B, H=H, dh=D // H, Tq=1, Tk=self.S_cap, ldq=D, ldk=2 * D, ldv=2 * D,
+                              ldo=D, q_bstride=D, k_bstride=self.S_cap * 2 * D, v_bstride=self.S_cap * 2 * D, o_bstride=D,
+                              klens=self.klens, v_off=D)
+                hip.skinny(self.att, w[pa + ".o.w"], oth, B=B, N=D, K=D, epilogue=hip.EPI_RES, R=oth, scale=w[pa + ".gate_scale"])
+                nl += 3
+            cur, oth = oth, cur
+        assert cur is self.x[0], "an even number of AR blocks is assumed by the two-buffer rotation"
+        hip.skinny(cur, w["ar.head.w"], self.logits, B=B, N=m.V + 1, K=D, norm_w=w["ar.norm.weight"], eps=RMS_EPS, bias=w["ar.head.b"])
+        # the sampler writes the next frame's input into state.x_cur, which must be where block 0 reads
+        hip.ar_sample(self.state, self.logits, m.V + 1)
+        self.nlaunch = nl + 2
+
+    def ensure_graph(self) -> None:
+        if self.graph is not None or not self.m.use_graph:
+            return
+        s = self.m.stream
+        with torch.cuda.stream(s):
+            hip.capture_begin()
+            try:
+                self.issue_step()
+            finally:
+                self.graph = hip.capture_end()
+
+    def step(self) -> None:
+        if self.m.use_graph:
+            self.graph.launch()
+        else:
+            self.issue_step()
+
+
+class _ARRun:
+    """One batch of utterances being generated on a plan."""
+
+    def __init__(self, m: SoproTTSModel, cond_ar: torch.Tensor, txt_seq: torch.Tensor, text_lens: Optional[torch.Tensor], *,
+                 top_p: float, temperature: float, anti_loop: bool, min_gen_frames: Optional[int]):
+        cfg, w, dev, D = m.cfg, m.w, m.device, m.D
+        if not bool(getattr(cfg, "use_bos", True)):
+            raise RuntimeError("BOS embedding disabled")
+        B, Tar, _ = cond_ar.shape
+        S = int(txt_seq.shape[1])
+        S_cap = ((S + 63) // 64) * 64
+        self.m = m
+        self.plan = plan = m._ar_plan(B, S_cap, Tar)
+        min_gen = int(min_gen_frames if min_gen_frames is not None else cfg.min_gen_frames)
+        with m.on_stream():
+            plan.cond.copy_(cond_ar.to(dev).float())
+            if text_lens is None:
+                plan.klens.fill_(S)
+            else:
+                plan.klens.copy_(text_lens.to(dev).to(torch.int32))
+            # K/V of the text for the three cross-attention layers (src/sopro/nn/text.py:75-83)
+            nkv = m.ws.get("ar.nkv", (B * S, D))
+            kvd = m.ws.get("ar.kvd", (B * S, 2 * D))
+            ts = txt_seq.to(dev).float().contiguous().view(B * S, D)
+            for i in cfg.ar_xattn_layers:
+                pa = f"ar.x_attns.{i}"
+                hip.norm(ts, nkv, w[pa + ".nkv.weight"], rows=B * S, C_=D, eps=RMS_EPS)
+                hip.gemm(nkv, w[pa + ".kv.w"], kvd, M=B * S, N=2 * D, K=D)
+                plan.kv[i][:, :S].copy_(kvd.view(B, S, 2 * D))
+            for r in plan.rings:
+                r.zero_()
+            plan.hist.zero_()
+            plan.params.copy_(torch.tensor([float(top_p), float(temperature), 1.0 if anti_loop else 0.0, 0.85, 1.2, 1.1, 50.0,
+                                            float(min_gen)], dtype=torch.float32), non_blocking=False)
+            hip.ar_init(plan.state)
+        plan.ensure_graph()
+
+    def advance(self, n: int) -> None:
+        with torch.cuda.stream(self.m.stream):
+            for _ in range(int(n)):
+                self.plan.step()
+
+    def n_stopped(self, first_eos: bool = False) -> int:
+        with torch.cuda.stream(self.m.stream):
+            if first_eos:
+                v = int((self.plan.first_eos >= 0).sum().item())
+            else:
+                v = int(self.plan.ctr[2].item())
+        return v
+
+    def tokens_host(self, t0: int, t1: int) -> List[int]:
+        with torch.cuda.stream(self.m.stream):
+            return self.plan.hist[0, t0:t1].tolist()
+
+    def history(self, steps: int) -> Tuple[torch.Tensor, List[int]]:
+        with torch.cuda.stream(self.m.stream):
+            h = self.plan.hist[:, :steps].clone()
+            fe = self.plan.first_eos.tolist()
+        return h, fe

@@ -1,0 +1,204 @@
+"""Host-side weight repacking: reference checkpoint layouts -> the [N, K] row-major fp32 operands
+the HIP kernels read (include/sopro_hip.h).  Runs once at load time, on the CPU, in torch;
+nothing here is on the timed path.
+
+Conventions (channels-last activations):
+  * GLU projections of full-sequence blocks are packed per 64 rows as [32 value | 32 gate] so the
+    GEMM epilogue can gate in registers (reference: src/sopro/nn/blocks.py:16-23);
+  * depthwise taps become tap-major [k, C] (reference layout [C, 1, k], blocks.py:45-49);
+  * Conv1d weights [Cout, Cin, k] become [Cout, k*Cin] (tap-major K), so that a causal conv is a
+    contraction over k consecutive channels-last rows (HF:modeling_mimi.py:210-347);
+  * ConvTranspose1d weights [Cin, Cout, 2s] (stride s) become [s*Cout, 2*Cin]: output row t holds
+    the s samples t*s..t*s+s-1, input row is [x[t-1] | x[t]] (HF:modeling_mimi.py:350-405).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+
+from .config import MimiDecoderConfig, SoproTTSConfig
+
+
+def _t(a) -> torch.Tensor:
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    return t.float() if t.is_floating_point() else t
+
+
+def pack_glu(w: torch.Tensor, b: torch.Tensor):
+    """[2D, K] (value rows then gate rows) -> per-64 blocks [32 value | 32 gate]."""
+    d = w.shape[0] // 2
+    assert d % 32 == 0
+    wv, wg = w[:d].reshape(d // 32, 32, -1), w[d:].reshape(d // 32, 32, -1)
+    wp = torch.cat([wv, wg], dim=1).reshape(2 * d, -1).contiguous()
+    bv, bg = b[:d].reshape(d // 32, 32), b[d:].reshape(d // 32, 32)
+    bp = torch.cat([bv, bg], dim=1).reshape(2 * d).contiguous()
+    return wp, bp
+
+
+def pack_dw(w: torch.Tensor) -> torch.Tensor:
+    """[C, 1, k] -> [k, C]"""
+    return w.squeeze(1).t().contiguous()
+
+
+def pack_conv1d(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, k] -> [Cout, k*Cin] with K index = tap*Cin + ci."""
+    co, ci, k = w.shape
+    return w.permute(0, 2, 1).reshape(co, k * ci).contiguous()
+
+
+def pack_convtr1d(w: torch.Tensor, b: torch.Tensor, stride: int):
+    """[Cin, Cout, 2s] -> ([s*Cout, 2*Cin], [s*Cout]); row r*Cout+co, col half*Cin+ci = w[ci, co, (1-half)*s + r]."""
+    ci, co, k = w.shape
+    assert k == 2 * stride
+    wv = w.reshape(ci, co, 2, stride)  # [ci, co, h2, r], tap = h2*s + r ; h2 = 0 multiplies x[t], h2 = 1 multiplies x[t-1]
+    wp = wv.flip(2).permute(3, 1, 2, 0).reshape(stride * co, 2 * ci).contiguous()
+    bp = b.repeat(stride).contiguous()
+    return wp, bp
+
+
+def _ssm_block(out: Dict[str, torch.Tensor], w: Dict[str, torch.Tensor], p: str, *, packed_glu: bool) -> None:
+    out[p + ".norm.weight"] = w[p + ".norm.weight"]
+    if packed_glu:
+        out[p + ".glu.w"], out[p + ".glu.b"] = pack_glu(w[p + ".glu.pro.weight"], w[p + ".glu.pro.bias"])
+    else:
+        out[p + ".glu.w"], out[p + ".glu.b"] = w[p + ".glu.pro.weight"], w[p + ".glu.pro.bias"]
+    out[p + ".dw.w"] = pack_dw(w[p + ".dw.dw.weight"])
+    out[p + ".dw.b"] = w[p + ".dw.dw.bias"]
+    out[p + ".ff.norm.weight"] = w[p + ".ff.0.weight"]
+    out[p + ".ff1.w"], out[p + ".ff1.b"] = w[p + ".ff.1.weight"], w[p + ".ff.1.bias"]
+    out[p + ".ff2.w"], out[p + ".ff2.b"] = w[p + ".ff.3.weight"], w[p + ".ff.3.bias"]
+
+
+def _xattn(out: Dict[str, torch.Tensor], w: Dict[str, torch.Tensor], p: str, gate_mul: float) -> None:
+    d = w[p + ".q_proj.weight"].shape[0]
+    out[p + ".nq.weight"] = w[p + ".nq.weight"]
+    out[p + ".nkv.weight"] = w[p + ".nkv.weight"]
+    out[p + ".q.w"] = w[p + ".q_proj.weight"]
+    out[p + ".kv.w"] = torch.cat([w[p + ".k_proj.weight"], w[p + ".v_proj.weight"]], dim=0).contiguous()
+    out[p + ".o.w"] = w[p + ".out_proj.weight"]
+    # x + (gmax *) tanh(gate) * a  -> per-column scale of the residual epilogue
+    out[p + ".gate_scale"] = (gate_mul * torch.tanh(w[p + ".gate"].float())).reshape(1).repeat(d).contiguous()
+
+
+def pack_sopro(weights: Dict[str, "np.ndarray"], cfg: SoproTTSConfig) -> Dict[str, torch.Tensor]:
+    """Reference ``SoproTTSModel.state_dict()`` names -> kernel operands (CPU tensors)."""
+    w = {k: _t(v) for k, v in weights.items()}
+    out: Dict[str, torch.Tensor] = {}
+    for i in range(int(cfg.n_layers_text)):
+        _ssm_block(out, w, f"text_enc.layers.{i}", packed_glu=True)
+    out["text_enc.embed"] = w["text_enc.embed.emb.weight"]
+    out["text_enc.norm.weight"] = w["text_enc.norm.weight"]
+    out["cb_embed"] = w["cb_embed.emb.weight"]
+    out["nar_prev_cb_weights"] = w["nar_prev_cb_weights"]
+    # Token2SV (reference: src/sopro/nn/speaker.py:12-61)
+    out["token2sv.emb"] = w["token2sv.emb.weight"]
+    out["token2sv.cw"] = torch.softmax(w["token2sv.cb_weights"].float(), dim=0)
+    for i in (0, 3):
+        out[f"token2sv.enc.{i}.w"] = pack_dw(w[f"token2sv.enc.{i}.dw.weight"])
+        out[f"token2sv.enc.{i}.b"] = w[f"token2sv.enc.{i}.dw.bias"]
+    for n in ("pool.attn.0", "pool.attn.2", "proj"):
+        out[f"token2sv.{n}.w"] = w[f"token2sv.{n}.weight"]
+        out[f"token2sv.{n}.b"] = w[f"token2sv.{n}.bias"]
+    # speaker FiLM
+    for n in ("mlp.0", "mlp.2"):
+        out[f"spk_film.{n}.w"], out[f"spk_film.{n}.b"] = w[f"spk_film.{n}.weight"], w[f"spk_film.{n}.bias"]
+    out["spk_film.norm.weight"], out["spk_film.norm.bias"] = w["spk_film.norm.weight"], w["spk_film.norm.bias"]
+    # AR generator: natural GLU layout (the step kernel pairs value/gate rows itself)
+    for i in range(int(cfg.n_layers_ar)):
+        _ssm_block(out, w, f"ar.blocks.{i}", packed_glu=False)
+    for i in cfg.ar_xattn_layers:
+        _xattn(out, w, f"ar.x_attns.{i}", 1.0)
+    out["ar.norm.weight"] = w["ar.norm.weight"]
+    out["ar.head.w"], out["ar.head.b"] = w["ar.head.weight"], w["ar.head.bias"]
+    # NAR refiner
+    for i in range(int(cfg.n_layers_nar)):
+        _ssm_block(out, w, f"nar.blocks.{i}", packed_glu=True)
+    out["nar.norm.weight"] = w["nar.norm.weight"]
+    out["nar.pre.w"], out["nar.pre.b"] = w["nar.pre.weight"], w["nar.pre.bias"]
+    out["nar.stage_emb"] = w["nar.stage_emb.weight"]
+    out["nar.adapter.norm.weight"] = w["nar.adapter.norm.weight"]
+    for n in ("mlp.0", "mlp.2"):
+        out[f"nar.adapter.{n}.w"], out[f"nar.adapter.{n}.b"] = w[f"nar.adapter.{n}.weight"], w[f"nar.adapter.{n}.bias"]
+    sc = cfg.stage_codebooks()
+    for s in cfg.stage_order():
+        for j in range(len(sc[s])):
+            out[f"nar.heads.{s}.{j}.w"], out[f"nar.heads.{s}.{j}.b"] = w[f"nar.heads.{s}.{j}.weight"], w[f"nar.heads.{s}.{j}.bias"]
+        out[f"nar.head_id_emb.{s}"] = w[f"nar.head_id_emb.{s}.weight"]
+        out[f"nar.mix.{s}"] = torch.softmax(w[f"nar.mix.{s}"].float(), dim=0)
+    out["cond_norm.weight"] = w["cond_norm.weight"]
+    # reference encoder + reference cross-attention
+    for i in range(int(cfg.ref_enc_layers)):
+        _ssm_block(out, w, f"ref_enc_blocks.{i}", packed_glu=True)
+    out["ref_enc_norm.weight"] = w["ref_enc_norm.weight"]
+    out["ref_cw"] = torch.softmax(w["ref_cb_weights"].float(), dim=0)
+    for i in range(int(cfg.ref_xattn_layers)):
+        _xattn(out, w, f"ref_xattn.blocks.{i}", float(cfg.ref_xattn_gmax))
+    return {k: v.contiguous() for k, v in out.items()}
+
+
+def pack_mimi(weights: Dict[str, "np.ndarray"], mc: MimiDecoderConfig) -> Dict[str, torch.Tensor]:
+    """HF ``MimiModel.state_dict()`` decode-side names -> kernel operands (CPU tensors)."""
+    w = {k: _t(v) for k, v in weights.items()}
+    out: Dict[str, torch.Tensor] = {}
+    ns = int(mc.num_semantic_quantizers)
+    tabs = []
+    for q in range(int(mc.num_quantizers)):
+        grp, i = ("semantic", q) if q < ns else ("acoustic", q - ns)
+        p = f"quantizer.{grp}_residual_vector_quantizer.layers.{i}.codebook"
+        # HF:modeling_mimi.py:979-983
+        tabs.append(w[p + ".embed_sum"] / w[p + ".cluster_usage"].clamp(min=1e-5)[:, None])
+    out["codebooks"] = torch.cat(tabs, dim=0).contiguous()  # [Q*2048, 256], row q*2048 + tok
+    psem = w["quantizer.semantic_residual_vector_quantizer.output_proj.weight"].squeeze(-1)
+    pac = w["quantizer.acoustic_residual_vector_quantizer.output_proj.weight"].squeeze(-1)
+    out["rvq_proj.w"] = torch.cat([psem, pac], dim=1).contiguous()  # [512, 256 sem | 256 ac]
+    out["upsample.w"] = w["upsample.conv.weight"].squeeze(1).contiguous()  # [512, 4]
+    for li in range(int(mc.num_hidden_layers)):
+        p = f"decoder_transformer.layers.{li}"
+        out[f"tr.{li}.qkv.w"] = torch.cat([w[p + f".self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], dim=0).contiguous()
+        out[f"tr.{li}.o.w"] = w[p + ".self_attn.o_proj.weight"]
+        out[f"tr.{li}.fc1.w"] = w[p + ".mlp.fc1.weight"]
+        out[f"tr.{li}.fc2.w"] = w[p + ".mlp.fc2.weight"]
+        out[f"tr.{li}.ln1.w"], out[f"tr.{li}.ln1.b"] = w[p + ".input_layernorm.weight"], w[p + ".input_layernorm.bias"]
+        out[f"tr.{li}.ln2.w"], out[f"tr.{li}.ln2.b"] = w[p + ".post_attention_layernorm.weight"], w[p + ".post_attention_layernorm.bias"]
+        out[f"tr.{li}.ls1"] = w[p + ".self_attn_layer_scale.scale"]
+        out[f"tr.{li}.ls2"] = w[p + ".mlp_layer_scale.scale"]
+    out["sea.conv0.w"] = pack_conv1d(w["decoder.layers.0.conv.weight"])
+    out["sea.conv0.b"] = w["decoder.layers.0.conv.bias"]
+    li = 1
+    for si, r in enumerate(mc.upsampling_ratios):
+        li += 1
+        out[f"sea.up{si}.w"], out[f"sea.up{si}.b"] = pack_convtr1d(w[f"decoder.layers.{li}.conv.weight"], w[f"decoder.layers.{li}.conv.bias"], int(r))
+        li += 1
+        p = f"decoder.layers.{li}.block"
+        out[f"sea.res{si}.c1.w"] = pack_conv1d(w[p + ".1.conv.weight"])
+        out[f"sea.res{si}.c1.b"] = w[p + ".1.conv.bias"]
+        out[f"sea.res{si}.c2.w"] = pack_conv1d(w[p + ".3.conv.weight"])
+        out[f"sea.res{si}.c2.b"] = w[p + ".3.conv.bias"]
+        li += 1
+    li += 1
+    fw = w[f"decoder.layers.{li}.conv.weight"]  # [1, 64, 3]
+    out["sea.final.w"] = fw[0].t().contiguous()  # [3, 64]
+    out["sea.final.b"] = w[f"decoder.layers.{li}.conv.bias"].reshape(1)
+    return {k: v.contiguous() for k, v in out.items()}
+
+
+def sinusoid_table(n: int, d: int) -> torch.Tensor:
+    """Rows 0..n-1 of the reference's sinusoidal table (src/sopro/nn/embeddings.py:11-25), made on the
+    host with the same torch ops so device code never evaluates sin/cos of positions."""
+    import math
+
+    pos = torch.arange(n, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * (-math.log(10000.0) / d))
+    pe = torch.zeros(n, d)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+def rope_tables(npos: int, dh: int, theta: float):
+    """cos/sin [npos, dh/2] as HF computes them (HF:modeling_mimi.py:511-566)."""
+    inv = 1.0 / (theta ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+    fr = torch.arange(npos, dtype=torch.float32)[:, None] * inv[None, :]
+    return fr.cos().contiguous(), fr.sin().contiguous()

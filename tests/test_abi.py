@@ -1,0 +1,84 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/sopro_hip.h declares, and
+rejects bad arguments with an error code + message instead of launching (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from sopro_amd import hip
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "sopro_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sopro_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = hip.load()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sopro_hip.h but not exported by libsopro_hip.so"
+    assert set(names) == set(hip.SYMBOLS), set(names) ^ set(hip.SYMBOLS)
+    assert lib.sopro_abi_version() == hip.ABI_VERSION
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """Compile include/sopro_hip.h with gcc and compare sizeof/offsetof with the ctypes mirrors:
+    field order/size drift between the two would corrupt every launch."""
+    import subprocess
+
+    checks = {
+        "sopro_gemm_args": (hip.GemmArgs, ["A", "W", "C", "R", "scale", "pro_vec", "M", "rows_per_seg", "epilogue"]),
+        "sopro_skinny_args": (hip.SkinnyArgs, ["X", "norm_w", "eps", "W", "Y", "scale", "B", "epilogue", "ring", "step", "ring_len", "ksize"]),
+        "sopro_attn_args": (hip.AttnArgs, ["Q", "K", "V", "O", "klens", "B", "Tk", "causal", "window", "scale"]),
+        "sopro_ar_state": (hip.ArState, ["x_cur", "emb", "hist", "params", "seed", "B", "bos_row"]),
+    }
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "sopro_hip.h"', "int main(void){"]
+    for cname, (_cls, fields) in checks.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in fields:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines += ["return 0;}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, (cls, fields) in checks.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f in fields:
+            assert int(got[f"{cname}.{f}"]) == getattr(cls, f).offset, f"{cname}.{f}"
+
+
+def test_bad_arguments_are_refused_with_a_message():
+    lib = hip.load()
+    assert lib.sopro_gemm_f32(None, None) == -2
+    assert b"args is NULL" in lib.sopro_last_error()
+    g = hip.GemmArgs()
+    g.M, g.N, g.K, g.rows_per_seg = 4, 4, 6, 4  # K not a multiple of 4
+    assert lib.sopro_gemm_f32(ctypes.byref(g), None) == -2
+    assert b"multiple of 4" in lib.sopro_last_error()
+    a = hip.SkinnyArgs()
+    a.B, a.N, a.K = 1, 16, 48
+    assert lib.sopro_skinny_f32(ctypes.byref(a), None) == -2
+    at = hip.AttnArgs()
+    assert lib.sopro_attention_f32(ctypes.byref(at), None) == -2
+    assert lib.sopro_capture_begin(None) == -2
+
+
+def test_engine_refuses_to_run_without_the_hip_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sopro_amd.config import SoproTTSConfig
+    from sopro_amd.model import SoproTTSModel
+
+    with pytest.raises(hip.SoproHipError):
+        SoproTTSModel(SoproTTSConfig(), {}, "cuda:0")
+    with pytest.raises(hip.SoproHipError):
+        hip.ptr(torch.zeros(4))

@@ -1,0 +1,419 @@
+"""Kernel-level parity (MI355X): every entry point of libsopro_hip.so against the CPU oracle / plain
+torch fp32 on the same seeded inputs, through the C ABI (sopro_amd/hip.py is marshalling only).
+Tolerances are fp32 round-off class: the kernels accumulate in fp32 (exact-f32 MFMA), only the
+summation order differs from the CPU."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sopro_oracle as O
+from sopro_amd import hip, pack
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def dev(t):
+    return t.to(DEV).contiguous()
+
+
+def close(a, b, atol, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    err = float((a - b).abs().max())
+    assert err <= atol, f"{what}: max abs err {err:.3e} > {atol:.1e}"
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (129, 64, 64), (1000, 32, 192), (70, 1, 192), (5, 384, 384), (257, 2048, 256)])
+def test_gemm_plain_bias(M, N, K):
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(dev(A), dev(W), C, M=M, N=N, K=K, bias=dev(b))
+    torch.cuda.synchronize()
+    close(C, A @ W.t() + b, 2e-5 * math.sqrt(K), f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_epilogues_and_prologues():
+    M, N, K = 200, 256, 128
+    A, W, b = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=K ** -0.5), rnd(N, seed=6)
+    R, sc, pv = rnd(M, N, seed=7), rnd(N, seed=8), rnd(K, seed=9)
+    ref = A @ W.t() + b
+    C = torch.empty(M, N, device=DEV)
+    hip.gemm(dev(A), dev(W), C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_GELU)
+    close(C, F.gelu(ref), 3e-5, "gelu")
+    hip.gemm(dev(A), dev(W), C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_TANH)
+    close(C, torch.tanh(ref), 3e-5, "tanh")
+    hip.gemm(dev(A), dev(W), C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_RES, R=dev(R), scale=dev(sc))
+    close(C, R + sc * ref, 5e-5, "res+scale")
+    Rd = dev(R)
+    hip.gemm(dev(A), dev(W), Rd, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_RES, R=Rd)  # in place
+    close(Rd, R + ref, 5e-5, "res in place")
+    hip.gemm(dev(A), dev(W), C, M=M, N=N, K=K, bias=dev(b), prologue=hip.PRO_ELU)
+    close(C, F.elu(A) @ W.t() + b, 5e-5, "elu prologue")
+    hip.gemm(dev(A), dev(W), C, M=M, N=N, K=K, bias=dev(b), prologue=hip.PRO_ADDVEC, pro_vec=dev(pv))
+    close(C, (A + pv) @ W.t() + b, 5e-5, "addvec prologue")
+    # GLU on packed value/gate blocks (reference: src/sopro/nn/blocks.py:16-23)
+    wp, bp = pack.pack_glu(W, b)
+    G = torch.empty(M, N // 2, device=DEV)
+    hip.gemm(dev(A), dev(wp), G, M=M, N=N, K=K, bias=dev(bp), epilogue=hip.EPI_GLU)
+    close(G, ref[:, : N // 2] * torch.sigmoid(ref[:, N // 2:]), 3e-5, "glu")
+
+
+def test_gemm_causal_conv_and_convtranspose_through_row_windows():
+    """Segmented, overlapping-row addressing == MimiConv1d / MimiConvTranspose1d (HF:modeling_mimi.py:210-405)."""
+    B, T, ci, co, k = 3, 37, 64, 96, 7
+    x = rnd(B, T, ci, seed=10)
+    w, b = rnd(co, ci, k, seed=11, scale=(ci * k) ** -0.5), rnd(co, seed=12)
+    ref = F.conv1d(F.pad(F.elu(x).transpose(1, 2), (k - 1, 0)), w, b).transpose(1, 2)
+    buf = torch.zeros(B, k - 1 + T, ci)
+    buf[:, k - 1:] = x
+    out = torch.zeros(B, 2 + T, co, device=DEV)
+    hip.gemm(dev(buf), dev(pack.pack_conv1d(w)), out, M=B * T, N=co, K=k * ci, lda=ci, bias=dev(b), prologue=hip.PRO_ELU,
+             rows_per_seg=T, a_seg_stride=(k - 1 + T) * ci, c_off=2 * co, c_seg_stride=(2 + T) * co, ldc=co)
+    close(out[:, 2:], ref, 5e-5, "causal conv1d")
+    assert float(out[:, :2].abs().max()) == 0.0  # padding rows untouched
+    for s in (4, 5, 8):
+        wt, bt = rnd(ci, co, 2 * s, seed=13 + s, scale=(2 * ci) ** -0.5), rnd(co, seed=14)
+        y = F.conv_transpose1d(x.transpose(1, 2), wt, bt, stride=s)
+        ref = y[..., : y.shape[-1] - s].transpose(1, 2)  # [B, T*s, co]
+        wp, bp = pack.pack_convtr1d(wt, bt, s)
+        buf = torch.zeros(B, 1 + T, ci)
+        buf[:, 1:] = x
+        out = torch.zeros(B, 2 + T * s, co, device=DEV)
+        hip.gemm(dev(buf), dev(wp), out, M=B * T, N=s * co, K=2 * ci, lda=ci, bias=dev(bp), rows_per_seg=T,
+                 a_seg_stride=(1 + T) * ci, c_off=2 * co, c_seg_stride=(2 + T * s) * co, ldc=s * co)
+        close(out[:, 2:], ref, 5e-5, f"conv transpose stride {s}")
+
+
+# ------------------------------------------------------------------------------------------- skinny
+@pytest.mark.parametrize("B", [1, 7, 16, 32, 40])
+def test_skinny_norm_head(B):
+    K, N = 384, 2049
+    X, nw, W, b = rnd(B, K, seed=20), 1 + 0.1 * rnd(K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23)
+    Y = torch.full((B, N), float("nan"), device=DEV)
+    hip.skinny(dev(X), dev(W), Y, B=B, N=N, K=K, norm_w=dev(nw), eps=1e-6, bias=dev(b))
+    close(Y, O.rmsnorm(X, nw) @ W.t() + b, 5e-5, f"skinny head B={B}")
+
+
+def test_skinny_epilogues():
+    B, K, N = 32, 1536, 384
+    X, W, b, R, sc = rnd(B, K, seed=24), rnd(N, K, seed=25, scale=K ** -0.5), rnd(N, seed=26), rnd(B, N, seed=27), rnd(N, seed=28)
+    ref = X @ W.t() + b
+    Y = torch.empty(B, N, device=DEV)
+    hip.skinny(dev(X), dev(W), Y, B=B, N=N, K=K, bias=dev(b), epilogue=hip.EPI_GELU)
+    close(Y, F.gelu(ref), 5e-5, "gelu")
+    Rd = dev(R)
+    hip.skinny(dev(X), dev(W), Rd, B=B, N=N, K=K, bias=dev(b), epilogue=hip.EPI_RES, R=Rd, scale=dev(sc))
+    close(Rd, R + sc * ref, 1e-4, "res in place")
+
+
+@pytest.mark.parametrize("B,dil", [(1, 1), (5, 2), (32, 4)])
+def test_skinny_glu_ring_buffer_step_matches_forward_step(B, dil, w, cfg):
+    """SSMLiteBlock.forward_step first half over 30 frames (src/sopro/nn/blocks.py:150-157, 76-110)."""
+    D, k = 384, 13
+    p = "ar.blocks.2"
+    L = (k - 1) * dil + 1
+    ring_o = torch.zeros(B, L, D)
+    ring = torch.zeros(L, B, D, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    gw, gb = dev(w[p + ".glu.pro.weight"]), dev(w[p + ".glu.pro.bias"])
+    dww, dwb, nw = dev(pack.pack_dw(w[p + ".dw.dw.weight"])), dev(w[p + ".dw.dw.bias"]), dev(w[p + ".norm.weight"])
+    Y = torch.empty(B, D, device=DEV)
+    for t in range(30):
+        x = rnd(B, D, seed=100 + t)
+        h = O.glu(O.rmsnorm(x, w[p + ".norm.weight"]), w, p + ".glu")
+        ring_o = torch.cat([ring_o[:, 1:], h.unsqueeze(1)], dim=1)
+        taps = ring_o[:, torch.arange(0, k * dil, dil)]
+        y = (taps.transpose(1, 2) * w[p + ".dw.dw.weight"].squeeze(1)).sum(-1) + w[p + ".dw.dw.bias"]
+        step.fill_(t)
+        hip.skinny(dev(x), gw, Y, B=B, N=2 * D, K=D, norm_w=nw, eps=1e-6, bias=gb, epilogue=hip.EPI_GLU_DW, ring=ring,
+                   dw_w=dww, dw_b=dwb, step=step, ring_len=L, ring_bcap=B, dil=dil, ksize=k)
+        close(Y, x + y, 5e-5, f"glu+dw step {t}")
+
+
+# ------------------------------------------------------------------------------- norms / elementwise
+def test_norms_and_small_ops():
+    rows, C = 77, 384
+    x, wt, b = rnd(rows, C, seed=30), 1 + 0.1 * rnd(C, seed=31), rnd(C, seed=32)
+    out = torch.empty(rows, C, device=DEV)
+    hip.norm(dev(x), out, dev(wt), rows=rows, C_=C, eps=1e-6)
+    close(out, O.rmsnorm(x, wt), 1e-5, "rmsnorm")
+    x5 = rnd(rows, 512, seed=33)
+    o5 = torch.empty(rows, 512, device=DEV)
+    w5, b5 = 1 + 0.1 * rnd(512, seed=34), rnd(512, seed=35)
+    hip.norm(dev(x5), o5, dev(w5), rows=rows, C_=512, eps=1e-5, kind=hip.NORM_LN, b=dev(b5))
+    close(o5, F.layer_norm(x5, (512,), w5, b5, 1e-5), 2e-5, "layernorm")
+    # FiLM-style per-segment modulation: 7 segments of 11 rows
+    mul, add = rnd(7, C, seed=36), rnd(7, C, seed=37)
+    hip.norm(dev(x), out, dev(wt), rows=rows, C_=C, eps=1e-5, kind=hip.NORM_LN, b=dev(b), mul=dev(mul), add=dev(add), rows_per_seg=11)
+    ref = F.layer_norm(x, (C,), wt, b, 1e-5).view(7, 11, C) * mul[:, None] + add[:, None]
+    close(out, ref.view(rows, C), 3e-5, "layernorm + film")
+    # segmented source rows (zero-padded stream)
+    buf = torch.zeros(7, 3 + 11, C)
+    buf[:, 3:] = x.view(7, 11, C)
+    hip.norm(dev(buf), out, dev(wt), rows=rows, C_=C, eps=1e-6, rows_per_seg=11, x_off=3 * C, x_seg_stride=14 * C)
+    close(out, O.rmsnorm(x, wt), 1e-5, "rmsnorm segmented")
+    a = rnd(rows, C, seed=38, scale=3.0)
+    hip.rms_match(dev(a), dev(x), out, rows, C)
+    rms = lambda t: torch.sqrt(t.pow(2).mean(-1, keepdim=True) + 1e-6)  # noqa: E731
+    close(out, a * (rms(x) / rms(a)).clamp(0, 10), 1e-5, "rms_match")
+    hip.tanh_affine(dev(x), out, 1.0, 1.2, rows * C)
+    close(out, 1.0 + 1.2 * torch.tanh(x), 1e-6, "tanh_affine")
+    pe = pack.sinusoid_table(64, C)
+    o3 = torch.empty(3, 20, C, device=DEV)
+    hip.add_pos(dev(x[:3]), dev(pe), o3, 3, 20, C, 5)
+    close(o3, x[:3, None] + pe[None, 5:25], 1e-6, "add_pos")
+    lens = torch.tensor([11, 4, 9], dtype=torch.int32)
+    xm = rnd(3, 11, C, seed=39)
+    om = torch.empty(3, C, device=DEV)
+    hip.masked_mean(dev(xm), dev(lens), om, 3, 11, C)
+    ref = torch.stack([xm[i, : lens[i]].sum(0) / (float(lens[i]) + 1e-6) for i in range(3)])
+    close(om, ref, 1e-5, "masked_mean")
+    lg = rnd(3, 11, seed=40)
+    st = torch.empty(3, 2 * C, device=DEV)
+    hip.stats_pool(dev(xm), dev(lg), None, st, 3, 11, C)
+    aw = torch.softmax(lg, 1).unsqueeze(-1)
+    mu = (xm * aw).sum(1)
+    sd = torch.sqrt((aw * (xm - mu[:, None]).pow(2)).sum(1).clamp_min(1e-6))
+    close(st, torch.cat([mu, sd], -1), 1e-5, "stats_pool")
+    e = rnd(4, 192, seed=41)
+    oe = torch.empty(4, 192, device=DEV)
+    hip.l2norm(dev(e), oe, 4, 192, 1e-6)
+    close(oe, F.normalize(e, dim=-1, eps=1e-6), 1e-6, "l2norm")
+    am = torch.empty(rows, dtype=torch.int32, device=DEV)
+    xx = rnd(rows, 2048, seed=42)
+    hip.argmax_rows(dev(xx), am, rows=rows, N=2048)
+    assert torch.equal(am.cpu().long(), xx.argmax(-1))
+
+
+@pytest.mark.parametrize("ksize,dil,causal", [(7, 1, False), (11, 8, False), (11, 2, False), (13, 4, True)])
+def test_dwconv(ksize, dil, causal):
+    B, T, C = 3, 50, 384
+    x, wt, b, res = rnd(B, T, C, seed=50), rnd(C, 1, ksize, seed=51), rnd(C, seed=52), rnd(B, T, C, seed=53)
+    total = (ksize - 1) * dil
+    left = total if causal else total // 2
+    ref = O.dwconv_full(x, wt, b, dil, causal)
+    out = torch.empty(B, T, C, device=DEV)
+    hip.dwconv(dev(x), dev(pack.pack_dw(wt)), dev(b), out, B=B, T=T, C_=C, ksize=ksize, dil=dil, left=left, mode=1, res=dev(res))
+    close(out, res + ref, 2e-5, "dwconv + res")
+    hip.dwconv(dev(x), dev(pack.pack_dw(wt)), dev(b), out, B=B, T=T, C_=C, ksize=ksize, dil=dil, left=left, mode=2)
+    close(out, F.gelu(ref), 2e-5, "dwconv + gelu")
+    # ragged: utterance b is zero-padded at its own end, like a single-utterance call of the reference
+    lens = [50, 17, 33]
+    hip.dwconv(dev(x), dev(pack.pack_dw(wt)), dev(b), out, B=B, T=T, C_=C, ksize=ksize, dil=dil, left=left, mode=0,
+               lens=dev(torch.tensor(lens, dtype=torch.int32)))
+    for i, n in enumerate(lens):
+        close(out[i, :n], O.dwconv_full(x[i: i + 1, :n], wt, b, dil, causal)[0], 2e-5, f"dwconv ragged {i}")
+
+
+def test_gathers():
+    V, Q, D, rows = 2048, 32, 384, 41
+    table = rnd(Q * V + 1, D, seed=60)
+    tok = torch.randint(0, V, (rows, Q), generator=torch.Generator().manual_seed(61), dtype=torch.int32)
+    cols = [0, 3, 4, 9]
+    wq = torch.softmax(rnd(len(cols), seed=62), 0)
+    base = rnd(rows, D, seed=63)
+    out = torch.empty(rows, D, device=DEV)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)  # noqa: E731
+    hip.codebook_sum(dev(tok), Q, i32(cols), i32([c * V for c in cols]), dev(wq), dev(table), out, rows=rows, D=D, base=dev(base),
+                     alpha=0.3, beta=0.7)
+    ref = 0.3 * base + 0.7 * sum(wq[j] * table[c * V + tok[:, c].long()] for j, c in enumerate(cols))
+    close(out, ref, 1e-5, "codebook_sum")
+    ids = torch.randint(0, 500, (2, 9), generator=torch.Generator().manual_seed(64), dtype=torch.int32)
+    lens = torch.tensor([9, 5], dtype=torch.int32)
+    tt, pe = rnd(500, D, seed=65), pack.sinusoid_table(32, D)
+    o2 = torch.empty(2, 9, D, device=DEV)
+    hip.text_embed(dev(ids), dev(lens), dev(tt), dev(pe), o2, 2, 9, D)
+    ref = tt[ids.long()] + pe[None, :9]
+    ref[1, 5:] = 0
+    close(o2, ref, 1e-6, "text_embed")
+
+
+# ---------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("H,dh,Tq,Tk", [(4, 96, 1, 19), (4, 96, 1, 130), (2, 192, 49, 30), (2, 192, 401, 150), (8, 64, 40, 40)])
+def test_attention_cross(H, dh, Tq, Tk):
+    B, D = 3, H * dh
+    q, k, v = rnd(B, Tq, D, seed=70), rnd(B, Tk, D, seed=71), rnd(B, Tk, D, seed=72)
+    klens = [Tk, max(1, Tk // 3), Tk - 1]
+    keep = torch.arange(Tk)[None, :] < torch.tensor(klens)[:, None]
+    ref = O._unheads(O.attention(O._heads(q, H), O._heads(k, H), O._heads(v, H), keep))
+    out = torch.empty(B, Tq, D, device=DEV)
+    hip.attention(dev(q), dev(k), dev(v), out, B=B, H=H, dh=dh, Tq=Tq, Tk=Tk, ldq=D, ldk=D, ldv=D, ldo=D, q_bstride=Tq * D,
+                  k_bstride=Tk * D, v_bstride=Tk * D, o_bstride=Tq * D, klens=dev(torch.tensor(klens, dtype=torch.int32)))
+    close(out, ref, 2e-5, "cross attention")
+
+
+@pytest.mark.parametrize("N,win,past", [(100, 250, 0), (400, 250, 0), (16, 250, 300), (300, 17, 5)])
+def test_attention_causal_sliding_window_with_cache(N, win, past):
+    """Mimi decoder attention incl. the cached-keys form (HF:modeling_mimi.py:657-726, 882-888)."""
+    B, H, dh = (2 if past == 0 else 1), 8, 64
+    D = H * dh
+    Tk = N + min(past, win - 1)
+    q, kv = rnd(B, N, D, seed=73), rnd(B, Tk, 2 * D, seed=74)
+    pos = torch.arange(N) + past
+    kpos = torch.arange(past + N - Tk, past + N)
+    vis = (kpos[None, :] <= pos[:, None]) & (kpos[None, :] > pos[:, None] - win)
+    s = torch.matmul(O._heads(q, H), O._heads(kv[..., :D].contiguous(), H).transpose(-1, -2)) / math.sqrt(dh)
+    s = s.masked_fill(~vis[None, None], float("-inf"))
+    ref = O._unheads(torch.matmul(torch.softmax(s, -1), O._heads(kv[..., D:].contiguous(), H)))
+    out = torch.empty(B, N, D, device=DEV)
+    kvd = dev(kv)
+    hip.attention(dev(q), kvd, kvd, out, B=B, H=H, dh=dh, Tq=N, Tk=Tk, ldq=D, ldk=2 * D, ldv=2 * D, ldo=D, q_bstride=N * D,
+                  k_bstride=Tk * 2 * D, v_bstride=Tk * 2 * D, o_bstride=N * D, causal=True, window=win, q_pos0=past,
+                  k_pos0=past + N - Tk, v_off=D)
+    close(out, ref, 2e-5, "causal window attention")
+
+
+def test_rope_upsample_final_conv():
+    H, dh, rows_per_seg, B = 8, 64, 21, 2
+    x = rnd(B * rows_per_seg, 3 * H * dh, seed=80)
+    c, s = pack.rope_tables(64, dh, 10000.0)
+    xd = dev(x)
+    hip.rope(xd, dev(c), dev(s), rows=B * rows_per_seg, rows_per_seg=rows_per_seg, pos0=7, H=H, dh=dh, ldx=3 * H * dh, x_off=H * dh)
+    cos, sin = O.rope_cos_sin(torch.arange(rows_per_seg) + 7, dh, 10000.0)
+    kk = O._heads(x[:, H * dh: 2 * H * dh].reshape(B, rows_per_seg, H * dh), H)
+    ref = O._unheads(kk * cos + O._rot_half(kk) * sin).reshape(B * rows_per_seg, H * dh)
+    close(xd[:, H * dh: 2 * H * dh], ref, 1e-5, "rope")
+    close(xd[:, : H * dh], x[:, : H * dh], 0.0, "rope leaves q alone")
+    # upsample (HF:modeling_mimi.py:1208-1216)
+    T, C = 9, 512
+    xu, wu = rnd(B, T, C, seed=81), rnd(C, 1, 4, seed=82)
+    ref = O.causal_convtr1d(xu.transpose(1, 2), wu, None, 2, groups=C).transpose(1, 2)
+    y = torch.zeros(B, 6 + 2 * T, C, device=DEV)
+    hip.upsample2(dev(xu), dev(wu.squeeze(1)), y, B=B, T=T, C_=C, y_seg_stride=(6 + 2 * T) * C, y_off=6 * C)
+    close(y[:, 6:], ref, 1e-5, "upsample")
+    # last conv (HF:modeling_mimi.py:957-960)
+    Tn = 1000
+    h, wf, bf = rnd(B, Tn, 64, seed=83), rnd(1, 64, 3, seed=84, scale=0.1), 0.05
+    ref = O.causal_conv1d(F.elu(h).transpose(1, 2), wf, torch.tensor([bf]))[:, 0]
+    hb = torch.zeros(B, 2 + Tn, 64)
+    hb[:, 2:] = h
+    wav = torch.empty(B, Tn, device=DEV)
+    hip.final_conv(dev(hb), dev(wf[0].t()), bf, wav, B=B, T=Tn, h_seg_stride=(2 + Tn) * 64, wav_seg_stride=Tn)
+    close(wav, ref, 2e-5, "final conv")
+
+
+# ------------------------------------------------------------------------------------------ sampler
+class _SamplerRig:
+    def __init__(self, B, Tar=64, D=384, V=2048):
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=DEV)  # noqa: E731
+        self.B, self.Tar, self.D, self.V = B, Tar, D, V
+        self.x, self.cond, self.emb = z(B, D), dev(rnd(B, Tar, D, seed=90)), dev(rnd(V * 2 + 1, D, seed=91))
+        self.hist, self.ctr = z(B, Tar, dt=torch.int32), z(8, dt=torch.int32)
+        self.first_eos, self.stop_t, self.params = z(B, dt=torch.int32), z(B, dt=torch.int32), z(8)
+        st = hip.ArState()
+        st.x_cur, st.cond, st.emb, st.hist = self.x.data_ptr(), self.cond.data_ptr(), self.emb.data_ptr(), self.hist.data_ptr()
+        st.step, st.arrive, st.n_stopped = self.ctr.data_ptr(), self.ctr.data_ptr() + 4, self.ctr.data_ptr() + 8
+        st.first_eos, st.stop_t, st.params = self.first_eos.data_ptr(), self.stop_t.data_ptr(), self.params.data_ptr()
+        st.seed, st.B, st.D, st.Tar, st.max_steps, st.V, st.bos_row = 7, B, D, Tar, Tar, V, 2 * V
+        self.st = st
+
+    def set_params(self, top_p, temp, anti, min_gen=12, rec_p=0.85, rec_t=1.2):
+        self.params.copy_(torch.tensor([top_p, temp, 1.0 if anti else 0.0, rec_p, rec_t, 1.1, 50.0, float(min_gen)]))
+
+
+def test_sampler_greedy_penalty_temperature_and_bookkeeping():
+    B, V1 = 6, 2049
+    rig = _SamplerRig(B)
+    rig.set_params(0.0, 0.8, False, min_gen=3)
+    hip.ar_init(rig.st)
+    torch.cuda.synchronize()
+    close(rig.x, rig.cond[:, 0].cpu() + rig.emb[2 * 2048].cpu(), 0.0, "ar_init x")
+    hist = [[] for _ in range(B)]
+    for t in range(8):
+        lg = rnd(B, V1, seed=200 + t, scale=3.0)
+        if t == 1:
+            lg[2, 2048] = 50.0  # EOS before min_gen: recorded as first_eos, row keeps going
+        if t == 5:
+            lg[4, 2048] = 50.0  # EOS after min_gen: row stops
+        hip.ar_sample(rig.st, dev(lg), V1)
+        torch.cuda.synchronize()
+        got = rig.hist[:, t].cpu().tolist()
+        for b in range(B):
+            want = int(torch.argmax(O.penalised_logits(lg[b], hist[b], 0.8, 1.1)))
+            assert got[b] == want, (t, b, got[b], want)
+            hist[b].append(want)
+        assert int(rig.ctr[0]) == t + 1
+        ref_x = rig.cond[:, t + 1].cpu() + rig.emb.cpu()[torch.tensor(got)]
+        close(rig.x, ref_x, 0.0, "next input")
+    assert rig.first_eos.cpu().tolist() == [-1, -1, 1, -1, 5, -1]
+    assert rig.stop_t.cpu().tolist() == [-1, -1, -1, -1, 5, -1]
+    assert int(rig.ctr[2]) == 1
+
+
+def test_sampler_topk_topp_support_and_frequencies():
+    """Stochastic draws: every token must lie in the reference's kept set and the head token's frequency
+    must match its probability (distributional parity; the CPU RNG stream cannot be matched)."""
+    B, V1, steps = 32, 2049, 24
+    rig = _SamplerRig(B, Tar=steps + 1)
+    rig.set_params(0.9, 1.05, False)
+    hip.ar_init(rig.st)
+    base = rnd(V1, seed=300, scale=2.0)
+    lg = base[None].repeat(B, 1)
+    hits, expect = 0, 0.0
+    hist = [[] for _ in range(B)]
+    for t in range(steps):
+        hip.ar_sample(rig.st, dev(lg), V1)
+        torch.cuda.synchronize()
+        got = rig.hist[:, t].cpu().tolist()
+        for b in range(B):
+            sp, si, forced = O.sampling_distribution(lg[b], hist[b], 0.9, 1.05)
+            kept = set(si[sp > 0].tolist())
+            assert got[b] in kept, (t, b, got[b])
+            hits += int(got[b] == int(si[0]))
+            expect += float(sp[0])
+            hist[b].append(got[b])
+    n = B * steps
+    p = expect / n
+    assert abs(hits / n - p) < 5 * math.sqrt(p * (1 - p) / n) + 0.02, (hits / n, p)
+
+
+def test_sampler_anti_loop_detection():
+    """repeated_tail / streak >= 8 switch that frame to the recovery parameters (model.py:274-279).
+    Recovery top_p is set to 0 here so that a detected loop shows up as an exact arg-max."""
+    B, V1 = 4, 2049
+    rig = _SamplerRig(B, Tar=40)
+    rig.set_params(1.0, 1.0, True, rec_p=0.0, rec_t=1.0)
+    hip.ar_init(rig.st)
+    h = torch.zeros(B, 40, dtype=torch.int32)
+    h[0, :6] = torch.tensor([5, 6, 7, 5, 6, 7])       # repeated tail n=3
+    h[1, :6] = torch.tensor([5, 6, 7, 5, 6, 8])       # no loop
+    h[2, :10] = torch.tensor([1] + [9] * 9)           # 9 equal tokens: streak 8
+    h[3, :10] = torch.tensor([1, 2] + [9] * 8)        # only 8 equal: streak 7
+    flat = 0.01 * rnd(V1, seed=400)
+    flags = []
+    for row, L in ((0, 6), (1, 6), (2, 10), (3, 10)):
+        rig.hist.copy_(h)
+        rig.ctr.zero_()
+        rig.ctr[0] = L
+        lg = flat[None].repeat(B, 1)
+        hip.ar_sample(rig.st, dev(lg), V1)
+        torch.cuda.synchronize()
+        want = int(torch.argmax(O.penalised_logits(flat, h[row, :L].tolist(), 1.0, 1.1)))
+        flags.append(int(rig.hist[row, L]) == want)
+    assert flags[0] and flags[2], flags
+    assert not (flags[1] and flags[3]), flags  # near-uniform logits over the top-50: a chance arg-max on both rows is ~4e-4 (and fixed by the Philox seed)
+
+
+def test_graph_capture_and_replay():
+    x = dev(rnd(64, seed=500))
+    out = torch.zeros(64, device=DEV)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        hip.capture_begin()
+        hip.tanh_affine(x, out, 1.0, 2.0, 64)
+        hip.tanh_affine(out, out, 0.0, 1.0, 64)
+        g = hip.capture_end()
+        assert float(out.abs().max()) == 0.0  # capture records, it does not run
+        g.launch()
+        g.launch()
+    s.synchronize()
+    close(out, torch.tanh(1.0 + 2.0 * torch.tanh(x.cpu())), 1e-6, "graph")

@@ -1,0 +1,121 @@
+"""The oracle (oracle/sopro_oracle.py) against outputs of THE REFERENCE ITSELF, stored by
+tests/golden/make_golden.py (which imports /root/reference/src/sopro and HF MimiModel in the build
+container).  This is what pins the oracle; the GPU tests then compare the HIP engine with it."""
+import numpy as np
+import torch
+
+from conftest import golden
+from oracle import sopro_oracle as O
+
+torch.set_num_threads(4)
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_prepare_reference_and_conditioning(cfg, w):
+    g = golden("prep")
+    ref = O.prepare_reference(_t(g["ref_tq"]), w, cfg)
+    assert torch.allclose(ref.sv_ref, _t(g["sv_ref"]), atol=2e-6)
+    assert torch.allclose(ref.ref_seq, _t(g["ref_seq"]), atol=2e-5)
+    assert torch.allclose(ref.ref_kv_caches[0]["k"], _t(g["ref_k0"]), atol=2e-5)
+    assert torch.allclose(ref.ref_kv_caches[2]["v"], _t(g["ref_v2"]), atol=2e-5)
+    prep = O.prepare_conditioning(_t(g["ids"]), ref, w, cfg, max_frames=int(g["max_frames"]), style_strength=float(g["style_strength"]))
+    assert torch.allclose(prep["txt_seq"], _t(g["txt_seq"]), atol=2e-5)
+    assert torch.allclose(prep["txt_pool"], _t(g["txt_pool"]), atol=2e-5)
+    assert torch.allclose(prep["cond_ar"], _t(g["cond_ar"]), atol=5e-5)
+
+
+def test_ar_teacher_forced_logits(cfg, w):
+    g = golden("ar_teacher")
+    x, txt, mask = _t(g["x"]), _t(g["txt"]), _t(g["mask"])
+    st = O.ar_init_state(2, txt, mask, w, cfg)
+    steps = torch.stack([O.ar_step(x[:, t], st, w, cfg) for t in range(x.shape[1])], dim=1)
+    assert float((steps - _t(g["logits"])).abs().max()) < 2e-4
+    par = O.ar_forward_teacher(x, txt, mask, w, cfg)
+    assert float((par - _t(g["logits"])).abs().max()) < 2e-4
+
+
+def _prep(cfg, w):
+    g = golden("prep")
+    ref = O.prepare_reference(_t(g["ref_tq"]), w, cfg)
+    prep = O.prepare_conditioning(_t(g["ids"]), ref, w, cfg, max_frames=int(g["max_frames"]), style_strength=float(g["style_strength"]))
+    return g, ref, prep
+
+
+def test_ar_greedy_tokens(cfg, w):
+    g, _ref, prep = _prep(cfg, w)
+    gg = golden("ar_greedy")
+    lg = []
+    toks = [tk for _t2, tk, _e in O.ar_generate(prep, w, cfg, max_frames=int(g["max_frames"]), top_p=0.0, temperature=1.0,
+                                                 anti_loop=False, collect_logits=lg)]
+    assert toks == gg["tokens"].tolist()
+    assert float((torch.stack(lg[:8]) - _t(gg["logits_first8"])).abs().max()) < 2e-4
+
+
+def test_ar_eos_rule_and_generate_tokens(cfg, w, sopro_np):
+    g, ref, prep = _prep(cfg, w)
+    ge = golden("ar_eos")
+    w2 = dict(w)
+    hb = w["ar.head.bias"].clone()
+    hb[2048] = float(ge["eos_bias"])
+    w2["ar.head.bias"] = hb
+    ev = list(O.ar_generate(prep, w2, cfg, max_frames=int(g["max_frames"]), top_p=0.0, temperature=float(ge["temperature"]),
+                            anti_loop=False, min_gen_frames=int(ge["min_gen_frames"])))
+    assert [tk for _a, tk, _e in ev] == ge["tokens"].tolist()
+    toks = O.generate_tokens(_t(g["ids"]), ref, w2, cfg, max_frames=int(g["max_frames"]), top_p=0.0,
+                             temperature=float(ge["temperature"]), anti_loop=False, style_strength=float(g["style_strength"]),
+                             min_gen_frames=int(ge["min_gen_frames"]))
+    assert torch.equal(toks, _t(ge["gen_tokens"]))
+
+
+def test_nar_refine(cfg, w):
+    g, _ref, prep = _prep(cfg, w)
+    gn = golden("nar")
+    T = int(gn["T"])
+    lgs = {}
+    toks = O.nar_refine(prep["cond_ar"][:, :T], _t(gn["rvq1"]), w, cfg, collect_logits=lgs)
+    assert torch.equal(toks, _t(gn["tokens"]))
+    assert float((lgs[1][:, :8] - _t(gn["logits_cb1"])).abs().max()) < 2e-4
+
+
+def test_mimi_decode(mc, mw):
+    g = golden("mimi")
+    codes8 = _t(g["tok8"]).permute(1, 0).unsqueeze(0).contiguous()
+    taps = {}
+    o8 = O.mimi_decode(codes8, mw, mc, taps=taps)
+    assert torch.allclose(taps["rvq"], _t(g["rvq"]), atol=1e-4)
+    assert torch.allclose(taps["upsample"], _t(g["upsample"]), atol=1e-4)
+    assert torch.allclose(taps["transformer"], _t(g["transformer"]), atol=5e-4)
+    scale = float(_t(g["wav32"]).abs().max())
+    assert float((o8 - _t(g["wav8"])).abs().max()) < 1e-4 * scale
+    o32 = O.decode_full(_t(g["tok32"]), mw, mc)
+    assert float((o32 - _t(g["wav32"])).abs().max()) < 1e-4 * scale
+
+
+def test_end_to_end_synthesize_and_stream(cfg, mc, w, mw):
+    g, ref, _prep_ = _prep(cfg, w)
+    ge = golden("e2e")
+    kw = dict(max_frames=int(ge["max_frames"]), top_p=0.0, temperature=1.0, anti_loop=False, style_strength=float(g["style_strength"]))
+    wav = O.synthesize(_t(g["ids"]), ref, w, mw, cfg, mc, **kw)
+    ref_wav = _t(ge["wav"])
+    scale = float(ref_wav.abs().max())
+    assert wav.shape == ref_wav.shape
+    assert float((wav - ref_wav).abs().max()) < 1e-4 * scale
+    chunks = list(O.stream(_t(g["ids"]), ref, w, mw, cfg, mc, chunk_frames=6, **kw))
+    assert [int(c.shape[1]) for c in chunks] == ge["chunk_sizes"].tolist()
+    assert float((torch.cat(chunks, dim=1) - _t(ge["stream"])).abs().max()) < 1e-4 * scale
+
+
+def test_repeated_tail_and_sampling_distribution():
+    # reference: src/sopro/sampling.py:16-21 and :52-80 (known-answer cases worked by hand)
+    assert O.repeated_tail([1, 2, 3, 1, 2, 3]) is True
+    assert O.repeated_tail([1, 2, 3, 1, 2, 4]) is False
+    assert O.repeated_tail([5, 5, 5, 5]) is False  # n starts at 3 and needs 2n <= L
+    lg = torch.tensor([2.0, 1.0, 0.0, -1.0])
+    sp, si, forced = O.sampling_distribution(lg, [], top_p=0.0, temperature=1.0)
+    assert forced is None and si[0].item() == 0 and float(sp[0]) == 1.0 and float(sp[1:].sum()) == 0.0
+    sp, si, _ = O.sampling_distribution(lg, [0], top_p=1.0, temperature=1.0, repetition_penalty=2.0)
+    p = torch.softmax(torch.tensor([1.0, 1.0, 0.0, -1.0]), 0)
+    assert torch.allclose(sp.sort(descending=True).values, p.sort(descending=True).values, atol=1e-6)
