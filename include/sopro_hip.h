@@ -51,7 +51,8 @@ enum { SOPRO_EPI_NONE = 0, SOPRO_EPI_GELU = 1, SOPRO_EPI_GLU = 2, SOPRO_EPI_RES 
 
 /* C[m, n] = epi( sum_k pro(A[m, k]) * W[n, k] + bias[n] ),  fp32 in / fp32 accumulate on
  * v_mfma_f32_32x32x2_f32 (bit-equal to an fmaf chain).
- * Row m lives at A + (m / rows_per_seg) * a_seg_stride + (m % rows_per_seg) * lda; rows may
+ * Row m lives at A + (m / rows_per_seg) * a_seg_stride + (m % rows_per_seg) * lda (a segment stride
+ * of 0 means dense: rows_per_seg * ld; same for C and R); rows may
  * overlap (lda < K) which turns a causal Conv1d / ConvTranspose1d over channels-last data
  * into this contraction.  K must be a multiple of 4, all base pointers 16-byte aligned and
  * lda / a_seg_stride / ldw multiples of 4.

@@ -198,7 +198,11 @@ int launch_cfg(const sopro_gemm_args& g, hipStream_t s) {
 
 extern "C" int sopro_gemm_f32(const sopro_gemm_args* a, void* stream) {
   SOPRO_CHECK_ARG(a != nullptr, "args is NULL");
-  const sopro_gemm_args& g = *a;
+  sopro_gemm_args g = *a;
+  // a zero segment stride means "dense": segments follow each other without padding rows
+  if (g.a_seg_stride == 0) g.a_seg_stride = (int64_t)g.rows_per_seg * g.lda;
+  if (g.c_seg_stride == 0) g.c_seg_stride = (int64_t)g.rows_per_seg * g.ldc;
+  if (g.r_seg_stride == 0) g.r_seg_stride = (int64_t)g.rows_per_seg * g.ldr;
   SOPRO_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0, "M, N, K must be positive");
   SOPRO_CHECK_ARG((g.K & 3) == 0, "K must be a multiple of 4");
   SOPRO_CHECK_ARG(g.rows_per_seg > 0, "rows_per_seg must be positive");

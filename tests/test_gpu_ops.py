@@ -80,6 +80,12 @@ def test_gemm_causal_conv_and_convtranspose_through_row_windows():
              rows_per_seg=T, a_seg_stride=(k - 1 + T) * ci, c_off=2 * co, c_seg_stride=(2 + T) * co, ldc=co)
     close(out[:, 2:], ref, 5e-5, "causal conv1d")
     assert float(out[:, :2].abs().max()) == 0.0  # padding rows untouched
+    # dense destination / dense residual with a segmented source (seg stride 0 == rows_per_seg * ld)
+    dense = torch.empty(B * T, co, device=DEV)
+    res = rnd(B * T, co, seed=15)
+    hip.gemm(dev(buf), dev(pack.pack_conv1d(w)), dense, M=B * T, N=co, K=k * ci, lda=ci, bias=dev(b), prologue=hip.PRO_ELU,
+             rows_per_seg=T, a_seg_stride=(k - 1 + T) * ci, epilogue=hip.EPI_RES, R=dev(res))
+    close(dense.view(B, T, co), res.view(B, T, co) + ref, 5e-5, "causal conv1d, dense C and R")
     for s in (4, 5, 8):
         wt, bt = rnd(ci, co, 2 * s, seed=13 + s, scale=(2 * ci) ** -0.5), rnd(co, seed=14)
         y = F.conv_transpose1d(x.transpose(1, 2), wt, bt, stride=s)
