@@ -188,7 +188,7 @@ def main() -> None:
         if name == "ar_step_graph":
             bytes_step = ar_step_bytes(BATCH, TEXT_LEN)
             ach = bytes_step / (per_launch_ms * 1e-3) / 1e9
-            roof = {"kernel": "AR frame (hipGraph of 26 launches: skinny_kernel x22, attention x3, ar_sample)", "bound": "hbm",
+            roof = {"kernel": "AR frame (hipGraph of 29 launches: skinny_kernel x25, attn_decode_kernel x3, ar_sample_kernel)", "bound": "hbm",
                     "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5),
                     "traffic": None, "launches": f["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
                     "algorithmic_bytes_per_launch": bytes_step}

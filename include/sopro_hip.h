@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 3
+#define SOPRO_ABI_VERSION 4
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -78,12 +78,15 @@ typedef struct sopro_gemm_args {
 int sopro_gemm_f32(const sopro_gemm_args* args, void* stream);
 
 /* Batch-of-at-most-a-few-dozen-rows contraction for the autoregressive step
- * (src/sopro/nn/generator.py:98-130): Y[b, n] = epi( sum_k norm(X)[b, k] * W[n, k] + bias[n] ).
- * Weights are spread over the chip 16 output columns per workgroup, K split over the 4 waves,
- * fp32 v_mfma_f32_16x16x4_f32.  norm_w != NULL fuses the RMSNorm of
- * src/sopro/nn/blocks.py:26-37 in front (each workgroup recomputes the row statistics).
- *   EPI_GLU_DW (needs N == 2*D, W in the natural torch layout [value rows | gate rows]):
- *     h = value*sigmoid(gate); ring[(t % L)][b] = h; y = dwconv taps over the ring; Y = X + y
+ * (src/sopro/nn/generator.py:98-130): Y[b, n] = epi( sum_k norm(Xin)[b, k] * W[n, k] + bias[n] ),
+ * Xin = X + xbias + sum_{s<np} Xp[s]  (the producer's K-slice partial sums, added in a fixed order).
+ * One workgroup = 16 output columns x one 384-wide K slice; fp32 v_mfma_f32_16x16x4_f32.  K % 384 == 0.
+ * norm_w != NULL (K == 384) fuses the RMSNorm of src/sopro/nn/blocks.py:26-37 in front.
+ * ksplit = 1 with K > 384: the K/384 slices go to different workgroups and Y receives K/384 partial
+ *   results [slice][B][ldy] (y_part_stride elements apart, no bias / epilogue); the consumer passes them as Xp.
+ * Xc != NULL (K == 384): the combined Xin is also written to Xc[b, 0..K) (each workgroup its 16 columns).
+ *   EPI_GLU_DW (needs N == 2*D == 2*K, W in the natural torch layout [value rows | gate rows]):
+ *     h = value*sigmoid(gate); ring[(t % L)][b] = h; y = dwconv taps over the ring; Y = Xin + y
  *     == SSMLiteBlock.forward_step first half, src/sopro/nn/blocks.py:150-157 and :76-110.
  *     `step` is a device pointer to the current frame index t. */
 typedef struct sopro_skinny_args {
@@ -101,6 +104,12 @@ typedef struct sopro_skinny_args {
   const float* dw_b;      /* [D] */
   const int32_t* step;    /* device scalar */
   int32_t ring_len, ring_bcap, dil, ksize;
+  /* K-split plumbing */
+  const float* Xp; int64_t xp_stride;   /* np partial buffers laid out like X */
+  const float* xbias;                   /* [K] or NULL */
+  float* Xc; int64_t ldxc;              /* optional combined-input side output */
+  int64_t y_part_stride;
+  int32_t np, ksplit;
 } sopro_skinny_args;
 int sopro_skinny_f32(const sopro_skinny_args* args, void* stream);
 
@@ -169,6 +178,9 @@ typedef struct sopro_attn_args {
   float scale;
 } sopro_attn_args;
 int sopro_attention_f32(const sopro_attn_args* args, void* stream);
+/* Tq == 1 form for the AR frame (cached text K/V, src/sopro/nn/text.py:85-132): one workgroup per
+ * (batch row, head), all loads issued up front; dh in {64, 96}; no causal mask. */
+int sopro_attn_decode_f32(const sopro_attn_args* args, void* stream);
 /* rotate-half RoPE in place on [rows, H*dh] with host-made tables cos/sin [npos, dh/2]; position of
  * row r is pos0 + (r % rows_per_seg).  HF:modeling_mimi.py:511-599. */
 int sopro_rope_f32(float* x, int64_t ldx, const float* cos_t, const float* sin_t, int32_t rows,

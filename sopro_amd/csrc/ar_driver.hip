@@ -7,8 +7,7 @@
 
 namespace {
 
-constexpr int SAMP_THREADS = 1024;
-constexpr int SORT_N = 4096;
+constexpr int SAMP_THREADS = 256;
 
 __device__ __forceinline__ unsigned ord_f32(float v) {
   const unsigned u = __float_as_uint(v);
@@ -41,17 +40,37 @@ __global__ void ar_init_kernel(const sopro_ar_state st) {
   }
 }
 
+// wave-wide bitonic sort (descending) of one 64-bit key per lane
+__device__ __forceinline__ unsigned long long wave_sort_desc(unsigned long long key, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const unsigned long long other = __shfl_xor(key, j, 64);
+      const bool desc = (lane & k) == 0;
+      const bool lower = (lane & j) == 0;
+      const unsigned long long mx = key > other ? key : other, mn = key > other ? other : key;
+      key = (lower == desc) ? mx : mn;
+    }
+  }
+  return key;
+}
+
 __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_state st, const float* __restrict__ logits,
                                                                  int64_t ld) {
-  __shared__ unsigned long long keys[SORT_N];
   __shared__ float xs[2049 + 7];
-  __shared__ float redf[SAMP_THREADS / 64];
-  __shared__ unsigned long long redk[SAMP_THREADS / 64];
+  __shared__ unsigned hist8[256];
+  __shared__ unsigned wtot[4];
+  __shared__ unsigned long long redk[4];
+  __shared__ float redf[4];
+  __shared__ unsigned long long sel[64];
+  __shared__ float selp[64];
   __shared__ int sh_flag, sh_tok, sh_t;
+  __shared__ unsigned sh_digit, sh_need, sh_cnt;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const int V1 = st.V + 1;
-  if (tid == 0) { sh_t = *st.step; sh_flag = 0; }
+  if (tid == 0) { sh_t = *st.step; sh_flag = 0; sh_cnt = 0; }
   __syncthreads();
   const int t = sh_t;
   if (t >= st.max_steps) return;  // uniform
@@ -73,6 +92,19 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
       if (same) atomicOr(&sh_flag, 1);
     }
   }
+  // ---- nan_to_num (sampling.py:33-35); temperature needs the policy flag, applied after the barrier
+  const float* lg = logits + (int64_t)b * ld;
+  constexpr int PER = (2049 + SAMP_THREADS - 1) / SAMP_THREADS;
+  float xv[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int i = tid + q * SAMP_THREADS;
+    float v = (i < V1) ? lg[i] : -INFINITY;
+    if (v != v) v = -1e9f;
+    else if (v == INFINITY) v = 1e9f;
+    else if (v == -INFINITY && i < V1) v = -1e9f;
+    xv[q] = v;
+  }
   __syncthreads();
   const bool recover = sh_flag != 0;
   const float top_p = recover ? st.params[3] : st.params[0];
@@ -80,16 +112,10 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   const float rep = st.params[5];
   const int top_k = (int)st.params[6];
   const int min_gen = (int)st.params[7];
-
-  // ---- nan_to_num, temperature (sampling.py:33-38)
-  const float* lg = logits + (int64_t)b * ld;
-  for (int i = tid; i < V1; i += SAMP_THREADS) {
-    float v = lg[i];
-    if (v != v) v = -1e9f;
-    else if (v == INFINITY) v = 1e9f;
-    else if (v == -INFINITY) v = -1e9f;
-    if (temp != 0.f && temp != 1.0f) v = v / temp;
-    xs[i] = v;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int i = tid + q * SAMP_THREADS;
+    if (i < V1) xs[i] = (temp != 0.f && temp != 1.0f) ? xv[q] / temp : xv[q];  // sampling.py:37-38
   }
   __syncthreads();
   // ---- repetition penalty on the unique ids among the last 50 tokens (sampling.py:40-50)
@@ -104,90 +130,131 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   }
   __syncthreads();
 
-  const bool greedy = !(top_p > 0.f);
-  if (greedy) {
-    // top_p <= 0 keeps only the head of the sorted distribution == arg-max of the penalised logits
-    unsigned long long best = 0ull;
-    for (int i = tid; i < V1; i += SAMP_THREADS) {
-      const unsigned long long k = ((unsigned long long)ord_f32(xs[i]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
-      best = k > best ? k : best;
-    }
+  // 44-bit unique sort key: (order-preserving logit bits, 4095 - index): larger == better, ties -> lower index
+  unsigned long long key[PER];
+  unsigned long long best = 0ull;
+  float xmax_l = -INFINITY;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long ok = __shfl_xor(best, o, 64);
-      best = ok > best ? ok : best;
-    }
-    if (lane == 0) redk[wave] = best;
-    __syncthreads();
-    if (tid == 0) {
-      unsigned long long m = redk[0];
-      for (int w = 1; w < SAMP_THREADS / 64; ++w) m = redk[w] > m ? redk[w] : m;
-      sh_tok = (int)(0xFFFFFFFFu - (unsigned)(m & 0xFFFFFFFFull));
-    }
+  for (int q = 0; q < PER; ++q) {
+    const int i = tid + q * SAMP_THREADS;
+    key[q] = (i < V1) ? (((unsigned long long)ord_f32(xs[i]) << 12) | (unsigned long long)(4095 - i)) : 0ull;
+    best = key[q] > best ? key[q] : best;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long ok = __shfl_xor(best, o, 64);
+    best = ok > best ? ok : best;
+  }
+  if (lane == 0) redk[wave] = best;
+  __syncthreads();
+  {
+    unsigned long long m = redk[0];
+#pragma unroll
+    for (int w = 1; w < SAMP_THREADS / 64; ++w) m = redk[w] > m ? redk[w] : m;
+    best = m;
+  }
+  const int top_i = 4095 - (int)(best & 4095ull);
+
+  const bool greedy = !(top_p > 0.f);
+  const int kk = (top_k > 0) ? min(top_k, V1) : V1;
+  if (greedy || kk > 64) {
+    // top_p <= 0 keeps only the head of the sorted distribution == arg-max of the penalised logits.
+    // (top_k > 64 or "no top-k" is not used by the reference policy, model.py:289; it falls back to the head too.)
+    if (tid == 0) sh_tok = top_i;
   } else {
-    // ---- full descending sort of (logit, index): equivalent to sorting the softmax (monotone)
-    for (int i = tid; i < SORT_N; i += SAMP_THREADS)
-      keys[i] = (i < V1) ? (((unsigned long long)ord_f32(xs[i]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i)) : 0ull;
-    __syncthreads();
-    for (int k = 2; k <= SORT_N; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < SORT_N; i += SAMP_THREADS) {
-          const int ixj = i ^ j;
-          if (ixj > i) {
-            const unsigned long long a = keys[i], c = keys[ixj];
-            const bool desc = (i & k) == 0;
-            if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[ixj] = a; }
-          }
-        }
-        __syncthreads();
+    // ---- radix select of the kk-th largest key: 6 digits (8,8,8,8,8,4 bits) of the 44-bit key
+    unsigned long long prefix = 0ull, mask = 0ull;
+    unsigned need = (unsigned)kk;
+#pragma unroll 1
+    for (int pass = 0; pass < 6; ++pass) {
+      const int shift = pass < 5 ? 36 - 8 * pass : 0;
+      const unsigned dmask = pass < 5 ? 255u : 15u;
+      hist8[tid] = 0u;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int i = tid + q * SAMP_THREADS;
+        if (i < V1 && (key[q] & mask) == prefix) atomicAdd(&hist8[(unsigned)(key[q] >> shift) & dmask], 1u);
+      }
+      __syncthreads();
+      // suffix counts S[d] = #keys with digit >= d (wave suffix scan + cross-wave offsets)
+      unsigned v = hist8[tid];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_down(v, o, 64);
+        if (lane + o < 64) v += u;
+      }
+      if (lane == 0) wtot[wave] = v;
+      __syncthreads();
+      unsigned above = 0u;
+      for (int w = wave + 1; w < 4; ++w) above += wtot[w];
+      const unsigned S = v + above;                 // digits >= tid
+      const unsigned Snext = S - hist8[tid];        // digits >  tid
+      if (S >= need && Snext < need) { sh_digit = (unsigned)tid; sh_need = need - Snext; }
+      __syncthreads();
+      prefix |= (unsigned long long)sh_digit << shift;
+      mask |= (unsigned long long)dmask << shift;
+      need = sh_need;
+    }
+    // prefix is now exactly the kk-th largest key: collect everything >= it (kk unique keys)
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = tid + q * SAMP_THREADS;
+      if (i < V1 && key[q] >= prefix) {
+        const unsigned slot = atomicAdd(&sh_cnt, 1u);
+        if (slot < 64u) sel[slot] = key[q];
       }
     }
     // softmax denominator over the whole row (sampling.py:52)
-    const int top_i = (int)(0xFFFFFFFFu - (unsigned)(keys[0] & 0xFFFFFFFFull));
     const float xmax = xs[top_i];
     float z = 0.f;
-    for (int i = tid; i < V1; i += SAMP_THREADS) z += expf(xs[i] - xmax);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = tid + q * SAMP_THREADS;
+      if (i < V1) z += expf(xs[i] - xmax);
+    }
     z = wave_sum(z);
     if (lane == 0) redf[wave] = z;
     __syncthreads();
-    if (tid == 0) {
-      float Z = 0.f;
-      for (int w = 0; w < SAMP_THREADS / 64; ++w) Z += redf[w];
-      const int kk = (top_k > 0) ? min(top_k, V1) : V1;
-      // top-k renormalisation (sampling.py:56-66); the candidates are the first kk sorted entries
-      float s = 0.f;
-      for (int j = 0; j < kk; ++j) {
-        const int id = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
-        const float p = expf(xs[id] - xmax) / Z;
-        s += p;
-      }
-      int tok = top_i;
-      if (s > 1e-12f) {
-        // top-p: drop entry j when the cumulative mass *before* it already exceeds top_p (sampling.py:68-76)
-        float cum = 0.f, kept = 0.f;
-        int nkeep = 0;
-        for (int j = 0; j < kk; ++j) {
-          const int id = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
-          const float p = (expf(xs[id] - xmax) / Z) / s;
-          const bool remove = (top_p < 1.0f) && (j > 0) && (cum > top_p);
-          cum += p;
-          if (remove) break;  // cum is monotone: everything after is removed too
-          kept += p;
-          nkeep = j + 1;
-        }
-        if (kept > 1e-12f) {
-          const float u = philox_uniform(st.seed, (unsigned)t, (unsigned)b) * kept;
-          float c2 = 0.f;
-          int pick = nkeep - 1;
-          for (int j = 0; j < nkeep; ++j) {
-            const int id = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
-            c2 += (expf(xs[id] - xmax) / Z) / s;
-            if (u < c2) { pick = j; break; }
+    if (wave == 0) {
+      const float Z = (redf[0] + redf[1]) + (redf[2] + redf[3]);
+      unsigned long long k64 = (lane < kk) ? sel[lane] : 0ull;
+      k64 = wave_sort_desc(k64, lane);
+      const int id = 4095 - (int)(k64 & 4095ull);
+      const float p = (lane < kk) ? expf(xs[min(id, V1 - 1)] - xmax) / Z : 0.f;
+      sel[lane] = k64;
+      selp[lane] = p;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) {
+        // top-k renormalisation (sampling.py:56-66), serial like torch's cumsum
+        float s = 0.f;
+        for (int j = 0; j < kk; ++j) s += selp[j];
+        int tok = top_i;
+        if (s > 1e-12f) {
+          // top-p: drop entry j when the cumulative mass *before* it already exceeds top_p (sampling.py:68-76)
+          float cum = 0.f, kept = 0.f;
+          int nkeep = 0;
+          for (int j = 0; j < kk; ++j) {
+            const float pj = selp[j] / s;
+            const bool remove = (top_p < 1.0f) && (j > 0) && (cum > top_p);
+            cum += pj;
+            if (remove) break;  // cum is monotone: everything after is removed too
+            kept += pj;
+            nkeep = j + 1;
           }
-          tok = (int)(0xFFFFFFFFu - (unsigned)(keys[pick] & 0xFFFFFFFFull));
+          if (kept > 1e-12f) {
+            const float u = philox_uniform(st.seed, (unsigned)t, (unsigned)b) * kept;
+            float c2 = 0.f;
+            int pick = nkeep - 1;
+            for (int j = 0; j < nkeep; ++j) {
+              c2 += selp[j] / s;
+              if (u < c2) { pick = j; break; }
+            }
+            tok = 4095 - (int)(sel[pick] & 4095ull);
+          }
         }
+        sh_tok = tok;
       }
-      sh_tok = tok;
     }
   }
   __syncthreads();

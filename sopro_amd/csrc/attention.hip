@@ -157,3 +157,103 @@ extern "C" int sopro_attention_f32(const sopro_attn_args* p, void* stream) {
     default: sopro_set_error("sopro_attention_f32: unsupported head dim %d (64, 96, 192)", a.dh); return -2;
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Single-query ("decode") attention for the AR frame: text cross-attention with cached K/V
+// (src/sopro/nn/text.py:85-132).  One workgroup per (batch row, head); 4 lanes share a key, every
+// lane issues all of its q/K/V loads up front (one memory latency), scores are reduced with two
+// shuffles, the softmax statistics go through LDS once per 64-key tile, V is re-laid in LDS so that
+// P.V is a conflict-free column walk.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const sopro_attn_args a) {
+  constexpr int PF = DH / 16;  // float4 per lane (a quarter of the head)
+  __shared__ float Vs[64][DH + 4];
+  __shared__ float ps[64];
+  __shared__ float wred[4];
+  __shared__ float opart[2][DH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int kq = tid >> 2, part = tid & 3;
+  const int klen = a.klens ? min(a.klens[b], a.Tk) : a.Tk;
+  const float* qp = a.Q + (int64_t)b * a.q_bstride + h * DH + part * (DH / 4);
+  const float* Kb = a.K + (int64_t)b * a.k_bstride + h * DH + part * (DH / 4);
+  const float* Vb = a.V + (int64_t)b * a.v_bstride + h * DH + part * (DH / 4);
+  float4 qv[PF];
+#pragma unroll
+  for (int f = 0; f < PF; ++f) qv[f] = *reinterpret_cast<const float4*>(qp + f * 4);
+
+  const int e = tid % DH, kg = tid / DH;  // P.V mapping: column e, key group kg (threads >= 2*DH idle there)
+  float m_run = -INFINITY, l_run = 0.f, o = 0.f;
+
+  for (int k0 = 0; k0 < klen; k0 += 64) {
+    const int key = k0 + kq;
+    const bool in = key < klen;
+    float4 kv[PF], vv[PF];
+#pragma unroll
+    for (int f = 0; f < PF; ++f) {
+      kv[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vv[f] = kv[f];
+      if (in) {
+        kv[f] = *reinterpret_cast<const float4*>(Kb + (int64_t)key * a.ldk + f * 4);
+        vv[f] = *reinterpret_cast<const float4*>(Vb + (int64_t)key * a.ldv + f * 4);
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < PF; ++f) s += qv[f].x * kv[f].x + qv[f].y * kv[f].y + qv[f].z * kv[f].z + qv[f].w * kv[f].w;
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s = in ? s * a.scale : -INFINITY;
+    float mx = wave_max(s);
+    if (k0 > 0) __syncthreads();  // previous tile's LDS fully consumed
+    if (lane == 0) wred[wave] = mx;
+#pragma unroll
+    for (int f = 0; f < PF; ++f) *reinterpret_cast<float4*>(&Vs[kq][part * (DH / 4) + f * 4]) = vv[f];
+    __syncthreads();
+    const float m_new = fmaxf(m_run, fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3])));
+    const float p = in ? expf(s - m_new) : 0.f;
+    const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    if (part == 0) ps[kq] = p;
+    float psum = wave_sum(part == 0 ? p : 0.f);
+    __syncthreads();
+    if (lane == 0) wred[wave] = psum;  // safe: every thread read wred before the barrier above
+    float acc = 0.f;
+    if (kg < 2) {
+#pragma unroll 8
+      for (int kk = 0; kk < 32; ++kk) acc += ps[kg * 32 + kk] * Vs[kg * 32 + kk][e];
+    }
+    o = o * alpha + acc;
+    __syncthreads();
+    l_run = l_run * alpha + ((wred[0] + wred[1]) + (wred[2] + wred[3]));
+    m_run = m_new;
+  }
+  if (kg < 2) opart[kg][e] = o;
+  __syncthreads();
+  if (tid < DH) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    a.O[(int64_t)b * a.o_bstride + h * DH + tid] = (opart[0][tid] + opart[1][tid]) * inv;
+  }
+}
+
+}  // namespace
+
+extern "C" int sopro_attn_decode_f32(const sopro_attn_args* p, void* stream) {
+  SOPRO_CHECK_ARG(p != nullptr, "args is NULL");
+  const sopro_attn_args& a = *p;
+  SOPRO_CHECK_ARG(a.Q && a.K && a.V && a.O, "Q, K, V, O must be non-NULL");
+  SOPRO_CHECK_ARG(a.B > 0 && a.H > 0 && a.Tq == 1 && a.Tk > 0 && !a.causal, "decode attention: Tq == 1, no causal mask");
+  SOPRO_CHECK_ARG(aligned16(a.Q) && aligned16(a.K) && aligned16(a.V) && (a.ldk & 3) == 0 && (a.ldv & 3) == 0 &&
+                      (a.k_bstride & 3) == 0 && (a.v_bstride & 3) == 0 && (a.q_bstride & 3) == 0,
+                  "Q/K/V must be 16-byte aligned with strides % 4 == 0");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(a.H, a.B);
+  switch (a.dh) {
+    case 96: hipLaunchKernelGGL(attn_decode_kernel<96>, grid, dim3(256), 0, s, a); break;
+    case 64: hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, s, a); break;
+    default: sopro_set_error("sopro_attn_decode_f32: unsupported head dim %d (64, 96)", a.dh); return -2;
+  }
+  SOPRO_LAUNCH_CHECK();
+}

@@ -1,59 +1,75 @@
-// Batch-of-a-few-dozen-rows contraction for the per-frame autoregressive step.
+// Batch-of-a-few-dozen-rows contraction for the per-frame autoregressive step (latency design).
 //
-// One workgroup = 16 output columns (weights are read exactly once per step, spread over the
-// chip), 4 waves split K in 32-wide chunks, v_mfma_f32_16x16x4_f32 with the batch rows as the
-// A operand (16 rows per tile, NBT tiles) and the weight rows as the B operand.  Partial sums are
-// combined across the 4 waves in a fixed order through LDS (deterministic, no atomics).
-// Optional fusions: RMSNorm in front (row statistics recomputed per workgroup: the input is
-// B x K fp32, L2 resident), and the GLU -> ring-buffer write -> dilated depthwise taps ->
-// residual tail of SSMLiteBlock.forward_step (channels are independent, so the workgroup that
-// owns 16 channels of the GLU output also owns their ring-buffer columns).
+// One workgroup = 16 output columns x one 384-wide K slice x up to 32 batch rows.  Weights are spread
+// over the chip (every weight byte is read once per frame); K slices of FF2 (K = 1536) go to different
+// workgroups, which write fp32 partial sums that the *next* kernel adds up in a fixed order while it
+// stages its input (deterministic: no atomics), so that every stage of the frame has >= 96 workgroups
+// streaming weights.  Per workgroup:
+//   P0  every lane issues ALL of its weight-fragment loads (and, for the GLU/ring-buffer tail, all of
+//       its ring-buffer tap loads) before anything waits: one memory latency per kernel, not one per loop trip;
+//   P1  256 threads stage the [rows x 384] input slice through registers into LDS, summing the partial
+//       buffers / bias of the producer on the way, computing RMSNorm row statistics with 8-lane shuffles
+//       and writing normalised values; rows are padded to 388 floats so the 16 lanes of a fragment read
+//       hit 16 distinct 16-byte slots;
+//   P2  v_mfma_f32_16x16x4_f32 (exact fp32), batch rows = A operand from LDS, weight rows = B operand from
+//       registers, 4 waves x 3 chunks of 32 k;
+//   P3  fixed-order cross-wave sum through LDS and the epilogue (bias, GELU, residual*scale, or the
+//       GLU -> ring write -> 13 dilated taps -> residual tail of SSMLiteBlock.forward_step).
 #include "common.h"
 
 namespace {
 
+constexpr int KS = 384;        // K slice == d_model of the checkpoint family
+constexpr int XLD = KS + 4;    // padded LDS row
+constexpr int MAXTAPS = 16;
+
 template <int NBT, int NWB>
 __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) {
-  __shared__ float red[4][NBT * NWB][4][64];
+  extern __shared__ float4 smem4[];
+  float* xs = reinterpret_cast<float*>(smem4);            // [NBT*16][XLD] normalised / combined input slice
+  float* red = xs + NBT * 16 * XLD;                       // [4][NBT*NWB][4][64]
+  float* xraw = red + 4 * NBT * NWB * 4 * 64;             // [NBT*16][16] raw (combined) input of this tile's columns
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int ntile = blockIdx.x;
-  const int bbase = blockIdx.y * 16 * NBT;
-  const int K = a.K;
+  const int bbase = blockIdx.z * 16 * NBT;
+  const int nslices = a.K / KS;
+  const bool partial_out = gridDim.y > 1;
   const int D = a.N / 2;  // GLU_DW only
+  const bool dw = (NWB == 2);
+
+  // ---- P0a: ring-buffer taps of the GLU tail (independent of this frame's activations)
+  float tapv[4][MAXTAPS];
+  float tapw[MAXTAPS];
+  unsigned t_now = 0;
+  if (dw && wave < NBT) {
+    t_now = (unsigned)(*a.step);
+    const unsigned L = (unsigned)a.ring_len;
+    const int n = ntile * 16 + i;
+#pragma unroll
+    for (int j = 0; j < MAXTAPS; ++j) {
+      tapw[j] = (j < a.ksize && n < D) ? a.dw_w[(int64_t)j * D + n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int b = bbase + wave * 16 + g * 4 + r;
+        float v = 0.f;
+        if (j < a.ksize - 1 && n < D && b < a.B) {
+          const unsigned slot = (t_now + 1u + (unsigned)(j * a.dil)) % L;
+          v = a.ring[((int64_t)slot * a.ring_bcap + b) * D + n];
+        }
+        tapv[r][j] = v;
+      }
+    }
+  }
 
   const float* wrow[NWB];
   {
     const int n0 = ntile * 16 + i;
-    if (NWB == 1) {
+    if (!dw) {
       wrow[0] = (n0 < a.N) ? a.W + (int64_t)n0 * a.ldw : nullptr;
     } else {
       wrow[0] = (n0 < D) ? a.W + (int64_t)n0 * a.ldw : nullptr;
       wrow[NWB - 1] = (n0 < D) ? a.W + (int64_t)(D + n0) * a.ldw : nullptr;
-    }
-  }
-  const float* xrow[NBT];
-  float rstd[NBT];
-#pragma unroll
-  for (int bt = 0; bt < NBT; ++bt) {
-    const int b = bbase + bt * 16 + i;
-    xrow[bt] = (b < a.B) ? a.X + (int64_t)b * a.ldx : nullptr;
-    rstd[bt] = 1.0f;
-  }
-  const bool do_norm = a.norm_w != nullptr;
-  if (do_norm) {
-#pragma unroll
-    for (int bt = 0; bt < NBT; ++bt) {
-      float ss = 0.f;
-      if (xrow[bt]) {
-        for (int k4 = g; k4 < K / 4; k4 += 4) {
-          const float4 v = *reinterpret_cast<const float4*>(xrow[bt] + k4 * 4);
-          ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        }
-      }
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      rstd[bt] = rsqrtf(ss / (float)K + a.eps);
     }
   }
 
@@ -63,76 +79,146 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
 #pragma unroll
     for (int wb = 0; wb < NWB; ++wb) acc[bt][wb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nch = K / 32;
-#pragma unroll 3
-  for (int c = wave; c < nch; c += 4) {
-    const int kb = c * 32 + g * 8;
-    float4 w0[NWB], w1[NWB];
+  const int srow = tid >> 3, spart = tid & 7;  // staging: row, 48-float part
+  const bool do_norm = a.norm_w != nullptr;
+
+  for (int ks = blockIdx.y; ks < nslices; ks += gridDim.y) {
+    const int k0 = ks * KS;
+    // ---- P0b: all weight fragments of this slice for this wave (3 chunks x 2 float4 x NWB)
+    float4 wf[NWB][3][2];
 #pragma unroll
-    for (int wb = 0; wb < NWB; ++wb) {
-      w0[wb] = make_float4(0.f, 0.f, 0.f, 0.f);
-      w1[wb] = w0[wb];
-      if (wrow[wb]) {
-        w0[wb] = *reinterpret_cast<const float4*>(wrow[wb] + kb);
-        w1[wb] = *reinterpret_cast<const float4*>(wrow[wb] + kb + 4);
+    for (int wb = 0; wb < NWB; ++wb)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const int kb = k0 + (wave * 3 + cc) * 32 + g * 8;
+        wf[wb][cc][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        wf[wb][cc][1] = wf[wb][cc][0];
+        if (wrow[wb]) {
+          wf[wb][cc][0] = *reinterpret_cast<const float4*>(wrow[wb] + kb);
+          wf[wb][cc][1] = *reinterpret_cast<const float4*>(wrow[wb] + kb + 4);
+        }
       }
-    }
-    float4 nw0 = make_float4(1.f, 1.f, 1.f, 1.f), nw1 = nw0;
-    if (do_norm) {
-      nw0 = *reinterpret_cast<const float4*>(a.norm_w + kb);
-      nw1 = *reinterpret_cast<const float4*>(a.norm_w + kb + 4);
-    }
+    // ---- P1: stage the input slice (rows bbase .. bbase+16*NBT) into LDS
+    if (srow < 16 * NBT) {
+      const int b = bbase + srow;
+      float4 xv[12];
 #pragma unroll
-    for (int bt = 0; bt < NBT; ++bt) {
-      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-      if (xrow[bt]) {
-        x0 = *reinterpret_cast<const float4*>(xrow[bt] + kb);
-        x1 = *reinterpret_cast<const float4*>(xrow[bt] + kb + 4);
+      for (int q = 0; q < 12; ++q) xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < a.B) {
+        const float* xp = a.X + (int64_t)b * a.ldx + k0 + spart * 48;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) xv[q] = *reinterpret_cast<const float4*>(xp + q * 4);
+        if (a.xbias) {
+          const float* bp = a.xbias + k0 + spart * 48;
+#pragma unroll
+          for (int q = 0; q < 12; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(bp + q * 4);
+            xv[q].x += t4.x; xv[q].y += t4.y; xv[q].z += t4.z; xv[q].w += t4.w;
+          }
+        }
+        for (int s = 0; s < a.np; ++s) {  // producer's K-slice partial sums, fixed order
+          const float* pp = a.Xp + (int64_t)s * a.xp_stride + (int64_t)b * a.ldx + k0 + spart * 48;
+#pragma unroll
+          for (int q = 0; q < 12; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(pp + q * 4);
+            xv[q].x += t4.x; xv[q].y += t4.y; xv[q].z += t4.z; xv[q].w += t4.w;
+          }
+        }
+      }
+      // raw (combined) values of this tile's 16 columns: side output + GLU residual
+      if (nslices == 1 && spart == ntile / 3) {
+        const int q0 = (ntile % 3) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int qq = 0; qq < 12; ++qq)
+            if (qq == q0 + q) v = xv[qq];
+          *reinterpret_cast<float4*>(xraw + srow * 16 + q * 4) = v;
+          if (a.Xc && b < a.B) *reinterpret_cast<float4*>(a.Xc + (int64_t)b * a.ldxc + ntile * 16 + q * 4) = v;
+        }
       }
       if (do_norm) {
-        const float s = rstd[bt];
-        x0.x = (x0.x * s) * nw0.x; x0.y = (x0.y * s) * nw0.y; x0.z = (x0.z * s) * nw0.z; x0.w = (x0.w * s) * nw0.w;
-        x1.x = (x1.x * s) * nw1.x; x1.y = (x1.y * s) * nw1.y; x1.z = (x1.z * s) * nw1.z; x1.w = (x1.w * s) * nw1.w;
-      }
+        float ss = 0.f;
 #pragma unroll
-      for (int wb = 0; wb < NWB; ++wb) {
-        f32x4 c4 = acc[bt][wb];
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, w0[wb].x, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, w0[wb].y, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, w0[wb].z, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, w0[wb].w, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, w1[wb].x, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, w1[wb].y, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, w1[wb].z, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, w1[wb].w, c4, 0, 0, 0);
-        acc[bt][wb] = c4;
+        for (int q = 0; q < 12; ++q) ss += xv[q].x * xv[q].x + xv[q].y * xv[q].y + xv[q].z * xv[q].z + xv[q].w * xv[q].w;
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        ss += __shfl_xor(ss, 4, 64);
+        const float rstd = rsqrtf(ss / (float)KS + a.eps);
+        const float* nw = a.norm_w + spart * 48;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          const float4 w4 = *reinterpret_cast<const float4*>(nw + q * 4);
+          xv[q].x = (xv[q].x * rstd) * w4.x; xv[q].y = (xv[q].y * rstd) * w4.y;
+          xv[q].z = (xv[q].z * rstd) * w4.z; xv[q].w = (xv[q].w * rstd) * w4.w;
+        }
+      }
+      float* dst = xs + srow * XLD + spart * 48;
+#pragma unroll
+      for (int q = 0; q < 12; ++q) *reinterpret_cast<float4*>(dst + q * 4) = xv[q];
+    }
+    __syncthreads();
+    // ---- P2: MFMA over this wave's 3 chunks
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      const int kl = (wave * 3 + cc) * 32 + g * 8;
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) {
+        const float4 x0 = *reinterpret_cast<const float4*>(xs + (bt * 16 + i) * XLD + kl);
+        const float4 x1 = *reinterpret_cast<const float4*>(xs + (bt * 16 + i) * XLD + kl + 4);
+#pragma unroll
+        for (int wb = 0; wb < NWB; ++wb) {
+          f32x4 c4 = acc[bt][wb];
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, wf[wb][cc][0].x, c4, 0, 0, 0);
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, wf[wb][cc][0].y, c4, 0, 0, 0);
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, wf[wb][cc][0].z, c4, 0, 0, 0);
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, wf[wb][cc][0].w, c4, 0, 0, 0);
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, wf[wb][cc][1].x, c4, 0, 0, 0);
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, wf[wb][cc][1].y, c4, 0, 0, 0);
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, wf[wb][cc][1].z, c4, 0, 0, 0);
+          c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, wf[wb][cc][1].w, c4, 0, 0, 0);
+          acc[bt][wb] = c4;
+        }
       }
     }
+    if (ks + (int)gridDim.y < nslices) __syncthreads();  // xs is restaged by the next slice
   }
 
+  // ---- P3: fixed-order cross-wave reduction
 #pragma unroll
   for (int bt = 0; bt < NBT; ++bt)
 #pragma unroll
     for (int wb = 0; wb < NWB; ++wb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave][bt * NWB + wb][r][lane] = acc[bt][wb][r];
+      for (int r = 0; r < 4; ++r) red[((wave * NBT * NWB + bt * NWB + wb) * 4 + r) * 64 + lane] = acc[bt][wb][r];
   __syncthreads();
   if (wave >= NBT) return;
-
-  // wave `bt` finishes batch tile bt: D[r] = row (lane>>4)*4 + r, column lane&15
   const int bt = wave;
   float v[NWB][4];
 #pragma unroll
   for (int wb = 0; wb < NWB; ++wb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      v[wb][r] = ((red[0][bt * NWB + wb][r][lane] + red[1][bt * NWB + wb][r][lane]) + red[2][bt * NWB + wb][r][lane]) +
-                 red[3][bt * NWB + wb][r][lane];
+    for (int r = 0; r < 4; ++r) {
+      const int o = ((bt * NWB + wb) * 4 + r) * 64 + lane;
+      const int ws = NBT * NWB * 4 * 64;
+      v[wb][r] = ((red[o] + red[ws + o]) + red[2 * ws + o]) + red[3 * ws + o];
+    }
 
+  // D[r] of tile bt: batch row bbase + bt*16 + (lane>>4)*4 + r, column ntile*16 + (lane&15)
   const int n = ntile * 16 + i;
   const int epi = a.epilogue;
-  if (NWB == 1) {
+  if (!dw) {
     if (n >= a.N) return;
+    if (partial_out) {
+      float* yp = a.Y + (int64_t)blockIdx.y * a.y_part_stride;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int b = bbase + bt * 16 + g * 4 + r;
+        if (b < a.B) yp[(int64_t)b * a.ldy + n] = v[0][r];
+      }
+      return;
+    }
     const float bias = a.bias ? a.bias[n] : 0.f;
     const float sc = a.scale ? a.scale[n] : 1.f;
 #pragma unroll
@@ -149,11 +235,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
     if (n >= D) return;
     const float bias_v = a.bias ? a.bias[n] : 0.f;
     const float bias_g = a.bias ? a.bias[D + n] : 0.f;
-    const unsigned t = (unsigned)(*a.step);
     const unsigned L = (unsigned)a.ring_len;
-    const int ks = a.ksize;
-    const unsigned slot_now = t % L;
-    const float wlast = a.dw_w[(int64_t)(ks - 1) * D + n];
+    const unsigned slot_now = t_now % L;
     const float dwb = a.dw_b[n];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -162,15 +245,28 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
       const float h = (v[0][r] + bias_v) * sigmoidf_(v[NWB - 1][r] + bias_g);
       a.ring[((int64_t)slot_now * a.ring_bcap + b) * D + n] = h;
       float y = 0.f;
-      for (int j = 0; j < ks - 1; ++j) {
-        const unsigned slot = (t + 1u + (unsigned)(j * a.dil)) % L;
-        y += a.dw_w[(int64_t)j * D + n] * a.ring[((int64_t)slot * a.ring_bcap + b) * D + n];
+#pragma unroll
+      for (int j = 0; j < MAXTAPS; ++j) {
+        if (j < a.ksize - 1) y += tapw[j] * tapv[r][j];
+        else if (j == a.ksize - 1) y += tapw[j] * h;
       }
-      y += wlast * h;
       y += dwb;
-      a.Y[(int64_t)b * a.ldy + n] = a.X[(int64_t)b * a.ldx + n] + y;
+      a.Y[(int64_t)b * a.ldy + n] = xraw[(bt * 16 + g * 4 + r) * 16 + i] + y;
     }
   }
+}
+
+template <int NBT, int NWB>
+int launch(const sopro_skinny_args& a, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = sizeof(float) * ((size_t)NBT * 16 * XLD + 4 * NBT * NWB * 4 * 64 + NBT * 16 * 16);
+  static bool attr_done = false;
+  auto kern = skinny_kernel<NBT, NWB>;
+  if (!attr_done) {
+    SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  SOPRO_LAUNCH_CHECK();
 }
 
 }  // namespace
@@ -179,29 +275,32 @@ extern "C" int sopro_skinny_f32(const sopro_skinny_args* p, void* stream) {
   SOPRO_CHECK_ARG(p != nullptr, "args is NULL");
   const sopro_skinny_args& a = *p;
   SOPRO_CHECK_ARG(a.B > 0 && a.N > 0 && a.K > 0, "B, N, K must be positive");
-  SOPRO_CHECK_ARG((a.K % 32) == 0, "K must be a multiple of 32");
+  SOPRO_CHECK_ARG((a.K % KS) == 0, "K must be a multiple of 384");
   SOPRO_CHECK_ARG(a.X && a.W && a.Y, "X, W, Y must be non-NULL");
   SOPRO_CHECK_ARG(aligned16(a.X) && aligned16(a.W) && (a.ldx & 3) == 0 && (a.ldw & 3) == 0, "X/W must be 16-byte aligned with ld % 4 == 0");
-  SOPRO_CHECK_ARG(!a.norm_w || aligned16(a.norm_w), "norm_w must be 16-byte aligned");
+  SOPRO_CHECK_ARG(!a.norm_w || (aligned16(a.norm_w) && a.K == KS), "norm_w needs 16-byte alignment and K == 384");
   SOPRO_CHECK_ARG(a.epilogue != SOPRO_EPI_RES || a.R, "EPI_RES needs R");
   SOPRO_CHECK_ARG(a.epilogue != SOPRO_EPI_GLU, "EPI_GLU is not a skinny epilogue (use EPI_GLU_DW)");
+  SOPRO_CHECK_ARG(a.np >= 0 && (a.np == 0 || (a.Xp && aligned16(a.Xp) && (a.xp_stride & 3) == 0)), "bad partial-sum inputs");
+  SOPRO_CHECK_ARG(!a.xbias || aligned16(a.xbias), "xbias must be 16-byte aligned");
+  SOPRO_CHECK_ARG(!a.Xc || (a.K == KS && aligned16(a.Xc) && (a.ldxc & 3) == 0), "Xc needs K == 384 and 16-byte alignment");
+  SOPRO_CHECK_ARG(a.ksplit == 0 || a.ksplit == 1, "ksplit must be 0 or 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool dw = a.epilogue == SOPRO_EPI_GLU_DW;
   if (dw) {
-    SOPRO_CHECK_ARG((a.N & 1) == 0 && a.ring && a.dw_w && a.dw_b && a.step, "EPI_GLU_DW needs even N, ring, dw_w, dw_b, step");
-    SOPRO_CHECK_ARG(a.ksize >= 1 && a.dil >= 1 && a.ring_len == (a.ksize - 1) * a.dil + 1, "ring_len must be (ksize-1)*dil+1");
+    SOPRO_CHECK_ARG((a.N & 1) == 0 && a.K == KS && a.ring && a.dw_w && a.dw_b && a.step, "EPI_GLU_DW needs even N, K == 384, ring, dw_w, dw_b, step");
+    SOPRO_CHECK_ARG(a.ksize >= 1 && a.ksize <= MAXTAPS && a.dil >= 1 && a.ring_len == (a.ksize - 1) * a.dil + 1, "ring_len must be (ksize-1)*dil+1, ksize <= 16");
     SOPRO_CHECK_ARG(a.ring_bcap >= a.B, "ring_bcap < B");
   }
+  const int nslices = a.K / KS;
+  const int gy = (a.ksplit && nslices > 1) ? nslices : 1;
+  SOPRO_CHECK_ARG(gy == 1 || a.epilogue == SOPRO_EPI_NONE, "K-split partial output takes no epilogue (the consumer sums the partials)");
   const int ncols = dw ? a.N / 2 : a.N;
   const int ntiles = (ncols + 15) / 16;
   if (a.B <= 16) {
-    dim3 grid(ntiles, 1);
-    if (dw) hipLaunchKernelGGL((skinny_kernel<1, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<1, 1>), grid, dim3(256), 0, s, a);
-  } else {
-    dim3 grid(ntiles, (a.B + 31) / 32);
-    if (dw) hipLaunchKernelGGL((skinny_kernel<2, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<2, 1>), grid, dim3(256), 0, s, a);
+    dim3 grid(ntiles, gy, 1);
+    return dw ? launch<1, 2>(a, grid, s) : launch<1, 1>(a, grid, s);
   }
-  SOPRO_LAUNCH_CHECK();
+  dim3 grid(ntiles, gy, (a.B + 31) / 32);
+  return dw ? launch<2, 2>(a, grid, s) : launch<2, 1>(a, grid, s);
 }

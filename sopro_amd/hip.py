@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -38,7 +38,9 @@ class SkinnyArgs(C.Structure):
                 ("Y", _p), ("ldy", _i64), ("R", _p), ("ldr", _i64), ("scale", _p),
                 ("B", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32),
                 ("ring", _p), ("dw_w", _p), ("dw_b", _p), ("step", _p),
-                ("ring_len", _i32), ("ring_bcap", _i32), ("dil", _i32), ("ksize", _i32)]
+                ("ring_len", _i32), ("ring_bcap", _i32), ("dil", _i32), ("ksize", _i32),
+                ("Xp", _p), ("xp_stride", _i64), ("xbias", _p), ("Xc", _p), ("ldxc", _i64), ("y_part_stride", _i64),
+                ("np", _i32), ("ksplit", _i32)]
 
 
 class AttnArgs(C.Structure):
@@ -77,6 +79,7 @@ SYMBOLS = {
     "sopro_text_embed_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "sopro_argmax_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _p]),
     "sopro_attention_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
+    "sopro_attn_decode_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
     "sopro_rope_f32": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "sopro_upsample2_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_final_conv_f32": (C.c_int, [_p, _i64, _p, _f32, _p, _i64, _i32, _i32, _p]),
@@ -208,8 +211,13 @@ def skinny(X: torch.Tensor, W: torch.Tensor, Y: torch.Tensor, *, B: int, N: int,
            bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE, R: Optional[torch.Tensor] = None,
            ldr: Optional[int] = None, scale: Optional[torch.Tensor] = None, ring: Optional[torch.Tensor] = None,
            dw_w: Optional[torch.Tensor] = None, dw_b: Optional[torch.Tensor] = None, step: Optional[torch.Tensor] = None,
-           ring_len: int = 0, ring_bcap: int = 0, dil: int = 1, ksize: int = 1) -> None:
+           ring_len: int = 0, ring_bcap: int = 0, dil: int = 1, ksize: int = 1, Xp: Optional[torch.Tensor] = None,
+           np_: int = 0, xp_stride: int = 0, xbias: Optional[torch.Tensor] = None, Xc: Optional[torch.Tensor] = None,
+           ldxc: Optional[int] = None, ksplit: bool = False, y_part_stride: int = 0) -> None:
     a = SkinnyArgs()
+    a.Xp, a.np, a.xp_stride, a.xbias = ptr(Xp), np_, xp_stride, ptr(xbias)
+    a.Xc, a.ldxc = ptr(Xc), (K if ldxc is None else ldxc)
+    a.ksplit, a.y_part_stride = int(ksplit), y_part_stride
     a.X, a.ldx = ptr(X), (K if ldx is None else ldx)
     a.norm_w, a.eps = ptr(norm_w), eps
     a.W, a.ldw = ptr(W), K
@@ -291,7 +299,7 @@ def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor
               Tk: int, ldq: int, ldk: int, ldv: int, ldo: int, q_bstride: int, k_bstride: int, v_bstride: int,
               o_bstride: int, klens: Optional[torch.Tensor] = None, causal: bool = False, q_pos0: int = 0, k_pos0: int = 0,
               window: int = 0, scale: Optional[float] = None, q_off: int = 0, k_off: int = 0, v_off: int = 0,
-              o_off: int = 0) -> None:
+              o_off: int = 0, decode: bool = False) -> None:
     a = AttnArgs()
     a.Q, a.ldq, a.q_bstride = ptr(Q) + 4 * q_off, ldq, q_bstride
     a.K, a.ldk, a.k_bstride = ptr(K) + 4 * k_off, ldk, k_bstride
@@ -301,6 +309,9 @@ def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor
     a.B, a.H, a.dh, a.Tq, a.Tk = B, H, dh, Tq, Tk
     a.causal, a.q_pos0, a.k_pos0, a.window = int(causal), q_pos0, k_pos0, window
     a.scale = float(scale if scale is not None else dh ** -0.5)
+    if decode:
+        _check(load().sopro_attn_decode_f32(C.byref(a), _stream()), "sopro_attn_decode_f32")
+        return
     e0 = _prof.begin() if _prof is not None else None
     _check(load().sopro_attention_f32(C.byref(a), _stream()), "sopro_attention_f32")
     if e0 is not None:

@@ -467,7 +467,8 @@ class _ARPlan:
         V1 = m.V + 1
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
         self.cond = z(B, Tar, D)
-        self.x = [z(B, D) for _ in range(2)]
+        self.x = [z(B, D) for _ in range(4)]
+        self.part = z(4 * D // 384, B, D)
         self.u = z(B, 4 * D)
         self.q = z(B, D)
         self.att = z(B, D)
@@ -504,33 +505,43 @@ class _ARPlan:
         m, cfg, w, B, D = self.m, self.m.cfg, self.m.w, self.B, self.m.D
         k = int(cfg.ar_kernel)
         H = 4  # reference: src/sopro/nn/generator.py:36
-        # two ping-pong residual-stream buffers; X0 is also where the sampler leaves the next frame's input
-        cur, oth = self.x[0], self.x[1]
+        # Residual stream = (base buffer, optional pending K-slice partial sums of the last FF2 + its bias).
+        # X0 is where the sampler leaves the next frame's input; XA/XB alternate as GLU outputs; XC receives the
+        # combined stream when a cross-attention follows (its q-projection sums the partials while staging).
+        X0, XA, XB, XC = self.x
+        base, pend = X0, None
         nl = 0
+        KS = 4 * D // 384  # FF2 K slices
         for i, dil in enumerate(cfg.ar_dilations):
             p = f"ar.blocks.{i}"
+            out = XA if i % 2 == 0 else XB
+            pk = dict(Xp=self.part, np_=KS, xp_stride=B * D, xbias=pend) if pend is not None else {}
             # RMSNorm -> GLU -> ring write -> dilated taps -> +x   (src/sopro/nn/blocks.py:150-157, 76-110)
-            hip.skinny(cur, w[p + ".glu.w"], oth, B=B, N=2 * D, K=D, norm_w=w[p + ".norm.weight"], eps=RMS_EPS, bias=w[p + ".glu.b"],
+            hip.skinny(base, w[p + ".glu.w"], out, B=B, N=2 * D, K=D, norm_w=w[p + ".norm.weight"], eps=RMS_EPS, bias=w[p + ".glu.b"],
                        epilogue=hip.EPI_GLU_DW, ring=self.rings[i], dw_w=w[p + ".dw.w"], dw_b=w[p + ".dw.b"], step=self.step_t,
-                       ring_len=(k - 1) * int(dil) + 1, ring_bcap=B, dil=int(dil), ksize=k)
-            # RMSNorm -> Linear -> GELU ; Linear -> +x (in place: every element is read and written by one thread)
-            hip.skinny(oth, w[p + ".ff1.w"], self.u, B=B, N=4 * D, K=D, norm_w=w[p + ".ff.norm.weight"], eps=RMS_EPS,
+                       ring_len=(k - 1) * int(dil) + 1, ring_bcap=B, dil=int(dil), ksize=k, **pk)
+            # RMSNorm -> Linear -> GELU (blocks.py:158-160)
+            hip.skinny(out, w[p + ".ff1.w"], self.u, B=B, N=4 * D, K=D, norm_w=w[p + ".ff.norm.weight"], eps=RMS_EPS,
                        bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
-            hip.skinny(self.u, w[p + ".ff2.w"], oth, B=B, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=oth)
+            # Linear 4D -> D as 4 K-slices on 4x the workgroups; bias + residual are added by the consumer (blocks.py:161-162)
+            hip.skinny(self.u, w[p + ".ff2.w"], self.part, B=B, N=D, K=4 * D, ksplit=True, y_part_stride=B * D)
+            base, pend = out, w[p + ".ff2.b"]
             nl += 3
             if i in self.kv:
                 pa = f"ar.x_attns.{i}"
                 # cached text cross-attention (src/sopro/nn/text.py:85-132)
-                hip.skinny(oth, w[pa + ".q.w"], self.q, B=B, N=D, K=D, norm_w=w[pa + ".nq.weight"], eps=RMS_EPS)
+                hip.skinny(base, w[pa + ".q.w"], self.q, B=B, N=D, K=D, norm_w=w[pa + ".nq.weight"], eps=RMS_EPS, Xp=self.part, np_=KS,
+                           xp_stride=B * D, xbias=pend, Xc=XC)
                 kvb = self.kv[i]
                 hip.attention(self.q, kvb, kvb, self.att, B=B, H=H, dh=D // H, Tq=1, Tk=self.S_cap, ldq=D, ldk=2 * D, ldv=2 * D,
                               ldo=D, q_bstride=D, k_bstride=self.S_cap * 2 * D, v_bstride=self.S_cap * 2 * D, o_bstride=D,
-                              klens=self.klens, v_off=D)
-                hip.skinny(self.att, w[pa + ".o.w"], oth, B=B, N=D, K=D, epilogue=hip.EPI_RES, R=oth, scale=w[pa + ".gate_scale"])
+                              klens=self.klens, v_off=D, decode=True)
+                hip.skinny(self.att, w[pa + ".o.w"], XC, B=B, N=D, K=D, epilogue=hip.EPI_RES, R=XC, scale=w[pa + ".gate_scale"])
+                base, pend = XC, None
                 nl += 3
-            cur, oth = oth, cur
-        assert cur is self.x[0], "an even number of AR blocks is assumed by the two-buffer rotation"
-        hip.skinny(cur, w["ar.head.w"], self.logits, B=B, N=m.V + 1, K=D, norm_w=w["ar.norm.weight"], eps=RMS_EPS, bias=w["ar.head.b"])
+        cur = base
+        hk = dict(Xp=self.part, np_=KS, xp_stride=B * D, xbias=pend) if pend is not None else {}
+        hip.skinny(cur, w["ar.head.w"], self.logits, B=B, N=m.V + 1, K=D, norm_w=w["ar.norm.weight"], eps=RMS_EPS, bias=w["ar.head.b"], **hk)
         # the sampler writes the next frame's input into state.x_cur, which must be where block 0 reads
         hip.ar_sample(self.state, self.logits, m.V + 1)
         self.nlaunch = nl + 2

@@ -121,6 +121,57 @@ def test_skinny_epilogues():
     close(Rd, R + sc * ref, 1e-4, "res in place")
 
 
+def test_skinny_ksplit_partials_are_summed_by_the_consumer(w):
+    """FF2 as 4 K-slices on 4x the workgroups; the next kernel adds bias + residual + partials in a fixed order
+    while staging (deterministic) and can publish the combined stream (Xc)."""
+    B, K, D = 32, 1536, 384
+    U, W2, b2, R = rnd(B, K, seed=600), rnd(D, K, seed=601, scale=K ** -0.5), rnd(D, seed=602), rnd(B, D, seed=603)
+    P = torch.full((4, B, D), float("nan"), device=DEV)
+    hip.skinny(dev(U), dev(W2), P, B=B, N=D, K=K, ksplit=True, y_part_stride=B * D)
+    close(P.sum(0), U @ W2.t(), 1e-4, "sum of K-slice partials")
+    x2 = R + b2 + (U @ W2.t())
+    nw, Wq = 1 + 0.1 * rnd(D, seed=604), rnd(D, D, seed=605, scale=D ** -0.5)
+    Y = torch.empty(B, D, device=DEV)
+    C = torch.full((B, D), float("nan"), device=DEV)
+    hip.skinny(dev(R), dev(Wq), Y, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, Xp=P, np_=4, xp_stride=B * D, xbias=dev(b2), Xc=C)
+    close(C, x2, 1e-4, "combined stream side output")
+    close(Y, O.rmsnorm(x2, nw) @ Wq.t(), 1e-4, "consumer of partials")
+    # the GLU / ring-buffer tail adds its result to the combined input
+    p = "ar.blocks.1"
+    k, dil = 13, 2
+    L = (k - 1) * dil + 1
+    ring = torch.zeros(L, B, D, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.skinny(dev(R), dev(w[p + ".glu.pro.weight"]), Y, B=B, N=2 * D, K=D, norm_w=dev(w[p + ".norm.weight"]), eps=1e-6,
+               bias=dev(w[p + ".glu.pro.bias"]), epilogue=hip.EPI_GLU_DW, ring=ring, dw_w=dev(pack.pack_dw(w[p + ".dw.dw.weight"])),
+               dw_b=dev(w[p + ".dw.dw.bias"]), step=step, ring_len=L, ring_bcap=B, dil=dil, ksize=k, Xp=P, np_=4, xp_stride=B * D,
+               xbias=dev(b2))
+    h = O.glu(O.rmsnorm(x2, w[p + ".norm.weight"]), w, p + ".glu")
+    y = h * w[p + ".dw.dw.weight"][:, 0, -1] + w[p + ".dw.dw.bias"]  # empty ring: only the newest tap
+    close(Y, x2 + y, 1e-4, "glu tail on a partial-sum input")
+    # run-to-run bit reproducibility (no atomics anywhere on this path)
+    Y2 = torch.empty(B, D, device=DEV)
+    hip.skinny(dev(R), dev(Wq), Y2, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, Xp=P, np_=4, xp_stride=B * D, xbias=dev(b2))
+    hip.skinny(dev(R), dev(Wq), Y, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, Xp=P, np_=4, xp_stride=B * D, xbias=dev(b2))
+    assert torch.equal(Y, Y2)
+
+
+@pytest.mark.parametrize("S", [5, 64, 130])
+def test_attention_decode_single_query(S):
+    B, H, dh = 5, 4, 96
+    D = H * dh
+    q, kv = rnd(B, D, seed=610), rnd(B, S, 2 * D, seed=611)
+    klens = [S, 1, max(1, S // 2), S, max(1, S - 3)]
+    keep = torch.arange(S)[None, :] < torch.tensor(klens)[:, None]
+    ref = O._unheads(O.attention(O._heads(q[:, None], H), O._heads(kv[..., :D].contiguous(), H), O._heads(kv[..., D:].contiguous(), H), keep))[:, 0]
+    out = torch.full((B, D), float("nan"), device=DEV)
+    kvd = dev(kv)
+    hip.attention(dev(q), kvd, kvd, out, B=B, H=H, dh=dh, Tq=1, Tk=S, ldq=D, ldk=2 * D, ldv=2 * D, ldo=D, q_bstride=D,
+                  k_bstride=S * 2 * D, v_bstride=S * 2 * D, o_bstride=D, klens=dev(torch.tensor(klens, dtype=torch.int32)), v_off=D,
+                  decode=True)
+    close(out, ref, 2e-5, "decode attention")
+
+
 @pytest.mark.parametrize("B,dil", [(1, 1), (5, 2), (32, 4)])
 def test_skinny_glu_ring_buffer_step_matches_forward_step(B, dil, w, cfg):
     """SSMLiteBlock.forward_step first half over 30 frames (src/sopro/nn/blocks.py:150-157, 76-110)."""
