@@ -209,6 +209,7 @@ typedef struct sopro_ar_state {
   int32_t* first_eos;      /* [bcap] first t with tok == EOS, -1 if none */
   int32_t* stop_t;         /* [bcap] first t with tok == EOS and t+1 >= min_gen, -1 if none */
   int32_t* n_stopped;      /* scalar: rows with stop_t >= 0 */
+  int32_t* recent;         /* [bcap, 64] rolling window: slot j = token sampled j+1 frames ago, -1 = none */
   const float* params;     /* [8] top_p, temperature, anti_loop, rec_top_p, rec_temperature, rep_penalty, top_k, min_gen */
   uint64_t seed;
   int32_t B, D, Tar, max_steps, V /* 2048, EOS id == V */, bos_row;

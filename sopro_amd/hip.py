@@ -52,7 +52,7 @@ class AttnArgs(C.Structure):
 
 class ArState(C.Structure):
     _fields_ = [("x_cur", _p), ("cond", _p), ("emb", _p), ("hist", _p), ("step", _p), ("arrive", _p),
-                ("first_eos", _p), ("stop_t", _p), ("n_stopped", _p), ("params", _p), ("seed", C.c_uint64),
+                ("first_eos", _p), ("stop_t", _p), ("n_stopped", _p), ("recent", _p), ("params", _p), ("seed", C.c_uint64),
                 ("B", _i32), ("D", _i32), ("Tar", _i32), ("max_steps", _i32), ("V", _i32), ("bos_row", _i32)]
 
 

@@ -482,6 +482,7 @@ class _ARPlan:
         self.first_eos = z(B, dt=torch.int32)
         self.stop_t = z(B, dt=torch.int32)
         self.params = z(8)
+        self.recent = z(B, 64, dt=torch.int32)
         st = hip.ArState()
         st.x_cur = self.x[0].data_ptr()
         st.cond = self.cond.data_ptr()
@@ -493,6 +494,7 @@ class _ARPlan:
         st.first_eos = self.first_eos.data_ptr()
         st.stop_t = self.stop_t.data_ptr()
         st.params = self.params.data_ptr()
+        st.recent = self.recent.data_ptr()
         st.seed = m.seed
         st.B, st.D, st.Tar, st.max_steps, st.V, st.bos_row = B, D, Tar, self.max_steps, m.V, int(cfg.bos_row)
         self.state = st
@@ -505,42 +507,44 @@ class _ARPlan:
         m, cfg, w, B, D = self.m, self.m.cfg, self.m.w, self.B, self.m.D
         k = int(cfg.ar_kernel)
         H = 4  # reference: src/sopro/nn/generator.py:36
-        # Residual stream = (base buffer, optional pending K-slice partial sums of the last FF2 + its bias).
+        # Residual stream = a base buffer, optionally with pending K-slice partial sums of the last FF2: slice 0 of
+        # the FF2 output already carries bias + residual, slices 1..3 are added by whoever stages the stream next.
         # X0 is where the sampler leaves the next frame's input; XA/XB alternate as GLU outputs; XC receives the
-        # combined stream when a cross-attention follows (its q-projection sums the partials while staging).
+        # combined stream when a cross-attention follows (its q-projection sums the slices while staging).
         X0, XA, XB, XC = self.x
-        base, pend = X0, None
-        nl = 0
         KS = 4 * D // 384  # FF2 K slices
+        P0, PR = self.part[0], self.part[1:]
+        pk = dict(Xp=PR, np_=KS - 1, xp_stride=B * D)
+        base, pend = X0, False
+        nl = 0
         for i, dil in enumerate(cfg.ar_dilations):
             p = f"ar.blocks.{i}"
             out = XA if i % 2 == 0 else XB
-            pk = dict(Xp=self.part, np_=KS, xp_stride=B * D, xbias=pend) if pend is not None else {}
             # RMSNorm -> GLU -> ring write -> dilated taps -> +x   (src/sopro/nn/blocks.py:150-157, 76-110)
             hip.skinny(base, w[p + ".glu.w"], out, B=B, N=2 * D, K=D, norm_w=w[p + ".norm.weight"], eps=RMS_EPS, bias=w[p + ".glu.b"],
                        epilogue=hip.EPI_GLU_DW, ring=self.rings[i], dw_w=w[p + ".dw.w"], dw_b=w[p + ".dw.b"], step=self.step_t,
-                       ring_len=(k - 1) * int(dil) + 1, ring_bcap=B, dil=int(dil), ksize=k, **pk)
+                       ring_len=(k - 1) * int(dil) + 1, ring_bcap=B, dil=int(dil), ksize=k, **(pk if pend else {}))
             # RMSNorm -> Linear -> GELU (blocks.py:158-160)
             hip.skinny(out, w[p + ".ff1.w"], self.u, B=B, N=4 * D, K=D, norm_w=w[p + ".ff.norm.weight"], eps=RMS_EPS,
                        bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
-            # Linear 4D -> D as 4 K-slices on 4x the workgroups; bias + residual are added by the consumer (blocks.py:161-162)
-            hip.skinny(self.u, w[p + ".ff2.w"], self.part, B=B, N=D, K=4 * D, ksplit=True, y_part_stride=B * D)
-            base, pend = out, w[p + ".ff2.b"]
+            # Linear 4D -> D + residual as 4 K-slices on 4x the workgroups (blocks.py:161-162)
+            hip.skinny(self.u, w[p + ".ff2.w"], self.part, B=B, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=out,
+                       ksplit=True, y_part_stride=B * D)
+            base, pend = P0, True
             nl += 3
             if i in self.kv:
                 pa = f"ar.x_attns.{i}"
                 # cached text cross-attention (src/sopro/nn/text.py:85-132)
-                hip.skinny(base, w[pa + ".q.w"], self.q, B=B, N=D, K=D, norm_w=w[pa + ".nq.weight"], eps=RMS_EPS, Xp=self.part, np_=KS,
-                           xp_stride=B * D, xbias=pend, Xc=XC)
+                hip.skinny(base, w[pa + ".q.w"], self.q, B=B, N=D, K=D, norm_w=w[pa + ".nq.weight"], eps=RMS_EPS, Xc=XC, **pk)
                 kvb = self.kv[i]
                 hip.attention(self.q, kvb, kvb, self.att, B=B, H=H, dh=D // H, Tq=1, Tk=self.S_cap, ldq=D, ldk=2 * D, ldv=2 * D,
                               ldo=D, q_bstride=D, k_bstride=self.S_cap * 2 * D, v_bstride=self.S_cap * 2 * D, o_bstride=D,
                               klens=self.klens, v_off=D, decode=True)
                 hip.skinny(self.att, w[pa + ".o.w"], XC, B=B, N=D, K=D, epilogue=hip.EPI_RES, R=XC, scale=w[pa + ".gate_scale"])
-                base, pend = XC, None
+                base, pend = XC, False
                 nl += 3
         cur = base
-        hk = dict(Xp=self.part, np_=KS, xp_stride=B * D, xbias=pend) if pend is not None else {}
+        hk = pk if pend else {}
         hip.skinny(cur, w["ar.head.w"], self.logits, B=B, N=m.V + 1, K=D, norm_w=w["ar.norm.weight"], eps=RMS_EPS, bias=w["ar.head.b"], **hk)
         # the sampler writes the next frame's input into state.x_cur, which must be where block 0 reads
         hip.ar_sample(self.state, self.logits, m.V + 1)

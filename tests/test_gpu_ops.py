@@ -122,18 +122,20 @@ def test_skinny_epilogues():
 
 
 def test_skinny_ksplit_partials_are_summed_by_the_consumer(w):
-    """FF2 as 4 K-slices on 4x the workgroups; the next kernel adds bias + residual + partials in a fixed order
-    while staging (deterministic) and can publish the combined stream (Xc)."""
+    """FF2 as 4 K-slices on 4x the workgroups (slice 0 carries bias + residual); the next kernel adds the slices in
+    a fixed order while staging (deterministic) and can publish the combined stream (Xc)."""
     B, K, D = 32, 1536, 384
     U, W2, b2, R = rnd(B, K, seed=600), rnd(D, K, seed=601, scale=K ** -0.5), rnd(D, seed=602), rnd(B, D, seed=603)
     P = torch.full((4, B, D), float("nan"), device=DEV)
-    hip.skinny(dev(U), dev(W2), P, B=B, N=D, K=K, ksplit=True, y_part_stride=B * D)
-    close(P.sum(0), U @ W2.t(), 1e-4, "sum of K-slice partials")
+    hip.skinny(dev(U), dev(W2), P, B=B, N=D, K=K, bias=dev(b2), epilogue=hip.EPI_RES, R=dev(R), ksplit=True, y_part_stride=B * D)
     x2 = R + b2 + (U @ W2.t())
+    close(P.sum(0), x2, 1e-4, "sum of K-slices (slice 0 holds bias + residual)")
+    close(P[1:].sum(0) + P[0] - R.to(DEV) - b2.to(DEV), U @ W2.t(), 1e-4, "raw partial sums")
+    pk = dict(Xp=P[1:], np_=3, xp_stride=B * D)
     nw, Wq = 1 + 0.1 * rnd(D, seed=604), rnd(D, D, seed=605, scale=D ** -0.5)
     Y = torch.empty(B, D, device=DEV)
     C = torch.full((B, D), float("nan"), device=DEV)
-    hip.skinny(dev(R), dev(Wq), Y, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, Xp=P, np_=4, xp_stride=B * D, xbias=dev(b2), Xc=C)
+    hip.skinny(P[0], dev(Wq), Y, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, Xc=C, **pk)
     close(C, x2, 1e-4, "combined stream side output")
     close(Y, O.rmsnorm(x2, nw) @ Wq.t(), 1e-4, "consumer of partials")
     # the GLU / ring-buffer tail adds its result to the combined input
@@ -142,17 +144,16 @@ def test_skinny_ksplit_partials_are_summed_by_the_consumer(w):
     L = (k - 1) * dil + 1
     ring = torch.zeros(L, B, D, device=DEV)
     step = torch.zeros(1, dtype=torch.int32, device=DEV)
-    hip.skinny(dev(R), dev(w[p + ".glu.pro.weight"]), Y, B=B, N=2 * D, K=D, norm_w=dev(w[p + ".norm.weight"]), eps=1e-6,
+    hip.skinny(P[0], dev(w[p + ".glu.pro.weight"]), Y, B=B, N=2 * D, K=D, norm_w=dev(w[p + ".norm.weight"]), eps=1e-6,
                bias=dev(w[p + ".glu.pro.bias"]), epilogue=hip.EPI_GLU_DW, ring=ring, dw_w=dev(pack.pack_dw(w[p + ".dw.dw.weight"])),
-               dw_b=dev(w[p + ".dw.dw.bias"]), step=step, ring_len=L, ring_bcap=B, dil=dil, ksize=k, Xp=P, np_=4, xp_stride=B * D,
-               xbias=dev(b2))
+               dw_b=dev(w[p + ".dw.dw.bias"]), step=step, ring_len=L, ring_bcap=B, dil=dil, ksize=k, **pk)
     h = O.glu(O.rmsnorm(x2, w[p + ".norm.weight"]), w, p + ".glu")
     y = h * w[p + ".dw.dw.weight"][:, 0, -1] + w[p + ".dw.dw.bias"]  # empty ring: only the newest tap
     close(Y, x2 + y, 1e-4, "glu tail on a partial-sum input")
     # run-to-run bit reproducibility (no atomics anywhere on this path)
     Y2 = torch.empty(B, D, device=DEV)
-    hip.skinny(dev(R), dev(Wq), Y2, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, Xp=P, np_=4, xp_stride=B * D, xbias=dev(b2))
-    hip.skinny(dev(R), dev(Wq), Y, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, Xp=P, np_=4, xp_stride=B * D, xbias=dev(b2))
+    hip.skinny(P[0], dev(Wq), Y2, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, **pk)
+    hip.skinny(P[0], dev(Wq), Y, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, **pk)
     assert torch.equal(Y, Y2)
 
 
@@ -366,10 +367,12 @@ class _SamplerRig:
         self.x, self.cond, self.emb = z(B, D), dev(rnd(B, Tar, D, seed=90)), dev(rnd(V * 2 + 1, D, seed=91))
         self.hist, self.ctr = z(B, Tar, dt=torch.int32), z(8, dt=torch.int32)
         self.first_eos, self.stop_t, self.params = z(B, dt=torch.int32), z(B, dt=torch.int32), z(8)
+        self.recent = z(B, 64, dt=torch.int32)
         st = hip.ArState()
         st.x_cur, st.cond, st.emb, st.hist = self.x.data_ptr(), self.cond.data_ptr(), self.emb.data_ptr(), self.hist.data_ptr()
         st.step, st.arrive, st.n_stopped = self.ctr.data_ptr(), self.ctr.data_ptr() + 4, self.ctr.data_ptr() + 8
         st.first_eos, st.stop_t, st.params = self.first_eos.data_ptr(), self.stop_t.data_ptr(), self.params.data_ptr()
+        st.recent = self.recent.data_ptr()
         st.seed, st.B, st.D, st.Tar, st.max_steps, st.V, st.bos_row = 7, B, D, Tar, Tar, V, 2 * V
         self.st = st
 
@@ -449,6 +452,10 @@ def test_sampler_anti_loop_detection():
     flags = []
     for row, L in ((0, 6), (1, 6), (2, 10), (3, 10)):
         rig.hist.copy_(h)
+        rec = torch.full((B, 64), -1, dtype=torch.int32)
+        for r_, L_ in ((0, 6), (1, 6), (2, 10), (3, 10)):
+            rec[r_, :L_] = h[r_, :L_].flip(0)  # slot j = token sampled j+1 frames ago
+        rig.recent.copy_(rec)
         rig.ctr.zero_()
         rig.ctr[0] = L
         lg = flat[None].repeat(B, 1)
@@ -456,6 +463,7 @@ def test_sampler_anti_loop_detection():
         torch.cuda.synchronize()
         want = int(torch.argmax(O.penalised_logits(flat, h[row, :L].tolist(), 1.0, 1.1)))
         flags.append(int(rig.hist[row, L]) == want)
+        assert rig.recent[row, : L + 1].cpu().tolist() == [int(rig.hist[row, L])] + h[row, :L].flip(0).tolist()
     assert flags[0] and flags[2], flags
     assert not (flags[1] and flags[3]), flags  # near-uniform logits over the top-50: a chance arg-max on both rows is ~4e-4 (and fixed by the Philox seed)
 
