@@ -55,11 +55,29 @@ __global__ __launch_bounds__(256) void attention_kernel(const sopro_attn_args a)
 
   for (int k0 = kt_begin * TK; k0 < k_end; k0 += TK) {
     __syncthreads();  // previous tile fully consumed (also orders the Q staging before first use)
-    for (int idx = tid; idx < TK * DH; idx += 256) {
-      const int r = idx / DH, e = idx - r * DH;
-      const bool in = (k0 + r) < klen;
-      Ks[r * KP + e] = in ? Kb[(int64_t)(k0 + r) * a.ldk + e] : 0.f;
-      Vs[r * DH + e] = in ? Vb[(int64_t)(k0 + r) * a.ldv + e] : 0.f;
+    {
+      // K/V tile: all of a thread's float4 loads are issued before the first LDS store (one memory latency per tile)
+      constexpr int F4 = TK * DH / 4 / 256;  // float4 per thread and matrix
+      float4 kreg[F4], vreg[F4];
+#pragma unroll
+      for (int f = 0; f < F4; ++f) {
+        const int idx4 = tid + f * 256;
+        const int r = idx4 / (DH / 4), e4 = idx4 - r * (DH / 4);
+        kreg[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vreg[f] = kreg[f];
+        if ((k0 + r) < klen) {
+          kreg[f] = *reinterpret_cast<const float4*>(Kb + (int64_t)(k0 + r) * a.ldk + e4 * 4);
+          vreg[f] = *reinterpret_cast<const float4*>(Vb + (int64_t)(k0 + r) * a.ldv + e4 * 4);
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < F4; ++f) {
+        const int idx4 = tid + f * 256;
+        const int r = idx4 / (DH / 4), e4 = idx4 - r * (DH / 4);
+        float* kd = Ks + r * KP + e4 * 4;
+        kd[0] = kreg[f].x; kd[1] = kreg[f].y; kd[2] = kreg[f].z; kd[3] = kreg[f].w;
+        *reinterpret_cast<float4*>(Vs + r * DH + e4 * 4) = vreg[f];
+      }
     }
     __syncthreads();
 
@@ -149,6 +167,9 @@ extern "C" int sopro_attention_f32(const sopro_attn_args* p, void* stream) {
   SOPRO_CHECK_ARG(a.Q && a.K && a.V && a.O, "Q, K, V, O must be non-NULL");
   SOPRO_CHECK_ARG(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "B, H, Tq, Tk must be positive");
   SOPRO_CHECK_ARG(!a.causal || a.window > 0, "causal attention needs window > 0");
+  SOPRO_CHECK_ARG(aligned16(a.K) && aligned16(a.V) && (a.ldk & 3) == 0 && (a.ldv & 3) == 0 && (a.k_bstride & 3) == 0 &&
+                      (a.v_bstride & 3) == 0,
+                  "K/V must be 16-byte aligned with strides % 4 == 0");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (a.dh) {
     case 64: return launch_attn<64>(a, s);

@@ -136,18 +136,47 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const sopro_gemm_
     __syncthreads();
   }
 
-  // ---- epilogue: D[reg r] is row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of the 32x32 tile
+  // ---- epilogue: D[reg r] is row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of the 32x32 tile.
+  // Row addresses: one division per 32-row tile, then incremental segment tracking.  Every residual / bias /
+  // scale operand is loaded into registers BEFORE the first store: R may alias C (in-place residual updates), so
+  // the compiler must not be left to interleave "load R, store C" pairs, each of which would expose a full
+  // memory latency.
   const int epi = g.epilogue;
   const int col = lane & 31;
+  float biasv[TN], scalev[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + col;
+    biasv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+    scalev[j] = (g.scale && n < g.N) ? g.scale[n] : 1.f;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {  // one 32-row tile at a time keeps the address / residual registers at 16 rows
+    int64_t coff[16];             // element offset of the row inside C (R: same row structure, own strides)
+    float rv[16][TN];
+    const int mb = m0 + (wm * TM + i) * 32;
+    const int seg0 = mb / rps;
+    const int rr0 = mb - seg0 * rps;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m >= g.M) continue;
-      const int seg = m / rps;
-      const int rr = m - seg * rps;
-      float* crow = g.C + (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc;
+      const int dr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      int seg = seg0, rr = rr0 + dr;
+      while (rr >= rps) { rr -= rps; ++seg; }
+      const bool ok = (mb + dr) < g.M;
+      coff[r] = ok ? (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc : (int64_t)-1;
+      if (epi == SOPRO_EPI_RES) {
+        const float* rrow = g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + (wn * TN + j) * 32 + col;
+          rv[r][j] = (ok && n < g.N) ? rrow[n] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (coff[r] < 0) continue;
+      float* crow = g.C + coff[r];
       if (epi == SOPRO_EPI_GLU) {
         if constexpr ((TN & 1) == 0) {
 #pragma unroll
@@ -155,23 +184,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const sopro_gemm_
             const int na = n0 + (wn * TN + j) * 32 + col;
             const int nb = na + 32;
             if (nb < g.N) {
-              float va = acc[i][j][r], vb = acc[i][j + 1][r];
-              if (g.bias) { va += g.bias[na]; vb += g.bias[nb]; }
+              const float va = acc[i][j][r] + biasv[j], vb = acc[i][j + 1][r] + biasv[j + 1];
               crow[(na - col) / 2 + col] = va * sigmoidf_(vb);
             }
           }
         }
       } else {
-        const float* rrow = (epi == SOPRO_EPI_RES) ? g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int n = n0 + (wn * TN + j) * 32 + col;
           if (n >= g.N) continue;
-          float v = acc[i][j][r];
-          if (g.bias) v += g.bias[n];
+          float v = acc[i][j][r] + biasv[j];
           if (epi == SOPRO_EPI_GELU) v = gelu_erf(v);
           else if (epi == SOPRO_EPI_TANH) v = tanhf(v);
-          else if (epi == SOPRO_EPI_RES) v = rrow[n] + (g.scale ? g.scale[n] * v : v);
+          else if (epi == SOPRO_EPI_RES) v = rv[r][j] + scalev[j] * v;
           crow[n] = v;
         }
       }
