@@ -192,35 +192,39 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
       }
     }
     __syncthreads();
-    if (tid == 0) {
-      // top-k renormalisation (sampling.py:56-66), serial like torch's cumsum
-      float s = 0.f;
-      for (int j = 0; j < kk; ++j) s += selp[j];
+    if (wave == 0) {
+      // top-k renormalisation, top-p cut and the draw on one wave (sampling.py:56-93): lane j owns sorted entry j
+      const float pj_raw = (lane < kk) ? selp[lane] : 0.f;
+      const float s = wave_sum(pj_raw);
       int tok = top_i;
       if (s > 1e-12f) {
-        // top-p: drop entry j when the cumulative mass *before* it already exceeds top_p (sampling.py:68-76)
-        float cum = 0.f, kept = 0.f;
-        int nkeep = 0;
-        for (int j = 0; j < kk; ++j) {
-          const float pj = selp[j] / s;
-          const bool remove = (top_p < 1.0f) && (j > 0) && (cum > top_p);
-          cum += pj;
-          if (remove) break;  // cum is monotone: everything after is removed too
-          kept += pj;
-          nkeep = j + 1;
+        const float pj = pj_raw / s;
+        float inc = pj;  // inclusive prefix sum over lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const float u2 = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += u2;
         }
+        const float before = inc - pj;
+        // drop entry j when the cumulative mass *before* it already exceeds top_p; entry 0 always stays (sampling.py:68-76)
+        const bool keep = lane < kk && (lane == 0 || !(top_p < 1.0f && before > top_p));
+        const float kp = keep ? pj : 0.f;
+        const float kept = wave_sum(kp);
         if (kept > 1e-12f) {
-          const float u = philox_uniform(st.seed, (unsigned)t, (unsigned)b) * kept;
-          float c2 = 0.f;
-          int pick = nkeep - 1;
-          for (int j = 0; j < nkeep; ++j) {
-            c2 += selp[j] / s;
-            if (u < c2) { pick = j; break; }
+          float kinc = kp;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const float u2 = __shfl_up(kinc, o, 64);
+            if (lane >= o) kinc += u2;
           }
+          const float u = philox_uniform(st.seed, (unsigned)t, (unsigned)b) * kept;
+          const unsigned long long hit = __ballot(keep && u < kinc);
+          const unsigned long long kmask = __ballot(keep);
+          const int pick = hit ? (int)__ffsll((long long)hit) - 1 : 63 - __clzll((long long)kmask);
           tok = 4095 - (int)(selk[pick] & 4095ull);
         }
       }
-      sh_tok = tok;
+      if (lane == 0) sh_tok = tok;
     }
   }
   __syncthreads();

@@ -241,7 +241,12 @@ extern "C" int sopro_gemm_f32(const sopro_gemm_args* a, void* stream) {
   SOPRO_CHECK_ARG(g.prologue != SOPRO_PRO_ADDVEC || (g.pro_vec && aligned16(g.pro_vec)), "PRO_ADDVEC needs an aligned pro_vec");
   SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_GLU || (g.N % 64) == 0, "EPI_GLU needs N % 64 == 0 (packed value/gate blocks)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (g.N > 64) return launch_cfg<2, 2, 2, 2>(g, s);
+  if (g.N > 64) {
+    // 128x128 tiles unless that leaves most of the 256 CUs without a workgroup (M ~ thousands of rows: NAR, transformer)
+    const int64_t tiles128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    if (tiles128 < 768) return launch_cfg<2, 2, 1, 2>(g, s);
+    return launch_cfg<2, 2, 2, 2>(g, s);
+  }
   if (g.N > 32 || g.epilogue == SOPRO_EPI_GLU) return launch_cfg<4, 1, 2, 2>(g, s);
   return launch_cfg<4, 1, 2, 1>(g, s);
 }
