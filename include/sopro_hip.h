@@ -196,6 +196,13 @@ int sopro_upsample2_f32(const float* x, const float* w, float* y, int64_t y_seg_
 int sopro_final_conv_f32(const float* h, int64_t h_seg_stride, const float* w, float bias, float* wav,
                          int64_t wav_seg_stride, int32_t B, int32_t T, void* stream);
 
+/* Fused 24 kHz tail of the SEANet decoder: last MimiResnetBlock (dim 64: k=3 conv 64->32, k=1 conv 32->64, residual)
+ * + last layer (ELU, k=3 conv 64->1), HF:modeling_mimi.py:408-447, 957-960.  h [B][2+T][64] (two zero rows in front of
+ * each segment) is read once; only wav [B][T] is written.  w1 [32][3*64] (tap-major K), w2 [64][32], wf [3][64]. */
+int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
+                          const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
+                          int32_t T, void* stream);
+
 /* ---- autoregressive driver state ----------------------------------------------------------- */
 /* Device-resident state of ar_stream (src/sopro/model.py:218-305) for up to `bcap` rows. All
  * pointers are caller-allocated device buffers. */

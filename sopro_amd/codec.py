@@ -14,6 +14,7 @@ which is SURVEY.md 8(f) rank 1 ("next") and raises here.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -50,6 +51,7 @@ class MimiCodec:
         self.ws = Workspace(self.device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.num_quantizers = int(self.mc.num_quantizers)
+        self.fuse_tail = os.environ.get("SOPRO_UNFUSED_TAIL", "0") != "1"
         self._rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._rope_n = 0
         Q, V = self.num_quantizers, int(self.mc.codebook_size)
@@ -172,8 +174,16 @@ class MimiCodec:
                 hip.gemm(Hc, w[f"sea.up{si}.w"], Ho, M=B * rows, N=r * co, K=2 * ch, lda=ch, bias=w[f"sea.up{si}.b"],
                          prologue=hip.PRO_ELU, rows_per_seg=rows, a_seg_stride=(pad_in + rows) * ch, a_off=(pad_in - 1) * ch,
                          c_off=2 * co, c_seg_stride=(2 + orow) * co, ldc=r * co)
-                # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x))))
                 hid = co // int(mc.compress)
+                last = si == len(mc.upsampling_ratios) - 1
+                if last and self.fuse_tail and co == 64 and hid == 32 and int(mc.residual_kernel_size) == 3 and int(mc.last_kernel_size) == 3:
+                    # last residual block + last conv in one kernel: the 64-channel 24 kHz activation is read once
+                    wav = torch.empty(B, orow, device=dev)
+                    hip.seanet_tail(Ho, w[f"sea.res{si}.c1.w"], w[f"sea.res{si}.c1.b"], w[f"sea.res{si}.c2.w"], w[f"sea.res{si}.c2.b"],
+                                    w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
+                    Hc, ch, rows, pad_in = Ho, co, orow, 2
+                    break
+                # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x))))
                 Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
                 hip.gemm(Ho, w[f"sea.res{si}.c1.w"], Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"],
                          prologue=hip.PRO_ELU, rows_per_seg=orow, a_seg_stride=(2 + orow) * co)
@@ -181,8 +191,9 @@ class MimiCodec:
                          epilogue=hip.EPI_RES, R=Ho, rows_per_seg=orow, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co,
                          r_seg_stride=(2 + orow) * co, ldc=co, ldr=co)
                 Hc, ch, rows, pad_in = Ho, co, orow, 2
-            wav = torch.empty(B, rows, device=dev)
-            hip.final_conv(Hc, w["sea.final.w"], self.final_bias, wav, B=B, T=rows, h_seg_stride=(2 + rows) * ch, wav_seg_stride=rows)
+            else:
+                wav = torch.empty(B, rows, device=dev)
+                hip.final_conv(Hc, w["sea.final.w"], self.final_bias, wav, B=B, T=rows, h_seg_stride=(2 + rows) * ch, wav_seg_stride=rows)
         self.stream.synchronize()
         return wav
 

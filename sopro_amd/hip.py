@@ -83,6 +83,7 @@ SYMBOLS = {
     "sopro_rope_f32": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "sopro_upsample2_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_final_conv_f32": (C.c_int, [_p, _i64, _p, _f32, _p, _i64, _i32, _i32, _p]),
+    "sopro_seanet_tail_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _f32, _p, _i64, _i32, _i32, _p]),
     "sopro_ar_init": (C.c_int, [C.POINTER(ArState), _p]),
     "sopro_ar_sample": (C.c_int, [C.POINTER(ArState), _p, _i64, _p]),
 }
@@ -333,6 +334,12 @@ def final_conv(h: torch.Tensor, w: torch.Tensor, bias: float, wav: torch.Tensor,
                wav_seg_stride: int) -> None:
     _check(load().sopro_final_conv_f32(ptr(h), h_seg_stride, ptr(w), bias, ptr(wav), wav_seg_stride, B, T, _stream()),
            "sopro_final_conv_f32")
+
+
+def seanet_tail(h: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, wf: torch.Tensor,
+                bf: float, wav: torch.Tensor, *, B: int, T: int, h_seg_stride: int, wav_seg_stride: int) -> None:
+    _check(load().sopro_seanet_tail_f32(ptr(h), h_seg_stride, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(wf), bf, ptr(wav),
+                                        wav_seg_stride, B, T, _stream()), "sopro_seanet_tail_f32")
 
 
 def ar_init(st: ArState) -> None:

@@ -359,6 +359,25 @@ def test_rope_upsample_final_conv():
     close(wav, ref, 2e-5, "final conv")
 
 
+def test_seanet_tail_fused_matches_unfused_layers():
+    """Last MimiResnetBlock + last conv in one kernel (HF:modeling_mimi.py:408-447, 957-960)."""
+    B, T = 2, 300  # 3 tiles of 126 samples, the last one partial
+    h = rnd(B, T, 64, seed=700)
+    w1, b1 = rnd(32, 64, 3, seed=701, scale=0.07), rnd(32, seed=702, scale=0.1)
+    w2, b2 = rnd(64, 32, 1, seed=703, scale=0.17), rnd(64, seed=704, scale=0.1)
+    wf, bf = rnd(1, 64, 3, seed=705, scale=0.07), 0.03
+    x = h.transpose(1, 2)
+    y = O.causal_conv1d(F.elu(x), w1, b1)
+    y = O.causal_conv1d(F.elu(y), w2, b2)
+    ref = O.causal_conv1d(F.elu(x + y), wf, torch.tensor([bf]))[:, 0]
+    hb = torch.zeros(B, 2 + T, 64)
+    hb[:, 2:] = h
+    wav = torch.full((B, T), float("nan"), device=DEV)
+    hip.seanet_tail(dev(hb), dev(pack.pack_conv1d(w1)), dev(b1), dev(pack.pack_conv1d(w2)), dev(b2), dev(wf[0].t()), bf, wav,
+                    B=B, T=T, h_seg_stride=(2 + T) * 64, wav_seg_stride=T)
+    close(wav, ref, 3e-5, "fused SEANet tail")
+
+
 # ------------------------------------------------------------------------------------------ sampler
 class _SamplerRig:
     def __init__(self, B, Tar=64, D=384, V=2048):
