@@ -181,6 +181,22 @@ int sopro_attention_f32(const sopro_attn_args* args, void* stream);
 /* Tq == 1 form for the AR frame (cached text K/V, src/sopro/nn/text.py:85-132): one workgroup per
  * (batch row, head), all loads issued up front; dh in {64, 96}; no causal mask. */
 int sopro_attn_decode_f32(const sopro_attn_args* args, void* stream);
+/* The whole cached text cross-attention block of the AR frame in one launch (src/sopro/nn/text.py:85-132) on
+ * per-utterance folded operands Kp[b,h] = K_h Wq_h and Vp[b,h] = V_h Wo_h^T (both [S_cap, D], D == 384):
+ * Y[h][b] = (h == 0 ? Xin[b] : 0) + gate * sum_k softmax_k(<RMSNorm(Xin[b]), Kp[b,h,k]> * scale) * Vp[b,h,k],
+ * Xin = X + sum_{s<np} Xp[s].  The H partial outputs (y_part_stride apart) are summed by the next kernel. */
+typedef struct sopro_xattn_args {
+  const float* X; int64_t ldx;
+  const float* Xp; int64_t xp_stride;
+  const float* norm_w;
+  const float* Kp; const float* Vp;
+  const int32_t* klens;
+  float* Y; int64_t y_part_stride;
+  float eps, gate, scale;
+  int32_t np, B, H, D, S_cap;
+} sopro_xattn_args;
+int sopro_xattn_step_f32(const sopro_xattn_args* args, void* stream);
+
 /* rotate-half RoPE in place on [rows, H*dh] with host-made tables cos/sin [npos, dh/2]; position of
  * row r is pos0 + (r % rows_per_seg).  HF:modeling_mimi.py:511-599. */
 int sopro_rope_f32(float* x, int64_t ldx, const float* cos_t, const float* sin_t, int32_t rows,

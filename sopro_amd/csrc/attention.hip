@@ -278,3 +278,148 @@ extern "C" int sopro_attn_decode_f32(const sopro_attn_args* p, void* stream) {
   }
   SOPRO_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Whole cached text cross-attention block of the AR frame in ONE launch (src/sopro/nn/text.py:85-132):
+//     x + tanh(gate) * out_proj( softmax( q_proj(RMSNorm(x)) K^T / sqrt(dh) ) V )
+// with the two projections folded, once per utterance, into the cached operands
+//     K'_h = K_h Wq_h   [S, D]   (score_h[k] = <RMSNorm(x), K'_h[k]>)
+//     V'_h = V_h Wo_h^T [S, D]   (head h's contribution to the block output, already in model space)
+// so that per frame there is no q / out projection kernel at all: three launches become one.  One
+// workgroup (8 waves) per (batch row, head); every K'/V' load is issued before the first wait; the four
+// heads write four partial outputs (slice 0 carries the residual) which the next kernel of the frame sums
+// while staging its input, exactly like the K-slices of the feed-forward output (deterministic, no atomics).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int XD = 384;
+
+__global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args a) {
+  __shared__ float xsum[XD];
+  __shared__ float xn[XD];
+  __shared__ float sc[64];
+  __shared__ float ps[64];
+  __shared__ float opart[4][XD];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int klen = a.klens ? min(a.klens[b], a.S_cap) : a.S_cap;
+  const float* Kb = a.Kp + ((int64_t)(b * a.H + h) * a.S_cap) * XD;
+  const float* Vb = a.Vp + ((int64_t)(b * a.H + h) * a.S_cap) * XD;
+  const int key = tid >> 3, part = tid & 7;   // score mapping: 8 lanes share a key, 48 floats each
+  const int vd4 = tid % 96, vg = tid / 96;    // P.V' mapping: float4 column, 16-key group (vg < 4)
+
+  float m_run = -INFINITY, l_run = 0.f;
+  float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int k0 = 0; k0 < klen; k0 += 64) {
+    // ---- every operand of this 64-key tile is requested up front
+    float4 kreg[12], vreg[16];
+    const bool kin = (k0 + key) < klen;
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+      kreg[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kin) kreg[f] = *reinterpret_cast<const float4*>(Kb + (int64_t)(k0 + key) * XD + part * 48 + f * 4);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      vreg[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vg < 4 && (k0 + vg * 16 + kk) < klen) vreg[kk] = *reinterpret_cast<const float4*>(Vb + (int64_t)(k0 + vg * 16 + kk) * XD + vd4 * 4);
+    }
+    if (k0 == 0) {
+      // ---- input stream (+ the producer's partial sums, fixed order), RMSNorm (src/sopro/nn/blocks.py:26-37)
+      float ss = 0.f;
+      if (tid < 96) {
+        float4 xv = *reinterpret_cast<const float4*>(a.X + (int64_t)b * a.ldx + tid * 4);
+        float4 pv[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          if (s < a.np) pv[s] = *reinterpret_cast<const float4*>(a.Xp + (int64_t)s * a.xp_stride + (int64_t)b * a.ldx + tid * 4);
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          if (s < a.np) { xv.x += pv[s].x; xv.y += pv[s].y; xv.z += pv[s].z; xv.w += pv[s].w; }
+        *reinterpret_cast<float4*>(xsum + tid * 4) = xv;
+        ss = xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+      }
+      ss = wave_sum(ss);
+      if (lane == 0 && wave < 2) red[wave] = ss;
+      __syncthreads();
+      const float rstd = rsqrtf((red[0] + red[1]) / (float)XD + a.eps);
+      if (tid < 96) {
+        const float4 xv = *reinterpret_cast<const float4*>(xsum + tid * 4);
+        const float4 nw = *reinterpret_cast<const float4*>(a.norm_w + tid * 4);
+        float4 y;
+        y.x = (xv.x * rstd) * nw.x; y.y = (xv.y * rstd) * nw.y; y.z = (xv.z * rstd) * nw.z; y.w = (xv.w * rstd) * nw.w;
+        *reinterpret_cast<float4*>(xn + tid * 4) = y;
+      }
+      __syncthreads();
+    }
+    // ---- scores of this tile
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+      const float4 q4 = *reinterpret_cast<const float4*>(xn + part * 48 + f * 4);
+      s += q4.x * kreg[f].x + q4.y * kreg[f].y + q4.z * kreg[f].z + q4.w * kreg[f].w;
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (part == 0) sc[key] = kin ? s * a.scale : -INFINITY;
+    __syncthreads();
+    if (wave == 0) {
+      const float v = sc[lane];
+      const float m_new = fmaxf(m_run, wave_max(v));
+      const float p = (v == -INFINITY) ? 0.f : expf(v - m_new);
+      ps[lane] = p;
+      const float lt = wave_sum(p);
+      if (lane == 0) { red[0] = m_new; red[1] = lt; }
+    }
+    __syncthreads();
+    const float m_new = red[0];
+    const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    l_run = l_run * alpha + red[1];
+    m_run = m_new;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vg < 4) {
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float p = ps[vg * 16 + kk];
+        acc.x += p * vreg[kk].x; acc.y += p * vreg[kk].y; acc.z += p * vreg[kk].z; acc.w += p * vreg[kk].w;
+      }
+    }
+    o4.x = o4.x * alpha + acc.x; o4.y = o4.y * alpha + acc.y; o4.z = o4.z * alpha + acc.z; o4.w = o4.w * alpha + acc.w;
+    __syncthreads();  // sc / ps / red are rewritten by the next tile
+  }
+  if (vg < 4) *reinterpret_cast<float4*>(&opart[vg][vd4 * 4]) = o4;
+  __syncthreads();
+  if (tid < 96) {
+    const float inv = l_run > 0.f ? a.gate / l_run : 0.f;
+    float4 y;
+    const float4 p0 = *reinterpret_cast<const float4*>(&opart[0][tid * 4]);
+    const float4 p1 = *reinterpret_cast<const float4*>(&opart[1][tid * 4]);
+    const float4 p2 = *reinterpret_cast<const float4*>(&opart[2][tid * 4]);
+    const float4 p3 = *reinterpret_cast<const float4*>(&opart[3][tid * 4]);
+    y.x = (((p0.x + p1.x) + p2.x) + p3.x) * inv; y.y = (((p0.y + p1.y) + p2.y) + p3.y) * inv;
+    y.z = (((p0.z + p1.z) + p2.z) + p3.z) * inv; y.w = (((p0.w + p1.w) + p2.w) + p3.w) * inv;
+    if (h == 0) {
+      const float4 xv = *reinterpret_cast<const float4*>(xsum + tid * 4);
+      y.x += xv.x; y.y += xv.y; y.z += xv.z; y.w += xv.w;
+    }
+    *reinterpret_cast<float4*>(a.Y + (int64_t)h * a.y_part_stride + (int64_t)b * a.ldx + tid * 4) = y;
+  }
+}
+
+}  // namespace
+
+extern "C" int sopro_xattn_step_f32(const sopro_xattn_args* p, void* stream) {
+  SOPRO_CHECK_ARG(p != nullptr, "args is NULL");
+  const sopro_xattn_args& a = *p;
+  SOPRO_CHECK_ARG(a.X && a.norm_w && a.Kp && a.Vp && a.Y, "X, norm_w, Kp, Vp, Y must be non-NULL");
+  SOPRO_CHECK_ARG(a.D == XD && a.H >= 1 && a.B > 0 && a.S_cap > 0, "D must be 384, H >= 1");
+  SOPRO_CHECK_ARG(a.np >= 0 && a.np <= 3 && (a.np == 0 || a.Xp), "np in 0..3");
+  SOPRO_CHECK_ARG(aligned16(a.X) && aligned16(a.Kp) && aligned16(a.Vp) && aligned16(a.Y) && aligned16(a.norm_w) && (a.ldx & 3) == 0 &&
+                      (a.xp_stride & 3) == 0 && (a.y_part_stride & 3) == 0,
+                  "16-byte alignment / strides % 4");
+  hipLaunchKernelGGL(xattn_step_kernel, dim3(a.H, a.B), dim3(512), 0, (hipStream_t)stream, a);
+  SOPRO_LAUNCH_CHECK();
+}

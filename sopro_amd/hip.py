@@ -50,6 +50,12 @@ class AttnArgs(C.Structure):
                 ("causal", _i32), ("q_pos0", _i32), ("k_pos0", _i32), ("window", _i32), ("scale", _f32)]
 
 
+class XattnArgs(C.Structure):
+    _fields_ = [("X", _p), ("ldx", _i64), ("Xp", _p), ("xp_stride", _i64), ("norm_w", _p), ("Kp", _p), ("Vp", _p), ("klens", _p),
+                ("Y", _p), ("y_part_stride", _i64), ("eps", _f32), ("gate", _f32), ("scale", _f32),
+                ("np", _i32), ("B", _i32), ("H", _i32), ("D", _i32), ("S_cap", _i32)]
+
+
 class ArState(C.Structure):
     _fields_ = [("x_cur", _p), ("cond", _p), ("emb", _p), ("hist", _p), ("step", _p), ("arrive", _p),
                 ("first_eos", _p), ("stop_t", _p), ("n_stopped", _p), ("recent", _p), ("params", _p), ("seed", C.c_uint64),
@@ -80,6 +86,7 @@ SYMBOLS = {
     "sopro_argmax_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _p]),
     "sopro_attention_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
     "sopro_attn_decode_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
+    "sopro_xattn_step_f32": (C.c_int, [C.POINTER(XattnArgs), _p]),
     "sopro_rope_f32": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "sopro_upsample2_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_final_conv_f32": (C.c_int, [_p, _i64, _p, _f32, _p, _i64, _i32, _i32, _p]),
@@ -317,6 +324,18 @@ def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor
     _check(load().sopro_attention_f32(C.byref(a), _stream()), "sopro_attention_f32")
     if e0 is not None:
         _prof.end("attention_kernel", 0.0, e0)
+
+
+def xattn_step(X: torch.Tensor, Y: torch.Tensor, norm_w: torch.Tensor, Kp: torch.Tensor, Vp: torch.Tensor, klens: Optional[torch.Tensor], *,
+               B: int, H: int, D: int, S_cap: int, gate: float, scale: float, eps: float, Xp: Optional[torch.Tensor] = None, np_: int = 0,
+               xp_stride: int = 0, y_part_stride: int = 0) -> None:
+    a = XattnArgs()
+    a.X, a.ldx, a.Xp, a.xp_stride, a.np = ptr(X), D, ptr(Xp), xp_stride, np_
+    a.norm_w, a.Kp, a.Vp, a.klens = ptr(norm_w), ptr(Kp), ptr(Vp), ptr(klens, torch.int32)
+    a.Y, a.y_part_stride = ptr(Y), y_part_stride
+    a.eps, a.gate, a.scale = eps, gate, scale
+    a.B, a.H, a.D, a.S_cap = B, H, D, S_cap
+    _check(load().sopro_xattn_step_f32(C.byref(a), _stream()), "sopro_xattn_step_f32")
 
 
 def rope(x: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, *, rows: int, rows_per_seg: int, pos0: int, H: int,

@@ -22,6 +22,7 @@ from .config import SoproTTSConfig
 from .pack import pack_sopro, sinusoid_table
 
 RMS_EPS = 1e-6  # reference: src/sopro/nn/blocks.py:27
+_PROBE_NOTAPS = __import__("os").environ.get("SOPRO_PROBE_NOTAPS") == "1"  # timing experiment only (wrong results)
 
 
 @dataclass
@@ -74,6 +75,7 @@ class SoproTTSModel:
         self.V = int(cfg.codebook_size)
         self.Q = int(cfg.num_codebooks)
         packed = pack_sopro(weights, cfg)
+        self.gates = {i: float(packed[f"ar.x_attns.{i}.gate_scale"][0]) for i in cfg.ar_xattn_layers}  # tanh(gate), text.py:131
         self.w: Dict[str, torch.Tensor] = {k: v.to(self.device) for k, v in packed.items()}
         npos = int(cfg.pos_emb_max) + 8  # reference: src/sopro/model.py:62-64
         self.pe = sinusoid_table(npos, self.D).to(self.device)
@@ -473,7 +475,10 @@ class _ARPlan:
         self.q = z(B, D)
         self.att = z(B, D)
         self.logits = z(B, V1)
-        self.kv = {i: z(B, S_cap, 2 * D) for i in cfg.ar_xattn_layers}
+        # folded cross-attention operands per layer: K' = K_h Wq_h, V' = V_h Wo_h^T, [B, H, S_cap, D]
+        self.kp = {i: z(B, 4, S_cap, D) for i in cfg.ar_xattn_layers}
+        self.vp = {i: z(B, 4, S_cap, D) for i in cfg.ar_xattn_layers}
+        self.xp = z(4, B, D)  # per-head partial outputs of the cross-attention block
         self.klens = z(B, dt=torch.int32)
         k = int(cfg.ar_kernel)
         self.rings = [z((k - 1) * int(d) + 1, B, D) for d in cfg.ar_dilations]
@@ -507,15 +512,14 @@ class _ARPlan:
         m, cfg, w, B, D = self.m, self.m.cfg, self.m.w, self.B, self.m.D
         k = int(cfg.ar_kernel)
         H = 4  # reference: src/sopro/nn/generator.py:36
-        # Residual stream = a base buffer, optionally with pending K-slice partial sums of the last FF2: slice 0 of
-        # the FF2 output already carries bias + residual, slices 1..3 are added by whoever stages the stream next.
-        # X0 is where the sampler leaves the next frame's input; XA/XB alternate as GLU outputs; XC receives the
-        # combined stream when a cross-attention follows (its q-projection sums the slices while staging).
-        X0, XA, XB, XC = self.x
+        # Residual stream = a base buffer plus (optionally) three pending partial buffers that the next kernel adds
+        # while staging: the K-slices of a feed-forward output (slice 0 carries bias + residual) or the per-head
+        # outputs of a cross-attention block (head 0 carries the residual).
+        X0, XA, XB, _XC = self.x
         KS = 4 * D // 384  # FF2 K slices
-        P0, PR = self.part[0], self.part[1:]
-        pk = dict(Xp=PR, np_=KS - 1, xp_stride=B * D)
-        base, pend = X0, False
+        pk_ff = dict(Xp=self.part[1:], np_=KS - 1, xp_stride=B * D)
+        pk_xa = dict(Xp=self.xp[1:], np_=H - 1, xp_stride=B * D)
+        base, pend = X0, {}
         nl = 0
         for i, dil in enumerate(cfg.ar_dilations):
             p = f"ar.blocks.{i}"
@@ -523,28 +527,25 @@ class _ARPlan:
             # RMSNorm -> GLU -> ring write -> dilated taps -> +x   (src/sopro/nn/blocks.py:150-157, 76-110)
             hip.skinny(base, w[p + ".glu.w"], out, B=B, N=2 * D, K=D, norm_w=w[p + ".norm.weight"], eps=RMS_EPS, bias=w[p + ".glu.b"],
                        epilogue=hip.EPI_GLU_DW, ring=self.rings[i], dw_w=w[p + ".dw.w"], dw_b=w[p + ".dw.b"], step=self.step_t,
-                       ring_len=(k - 1) * int(dil) + 1, ring_bcap=B, dil=int(dil), ksize=k, **(pk if pend else {}))
+                       **(dict(ring_len=1, dil=1, ksize=1) if _PROBE_NOTAPS else dict(ring_len=(k - 1) * int(dil) + 1, dil=int(dil), ksize=k)),
+                       ring_bcap=B, **pend)
             # RMSNorm -> Linear -> GELU (blocks.py:158-160)
             hip.skinny(out, w[p + ".ff1.w"], self.u, B=B, N=4 * D, K=D, norm_w=w[p + ".ff.norm.weight"], eps=RMS_EPS,
                        bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
             # Linear 4D -> D + residual as 4 K-slices on 4x the workgroups (blocks.py:161-162)
             hip.skinny(self.u, w[p + ".ff2.w"], self.part, B=B, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=out,
                        ksplit=True, y_part_stride=B * D)
-            base, pend = P0, True
+            base, pend = self.part[0], pk_ff
             nl += 3
-            if i in self.kv:
+            if i in self.kp:
                 pa = f"ar.x_attns.{i}"
-                # cached text cross-attention (src/sopro/nn/text.py:85-132)
-                hip.skinny(base, w[pa + ".q.w"], self.q, B=B, N=D, K=D, norm_w=w[pa + ".nq.weight"], eps=RMS_EPS, Xc=XC, **pk)
-                kvb = self.kv[i]
-                hip.attention(self.q, kvb, kvb, self.att, B=B, H=H, dh=D // H, Tq=1, Tk=self.S_cap, ldq=D, ldk=2 * D, ldv=2 * D,
-                              ldo=D, q_bstride=D, k_bstride=self.S_cap * 2 * D, v_bstride=self.S_cap * 2 * D, o_bstride=D,
-                              klens=self.klens, v_off=D, decode=True)
-                hip.skinny(self.att, w[pa + ".o.w"], XC, B=B, N=D, K=D, epilogue=hip.EPI_RES, R=XC, scale=w[pa + ".gate_scale"])
-                base, pend = XC, False
-                nl += 3
+                # cached text cross-attention, projections folded into the cached operands (src/sopro/nn/text.py:85-132)
+                hip.xattn_step(base, self.xp, w[pa + ".nq.weight"], self.kp[i], self.vp[i], self.klens, B=B, H=H, D=D, S_cap=self.S_cap,
+                               gate=m.gates[i], scale=float(D // H) ** -0.5, eps=RMS_EPS, y_part_stride=B * D, **pend)
+                base, pend = self.xp[0], pk_xa
+                nl += 1
         cur = base
-        hk = pk if pend else {}
+        hk = pend
         hip.skinny(cur, w["ar.head.w"], self.logits, B=B, N=m.V + 1, K=D, norm_w=w["ar.norm.weight"], eps=RMS_EPS, bias=w["ar.head.b"], **hk)
         # the sampler writes the next frame's input into state.x_cur, which must be where block 0 reads
         hip.ar_sample(self.state, self.logits, m.V + 1)
@@ -592,11 +593,16 @@ class _ARRun:
             nkv = m.ws.get("ar.nkv", (B * S, D))
             kvd = m.ws.get("ar.kvd", (B * S, 2 * D))
             ts = txt_seq.to(dev).float().contiguous().view(B * S, D)
+            H, dh = 4, D // 4
             for i in cfg.ar_xattn_layers:
                 pa = f"ar.x_attns.{i}"
                 hip.norm(ts, nkv, w[pa + ".nkv.weight"], rows=B * S, C_=D, eps=RMS_EPS)
                 hip.gemm(nkv, w[pa + ".kv.w"], kvd, M=B * S, N=2 * D, K=D)
-                plan.kv[i][:, :S].copy_(kvd.view(B, S, 2 * D))
+                # fold the query / output projections into the cached operands (once per utterance)
+                seg = dict(M=B * S, N=D, K=dh, lda=2 * D, rows_per_seg=S, ldc=D, c_seg_stride=H * S_cap * D)
+                for h in range(H):
+                    hip.gemm(kvd, w[pa + ".q.wT"][h], plan.kp[i], a_off=h * dh, c_off=h * S_cap * D, **seg)
+                    hip.gemm(kvd, w[pa + ".o.w"][:, h * dh:], plan.vp[i], a_off=D + h * dh, c_off=h * S_cap * D, ldw=D, **seg)
             for r in plan.rings:
                 r.zero_()
             plan.hist.zero_()

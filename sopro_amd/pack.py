@@ -71,13 +71,16 @@ def _ssm_block(out: Dict[str, torch.Tensor], w: Dict[str, torch.Tensor], p: str,
     out[p + ".ff2.w"], out[p + ".ff2.b"] = w[p + ".ff.3.weight"], w[p + ".ff.3.bias"]
 
 
-def _xattn(out: Dict[str, torch.Tensor], w: Dict[str, torch.Tensor], p: str, gate_mul: float) -> None:
+def _xattn(out: Dict[str, torch.Tensor], w: Dict[str, torch.Tensor], p: str, gate_mul: float, heads: int = 0) -> None:
     d = w[p + ".q_proj.weight"].shape[0]
     out[p + ".nq.weight"] = w[p + ".nq.weight"]
     out[p + ".nkv.weight"] = w[p + ".nkv.weight"]
     out[p + ".q.w"] = w[p + ".q_proj.weight"]
     out[p + ".kv.w"] = torch.cat([w[p + ".k_proj.weight"], w[p + ".v_proj.weight"]], dim=0).contiguous()
     out[p + ".o.w"] = w[p + ".out_proj.weight"]
+    # per-head transposed query projection [H, d, dh]: folds q_proj into the cached keys (K'_h = K_h Wq_h)
+    if heads:
+        out[p + ".q.wT"] = w[p + ".q_proj.weight"].reshape(heads, d // heads, d).permute(0, 2, 1).contiguous()
     # x + (gmax *) tanh(gate) * a  -> per-column scale of the residual epilogue
     out[p + ".gate_scale"] = (gate_mul * torch.tanh(w[p + ".gate"].float())).reshape(1).repeat(d).contiguous()
 
@@ -109,7 +112,7 @@ def pack_sopro(weights: Dict[str, "np.ndarray"], cfg: SoproTTSConfig) -> Dict[st
     for i in range(int(cfg.n_layers_ar)):
         _ssm_block(out, w, f"ar.blocks.{i}", packed_glu=False)
     for i in cfg.ar_xattn_layers:
-        _xattn(out, w, f"ar.x_attns.{i}", 1.0)
+        _xattn(out, w, f"ar.x_attns.{i}", 1.0, heads=4)  # 4 heads: reference src/sopro/nn/generator.py:36
     out["ar.norm.weight"] = w["ar.norm.weight"]
     out["ar.head.w"], out["ar.head.b"] = w["ar.head.weight"], w["ar.head.bias"]
     # NAR refiner

@@ -157,6 +157,35 @@ def test_skinny_ksplit_partials_are_summed_by_the_consumer(w):
     assert torch.equal(Y, Y2)
 
 
+@pytest.mark.parametrize("S,np_", [(19, 0), (64, 3), (130, 3)])
+def test_xattn_step_folded_block_matches_text_xattn(S, np_, w):
+    """One-launch cross-attention block on folded operands == TextXAttnBlock.forward with cached K/V
+    (src/sopro/nn/text.py:85-132), including the partial-sum input and the per-head partial outputs."""
+    B, H, D = 5, 4, 384
+    dh = D // H
+    p = "ar.x_attns.3"
+    S_cap = ((S + 63) // 64) * 64
+    parts = [rnd(B, D, seed=800 + i) for i in range(np_ + 1)]
+    x = sum(parts)
+    ctx = rnd(B, S, D, seed=810)
+    klens = [S, 1, max(1, S // 2), S, max(1, S - 3)]
+    keep = torch.arange(S)[None, :] < torch.tensor(klens)[:, None]
+    k, v = O.xattn_kv(ctx, w, p, H)
+    ref = O.text_xattn(x[:, None], k, v, keep, w, p)[:, 0]
+    Wq, Wo = w[p + ".q_proj.weight"], w[p + ".out_proj.weight"]
+    Kp = torch.zeros(B, H, S_cap, D)
+    Vp = torch.zeros(B, H, S_cap, D)
+    for h in range(H):
+        Kp[:, h, :S] = k[:, h] @ Wq[h * dh:(h + 1) * dh]              # [B,S,dh] @ [dh,D]
+        Vp[:, h, :S] = v[:, h] @ Wo[:, h * dh:(h + 1) * dh].t()       # [B,S,dh] @ [dh,D]
+    Y = torch.full((H, B, D), float("nan"), device=DEV)
+    Pd = dev(torch.stack(parts))
+    hip.xattn_step(Pd[0], Y, dev(w[p + ".nq.weight"]), dev(Kp), dev(Vp), dev(torch.tensor(klens, dtype=torch.int32)), B=B, H=H, D=D,
+                   S_cap=S_cap, gate=float(torch.tanh(w[p + ".gate"])), scale=dh ** -0.5, eps=1e-6, Xp=Pd[1:] if np_ else None, np_=np_,
+                   xp_stride=B * D, y_part_stride=B * D)
+    close(Y.sum(0), ref, 5e-5, "folded cross-attention block")
+
+
 @pytest.mark.parametrize("S", [5, 64, 130])
 def test_attention_decode_single_query(S):
     B, H, dh = 5, 4, 96
