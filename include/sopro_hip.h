@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 4
+#define SOPRO_ABI_VERSION 5
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -78,38 +78,36 @@ typedef struct sopro_gemm_args {
 int sopro_gemm_f32(const sopro_gemm_args* args, void* stream);
 
 /* Batch-of-at-most-a-few-dozen-rows contraction for the autoregressive step
- * (src/sopro/nn/generator.py:98-130): Y[b, n] = epi( sum_k norm(Xin)[b, k] * W[n, k] + bias[n] ),
- * Xin = X + xbias + sum_{s<np} Xp[s]  (the producer's K-slice partial sums, added in a fixed order).
- * One workgroup = 16 output columns x one 384-wide K slice; fp32 v_mfma_f32_16x16x4_f32.  K % 384 == 0.
- * norm_w != NULL (K == 384) fuses the RMSNorm of src/sopro/nn/blocks.py:26-37 in front.
- * ksplit = 1 with K > 384: the K/384 slices go to different workgroups and Y receives K/384 partial
- *   results [slice][B][ldy] (y_part_stride elements apart, no bias / epilogue); the consumer passes them as Xp.
- * Xc != NULL (K == 384): the combined Xin is also written to Xc[b, 0..K) (each workgroup its 16 columns).
- *   EPI_GLU_DW (needs N == 2*D == 2*K, W in the natural torch layout [value rows | gate rows]):
+ * (src/sopro/nn/generator.py:98-130): Y[b, n] = epi( rs[b] * sum_k Xin[b, k] * W[n, k] + bias[n] ),
+ * Xin = X + sum_{s<np} Xp[s]  (the producer's partial sums, added in a fixed order; np is 0 or 3).
+ * One workgroup = 16 output columns x one 384-wide K slice x 16 batch rows; fp32 v_mfma_f32_16x16x4_f32.
+ * K % 384 == 0.  rms_norm != 0 (K == 384): rs[b] = rsqrt(mean(Xin[b]^2) + eps), i.e. the RMSNorm of
+ * src/sopro/nn/blocks.py:26-37 whose weight vector the host has folded into W (W[n,k] * w_norm[k]); else rs = 1.
+ * ksplit = 1 with K > 384: the K/384 slices go to different workgroups and Y receives K/384 partial results
+ *   [slice][B][ldy] (y_part_stride elements apart); with EPI_RES slice 0 carries bias + residual, the other
+ *   slices are raw; the consumer passes slice 0 as X and slices 1..3 as Xp.
+ *   EPI_GLU_DW (N == 2*K == 768, W in the natural torch layout [value rows | gate rows], rms_norm set):
  *     h = value*sigmoid(gate); ring[(t % L)][b] = h; y = dwconv taps over the ring; Y = Xin + y
  *     == SSMLiteBlock.forward_step first half, src/sopro/nn/blocks.py:150-157 and :76-110.
- *     `step` is a device pointer to the current frame index t. */
+ *     `step` is a device pointer to the current frame index t; ksize <= 13. */
 typedef struct sopro_skinny_args {
   const float* X; int64_t ldx;
-  const float* norm_w; float eps;
   const float* W; int64_t ldw;
   const float* bias;
   float* Y; int64_t ldy;
   const float* R; int64_t ldr;
   const float* scale;
-  int32_t B, N, K, epilogue;
-  /* EPI_GLU_DW */
-  float* ring;            /* [L, ring_bcap, D] */
+  float* ring;            /* EPI_GLU_DW: [L, ring_bcap, D] */
   const float* dw_w;      /* [ksize, D] (tap-major, oldest tap first) */
   const float* dw_b;      /* [D] */
   const int32_t* step;    /* device scalar */
-  int32_t ring_len, ring_bcap, dil, ksize;
-  /* K-split plumbing */
   const float* Xp; int64_t xp_stride;   /* np partial buffers laid out like X */
-  const float* xbias;                   /* [K] or NULL */
-  float* Xc; int64_t ldxc;              /* optional combined-input side output */
   int64_t y_part_stride;
-  int32_t np, ksplit;
+  long long* dbg;         /* optional [workgroups][8] shader-clock stamps (profiling aid), NULL in production */
+  float eps;
+  int32_t B, N, K, epilogue;
+  int32_t ring_len, ring_bcap, dil, ksize;
+  int32_t np, ksplit, rms_norm;
 } sopro_skinny_args;
 int sopro_skinny_f32(const sopro_skinny_args* args, void* stream);
 

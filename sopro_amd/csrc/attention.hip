@@ -347,7 +347,8 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
       const float rstd = rsqrtf((red[0] + red[1]) / (float)XD + a.eps);
       if (tid < 96) {
         const float4 xv = *reinterpret_cast<const float4*>(xsum + tid * 4);
-        const float4 nw = *reinterpret_cast<const float4*>(a.norm_w + tid * 4);
+        float4 nw = make_float4(1.f, 1.f, 1.f, 1.f);  // NULL: the norm weight is folded into Kp by the host
+        if (a.norm_w) nw = *reinterpret_cast<const float4*>(a.norm_w + tid * 4);
         float4 y;
         y.x = (xv.x * rstd) * nw.x; y.y = (xv.y * rstd) * nw.y; y.z = (xv.z * rstd) * nw.z; y.w = (xv.w * rstd) * nw.w;
         *reinterpret_cast<float4*>(xn + tid * 4) = y;
@@ -414,10 +415,10 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
 extern "C" int sopro_xattn_step_f32(const sopro_xattn_args* p, void* stream) {
   SOPRO_CHECK_ARG(p != nullptr, "args is NULL");
   const sopro_xattn_args& a = *p;
-  SOPRO_CHECK_ARG(a.X && a.norm_w && a.Kp && a.Vp && a.Y, "X, norm_w, Kp, Vp, Y must be non-NULL");
+  SOPRO_CHECK_ARG(a.X && a.Kp && a.Vp && a.Y, "X, Kp, Vp, Y must be non-NULL");
   SOPRO_CHECK_ARG(a.D == XD && a.H >= 1 && a.B > 0 && a.S_cap > 0, "D must be 384, H >= 1");
   SOPRO_CHECK_ARG(a.np >= 0 && a.np <= 3 && (a.np == 0 || a.Xp), "np in 0..3");
-  SOPRO_CHECK_ARG(aligned16(a.X) && aligned16(a.Kp) && aligned16(a.Vp) && aligned16(a.Y) && aligned16(a.norm_w) && (a.ldx & 3) == 0 &&
+  SOPRO_CHECK_ARG(aligned16(a.X) && aligned16(a.Kp) && aligned16(a.Vp) && aligned16(a.Y) && (!a.norm_w || aligned16(a.norm_w)) && (a.ldx & 3) == 0 &&
                       (a.xp_stride & 3) == 0 && (a.y_part_stride & 3) == 0,
                   "16-byte alignment / strides % 4");
   hipLaunchKernelGGL(xattn_step_kernel, dim3(a.H, a.B), dim3(512), 0, (hipStream_t)stream, a);

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -34,13 +34,12 @@ class GemmArgs(C.Structure):
 
 
 class SkinnyArgs(C.Structure):
-    _fields_ = [("X", _p), ("ldx", _i64), ("norm_w", _p), ("eps", _f32), ("W", _p), ("ldw", _i64), ("bias", _p),
-                ("Y", _p), ("ldy", _i64), ("R", _p), ("ldr", _i64), ("scale", _p),
+    _fields_ = [("X", _p), ("ldx", _i64), ("W", _p), ("ldw", _i64), ("bias", _p), ("Y", _p), ("ldy", _i64),
+                ("R", _p), ("ldr", _i64), ("scale", _p), ("ring", _p), ("dw_w", _p), ("dw_b", _p), ("step", _p),
+                ("Xp", _p), ("xp_stride", _i64), ("y_part_stride", _i64), ("dbg", _p), ("eps", _f32),
                 ("B", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32),
-                ("ring", _p), ("dw_w", _p), ("dw_b", _p), ("step", _p),
                 ("ring_len", _i32), ("ring_bcap", _i32), ("dil", _i32), ("ksize", _i32),
-                ("Xp", _p), ("xp_stride", _i64), ("xbias", _p), ("Xc", _p), ("ldxc", _i64), ("y_part_stride", _i64),
-                ("np", _i32), ("ksplit", _i32)]
+                ("np", _i32), ("ksplit", _i32), ("rms_norm", _i32)]
 
 
 class AttnArgs(C.Structure):
@@ -215,29 +214,25 @@ def gemm(A: torch.Tensor, W: torch.Tensor, Cout: torch.Tensor, *, M: int, N: int
 
 
 def skinny(X: torch.Tensor, W: torch.Tensor, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: Optional[int] = None,
-           ldy: Optional[int] = None, norm_w: Optional[torch.Tensor] = None, eps: float = 1e-6,
-           bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE, R: Optional[torch.Tensor] = None,
-           ldr: Optional[int] = None, scale: Optional[torch.Tensor] = None, ring: Optional[torch.Tensor] = None,
-           dw_w: Optional[torch.Tensor] = None, dw_b: Optional[torch.Tensor] = None, step: Optional[torch.Tensor] = None,
-           ring_len: int = 0, ring_bcap: int = 0, dil: int = 1, ksize: int = 1, Xp: Optional[torch.Tensor] = None,
-           np_: int = 0, xp_stride: int = 0, xbias: Optional[torch.Tensor] = None, Xc: Optional[torch.Tensor] = None,
-           ldxc: Optional[int] = None, ksplit: bool = False, y_part_stride: int = 0) -> None:
+           ldy: Optional[int] = None, rms_norm: bool = False, eps: float = 1e-6, bias: Optional[torch.Tensor] = None,
+           epilogue: int = EPI_NONE, R: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
+           scale: Optional[torch.Tensor] = None, ring: Optional[torch.Tensor] = None, dw_w: Optional[torch.Tensor] = None,
+           dw_b: Optional[torch.Tensor] = None, step: Optional[torch.Tensor] = None, ring_len: int = 0, ring_bcap: int = 0,
+           dil: int = 1, ksize: int = 1, Xp: Optional[torch.Tensor] = None, np_: int = 0, xp_stride: int = 0,
+           ksplit: bool = False, y_part_stride: int = 0, dbg: Optional[torch.Tensor] = None) -> None:
+    """AR-step contraction.  With rms_norm the RMSNorm weight must already be folded into W (W * w_norm[None, :])."""
     a = SkinnyArgs()
-    a.Xp, a.np, a.xp_stride, a.xbias = ptr(Xp), np_, xp_stride, ptr(xbias)
-    a.Xc, a.ldxc = ptr(Xc), (K if ldxc is None else ldxc)
-    a.ksplit, a.y_part_stride = int(ksplit), y_part_stride
     a.X, a.ldx = ptr(X), (K if ldx is None else ldx)
-    a.norm_w, a.eps = ptr(norm_w), eps
-    a.W, a.ldw = ptr(W), K
-    a.bias = ptr(bias)
+    a.W, a.ldw, a.bias = ptr(W), K, ptr(bias)
     n_out = N // 2 if epilogue == EPI_GLU_DW else N
     a.Y, a.ldy = ptr(Y), (n_out if ldy is None else ldy)
-    a.R, a.ldr = ptr(R), (n_out if ldr is None else ldr)
-    a.scale = ptr(scale)
+    a.R, a.ldr, a.scale = ptr(R), (n_out if ldr is None else ldr), ptr(scale)
+    a.ring, a.dw_w, a.dw_b, a.step = ptr(ring), ptr(dw_w), ptr(dw_b), ptr(step, torch.int32)
+    a.Xp, a.xp_stride, a.y_part_stride, a.dbg = ptr(Xp), xp_stride, y_part_stride, ptr(dbg, torch.int64)
+    a.eps = eps
     a.B, a.N, a.K, a.epilogue = B, N, K, epilogue
-    a.ring, a.dw_w, a.dw_b = ptr(ring), ptr(dw_w), ptr(dw_b)
-    a.step = ptr(step, torch.int32)
     a.ring_len, a.ring_bcap, a.dil, a.ksize = ring_len, ring_bcap, dil, ksize
+    a.np, a.ksplit, a.rms_norm = np_, int(ksplit), int(rms_norm)
     _check(load().sopro_skinny_f32(C.byref(a), _stream()), "sopro_skinny_f32")
 
 
@@ -326,7 +321,7 @@ def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor
         _prof.end("attention_kernel", 0.0, e0)
 
 
-def xattn_step(X: torch.Tensor, Y: torch.Tensor, norm_w: torch.Tensor, Kp: torch.Tensor, Vp: torch.Tensor, klens: Optional[torch.Tensor], *,
+def xattn_step(X: torch.Tensor, Y: torch.Tensor, norm_w: Optional[torch.Tensor], Kp: torch.Tensor, Vp: torch.Tensor, klens: Optional[torch.Tensor], *,
                B: int, H: int, D: int, S_cap: int, gate: float, scale: float, eps: float, Xp: Optional[torch.Tensor] = None, np_: int = 0,
                xp_stride: int = 0, y_part_stride: int = 0) -> None:
     a = XattnArgs()

@@ -525,12 +525,12 @@ class _ARPlan:
             p = f"ar.blocks.{i}"
             out = XA if i % 2 == 0 else XB
             # RMSNorm -> GLU -> ring write -> dilated taps -> +x   (src/sopro/nn/blocks.py:150-157, 76-110)
-            hip.skinny(base, w[p + ".glu.w"], out, B=B, N=2 * D, K=D, norm_w=w[p + ".norm.weight"], eps=RMS_EPS, bias=w[p + ".glu.b"],
+            hip.skinny(base, w[p + ".glu.w"], out, B=B, N=2 * D, K=D, rms_norm=True, eps=RMS_EPS, bias=w[p + ".glu.b"],
                        epilogue=hip.EPI_GLU_DW, ring=self.rings[i], dw_w=w[p + ".dw.w"], dw_b=w[p + ".dw.b"], step=self.step_t,
                        **(dict(ring_len=1, dil=1, ksize=1) if _PROBE_NOTAPS else dict(ring_len=(k - 1) * int(dil) + 1, dil=int(dil), ksize=k)),
                        ring_bcap=B, **pend)
             # RMSNorm -> Linear -> GELU (blocks.py:158-160)
-            hip.skinny(out, w[p + ".ff1.w"], self.u, B=B, N=4 * D, K=D, norm_w=w[p + ".ff.norm.weight"], eps=RMS_EPS,
+            hip.skinny(out, w[p + ".ff1.w"], self.u, B=B, N=4 * D, K=D, rms_norm=True, eps=RMS_EPS,
                        bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
             # Linear 4D -> D + residual as 4 K-slices on 4x the workgroups (blocks.py:161-162)
             hip.skinny(self.u, w[p + ".ff2.w"], self.part, B=B, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=out,
@@ -540,13 +540,13 @@ class _ARPlan:
             if i in self.kp:
                 pa = f"ar.x_attns.{i}"
                 # cached text cross-attention, projections folded into the cached operands (src/sopro/nn/text.py:85-132)
-                hip.xattn_step(base, self.xp, w[pa + ".nq.weight"], self.kp[i], self.vp[i], self.klens, B=B, H=H, D=D, S_cap=self.S_cap,
+                hip.xattn_step(base, self.xp, None, self.kp[i], self.vp[i], self.klens, B=B, H=H, D=D, S_cap=self.S_cap,
                                gate=m.gates[i], scale=float(D // H) ** -0.5, eps=RMS_EPS, y_part_stride=B * D, **pend)
                 base, pend = self.xp[0], pk_xa
                 nl += 1
         cur = base
         hk = pend
-        hip.skinny(cur, w["ar.head.w"], self.logits, B=B, N=m.V + 1, K=D, norm_w=w["ar.norm.weight"], eps=RMS_EPS, bias=w["ar.head.b"], **hk)
+        hip.skinny(cur, w["ar.head.w"], self.logits, B=B, N=m.V + 1, K=D, rms_norm=True, eps=RMS_EPS, bias=w["ar.head.b"], **hk)
         # the sampler writes the next frame's input into state.x_cur, which must be where block 0 reads
         hip.ar_sample(self.state, self.logits, m.V + 1)
         self.nlaunch = nl + 2

@@ -109,12 +109,20 @@ def pack_sopro(weights: Dict[str, "np.ndarray"], cfg: SoproTTSConfig) -> Dict[st
         out[f"spk_film.{n}.w"], out[f"spk_film.{n}.b"] = w[f"spk_film.{n}.weight"], w[f"spk_film.{n}.bias"]
     out["spk_film.norm.weight"], out["spk_film.norm.bias"] = w["spk_film.norm.weight"], w["spk_film.norm.bias"]
     # AR generator: natural GLU layout (the step kernel pairs value/gate rows itself)
+    # The step kernels apply the RMSNorm row scale to the accumulator, so the norm's weight vector is folded into the
+    # following projection here: (x * rstd * w_norm) @ W^T == rstd * (x @ (W * w_norm)^T)   (blocks.py:26-37)
     for i in range(int(cfg.n_layers_ar)):
-        _ssm_block(out, w, f"ar.blocks.{i}", packed_glu=False)
+        p = f"ar.blocks.{i}"
+        _ssm_block(out, w, p, packed_glu=False)
+        out[p + ".glu.w"] = (out[p + ".glu.w"] * w[p + ".norm.weight"][None, :]).contiguous()
+        out[p + ".ff1.w"] = (out[p + ".ff1.w"] * w[p + ".ff.0.weight"][None, :]).contiguous()
     for i in cfg.ar_xattn_layers:
-        _xattn(out, w, f"ar.x_attns.{i}", 1.0, heads=4)  # 4 heads: reference src/sopro/nn/generator.py:36
+        p = f"ar.x_attns.{i}"
+        _xattn(out, w, p, 1.0, heads=4)  # 4 heads: reference src/sopro/nn/generator.py:36
+        out[p + ".q.wT"] = (out[p + ".q.wT"] * w[p + ".nq.weight"][None, :, None]).contiguous()  # fold RMSNorm_nq's weight
     out["ar.norm.weight"] = w["ar.norm.weight"]
-    out["ar.head.w"], out["ar.head.b"] = w["ar.head.weight"], w["ar.head.bias"]
+    out["ar.head.w"] = (w["ar.head.weight"] * w["ar.norm.weight"][None, :]).contiguous()
+    out["ar.head.b"] = w["ar.head.bias"]
     # NAR refiner
     for i in range(int(cfg.n_layers_nar)):
         _ssm_block(out, w, f"nar.blocks.{i}", packed_glu=True)

@@ -33,7 +33,7 @@ def test_struct_layouts_match_the_header(tmp_path):
 
     checks = {
         "sopro_gemm_args": (hip.GemmArgs, ["A", "W", "C", "R", "scale", "pro_vec", "M", "rows_per_seg", "epilogue"]),
-        "sopro_skinny_args": (hip.SkinnyArgs, ["X", "norm_w", "eps", "W", "Y", "scale", "B", "epilogue", "ring", "step", "ring_len", "ksize", "Xp", "xbias", "Xc", "y_part_stride", "np", "ksplit"]),
+        "sopro_skinny_args": (hip.SkinnyArgs, ["X", "W", "Y", "scale", "ring", "step", "Xp", "y_part_stride", "dbg", "eps", "B", "epilogue", "ring_len", "ksize", "np", "ksplit", "rms_norm"]),
         "sopro_attn_args": (hip.AttnArgs, ["Q", "K", "V", "O", "klens", "B", "Tk", "causal", "window", "scale"]),
         "sopro_xattn_args": (hip.XattnArgs, ["X", "Xp", "norm_w", "Kp", "klens", "Y", "eps", "scale", "np", "S_cap"]),
         "sopro_ar_state": (hip.ArState, ["x_cur", "emb", "hist", "recent", "params", "seed", "B", "bos_row"]),

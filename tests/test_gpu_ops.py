@@ -105,7 +105,7 @@ def test_skinny_norm_head(B):
     K, N = 384, 2049
     X, nw, W, b = rnd(B, K, seed=20), 1 + 0.1 * rnd(K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23)
     Y = torch.full((B, N), float("nan"), device=DEV)
-    hip.skinny(dev(X), dev(W), Y, B=B, N=N, K=K, norm_w=dev(nw), eps=1e-6, bias=dev(b))
+    hip.skinny(dev(X), dev(W * nw[None, :]), Y, B=B, N=N, K=K, rms_norm=True, eps=1e-6, bias=dev(b))  # norm weight folded into W
     close(Y, O.rmsnorm(X, nw) @ W.t() + b, 5e-5, f"skinny head B={B}")
 
 
@@ -133,10 +133,9 @@ def test_skinny_ksplit_partials_are_summed_by_the_consumer(w):
     close(P[1:].sum(0) + P[0] - R.to(DEV) - b2.to(DEV), U @ W2.t(), 1e-4, "raw partial sums")
     pk = dict(Xp=P[1:], np_=3, xp_stride=B * D)
     nw, Wq = 1 + 0.1 * rnd(D, seed=604), rnd(D, D, seed=605, scale=D ** -0.5)
+    Wqf = dev(Wq * nw[None, :])
     Y = torch.empty(B, D, device=DEV)
-    C = torch.full((B, D), float("nan"), device=DEV)
-    hip.skinny(P[0], dev(Wq), Y, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, Xc=C, **pk)
-    close(C, x2, 1e-4, "combined stream side output")
+    hip.skinny(P[0], Wqf, Y, B=B, N=D, K=D, rms_norm=True, eps=1e-6, **pk)
     close(Y, O.rmsnorm(x2, nw) @ Wq.t(), 1e-4, "consumer of partials")
     # the GLU / ring-buffer tail adds its result to the combined input
     p = "ar.blocks.1"
@@ -144,7 +143,8 @@ def test_skinny_ksplit_partials_are_summed_by_the_consumer(w):
     L = (k - 1) * dil + 1
     ring = torch.zeros(L, B, D, device=DEV)
     step = torch.zeros(1, dtype=torch.int32, device=DEV)
-    hip.skinny(P[0], dev(w[p + ".glu.pro.weight"]), Y, B=B, N=2 * D, K=D, norm_w=dev(w[p + ".norm.weight"]), eps=1e-6,
+    gwf = dev(w[p + ".glu.pro.weight"] * w[p + ".norm.weight"][None, :])
+    hip.skinny(P[0], gwf, Y, B=B, N=2 * D, K=D, rms_norm=True, eps=1e-6,
                bias=dev(w[p + ".glu.pro.bias"]), epilogue=hip.EPI_GLU_DW, ring=ring, dw_w=dev(pack.pack_dw(w[p + ".dw.dw.weight"])),
                dw_b=dev(w[p + ".dw.dw.bias"]), step=step, ring_len=L, ring_bcap=B, dil=dil, ksize=k, **pk)
     h = O.glu(O.rmsnorm(x2, w[p + ".norm.weight"]), w, p + ".glu")
@@ -152,8 +152,8 @@ def test_skinny_ksplit_partials_are_summed_by_the_consumer(w):
     close(Y, x2 + y, 1e-4, "glu tail on a partial-sum input")
     # run-to-run bit reproducibility (no atomics anywhere on this path)
     Y2 = torch.empty(B, D, device=DEV)
-    hip.skinny(P[0], dev(Wq), Y2, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, **pk)
-    hip.skinny(P[0], dev(Wq), Y, B=B, N=D, K=D, norm_w=dev(nw), eps=1e-6, **pk)
+    hip.skinny(P[0], Wqf, Y2, B=B, N=D, K=D, rms_norm=True, eps=1e-6, **pk)
+    hip.skinny(P[0], Wqf, Y, B=B, N=D, K=D, rms_norm=True, eps=1e-6, **pk)
     assert torch.equal(Y, Y2)
 
 
@@ -176,11 +176,11 @@ def test_xattn_step_folded_block_matches_text_xattn(S, np_, w):
     Kp = torch.zeros(B, H, S_cap, D)
     Vp = torch.zeros(B, H, S_cap, D)
     for h in range(H):
-        Kp[:, h, :S] = k[:, h] @ Wq[h * dh:(h + 1) * dh]              # [B,S,dh] @ [dh,D]
+        Kp[:, h, :S] = (k[:, h] @ Wq[h * dh:(h + 1) * dh]) * w[p + ".nq.weight"]   # [B,S,dh] @ [dh,D], RMSNorm weight folded in
         Vp[:, h, :S] = v[:, h] @ Wo[:, h * dh:(h + 1) * dh].t()       # [B,S,dh] @ [dh,D]
     Y = torch.full((H, B, D), float("nan"), device=DEV)
     Pd = dev(torch.stack(parts))
-    hip.xattn_step(Pd[0], Y, dev(w[p + ".nq.weight"]), dev(Kp), dev(Vp), dev(torch.tensor(klens, dtype=torch.int32)), B=B, H=H, D=D,
+    hip.xattn_step(Pd[0], Y, None, dev(Kp), dev(Vp), dev(torch.tensor(klens, dtype=torch.int32)), B=B, H=H, D=D,
                    S_cap=S_cap, gate=float(torch.tanh(w[p + ".gate"])), scale=dh ** -0.5, eps=1e-6, Xp=Pd[1:] if np_ else None, np_=np_,
                    xp_stride=B * D, y_part_stride=B * D)
     close(Y.sum(0), ref, 5e-5, "folded cross-attention block")
@@ -211,8 +211,8 @@ def test_skinny_glu_ring_buffer_step_matches_forward_step(B, dil, w, cfg):
     ring_o = torch.zeros(B, L, D)
     ring = torch.zeros(L, B, D, device=DEV)
     step = torch.zeros(1, dtype=torch.int32, device=DEV)
-    gw, gb = dev(w[p + ".glu.pro.weight"]), dev(w[p + ".glu.pro.bias"])
-    dww, dwb, nw = dev(pack.pack_dw(w[p + ".dw.dw.weight"])), dev(w[p + ".dw.dw.bias"]), dev(w[p + ".norm.weight"])
+    gw, gb = dev(w[p + ".glu.pro.weight"] * w[p + ".norm.weight"][None, :]), dev(w[p + ".glu.pro.bias"])
+    dww, dwb = dev(pack.pack_dw(w[p + ".dw.dw.weight"])), dev(w[p + ".dw.dw.bias"])
     Y = torch.empty(B, D, device=DEV)
     for t in range(30):
         x = rnd(B, D, seed=100 + t)
@@ -221,7 +221,7 @@ def test_skinny_glu_ring_buffer_step_matches_forward_step(B, dil, w, cfg):
         taps = ring_o[:, torch.arange(0, k * dil, dil)]
         y = (taps.transpose(1, 2) * w[p + ".dw.dw.weight"].squeeze(1)).sum(-1) + w[p + ".dw.dw.bias"]
         step.fill_(t)
-        hip.skinny(dev(x), gw, Y, B=B, N=2 * D, K=D, norm_w=nw, eps=1e-6, bias=gb, epilogue=hip.EPI_GLU_DW, ring=ring,
+        hip.skinny(dev(x), gw, Y, B=B, N=2 * D, K=D, rms_norm=True, eps=1e-6, bias=gb, epilogue=hip.EPI_GLU_DW, ring=ring,
                    dw_w=dww, dw_b=dwb, step=step, ring_len=L, ring_bcap=B, dil=dil, ksize=k)
         close(Y, x + y, 5e-5, f"glu+dw step {t}")
 
