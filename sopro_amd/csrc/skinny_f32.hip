@@ -28,82 +28,71 @@ constexpr int XLD = KS + 4;    // padded LDS row
 constexpr int MAXTAPS = 13;
 constexpr int SQ = 6;          // float4 per staging thread and source (24 floats)
 
-template <int NWB, int NP, bool NORM>
+template <bool GLU, int NP, bool NORM>
 __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) {
   __shared__ float xs[16 * XLD];          // raw (combined) input slice
-  __shared__ float red[4 * NWB * 4 * 64];
+  __shared__ float red[4 * 4 * 64];
   __shared__ float rstd_s[16];
-  __shared__ float taps_s[NWB == 2 ? 4 * (MAXTAPS - 1) * 64 : 1];  // [row-in-quad r][tap j][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int ntile = blockIdx.x;
   const int bbase = blockIdx.z * 16;
   const int nslices = a.K / KS;
   const bool partial_out = gridDim.y > 1;
-  const int D = a.N / 2;  // GLU_DW only
-  constexpr bool dw = (NWB == 2);
+  const int D = a.N / 2;  // GLU tail only
   long long* dbg = a.dbg ? a.dbg + ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 : nullptr;
   if (dbg && tid == 0) dbg[0] = clock64();
 
   // frame index: scalar load (own counter), waited for only where the tap addresses are formed
   int t_now = 0;
-  if (dw) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t_now) : "s"(a.step) : "memory");
+  if (GLU) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t_now) : "s"(a.step) : "memory");
 
-  const int ncols = dw ? D : a.N;
-  const int n_col = ntile * 16 + i;
-  const bool col_ok = n_col < ncols;
-  const int n_ld = col_ok ? n_col : ncols - 1;  // clamped: loads stay in bounds, results are discarded
+  // Column owned by this lane.  Plain: 16 output columns per workgroup.  GLU tail: 8 channels per workgroup, lanes
+  // 0-7 carry the value rows and lanes 8-15 the gate rows of the same channels (one B operand, paired by a shuffle).
+  const int ncols = GLU ? D : a.N;
+  const int n_col = GLU ? ntile * 8 + (i & 7) : ntile * 16 + i;
+  const bool col_ok = n_col < ncols && (!GLU || i < 8);
+  const int n_ld = min(n_col, ncols - 1);  // clamped: loads stay in bounds, results are discarded
+  const int w_row = GLU ? ((i < 8) ? n_ld : D + n_ld) : n_ld;
   const bool res_here = a.epilogue == SOPRO_EPI_RES && (!partial_out || blockIdx.y == 0);
   const bool bias_here = !partial_out || (blockIdx.y == 0 && a.epilogue == SOPRO_EPI_RES);
 
-  // ---- epilogue operands (wave 0 finishes the tile: D[r] = row (lane>>4)*4 + r, column lane&15)
-  float e_bias = 0.f, e_bias_g = 0.f, e_scale = 1.f, e_dwb = 0.f;
-  float e_res[4] = {0.f, 0.f, 0.f, 0.f};
+  // ---- epilogue operands: wave w finishes accumulator row r == w, i.e. batch row bbase + (lane>>4)*4 + w, column lane&15
+  const int b_row = bbase + g * 4 + wave;
+  const int b_cl = min(b_row, a.B - 1);
+  float e_bias = 0.f, e_scale = 1.f, e_dwb = 0.f, e_res = 0.f;
   float tapw[MAXTAPS];
-  int brow[4];
+  if (a.bias && bias_here) e_bias = a.bias[w_row];
+  if (a.scale) e_scale = a.scale[n_ld];
+  if (res_here) e_res = a.R[(int64_t)b_cl * a.ldr + n_ld];
+  if (GLU) {
+    e_dwb = a.dw_b[n_ld];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) brow[r] = min(bbase + g * 4 + r, a.B - 1);
-  if (wave == 0) {
-    if (a.bias && bias_here) {
-      e_bias = a.bias[n_ld];
-      if (dw) e_bias_g = a.bias[D + n_ld];
-    }
-    if (a.scale) e_scale = a.scale[n_ld];
-    if (res_here) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) e_res[r] = a.R[(int64_t)brow[r] * a.ldr + n_ld];
-    }
-    if (dw) {
-      e_dwb = a.dw_b[n_ld];
-#pragma unroll
-      for (int j = 0; j < MAXTAPS; ++j) tapw[j] = a.dw_w[(int64_t)min(j, a.ksize - 1) * D + n_ld];
+    for (int j = 0; j < MAXTAPS; ++j) {
+      // slots 0..11: weights of the older taps (0 beyond ksize-1), slot 12: weight of the newest tap
+      const float wv = a.dw_w[(int64_t)min(j, a.ksize - 1) * D + n_ld];
+      tapw[j] = (j == MAXTAPS - 1 || j < a.ksize - 1) ? wv : 0.f;
     }
   }
 
-  const float* wrow[NWB];
-  wrow[0] = a.W + (int64_t)n_ld * a.ldw;
-  if (dw) wrow[NWB - 1] = a.W + (int64_t)(D + n_ld) * a.ldw;
-
-  f32x4 acc[NWB];
-#pragma unroll
-  for (int wb = 0; wb < NWB; ++wb) acc[wb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* wrow = a.W + (int64_t)w_row * a.ldw;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int srow = tid >> 4, spart = tid & 15;  // staging: row, 24-float part
   const int b_ld = min(bbase + srow, a.B - 1);
-  float tapv[MAXTAPS - 1];  // wave w fetches the taps of accumulator row r == w; wave 0 picks them up from LDS
+  unsigned slot0 = 0;  // ring slot of the oldest tap, (t + 1) mod L: one division, then increments
+  float tapv[MAXTAPS - 1];
 
   for (int ks = blockIdx.y; ks < nslices; ks += gridDim.y) {
     const int k0 = ks * KS;
-    // ---- all weight fragments of this slice for this wave (3 chunks x 2 float4 x NWB)
-    float4 wf[NWB][3][2];
+    // ---- all weight fragments of this slice for this wave (3 chunks x 2 float4)
+    float4 wf[3][2];
 #pragma unroll
-    for (int wb = 0; wb < NWB; ++wb)
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
-        const int kb = k0 + (wave * 3 + cc) * 32 + g * 8;
-        wf[wb][cc][0] = *reinterpret_cast<const float4*>(wrow[wb] + kb);
-        wf[wb][cc][1] = *reinterpret_cast<const float4*>(wrow[wb] + kb + 4);
-      }
+    for (int cc = 0; cc < 3; ++cc) {
+      const int kb = k0 + (wave * 3 + cc) * 32 + g * 8;
+      wf[cc][0] = *reinterpret_cast<const float4*>(wrow + kb);
+      wf[cc][1] = *reinterpret_cast<const float4*>(wrow + kb + 4);
+    }
     // ---- input slice (+ producer's partial sums, fixed order) -> LDS
     {
       float4 xv[SQ], pv[NP > 0 ? NP : 1][SQ];
@@ -137,14 +126,16 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
       for (int q = 0; q < SQ; ++q) *reinterpret_cast<float4*>(dst + q * 4) = xv[q];
     }
     // ---- ring-buffer taps of earlier frames: addresses need the frame index; values are used in the epilogue
-    if (dw) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t_now));  // uniform: every wave waits for the scalar load
-    if (dw) {
+    if (GLU) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t_now));
       const unsigned L = (unsigned)a.ring_len;
-      const int bw = min(bbase + g * 4 + wave, a.B - 1);
+      slot0 = ((unsigned)t_now + 1u) % L;
+      unsigned slot = slot0;
 #pragma unroll
       for (int j = 0; j < MAXTAPS - 1; ++j) {
-        const unsigned slot = ((unsigned)t_now + 1u + (unsigned)(j * a.dil)) % L;
-        tapv[j] = a.ring[((int64_t)slot * a.ring_bcap + bw) * D + n_ld];
+        tapv[j] = a.ring[((int64_t)slot * a.ring_bcap + b_cl) * D + n_ld];
+        slot += (unsigned)a.dil;
+        if (slot >= L) slot -= L;
       }
     }
     if (dbg && tid == 0) dbg[1] = clock64();
@@ -156,82 +147,60 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
       const int kl = (wave * 3 + cc) * 32 + g * 8;
       const float4 x0 = *reinterpret_cast<const float4*>(xs + i * XLD + kl);
       const float4 x1 = *reinterpret_cast<const float4*>(xs + i * XLD + kl + 4);
-#pragma unroll
-      for (int wb = 0; wb < NWB; ++wb) {
-        f32x4 c4 = acc[wb];
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, wf[wb][cc][0].x, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, wf[wb][cc][0].y, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, wf[wb][cc][0].z, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, wf[wb][cc][0].w, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, wf[wb][cc][1].x, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, wf[wb][cc][1].y, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, wf[wb][cc][1].z, c4, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, wf[wb][cc][1].w, c4, 0, 0, 0);
-        acc[wb] = c4;
-      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, wf[cc][0].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, wf[cc][0].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, wf[cc][0].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, wf[cc][0].w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, wf[cc][1].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, wf[cc][1].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, wf[cc][1].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, wf[cc][1].w, acc, 0, 0, 0);
     }
     if (ks + (int)gridDim.y < nslices) __syncthreads();  // xs is restaged by the next slice
   }
 
   if (dbg && tid == 0) dbg[3] = clock64();
-  // ---- fixed-order cross-wave reduction
+  // ---- fixed-order cross-wave reduction; afterwards wave w owns accumulator row r == w of every 4-row group
 #pragma unroll
-  for (int wb = 0; wb < NWB; ++wb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[((wave * NWB + wb) * 4 + r) * 64 + lane] = acc[wb][r];
+  for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
   __syncthreads();
-  if (wave != 0) return;
   if (dbg && tid == 0) dbg[4] = clock64();
-  float v[NWB][4];
-#pragma unroll
-  for (int wb = 0; wb < NWB; ++wb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int o = (wb * 4 + r) * 64 + lane;
-      constexpr int ws = NWB * 4 * 64;
-      v[wb][r] = ((red[o] + red[ws + o]) + red[2 * ws + o]) + red[3 * ws + o];
-      if (NORM) v[wb][r] *= rstd_s[g * 4 + r];  // RMSNorm row scale (its weight is folded into W)
-    }
+  float v = ((red[(0 * 4 + wave) * 64 + lane] + red[(1 * 4 + wave) * 64 + lane]) + red[(2 * 4 + wave) * 64 + lane]) +
+            red[(3 * 4 + wave) * 64 + lane];
+  if (NORM) v *= rstd_s[g * 4 + wave];  // RMSNorm row scale (its weight is folded into W)
 
   const int epi = a.epilogue;
-  if (!dw) {
+  if (!GLU) {
     float* yp = partial_out ? a.Y + (int64_t)blockIdx.y * a.y_part_stride : a.Y;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = bbase + g * 4 + r;
-      float y = v[0][r] + e_bias;
-      if (!partial_out) {
-        if (epi == SOPRO_EPI_GELU) y = gelu_erf(y);
-        else if (epi == SOPRO_EPI_TANH) y = tanhf(y);
-      }
-      if (res_here) y = e_res[r] + e_scale * y;
-      if (col_ok && b < a.B) yp[(int64_t)b * a.ldy + n_col] = y;
+    float y = v + e_bias;
+    if (!partial_out) {
+      if (epi == SOPRO_EPI_GELU) y = gelu_erf(y);
+      else if (epi == SOPRO_EPI_TANH) y = tanhf(y);
     }
+    if (res_here) y = e_res + e_scale * y;
+    if (col_ok && b_row < a.B) yp[(int64_t)b_row * a.ldy + n_col] = y;
   } else {
     const unsigned L = (unsigned)a.ring_len;
-    const unsigned slot_now = (unsigned)t_now % L;
+    const unsigned slot_now = slot0 == 0 ? L - 1 : slot0 - 1;  // t mod L
+    const float pre = v + e_bias;                    // lanes 0-7: value, lanes 8-15: gate pre-activation
+    const float gate = __shfl_xor(pre, 8, 64);
+    const float h = pre * sigmoidf_(gate);
+    float y = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = bbase + g * 4 + r;
-      const float h = (v[0][r] + e_bias) * sigmoidf_(v[NWB - 1][r] + e_bias_g);
-      float y = 0.f;
-#pragma unroll
-      for (int j = 0; j < MAXTAPS - 1; ++j)
-        if (j < a.ksize - 1) y += tapw[j] * taps_s[(r * (MAXTAPS - 1) + j) * 64 + lane];
-      y += tapw[MAXTAPS - 1] * h;  // tapw[j >= ksize-1] all hold the newest tap's weight
-      y += e_dwb;
-      if (col_ok && b < a.B) {
-        a.ring[((int64_t)slot_now * a.ring_bcap + b) * D + n_col] = h;
-        a.Y[(int64_t)b * a.ldy + n_col] = xs[(g * 4 + r) * XLD + n_col] + y;
-      }
+    for (int j = 0; j < MAXTAPS - 1; ++j) y += tapw[j] * tapv[j];
+    y += tapw[MAXTAPS - 1] * h;
+    y += e_dwb;
+    if (col_ok && b_row < a.B) {
+      a.ring[((int64_t)slot_now * a.ring_bcap + b_row) * D + n_col] = h;
+      a.Y[(int64_t)b_row * a.ldy + n_col] = xs[(g * 4 + wave) * XLD + n_col] + y;
     }
   }
   if (dbg && tid == 0) dbg[5] = clock64();
 }
 
-template <int NWB, int NP, bool NORM>
+template <bool GLU, int NP, bool NORM>
 int launch(const sopro_skinny_args& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((skinny_kernel<NWB, NP, NORM>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM>), grid, dim3(256), 0, s, a);
   SOPRO_LAUNCH_CHECK();
 }
 
@@ -261,10 +230,10 @@ extern "C" int sopro_skinny_f32(const sopro_skinny_args* p, void* stream) {
   const int gy = (a.ksplit && nslices > 1) ? nslices : 1;
   SOPRO_CHECK_ARG(gy == 1 || a.epilogue == SOPRO_EPI_NONE || a.epilogue == SOPRO_EPI_RES,
                   "K-split output takes EPI_NONE or EPI_RES (slice 0 then carries bias + residual; the consumer sums the slices)");
-  const int ncols = dw ? a.N / 2 : a.N;
-  dim3 grid((ncols + 15) / 16, gy, (a.B + 15) / 16);
+  const int ntiles = dw ? (a.N / 2 + 7) / 8 : (a.N + 15) / 16;
+  dim3 grid(ntiles, gy, (a.B + 15) / 16);
   const bool np3 = a.np == 3, nrm = a.rms_norm != 0;
-  if (dw) return np3 ? launch<2, 3, true>(a, grid, s) : launch<2, 0, true>(a, grid, s);
-  if (nrm) return np3 ? launch<1, 3, true>(a, grid, s) : launch<1, 0, true>(a, grid, s);
-  return np3 ? launch<1, 3, false>(a, grid, s) : launch<1, 0, false>(a, grid, s);
+  if (dw) return np3 ? launch<true, 3, true>(a, grid, s) : launch<true, 0, true>(a, grid, s);
+  if (nrm) return np3 ? launch<false, 3, true>(a, grid, s) : launch<false, 0, true>(a, grid, s);
+  return np3 ? launch<false, 3, false>(a, grid, s) : launch<false, 0, false>(a, grid, s);
 }

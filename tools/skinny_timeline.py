@@ -11,11 +11,12 @@ B, D = 32, 384
 
 
 def run(name, nwg, **kw):
-    dbg = torch.zeros(nwg, 8, dtype=torch.int64, device=DEV)
+    dbg = torch.zeros(1024, 8, dtype=torch.int64, device=DEV)
     for _ in range(3):
         hip.skinny(dbg=dbg, **kw)
     torch.cuda.synchronize()
     d = dbg.cpu().double()
+    d = d[d[:, 0] > 0]
     t0 = d[:, 0].min()
     rel = (d[:, :6] - t0)
     print(f"{name}: start spread {float(d[:,0].max()-t0):.0f} cyc | per-WG median phases (cycles since own start): "
