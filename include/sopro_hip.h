@@ -76,6 +76,8 @@ typedef struct sopro_gemm_args {
   int32_t prologue, epilogue;
 } sopro_gemm_args;
 int sopro_gemm_f32(const sopro_gemm_args* args, void* stream);
+/* developer probe: force a tile shape (0 = heuristic, 1: 128x128, 2: 64x128, 3: 256x64, 4: 256x32, 5: 64x64) */
+int sopro_gemm_set_tile_override(int cfg);
 
 /* Batch-of-at-most-a-few-dozen-rows contraction for the autoregressive step
  * (src/sopro/nn/generator.py:98-130): Y[b, n] = epi( rs[b] * sum_k Xin[b, k] * W[n, k] + bias[n] ),

@@ -52,6 +52,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const sopro_gemm_
     wp[i] = (n < g.N) ? g.W + (int64_t)n * g.ldw + lc4 * 4 : nullptr;
   }
 
+  // epilogue operands that do not depend on the contraction are requested before the main loop
+  float biasv[TN], scalev[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    biasv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+    scalev[j] = (g.scale && n < g.N) ? g.scale[n] : 1.f;
+  }
+
   float4 ra[A_F4], rw[W_F4];
   const int KT = (g.K + BK - 1) / BK;
   const int pro = g.prologue;
@@ -143,13 +152,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const sopro_gemm_
   // memory latency.
   const int epi = g.epilogue;
   const int col = lane & 31;
-  float biasv[TN], scalev[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + col;
-    biasv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
-    scalev[j] = (g.scale && n < g.N) ? g.scale[n] : 1.f;
-  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {  // one 32-row tile at a time keeps the address / residual registers at 16 rows
     int64_t coff[16];             // element offset of the row inside C (R: same row structure, own strides)
@@ -222,6 +224,12 @@ int launch_cfg(const sopro_gemm_args& g, hipStream_t s) {
 
 }  // namespace
 
+static int g_tile_override = 0;  // 0 = heuristic; 1: 128x128, 2: 64x128, 3: 256x64, 4: 256x32, 5: 64x64 (developer probe)
+extern "C" int sopro_gemm_set_tile_override(int cfg) {
+  g_tile_override = cfg;
+  return 0;
+}
+
 extern "C" int sopro_gemm_f32(const sopro_gemm_args* a, void* stream) {
   SOPRO_CHECK_ARG(a != nullptr, "args is NULL");
   sopro_gemm_args g = *a;
@@ -241,12 +249,22 @@ extern "C" int sopro_gemm_f32(const sopro_gemm_args* a, void* stream) {
   SOPRO_CHECK_ARG(g.prologue != SOPRO_PRO_ADDVEC || (g.pro_vec && aligned16(g.pro_vec)), "PRO_ADDVEC needs an aligned pro_vec");
   SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_GLU || (g.N % 64) == 0, "EPI_GLU needs N % 64 == 0 (packed value/gate blocks)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (g.N > 64) {
-    // 128x128 tiles unless that leaves most of the 256 CUs without a workgroup (M ~ thousands of rows: NAR, transformer)
-    const int64_t tiles128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (tiles128 < 768) return launch_cfg<2, 2, 1, 2>(g, s);
-    return launch_cfg<2, 2, 2, 2>(g, s);
+  switch (g_tile_override) {
+    case 1: return launch_cfg<2, 2, 2, 2>(g, s);
+    case 2: return launch_cfg<2, 2, 1, 2>(g, s);
+    case 3: return launch_cfg<4, 1, 2, 2>(g, s);
+    case 4: if (g.epilogue != SOPRO_EPI_GLU) return launch_cfg<4, 1, 2, 1>(g, s); break;
+    case 5: if (g.epilogue != SOPRO_EPI_GLU) return launch_cfg<2, 2, 1, 1>(g, s); break;
+    default: break;
   }
-  if (g.N > 32 || g.epilogue == SOPRO_EPI_GLU) return launch_cfg<4, 1, 2, 2>(g, s);
-  return launch_cfg<4, 1, 2, 1>(g, s);
+  // Tile shape (measured with tools/gemm_probe.py on the NAR / Mimi shapes): 128x128 only pays on very large grids or
+  // long contractions; everywhere else 64x64 tiles (4x the workgroups, same LDS traffic per flop) hide the
+  // prologue / epilogue latency better.  The GLU epilogue needs a value/gate tile pair per wave (64x128).
+  if (g.N <= 32 && g.epilogue != SOPRO_EPI_GLU) return launch_cfg<4, 1, 2, 1>(g, s);
+  const int64_t tiles128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  const bool big = g.N > 64 && g.K > 128 && (tiles128 >= 3000 || (g.K >= 1024 && tiles128 >= 512));
+  if (big) return launch_cfg<2, 2, 2, 2>(g, s);
+  if (g.epilogue == SOPRO_EPI_GLU) return launch_cfg<2, 2, 1, 2>(g, s);
+  return launch_cfg<2, 2, 1, 1>(g, s);
 }
+

@@ -71,6 +71,7 @@ SYMBOLS = {
     "sopro_graph_launch": (C.c_int, [_p, _p]),
     "sopro_graph_destroy": (C.c_int, [_p]),
     "sopro_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), _p]),
+    "sopro_gemm_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_skinny_f32": (C.c_int, [C.POINTER(SkinnyArgs), _p]),
     "sopro_norm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32, _p]),
     "sopro_rms_match_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
