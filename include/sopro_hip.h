@@ -72,6 +72,7 @@ typedef struct sopro_gemm_args {
   const float* R; int64_t ldr; int64_t r_seg_stride;
   const float* scale;
   const float* pro_vec; /* PRO_ADDVEC: a + pro_vec[k] */
+  long long* dbg;       /* optional [workgroups][8] shader-clock stamps (profiling aid), NULL in production */
   int32_t M, N, K, rows_per_seg;
   int32_t prologue, epilogue;
 } sopro_gemm_args;

@@ -13,7 +13,7 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDT = BK + 4;
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const sopro_gemm_args g) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
@@ -27,6 +27,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const sopro_gemm_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
+  long long* dbg = g.dbg ? g.dbg + (int64_t)blockIdx.x * 8 : nullptr;
+  if (dbg && tid == 0) dbg[0] = clock64();
   const int ntn = (g.N + BN - 1) / BN;
   const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -53,12 +55,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const sopro_gemm_
   }
 
   // epilogue operands that do not depend on the contraction are requested before the main loop
-  float biasv[TN], scalev[TN];
+  float biasv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
     biasv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
-    scalev[j] = (g.scale && n < g.N) ? g.scale[n] : 1.f;
   }
 
   float4 ra[A_F4], rw[W_F4];
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const sopro_gemm_
   gload(0);
   lstore(0);
   __syncthreads();
+  if (dbg && tid == 0) dbg[1] = clock64();
 
   const int frow = lane & 31, fk = (lane >> 5) * 4;
   for (int kt = 0; kt < KT; ++kt) {
@@ -145,74 +147,116 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const sopro_gemm_
     __syncthreads();
   }
 
-  // ---- epilogue: D[reg r] is row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of the 32x32 tile.
-  // Row addresses: one division per 32-row tile, then incremental segment tracking.  Every residual / bias /
-  // scale operand is loaded into registers BEFORE the first store: R may alias C (in-place residual updates), so
-  // the compiler must not be left to interleave "load R, store C" pairs, each of which would expose a full
-  // memory latency.
-  const int epi = g.epilogue;
-  const int col = lane & 31;
+  if (dbg && tid == 0) dbg[2] = clock64();
+  // ---- epilogue through LDS.  The MFMA accumulator layout gives a lane ONE column of 16 rows, i.e. 4-byte
+  // stores/loads (measured: 26k of a workgroup's 119k cycles for a 128x128x256 tile).  The tile buffers are free
+  // now, so the accumulators are transposed through LDS and every thread streams whole 16-byte pieces of rows:
+  // residual loads and output stores are fully coalesced dwordx4 accesses.  Residual operands are loaded in
+  // batches BEFORE the stores of the same batch (R may alias C: in-place residual updates).
+  constexpr int CLD = BN + 4;
+  float* Cs = reinterpret_cast<float*>(smem4);  // [BM][CLD]
+  {
+    const int col = lane & 31;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {  // one 32-row tile at a time keeps the address / residual registers at 16 rows
-    int64_t coff[16];             // element offset of the row inside C (R: same row structure, own strides)
-    float rv[16][TN];
-    const int mb = m0 + (wm * TM + i) * 32;
-    const int seg0 = mb / rps;
-    const int rr0 = mb - seg0 * rps;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      int seg = seg0, rr = rr0 + dr;
-      while (rr >= rps) { rr -= rps; ++seg; }
-      const bool ok = (mb + dr) < g.M;
-      coff[r] = ok ? (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc : (int64_t)-1;
-      if (epi == SOPRO_EPI_RES) {
-        const float* rrow = g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr;
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + (wn * TN + j) * 32 + col;
-          rv[r][j] = (ok && n < g.N) ? rrow[n] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          Cs[row * CLD + (wn * TN + j) * 32 + col] = acc[i][j][r] + biasv[j];
         }
+  }
+  __syncthreads();
+  constexpr bool glu = EPI == SOPRO_EPI_GLU;
+  constexpr bool res = EPI == SOPRO_EPI_RES;
+  constexpr int TPR = BN / 4;          // threads per tile row (one float4 each)
+  constexpr int RPP = NT / TPR;        // rows per pass
+  constexpr int NPASS = BM / RPP;
+  const int prow = tid / TPR, pc4 = tid % TPR;
+  const int n_out_total = glu ? g.N / 2 : g.N;
+  // GLU: columns are packed per 64 as [32 value | 32 gate]; the thread that owns value columns c..c+3 also reads
+  // the gate columns c+32..c+35 and writes output columns (c/64)*32 + c%32 ..; threads on gate columns idle.
+  const int ncol = n0 + pc4 * 4;                       // first tile column of this thread (pre-activation index)
+  const int ocol = glu ? (ncol >> 6) * 32 + (ncol & 31) : ncol;
+  const bool col_ok = ocol < n_out_total && (!glu || ((pc4 * 4) & 32) == 0);
+  const bool vec_ok = ((n_out_total & 3) == 0) && ((g.ldc & 3) == 0) && ((g.c_seg_stride & 3) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(g.C) & 15u) == 0) &&
+                      (!res || (((g.ldr & 3) == 0) && ((g.r_seg_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.R) & 15u) == 0)));
+  float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (res && g.scale) {
+    sc4.x = ncol + 0 < g.N ? g.scale[ncol + 0] : 1.f; sc4.y = ncol + 1 < g.N ? g.scale[ncol + 1] : 1.f;
+    sc4.z = ncol + 2 < g.N ? g.scale[ncol + 2] : 1.f; sc4.w = ncol + 3 < g.N ? g.scale[ncol + 3] : 1.f;
+  }
+  // row walk: one division, then pointer increments; a segment wrap (rare) recomputes the pointers
+  int m = m0 + prow;
+  int seg = m / rps, rr = m - seg * rps;
+  float* cptr = g.C + (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc + ocol;
+  const float* rptr = res ? g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr + ocol : nullptr;
+  const int64_t cstep = (int64_t)RPP * g.ldc, rstep = (int64_t)RPP * g.ldr;
+  const float* csrc = Cs + prow * CLD + pc4 * 4;
+  constexpr int BATCH = NPASS < 8 ? NPASS : 8;
+#pragma unroll 1
+  for (int p0 = 0; p0 < NPASS; p0 += BATCH) {
+    float* cp[BATCH];
+    float4 rv[BATCH];
+#pragma unroll
+    for (int q = 0; q < BATCH; ++q) {
+      const bool ok = col_ok && m < g.M;
+      cp[q] = ok ? cptr : nullptr;
+      rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res && ok) {
+        if (vec_ok) {
+          rv[q] = *reinterpret_cast<const float4*>(rptr);
+        } else {
+          rv[q].x = rptr[0];
+          if (ocol + 1 < n_out_total) rv[q].y = rptr[1];
+          if (ocol + 2 < n_out_total) rv[q].z = rptr[2];
+          if (ocol + 3 < n_out_total) rv[q].w = rptr[3];
+        }
+      }
+      m += RPP; rr += RPP; cptr += cstep;
+      if (res) rptr += rstep;
+      if (rr >= rps) {
+        do { rr -= rps; ++seg; } while (rr >= rps);
+        cptr = g.C + (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc + ocol;
+        if (res) rptr = g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr + ocol;
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (coff[r] < 0) continue;
-      float* crow = g.C + coff[r];
-      if (epi == SOPRO_EPI_GLU) {
-        if constexpr ((TN & 1) == 0) {
-#pragma unroll
-          for (int j = 0; j < TN; j += 2) {
-            const int na = n0 + (wn * TN + j) * 32 + col;
-            const int nb = na + 32;
-            if (nb < g.N) {
-              const float va = acc[i][j][r] + biasv[j], vb = acc[i][j + 1][r] + biasv[j + 1];
-              crow[(na - col) / 2 + col] = va * sigmoidf_(vb);
-            }
-          }
-        }
+    for (int q = 0; q < BATCH; ++q) {
+      if (!cp[q]) continue;
+      float4 v = *reinterpret_cast<const float4*>(csrc + (p0 + q) * RPP * CLD);
+      if (glu) {
+        const float4 gt = *reinterpret_cast<const float4*>(csrc + (p0 + q) * RPP * CLD + 32);
+        v.x *= sigmoidf_(gt.x); v.y *= sigmoidf_(gt.y); v.z *= sigmoidf_(gt.z); v.w *= sigmoidf_(gt.w);
+      } else if (EPI == SOPRO_EPI_GELU) {
+        v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+      } else if (EPI == SOPRO_EPI_TANH) {
+        v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+      } else if (res) {
+        v.x = rv[q].x + sc4.x * v.x; v.y = rv[q].y + sc4.y * v.y; v.z = rv[q].z + sc4.z * v.z; v.w = rv[q].w + sc4.w * v.w;
+      }
+      if (vec_ok) {
+        *reinterpret_cast<float4*>(cp[q]) = v;
       } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + (wn * TN + j) * 32 + col;
-          if (n >= g.N) continue;
-          float v = acc[i][j][r] + biasv[j];
-          if (epi == SOPRO_EPI_GELU) v = gelu_erf(v);
-          else if (epi == SOPRO_EPI_TANH) v = tanhf(v);
-          else if (epi == SOPRO_EPI_RES) v = rv[r][j] + scalev[j] * v;
-          crow[n] = v;
-        }
+        cp[q][0] = v.x;
+        if (ocol + 1 < n_out_total) cp[q][1] = v.y;
+        if (ocol + 2 < n_out_total) cp[q][2] = v.z;
+        if (ocol + 3 < n_out_total) cp[q][3] = v.w;
       }
     }
   }
+  if (dbg && tid == 0) dbg[3] = clock64();
 }
 
-template <int WM, int WN, int TM, int TN>
-int launch_cfg(const sopro_gemm_args& g, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, int EPI>
+int launch_epi(const sopro_gemm_args& g, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
+  static_assert((size_t)BM * (BN + 4) * sizeof(float) <= lds, "the epilogue tile must fit in the main-loop buffers");
   static bool attr_done = false;
-  auto kern = gemm_f32_kernel<WM, WN, TM, TN>;
+  auto kern = gemm_f32_kernel<WM, WN, TM, TN, EPI>;
   if (!attr_done) {
     SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -220,6 +264,22 @@ int launch_cfg(const sopro_gemm_args& g, hipStream_t s) {
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, g);
   SOPRO_LAUNCH_CHECK();
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const sopro_gemm_args& g, hipStream_t s) {
+  switch (g.epilogue) {
+    case SOPRO_EPI_NONE: return launch_epi<WM, WN, TM, TN, SOPRO_EPI_NONE>(g, s);
+    case SOPRO_EPI_GELU: return launch_epi<WM, WN, TM, TN, SOPRO_EPI_GELU>(g, s);
+    case SOPRO_EPI_RES: return launch_epi<WM, WN, TM, TN, SOPRO_EPI_RES>(g, s);
+    case SOPRO_EPI_TANH: return launch_epi<WM, WN, TM, TN, SOPRO_EPI_TANH>(g, s);
+    case SOPRO_EPI_GLU:
+      if constexpr (WN * TN * 32 >= 64) return launch_epi<WM, WN, TM, TN, SOPRO_EPI_GLU>(g, s);
+      break;
+    default: break;
+  }
+  sopro_set_error("sopro_gemm_f32: epilogue %d is not available for this tile shape", g.epilogue);
+  return -2;
 }
 
 }  // namespace

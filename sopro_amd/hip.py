@@ -29,7 +29,7 @@ _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 class GemmArgs(C.Structure):
     _fields_ = [("A", _p), ("lda", _i64), ("a_seg_stride", _i64), ("W", _p), ("ldw", _i64), ("bias", _p),
                 ("C", _p), ("ldc", _i64), ("c_seg_stride", _i64), ("R", _p), ("ldr", _i64), ("r_seg_stride", _i64),
-                ("scale", _p), ("pro_vec", _p), ("M", _i32), ("N", _i32), ("K", _i32), ("rows_per_seg", _i32),
+                ("scale", _p), ("pro_vec", _p), ("dbg", _p), ("M", _i32), ("N", _i32), ("K", _i32), ("rows_per_seg", _i32),
                 ("prologue", _i32), ("epilogue", _i32)]
 
 
@@ -187,7 +187,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, Cout: torch.Tensor, *, M: int, N: int
          prologue: int = PRO_NONE, R: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
          scale: Optional[torch.Tensor] = None, pro_vec: Optional[torch.Tensor] = None, rows_per_seg: Optional[int] = None,
          a_seg_stride: int = 0, c_seg_stride: int = 0, r_seg_stride: int = 0, a_off: int = 0, c_off: int = 0,
-         r_off: int = 0, ldw: Optional[int] = None) -> None:
+         r_off: int = 0, ldw: Optional[int] = None, dbg: Optional[torch.Tensor] = None) -> None:
     """C = epi(pro(A) @ W^T + bias); offsets are in elements from the tensors' first element."""
     n_out = N // 2 if epilogue == EPI_GLU else N
     g = GemmArgs()
@@ -205,6 +205,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, Cout: torch.Tensor, *, M: int, N: int
     g.r_seg_stride = r_seg_stride
     g.scale = ptr(scale)
     g.pro_vec = ptr(pro_vec)
+    g.dbg = ptr(dbg, torch.int64)
     g.M, g.N, g.K = M, N, K
     g.rows_per_seg = M if rows_per_seg is None else rows_per_seg
     g.prologue, g.epilogue = prologue, epilogue
