@@ -41,6 +41,32 @@ __global__ void ar_init_kernel(const sopro_ar_state st) {
   }
 }
 
+// wave-wide bitonic sort (descending) of one 64-bit key per lane
+__device__ __forceinline__ unsigned long long wave_sort_desc(unsigned long long key, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const unsigned long long other = __shfl_xor(key, j, 64);
+      const bool desc = (lane & k) == 0;
+      const bool lower = (lane & j) == 0;
+      const unsigned long long mx = key > other ? key : other, mn = key > other ? other : key;
+      key = (lower == desc) ? mx : mn;
+    }
+  }
+  return key;
+}
+
+// number of entries of a descending 64-entry array that are greater than x (binary search, <= 7 probes)
+__device__ __forceinline__ int count_greater64(const unsigned long long* arr, unsigned long long x) {
+  int lo = 0, hi = 64;  // invariant: arr[0..lo) > x >= arr[hi..64)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (arr[mid] > x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 constexpr int RECENT = 64;  // rolling token window per row: slot j = token sampled j+1 frames ago (-1 = none)
 constexpr int MAXCAND = 9 * 64;  // PER * max kk: the candidate bound of the scheme below
 
@@ -145,17 +171,20 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
     key[q] = (i < V1) ? (((unsigned long long)ord_f32(xs[i]) << 12) | (unsigned long long)(4095 - i)) : 0ull;
     lm = key[q] > lm ? key[q] : lm;
   }
-  lmax[tid] = lm;
+  // per-wave sort of the 64 per-thread maxima, then each lane ranks its entry against the other three sorted lists
+  const unsigned long long lms = wave_sort_desc(lm, lane);  // lane i: i-th largest maximum of this wave
+  lmax[tid] = lms;
   __syncthreads();
   const bool greedy = !(top_p > 0.f);
   int kk = (top_k > 0) ? min(top_k, V1) : V1;
   const bool head_only = greedy || kk > 64;  // top_k > 64 / "no top-k" is outside the reference policy (model.py:289)
   {
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < SAMP_THREADS; ++j) rank += (lmax[j] > lm) ? 1 : 0;
-    if (rank == 0) sh_best = lm;
-    if (!head_only && rank == kk - 1) sh_thr = lm;
+    int rank = lane;
+#pragma unroll
+    for (int w2 = 0; w2 < SAMP_THREADS / 64; ++w2)
+      if (w2 != wave) rank += count_greater64(lmax + w2 * 64, lms);
+    if (rank == 0) sh_best = lms;
+    if (!head_only && rank == kk - 1) sh_thr = lms;
   }
   __syncthreads();
   const int top_i = 4095 - (int)(sh_best & 4095ull);
@@ -182,13 +211,24 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
     __syncthreads();
     const int C = min((int)sh_cnt, MAXCAND);
     const float Z = (redf[0] + redf[1]) + (redf[2] + redf[3]);
-    for (int c = tid; c < C; c += SAMP_THREADS) {
-      const unsigned long long kc = cand[c];
-      int rank = 0;
-      for (int j = 0; j < C; ++j) rank += (cand[j] > kc) ? 1 : 0;
-      if (rank < kk) {
-        selk[rank] = kc;
-        selp[rank] = expf(xs[4095 - (int)(kc & 4095ull)] - xmax) / Z;
+    if (C <= 64) {
+      // usual case: one wave sorts the candidates directly (lane j ends up with the j-th largest)
+      if (wave == 0) {
+        const unsigned long long ks = wave_sort_desc(lane < C ? cand[lane] : 0ull, lane);
+        if (lane < kk) {
+          selk[lane] = ks;
+          selp[lane] = expf(xs[4095 - (int)(ks & 4095ull)] - xmax) / Z;
+        }
+      }
+    } else {
+      for (int c = tid; c < C; c += SAMP_THREADS) {
+        const unsigned long long kc = cand[c];
+        int rank = 0;
+        for (int j = 0; j < C; ++j) rank += (cand[j] > kc) ? 1 : 0;
+        if (rank < kk) {
+          selk[rank] = kc;
+          selp[rank] = expf(xs[4095 - (int)(kc & 4095ull)] - xmax) / Z;
+        }
       }
     }
     __syncthreads();
