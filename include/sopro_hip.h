@@ -43,6 +43,9 @@ int sopro_capture_begin(void* stream);
 int sopro_capture_end(void* stream, void** graph_exec_out);
 int sopro_graph_launch(void* graph_exec, void* stream);
 int sopro_graph_destroy(void* graph_exec);
+/* stream restricted to CUs [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask); destroy with sopro_stream_destroy */
+int sopro_stream_create_cu_range(int first_cu, int n_cus, void** stream_out);
+int sopro_stream_destroy(void* stream);
 
 /* ---- dense contraction ------------------------------------------------------------------ */
 enum { SOPRO_PRO_NONE = 0, SOPRO_PRO_ELU = 1, SOPRO_PRO_ADDVEC = 2 };

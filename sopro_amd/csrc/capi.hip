@@ -61,6 +61,30 @@ int sopro_graph_launch(void* graph_exec, void* stream) {
   return 0;
 }
 
+/* A HIP stream whose kernels may only use CUs [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask): lets a
+ * latency-bound launch sequence keep a slice of the chip while a throughput-bound phase runs on the rest. */
+int sopro_stream_create_cu_range(int first_cu, int n_cus, void** stream_out) {
+  SOPRO_CHECK_ARG(stream_out != nullptr && first_cu >= 0 && n_cus > 0, "bad CU range");
+  int dev = 0;
+  SOPRO_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  SOPRO_HIP(hipGetDeviceProperties(&p, dev));
+  const int total = p.multiProcessorCount;
+  SOPRO_CHECK_ARG(first_cu + n_cus <= total, "CU range exceeds the device");
+  uint32_t mask[16];
+  memset(mask, 0, sizeof(mask));
+  for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+  hipStream_t s = nullptr;
+  SOPRO_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask));
+  *stream_out = (void*)s;
+  return 0;
+}
+
+int sopro_stream_destroy(void* stream) {
+  if (stream) SOPRO_HIP(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
 int sopro_graph_destroy(void* graph_exec) {
   if (graph_exec) SOPRO_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
   return 0;

@@ -70,6 +70,8 @@ SYMBOLS = {
     "sopro_capture_end": (C.c_int, [_p, C.POINTER(_p)]),
     "sopro_graph_launch": (C.c_int, [_p, _p]),
     "sopro_graph_destroy": (C.c_int, [_p]),
+    "sopro_stream_create_cu_range": (C.c_int, [C.c_int, C.c_int, C.POINTER(_p)]),
+    "sopro_stream_destroy": (C.c_int, [_p]),
     "sopro_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "sopro_gemm_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_skinny_f32": (C.c_int, [C.POINTER(SkinnyArgs), _p]),
@@ -165,7 +167,7 @@ def _check(rc: int, what: str) -> None:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream().cuda_stream  # ~1 us; the engines enqueue a few hundred launches per call
 
 
 def ptr(t: Optional[torch.Tensor], dtype: torch.dtype = torch.float32) -> Optional[int]:
@@ -394,6 +396,13 @@ def capture_end() -> Graph:
     out = _p()
     _check(load().sopro_capture_end(_stream(), C.byref(out)), "sopro_capture_end")
     return Graph(out.value)
+
+
+def cu_range_stream(first_cu: int, n_cus: int, device: Optional[torch.device] = None) -> "torch.cuda.Stream":
+    """A torch-visible stream whose kernels are confined to CUs [first_cu, first_cu + n_cus)."""
+    out = _p()
+    _check(load().sopro_stream_create_cu_range(first_cu, n_cus, C.byref(out)), "sopro_stream_create_cu_range")
+    return torch.cuda.ExternalStream(out.value, device=device)
 
 
 def device_info(device: int = 0) -> dict:

@@ -76,6 +76,17 @@ class SoproTTSModel:
         self.Q = int(cfg.num_codebooks)
         packed = pack_sopro(weights, cfg)
         self.gates = {i: float(packed[f"ar.x_attns.{i}.gate_scale"][0]) for i in cfg.ar_xattn_layers}  # tanh(gate), text.py:131
+        # per-stage constants of nar_refine, resolved once on the host (no device round trips on the hot path)
+        sc0 = cfg.stage_codebooks()
+        self._nar_const = []
+        known: List[int] = [0]
+        for stage in cfg.stage_order():
+            cw = torch.softmax(packed["nar_prev_cb_weights"][torch.tensor(known)].float(), dim=0)  # embeddings.py:77-112
+            mix = packed[f"nar.mix.{stage}"]
+            self._nar_const.append({"cols": torch.tensor(known, dtype=torch.int32).to(self.device),
+                                    "offs": torch.tensor([c * self.V for c in known], dtype=torch.int32).to(self.device),
+                                    "cw": cw.contiguous().to(self.device), "mix0": float(mix[0]), "mix1": float(mix[1])})
+            known = known + list(sc0[stage])
         self.w: Dict[str, torch.Tensor] = {k: v.to(self.device) for k, v in packed.items()}
         npos = int(cfg.pos_emb_max) + 8  # reference: src/sopro/model.py:62-64
         self.pe = sinusoid_table(npos, self.D).to(self.device)
@@ -368,20 +379,16 @@ class SoproTTSModel:
             toks[:, 0] = tokens_A_1xT.to(dev).reshape(M).to(torch.int32)
             lens_d = _i32(lens, dev) if lens is not None and min(lens) != T else None
             adapters = self._adapter_coeffs()
-            pcw = w["nar_prev_cb_weights"]
             xa = self.ws.get("nar.xa", (M, D))
             xb = self.ws.get("nar.xb", (M, D))
             z = self.ws.get("nar.z", (M, int(cfg.nar_head_dim)))
             logits = self.ws.get("nar.logits", (M, V))
-            known: List[int] = [0]
             HD = int(cfg.nar_head_dim)
             for sid, (stage, cbs) in enumerate(self._stage_cbs):
                 # prev = sum_j softmax(w[known])_j * E[cb_j*V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
-                cw = torch.softmax(pcw[torch.tensor(known, device=dev)].float(), dim=0).contiguous()
-                mix = w[f"nar.mix.{stage}"]
-                mix_h = mix.tolist()
-                hip.codebook_sum(toks, Q, _i32(known, dev), _i32([c * V for c in known], dev), cw, w["cb_embed"], xa,
-                                 rows=M, D=D, base=cond, alpha=float(mix_h[0]), beta=float(mix_h[1]))
+                nc = self._nar_const[sid]
+                hip.codebook_sum(toks, Q, nc["cols"], nc["offs"], nc["cw"], w["cb_embed"], xa,
+                                 rows=M, D=D, base=cond, alpha=nc["mix0"], beta=nc["mix1"])
                 mul, add = adapters[sid]
                 hip.norm(xa, xb, w["nar.adapter.norm.weight"], rows=M, C_=D, eps=RMS_EPS, mul=mul, add=add, rows_per_seg=M)
                 xa, xb = xb, xa
@@ -396,7 +403,6 @@ class SoproTTSModel:
                     hip.gemm(z, w[f"nar.heads.{stage}.{j}.w"], logits, M=M, N=V, K=HD, bias=w[f"nar.heads.{stage}.{j}.b"],
                              prologue=hip.PRO_ADDVEC, pro_vec=hid[j])
                     hip.argmax_rows(logits, toks, rows=M, N=V, ldo=Q, o_off=cb)
-                known = known + list(cbs)
             out = toks.view(B, T, Q).long()
         self.stream.synchronize()
         return out
