@@ -111,6 +111,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=6)
     ap.add_argument("--ttfa-runs", type=int, default=20)
+    ap.add_argument("--lanes", type=int, default=2, help="engines pipelined on one GPU (1 = strictly sequential batches)")
+    ap.add_argument("--ar-cus", type=int, default=64, help="CUs reserved for the latency-bound AR phase when lanes > 1")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -147,10 +149,25 @@ def main() -> None:
     refs = [ref] * BATCH
     kw = dict(max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True, text_ids=ids)
 
-    def step(timings=None):
-        out = tts.synthesize_batch([""] * BATCH, refs, timings=timings, **kw)
+    job = dict(texts=[""] * BATCH, refs=refs, **kw)
+
+    def check(out):
         assert all(o.shape[-1] == FRAMES * 1920 for o in out)
-        return out
+
+    pipe = None
+    if args.lanes > 1:
+        from sopro_amd.pipeline import PipelinedSynthesizer
+
+        pipe = PipelinedSynthesizer(tts, lanes=args.lanes, ar_cus=args.ar_cus)
+
+    def run_steps(n, timings=None):
+        """n passes of the hot path over n independent batches (pipelined across lanes when lanes > 1)."""
+        if pipe is None:
+            for _ in range(n):
+                check(tts.synthesize_batch(timings=timings, **job))
+        else:
+            for out in pipe.run([job] * n, timings=timings):
+                check(out)
 
     def fence():
         torch.cuda.synchronize()
@@ -159,16 +176,14 @@ def main() -> None:
         torch.cuda.synchronize()
 
     log("warmup")
-    for _ in range(args.warmup):
-        step()
+    run_steps(max(args.warmup, args.lanes if pipe is not None else 0))  # every lane records its graph / sizes its scratch once
     fence()
     log("timed steps")
     prof = hip.Profiler()
     hip.set_profiler(prof)
     phases = {}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(phases)
+    run_steps(args.steps, phases)
     fence()
     dt = time.perf_counter() - t0
     hip.set_profiler(None)
@@ -189,8 +204,10 @@ def main() -> None:
     if "gemm_f32_kernel" in fam:
         f = fam["gemm_f32_kernel"]
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        share = (256 - args.ar_cus) / 256.0 if args.lanes > 1 else 1.0  # CUs this kernel may run on (CU-masked bulk stream)
         roof = {"kernel": "gemm_f32_kernel (all tile shapes; v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": round(ach, 3),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
+                "peak": round(PEAK_F32_MFMA_TFLOPS * share, 2), "unit": "TFLOP/s", "frac": round(ach / (PEAK_F32_MFMA_TFLOPS * share), 5),
+                "cu_share": share, "peak_full_chip": PEAK_F32_MFMA_TFLOPS, "frac_full_chip": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
                 "traffic": pmc.get("gemm_f32_kernel", {}).get("traffic_bytes_per_launch"), "launches": f["launches"],
                 "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2),
                 "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"]))}
@@ -211,6 +228,9 @@ def main() -> None:
         roof, roof_ar = roof_ar, roof  # `roofline` is always the family with the larger share of the step
     families = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] // args.steps,
                     "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 3) if v["flops"] else None} for k, v in fam.items()}
+
+    if pipe is not None:
+        pipe.close()  # the latency leg below runs on the whole chip
 
     # ---- p50 time-to-first-audio of stream(), batch 1 (BASELINE.json configs[2]); outside the timed steps
     ttfa = None
@@ -251,7 +271,10 @@ def main() -> None:
             "config": {"workload": f"Sopro-135M synthesize, {BATCH} utterances x {FRAMES} frames per GPU (BASELINE configs[1]), "
                                    f"S={TEXT_LEN} text tokens, {REF_FRAMES}-frame reference voice prepared outside the timed region, "
                                    "top_p=0.9 T=1.05 anti_loop (reference defaults), synthetic weights with EOS suppressed",
-                       "batch_per_gpu": BATCH, "frames": FRAMES, "parallelism": f"replicas x{world} (utterance sharding, no collective)"},
+                       "batch_per_gpu": BATCH, "frames": FRAMES, "parallelism": f"replicas x{world} (utterance sharding, no collective)",
+                       "lanes_per_gpu": args.lanes,
+                       "pipelining": (f"{args.lanes} engines per GPU share the weights: AR phase of batch k+1 on a {args.ar_cus}-CU stream while NAR+Mimi of "
+                                      f"batch k run on the other {256 - args.ar_cus} CUs (hipExtStreamCreateWithCUMask)") if args.lanes > 1 else "none"},
             "phase_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phases.items()},
             "kernel_families": families,
             "ttfa_ms_p50": None if ttfa is None else round(ttfa, 3),

@@ -64,6 +64,15 @@ class MimiCodec:
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         return torch.cuda.stream(self.stream)
 
+    def clone_lane(self) -> "MimiCodec":
+        """A second decoder over the SAME device weights with its own stream and scratch buffers (pipelining)."""
+        import copy
+
+        other = copy.copy(self)
+        other.ws = Workspace(self.device)
+        other.stream = torch.cuda.Stream(device=self.device)
+        return other
+
     def _rope_tables(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
         if self._rope is None or self._rope_n < n:
             n2 = max(1024, 2 * n)

@@ -92,6 +92,7 @@ class SoproTTSModel:
         self.pe = sinusoid_table(npos, self.D).to(self.device)
         self.ws = Workspace(self.device)
         self.stream = torch.cuda.Stream(device=self.device)
+        self.bulk_stream = self.stream  # throughput-bound phase (NAR); a pipeline may point it at another CU partition
         self._ar_cache: Dict[Tuple[int, int, int], "_ARPlan"] = {}
         self._ones: Dict[int, torch.Tensor] = {}
         sc = cfg.stage_codebooks()
@@ -100,10 +101,22 @@ class SoproTTSModel:
         self._adapter: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None
 
     # ------------------------------------------------------------------ helpers
-    def on_stream(self):
+    def on_stream(self, bulk: bool = False):
         """Context: run on the engine's stream, ordered after whatever the caller queued so far."""
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        return torch.cuda.stream(self.stream)
+        s = self.bulk_stream if bulk else self.stream
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(s)
+
+    def clone_lane(self) -> "SoproTTSModel":
+        """A second engine over the SAME device weights with its own streams, scratch and AR plans (pipelining)."""
+        import copy
+
+        other = copy.copy(self)
+        other.ws = Workspace(self.device)
+        other.stream = torch.cuda.Stream(device=self.device)
+        other.bulk_stream = other.stream
+        other._ar_cache = {}
+        return other
 
     def rf_ar(self) -> int:
         return self.cfg.rf_ar()
@@ -373,7 +386,7 @@ class SoproTTSModel:
         cfg, w, dev, D, V, Q = self.cfg, self.w, self.device, self.D, self.V, self.Q
         B, T, _ = cond_seq.shape
         M = B * T
-        with self.on_stream():
+        with self.on_stream(bulk=True):
             cond = cond_seq.to(dev).float().contiguous().view(M, D)
             toks = torch.zeros(M, Q, dtype=torch.int32, device=dev)
             toks[:, 0] = tokens_A_1xT.to(dev).reshape(M).to(torch.int32)
@@ -404,7 +417,7 @@ class SoproTTSModel:
                              prologue=hip.PRO_ADDVEC, pro_vec=hid[j])
                     hip.argmax_rows(logits, toks, rows=M, N=V, ldo=Q, o_off=cb)
             out = toks.view(B, T, Q).long()
-        self.stream.synchronize()
+        self.bulk_stream.synchronize()
         return out
 
     # ------------------------------------------------------------------ text + reference -> tokens
@@ -425,20 +438,32 @@ class SoproTTSModel:
                               timings: Optional[Dict[str, float]] = None) -> List[torch.Tensor]:
         """B utterances -> list of [T_b, Q] int64 token matrices (new, batched form of generate_tokens)."""
         ev = _PhaseTimer(self.stream, timings)
+        state = self.phase_ar(ids_list, refs, max_frames=max_frames, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
+                              style_strength=style_strength, min_gen_frames=min_gen_frames, ev=ev)
+        toks = self.phase_nar(state)
+        ev.mark("nar")
+        return toks
+
+    def phase_ar(self, ids_list, refs, *, max_frames, top_p, temperature, anti_loop, style_strength, min_gen_frames, ev=None):
+        """Latency-bound half of generate_tokens_batch: conditioning + the AR graph replay."""
         prep = self.prepare_conditioning_batch(ids_list, refs, max_frames=max_frames, style_strength=style_strength)
-        ev.mark("cond")
+        if ev is not None:
+            ev.mark("cond")
         hist, lens = self.ar_generate_batch(prep["cond_ar"], prep["txt_seq"], prep["text_lens"], max_frames=max_frames,
                                             top_p=top_p, temperature=temperature, anti_loop=anti_loop,
                                             min_gen_frames=min_gen_frames)
-        ev.mark("ar")
-        B = len(ids_list)
+        if ev is not None:
+            ev.mark("ar")
+        return {"cond_ar": prep["cond_ar"], "hist": hist, "lens": lens, "B": len(ids_list)}
+
+    def phase_nar(self, state) -> List[torch.Tensor]:
+        """Throughput-bound half: NAR refinement of the generated codebook-0 tokens."""
+        lens, hist, B = state["lens"], state["hist"], state["B"]
         Tm = max(lens)
         if Tm <= 0:
-            ev.mark("nar")
             return [torch.zeros(0, self.Q, dtype=torch.long, device=self.device) for _ in range(B)]
         rvq1 = hist[:, :Tm].clamp(max=self.V - 1)  # rows past their own length are ignored below
-        toks = self.nar_refine(prep["cond_ar"][:, :Tm, :], rvq1, lens=[max(1, n) for n in lens])
-        ev.mark("nar")
+        toks = self.nar_refine(state["cond_ar"][:, :Tm, :], rvq1, lens=[max(1, n) for n in lens])
         return [toks[b, : lens[b]] for b in range(B)]
 
 

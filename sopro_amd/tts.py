@@ -120,30 +120,43 @@ class SoproTTS:
     def synthesize_batch(self, texts: Sequence[str], refs: Sequence[PreparedReference], *, max_frames: int = 400,
                          top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True,
                          style_strength: Optional[float] = None, min_gen_frames: Optional[int] = None,
-                         timings: Optional[Dict[str, float]] = None, text_ids: Optional[Sequence[torch.Tensor]] = None
-                         ) -> List[torch.Tensor]:
+                         timings: Optional[Dict[str, float]] = None, text_ids: Optional[Sequence[torch.Tensor]] = None,
+                         phase_locks: Optional[tuple] = None) -> List[torch.Tensor]:
         """New: B utterances in one pass (batched AR graph, NAR and Mimi decode) -> list of [1, 1, N_b]."""
-        ids = list(text_ids) if text_ids is not None else [self.encode_text(t) for t in texts]
-        toks = self.model.generate_tokens_batch(
-            ids, refs, max_frames=max_frames, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-            style_strength=float(style_strength if style_strength is not None else self.cfg.style_strength),
-            min_gen_frames=min_gen_frames, timings=timings)
-        lens = [int(t.shape[0]) for t in toks]
-        Tm = max(lens)
-        B = len(toks)
-        if Tm == 0:
-            return [torch.zeros(1, 1, 0, device=self.device) for _ in range(B)]
+        import contextlib
         import time
 
-        t0 = time.perf_counter()
-        codes = torch.zeros(B, Tm, int(self.cfg.num_codebooks), dtype=torch.long, device=self.device)
-        for b, t in enumerate(toks):
-            codes[b, : lens[b]] = t
-        wav = self.codec.decode_batch(codes)  # causal decoder: padding frames never reach earlier samples
-        if timings is not None:
-            timings["mimi"] = timings.get("mimi", 0.0) + (time.perf_counter() - t0)
+        ids = list(text_ids) if text_ids is not None else [self.encode_text(t) for t in texts]
+        ar_lock, bulk_lock = phase_locks if phase_locks is not None else (contextlib.nullcontext(), contextlib.nullcontext())
+        ss = float(style_strength if style_strength is not None else self.cfg.style_strength)
+        with ar_lock:  # latency-bound phase: conditioning + AR graph replay
+            from .model import _PhaseTimer
+
+            ev = _PhaseTimer(self.model.stream, timings)
+            state = self.model.phase_ar(ids, refs, max_frames=max_frames, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
+                                        style_strength=ss, min_gen_frames=min_gen_frames, ev=ev)
+        with bulk_lock:  # throughput-bound phase: NAR refinement + Mimi decode
+            t0 = time.perf_counter()
+            toks = self.model.phase_nar(state)
+            t1 = time.perf_counter()
+            lens = [int(t.shape[0]) for t in toks]
+            Tm = max(lens)
+            B = len(toks)
+            if Tm == 0:
+                return [torch.zeros(1, 1, 0, device=self.device) for _ in range(B)]
+            codes = torch.zeros(B, Tm, int(self.cfg.num_codebooks), dtype=torch.long, device=self.device)
+            for b, t in enumerate(toks):
+                codes[b, : lens[b]] = t
+            wav = self.codec.decode_batch(codes)  # causal decoder: padding frames never reach earlier samples
+            if timings is not None:
+                timings["nar"] = timings.get("nar", 0.0) + (t1 - t0)
+                timings["mimi"] = timings.get("mimi", 0.0) + (time.perf_counter() - t1)
         hop = int(self.codec.mc.frame_samples)
         return [wav[b, : lens[b] * hop].reshape(1, 1, -1) for b in range(B)]
+
+    def clone_lane(self) -> "SoproTTS":
+        """Another engine over the same device weights (own streams / scratch), for pipelining batches."""
+        return SoproTTS(self.model.clone_lane(), self.cfg, self.tokenizer, self.codec.clone_lane(), str(self.device))
 
     def stream(self, text: str, **kwargs) -> Iterator[torch.Tensor]:
         """reference: src/sopro/model.py:577-580"""
