@@ -399,10 +399,15 @@ def capture_end() -> Graph:
 
 
 def cu_range_stream(first_cu: int, n_cus: int, device: Optional[torch.device] = None) -> "torch.cuda.Stream":
-    """A torch-visible stream whose kernels are confined to CUs [first_cu, first_cu + n_cus)."""
+    """A torch-visible stream whose kernels are confined to CUs [first_cu, first_cu + n_cus).
+    The owner must hand it back with ``destroy_stream`` (torch does not own external streams)."""
     out = _p()
     _check(load().sopro_stream_create_cu_range(first_cu, n_cus, C.byref(out)), "sopro_stream_create_cu_range")
     return torch.cuda.ExternalStream(out.value, device=device)
+
+
+def destroy_stream(s: "torch.cuda.Stream") -> None:
+    _check(load().sopro_stream_destroy(s.cuda_stream), "sopro_stream_destroy")
 
 
 def device_info(device: int = 0) -> dict:

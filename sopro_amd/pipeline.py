@@ -28,10 +28,12 @@ class PipelinedSynthesizer:
             raise ValueError("ar_cus must leave CUs for the bulk phase")
         self.lanes = []
         self._saved = (tts.model.stream, tts.model.bulk_stream, tts.codec.stream)
+        self._streams = []
         for i in range(int(lanes)):
             lane = tts if i == 0 else tts.clone_lane()
             lane.model.stream = hip.cu_range_stream(0, ar_cus, self.device)
             lane.model.bulk_stream = hip.cu_range_stream(ar_cus, total - ar_cus, self.device)
+            self._streams += [lane.model.stream, lane.model.bulk_stream]
             lane.codec.stream = lane.model.bulk_stream
             lane.model._ar_cache.clear()  # recorded graphs belong to the stream they were captured on
             self.lanes.append(lane)
@@ -39,11 +41,22 @@ class PipelinedSynthesizer:
         self.ar_cus, self.bulk_cus = ar_cus, total - ar_cus
 
     def close(self) -> None:
-        """Give lane 0 (the caller's engine) its full-chip streams back."""
-        lane = self.lanes[0]
+        """Drop the extra lanes, destroy the CU-masked streams (and the graphs recorded on them) and give lane 0
+        (the caller's engine) its full-chip streams back."""
+        if not self.lanes:
+            return
         torch.cuda.synchronize(self.device)
-        lane.model.stream, lane.model.bulk_stream, lane.codec.stream = self._saved
-        lane.model._ar_cache.clear()
+        for lane in self.lanes:
+            lane.model._ar_cache.clear()  # hipGraphExecDestroy now, not at interpreter shutdown
+            lane.model.ws.clear()
+            lane.codec.ws.clear()
+        lane0 = self.lanes[0]
+        lane0.model.stream, lane0.model.bulk_stream, lane0.codec.stream = self._saved
+        self.lanes = []
+        torch.cuda.synchronize(self.device)
+        for st in self._streams:
+            hip.destroy_stream(st)
+        self._streams = []
 
     def run(self, jobs: Sequence[Dict[str, Any]], timings: Optional[Dict[str, float]] = None) -> List[Any]:
         """Each job is the keyword dict of ``SoproTTS.synthesize_batch``; results come back in job order."""
