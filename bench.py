@@ -158,7 +158,11 @@ def main() -> None:
     if args.lanes > 1:
         from sopro_amd.pipeline import PipelinedSynthesizer
 
-        pipe = PipelinedSynthesizer(tts, lanes=args.lanes, ar_cus=args.ar_cus)
+        try:
+            pipe = PipelinedSynthesizer(tts, lanes=args.lanes, ar_cus=args.ar_cus)
+        except Exception as e:  # noqa: BLE001  (e.g. a device without CU-mask support): fall back to sequential batches
+            log(f"pipelining unavailable ({e!r}); running sequential batches")
+            pipe, args.lanes = None, 1
 
     def run_steps(n, timings=None):
         """n passes of the hot path over n independent batches (pipelined across lanes when lanes > 1)."""
