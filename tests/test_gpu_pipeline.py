@@ -136,6 +136,35 @@ def test_eos_rule_and_generate_tokens(cfg, sopro_np, mimi_np):
     assert torch.equal(toks.cpu(), _t(ge["gen_tokens"]))
 
 
+def test_batch_with_rows_stopping_at_different_frames(cfg, sopro_np, mimi_np, w):
+    """Ragged EOS in a batch: every row must equal its own single-utterance reference run
+    (generate_tokens cut rule, src/sopro/model.py:385-390), rows keep stepping after they stopped."""
+    from sopro_amd import SoproTTS
+
+    wts = dict(sopro_np)
+    hb = sopro_np["ar.head.bias"].copy()
+    hb[2048] = 3.9
+    wts["ar.head.bias"] = hb
+    t2 = SoproTTS.from_weights(cfg, wts, mimi_np, FakeTok(), device="cuda:0")
+    w2 = dict(w)
+    w2["ar.head.bias"] = torch.from_numpy(hb)
+    rng = np.random.default_rng(61)
+    ids = [torch.from_numpy(rng.integers(0, 512, size=n)) for n in (19, 11, 26, 7)]
+    refs_tq = [torch.from_numpy(rng.integers(0, 2048, size=(22, 32))) for _ in ids]
+    refs = [t2.prepare_reference(ref_tokens_tq=r) for r in refs_tq]
+    kw = dict(max_frames=40, top_p=0.0, temperature=0.8, anti_loop=False, min_gen_frames=6)
+    got = t2.model.generate_tokens_batch(ids, refs, style_strength=1.0, **kw)
+    lens = []
+    for b in range(len(ids)):
+        oref = O.prepare_reference(refs_tq[b], w2, cfg)
+        want = O.generate_tokens(ids[b], oref, w2, cfg, style_strength=1.0, **kw)
+        lens.append(int(want.shape[0]))
+        assert tuple(got[b].shape) == tuple(want.shape), (b, tuple(got[b].shape), tuple(want.shape))
+        assert int((got[b].cpu() != want).sum()) <= 1, b  # codebook-0 exact; at most one NAR near-tie
+        assert torch.equal(got[b][:, 0].cpu(), want[:, 0]), b
+    assert len(set(lens)) > 1, f"fixture is not ragged: {lens}"
+
+
 def test_nar_refine_tokens_bit_exact(tts, ref_prep):
     g, _, prep = ref_prep
     gn = golden("nar")
