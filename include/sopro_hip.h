@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 5
+#define SOPRO_ABI_VERSION 6
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -164,6 +164,21 @@ int sopro_text_embed_f32(const int32_t* ids, const int32_t* lens, const float* t
 /* argmax over each row of [rows, N] -> int32 written at out[r * ldo]  (src/sopro/model.py:340-343) */
 int sopro_argmax_rows_f32(const float* x, int64_t ldx, int32_t* out, int64_t ldo, int32_t rows, int32_t N,
                           void* stream);
+
+/* ---- Mimi encode side (reference audio -> tokens: src/sopro/codec/mimi.py:42-63) ---------------------- */
+/* Single-input-channel FIR bank, channels-last output:
+ *   out[b, t, c] = bias[c] + sum_k w[c, k] * x[b, t*stride + k - left]   (x = 0 outside [0, n_in))
+ * The first SEANet encoder conv (HF:modeling_mimi.py MimiEncoder layers[0], 1 -> 64, k = 7, left = 6) and the
+ * polyphase windowed-sinc resampler (src/sopro/audio.py:113-123 -> torchaudio.functional.resample: C = new_freq/gcd
+ * phases, stride = orig_freq/gcd, left = filter half width).  bias may be NULL. */
+int sopro_fir1_f32(const float* x, int64_t x_seg_stride, int32_t n_in, const float* w, const float* bias, float* out,
+                   int64_t ldo, int64_t o_seg_stride, int32_t B, int32_t n_out, int32_t C, int32_t K, int32_t stride,
+                   int32_t left, void* stream);
+/* One residual-VQ layer's assignment (HF:modeling_mimi.py MimiEuclideanCodebook.quantize + the residual update of
+ * MimiResidualVectorQuantizer.encode): codes[r*ldc] = first argmax of scores[r, :V]
+ * (scores = r.e - |e|^2/2, i.e. the nearest code), then res[r, :D] -= table[code, :D]. */
+int sopro_rvq_assign_f32(const float* scores, int64_t lds, int32_t V, const float* table, float* res, int64_t ldr,
+                         int32_t D, int32_t* codes, int64_t ldc, int32_t rows, void* stream);
 
 /* ---- attention ---------------------------------------------------------------------------- */
 /* softmax(q k^T * scale + mask) v, fp32, heads interleaved in the row ([.., H*dh]).

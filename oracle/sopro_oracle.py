@@ -514,7 +514,7 @@ class MimiKV:
     seen: int = 0
 
 
-def mimi_transformer(x_bnc: torch.Tensor, mw: W, mc, cache: Optional[MimiKV] = None) -> torch.Tensor:
+def mimi_transformer(x_bnc: torch.Tensor, mw: W, mc, cache: Optional[MimiKV] = None, prefix: str = "decoder_transformer") -> torch.Tensor:
     """8 pre-LN layers, RoPE, causal sliding window, LayerScale.  HF:modeling_mimi.py:729-928"""
     B, N, C = x_bnc.shape
     H, dh = int(mc.num_attention_heads), int(mc.head_dim)
@@ -524,7 +524,7 @@ def mimi_transformer(x_bnc: torch.Tensor, mw: W, mc, cache: Optional[MimiKV] = N
     win = int(mc.sliding_window)
     h = x_bnc
     for li in range(int(mc.num_hidden_layers)):
-        p = f"decoder_transformer.layers.{li}"
+        p = f"{prefix}.layers.{li}"
         y = F.layer_norm(h, (C,), mw[p + ".input_layernorm.weight"], mw[p + ".input_layernorm.bias"], float(mc.norm_eps))
         q = _heads(F.linear(y, mw[p + ".self_attn.q_proj.weight"]), H)
         k = _heads(F.linear(y, mw[p + ".self_attn.k_proj.weight"]), H)
@@ -584,6 +584,125 @@ def mimi_decode(codes_bqt: torch.Tensor, mw: W, mc, cache: Optional[MimiKV] = No
     if taps is not None:
         taps["rvq"], taps["upsample"], taps["transformer"] = emb, up, tr
     return seanet_decoder(tr, mw, mc, taps)
+
+
+# -----------------------------------------------------------------------------
+# Mimi codec, encode side (reference audio -> tokens)
+# -----------------------------------------------------------------------------
+def causal_conv1d_strided(x: torch.Tensor, wt: torch.Tensor, b: Optional[torch.Tensor], stride: int, pad_mode: str = "constant") -> torch.Tensor:
+    """MimiConv1d.forward, causal: left pad k - stride, right pad up to a whole frame.  HF:modeling_mimi.py:300-347"""
+    k = int(wt.shape[-1])
+    L = int(x.shape[-1])
+    pt = k - stride
+    n_frames = math.ceil((L - k + pt) / stride + 1) - 1
+    extra = n_frames * stride + k - pt - L
+    return F.conv1d(F.pad(x, (pt, extra), mode=pad_mode), wt, b, stride=stride)
+
+
+def seanet_encoder(x_b1n: torch.Tensor, mw: W, mc) -> torch.Tensor:
+    """HF:modeling_mimi.py MimiEncoder (conv k7, then per ratio [residual block, ELU, strided conv], ELU, conv k3)."""
+    h = causal_conv1d(x_b1n, mw["encoder.layers.0.conv.weight"], mw["encoder.layers.0.conv.bias"])
+    li = 1
+    for r in reversed(mc.upsampling_ratios):
+        p = f"encoder.layers.{li}.block"
+        y = causal_conv1d(F.elu(h), mw[p + ".1.conv.weight"], mw[p + ".1.conv.bias"])
+        y = causal_conv1d(F.elu(y), mw[p + ".3.conv.weight"], mw[p + ".3.conv.bias"])
+        h = h + y
+        li += 2
+        h = causal_conv1d_strided(F.elu(h), mw[f"encoder.layers.{li}.conv.weight"], mw[f"encoder.layers.{li}.conv.bias"], int(r))
+        li += 1
+    li += 1
+    return causal_conv1d(F.elu(h), mw[f"encoder.layers.{li}.conv.weight"], mw[f"encoder.layers.{li}.conv.bias"])
+
+
+def rvq_encode(emb_bct: torch.Tensor, mw: W, mc) -> torch.Tensor:
+    """Split residual VQ encode -> codes [B, Q, T].  HF:modeling_mimi.py MimiSplitResidualVectorQuantizer.encode,
+    MimiEuclideanCodebook.quantize (cdist + argmin)."""
+    cbs = mimi_codebooks(mw, mc)
+    ns = int(mc.num_semantic_quantizers)
+    out = []
+    for group, q0, q1 in (("semantic", 0, ns), ("acoustic", ns, int(mc.num_quantizers))):
+        res = F.conv1d(emb_bct, mw[f"quantizer.{group}_residual_vector_quantizer.input_proj.weight"])
+        for q in range(q0, q1):
+            r = res.permute(0, 2, 1)  # [B, T, D]
+            d = torch.cdist(r.reshape(1, -1, r.shape[-1]).float(), cbs[q][None].float(), p=2)[0]
+            idx = d.argmin(dim=-1).view(r.shape[0], r.shape[1])
+            res = res - cbs[q][idx].permute(0, 2, 1)
+            out.append(idx)
+    return torch.stack(out, dim=1)
+
+
+def mimi_encode(wav_b1n: torch.Tensor, mw: W, mc, taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """waveform [B, 1, N] -> codes [B, Q, T].  HF:modeling_mimi.py MimiModel._encode_frame"""
+    emb = seanet_encoder(wav_b1n, mw, mc)
+    tr = mimi_transformer(emb.transpose(1, 2), mw, mc, None, prefix="encoder_transformer").transpose(1, 2)
+    ds = causal_conv1d_strided(tr, mw["downsample.conv.weight"], None, int(mc.upsample_stride), pad_mode="replicate")
+    if taps is not None:
+        taps["enc_seanet"], taps["enc_transformer"], taps["enc_downsample"] = emb, tr, ds
+    return rvq_encode(ds, mw, mc)
+
+
+def trim_silence_energy(wav: torch.Tensor, sr: int, frame_ms: float = 25.0, hop_ms: float = 10.0, thresh_db_floor: float = -40.0,
+                        prepad_ms: float = 30.0, postpad_ms: float = 30.0, min_keep_sec: float = 0.5) -> torch.Tensor:
+    """Energy-threshold silence trim of a mono [N] waveform.  reference: src/sopro/audio.py:30-86"""
+    T = int(wav.shape[-1])
+    frame_len, hop = max(1, int(sr * frame_ms / 1000.0)), max(1, int(sr * hop_ms / 1000.0))
+    if T == 0 or T < int(sr * 0.1) or T < frame_len:
+        return wav
+    energy = wav.unfold(-1, frame_len, hop).pow(2).mean(dim=-1)
+    energy_db = 10.0 * torch.log10(energy + 1e-10)
+    thresh_db = max(float(energy_db.max()) + thresh_db_floor, thresh_db_floor)
+    idx = torch.nonzero(energy_db > thresh_db)
+    if idx.numel() == 0:
+        return wav
+    start = max(0, int(idx[0, 0]) * hop - int(sr * prepad_ms / 1000.0))
+    end = min(T, int(idx[-1, 0]) * hop + frame_len + int(sr * postpad_ms / 1000.0))
+    if end <= start or (end - start) < int(min_keep_sec * sr):
+        return wav
+    return wav[start:end]
+
+
+def center_crop_audio(wav: torch.Tensor, win_samples: int) -> torch.Tensor:
+    """reference: src/sopro/audio.py:148-155"""
+    T = int(wav.shape[-1])
+    if win_samples <= 0 or T <= win_samples:
+        return wav
+    s = (T - win_samples) // 2
+    return wav[..., s:s + win_samples]
+
+
+def sinc_resample(wav_n: torch.Tensor, sr_in: int, sr_out: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> torch.Tensor:
+    """reference: src/sopro/audio.py:113-123 calls ``torchaudio.functional.resample(wav, sr_in, sr_out)``.  torchaudio is
+    NOT in this image, so this restates its published algorithm (functional.py ``_get_sinc_resample_kernel`` +
+    ``_apply_sinc_resample_kernel``, Hann-windowed sinc, defaults width 6 / rolloff 0.99) -- PARITY UNPINNED for this
+    one function: no torchaudio output was available to check it against."""
+    if int(sr_in) == int(sr_out):
+        return wav_n
+    g = math.gcd(int(sr_in), int(sr_out))
+    orig, new = int(sr_in) // g, int(sr_out) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kern = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / orig)
+    n = int(wav_n.shape[-1])
+    x = F.pad(wav_n.view(1, 1, n).float(), (width, width + orig))
+    y = F.conv1d(x, kern.float(), stride=orig).transpose(1, 2).reshape(-1)
+    return y[: math.ceil(new * n / orig)]
+
+
+def encode_audio(wav_n: torch.Tensor, sr: int, mw: W, mc, crop_seconds: Optional[float] = None) -> torch.Tensor:
+    """mono waveform -> codes [T, Q].  reference: src/sopro/codec/mimi.py:42-63 (after the file has been read)"""
+    wav = trim_silence_energy(wav_n, sr)
+    sr_t = int(mc.sampling_rate)
+    wav = sinc_resample(wav, sr, sr_t)
+    if crop_seconds is not None and crop_seconds > 0:
+        hop = int(round(sr_t / float(mc.frame_rate)))
+        wav = center_crop_audio(wav, max(1, int(round(crop_seconds * float(mc.frame_rate)))) * hop)
+    return mimi_encode(wav.view(1, 1, -1), mw, mc)[0].permute(1, 0).contiguous()
 
 
 def decode_full(tokens_tq: torch.Tensor, mw: W, mc) -> torch.Tensor:

@@ -9,8 +9,9 @@ Pipeline, all channels-last fp32 on HIP kernels:
   ConvTranspose1d is the overlapping-row contraction of ``sopro_gemm_f32`` with ELU fused on the
   operand load and the residual add fused on the store (HF:931-961, 408-447) -> last 64->1 conv.
 
-Only decoding is on the hot path.  Encoding a reference WAV (``encode_file``) needs the Mimi encoder,
-which is SURVEY.md 8(f) rank 1 ("next") and raises here.
+Decoding is the hot path.  Encoding a reference WAV (``encode_file`` / ``encode_waveform``) runs the
+Mimi encoder through the same kernels: first conv and resampler = ``sopro_fir1_f32``; residual blocks, strided
+convs, transformer, downsample and the RVQ nearest-code scores = ``sopro_gemm_f32``; assignment = ``sopro_rvq_assign_f32``.
 """
 from __future__ import annotations
 
@@ -54,6 +55,7 @@ class MimiCodec:
         self.fuse_tail = os.environ.get("SOPRO_UNFUSED_TAIL", "0") != "1"
         self._rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._rope_n = 0
+        self._banks: Dict[Tuple[int, int], tuple] = {}
         Q, V = self.num_quantizers, int(self.mc.codebook_size)
         ns = int(self.mc.num_semantic_quantizers)
         i32 = lambda v: torch.tensor(list(v), dtype=torch.int32, device=self.device)  # noqa: E731
@@ -82,9 +84,120 @@ class MimiCodec:
         return self._rope
 
     # ------------------------------------------------------------------ reference API
-    def encode_file(self, *a, **k):
-        raise NotImplementedError("Mimi encoding of reference audio is not on the MI355X hot path yet "
-                                  "(SURVEY.md 8f rank 1): pass ref_tokens_tq= or a PreparedReference")
+    def encode_file(self, wav_path: str, *, crop_seconds: Optional[float] = None) -> torch.Tensor:
+        """Reference WAV -> Mimi codes [T, Q] (int64, on the device).  reference: src/sopro/codec/mimi.py:42-63:
+        load (mono) -> energy trim -> resample to the codec rate -> optional centre crop -> MimiModel.encode."""
+        from . import audio
+
+        wav, sr = audio.load_audio_file(wav_path)
+        wav = audio.trim_silence_energy(wav, sr)
+        sr_t = int(self.mc.sampling_rate)
+        x = self.resample(torch.from_numpy(np.ascontiguousarray(wav)).to(self.device), sr, sr_t)
+        if crop_seconds is not None and crop_seconds > 0:
+            fps = float(self.mc.frame_rate)
+            hop = int(round(sr_t / fps))
+            win_frames = max(1, int(round(crop_seconds * fps)))
+            x = audio.center_crop_audio(x, win_frames * hop).contiguous()
+        return self.encode_waveform(x)
+
+    @torch.inference_mode()
+    def resample(self, wav_n: torch.Tensor, sr_in: int, sr_out: int) -> torch.Tensor:
+        """[N] device waveform -> [ceil(N * sr_out / sr_in)]: polyphase windowed-sinc bank on the GPU
+        (reference: src/sopro/audio.py:113-123 -> torchaudio.functional.resample defaults)."""
+        from . import audio
+
+        wav_n = wav_n.to(self.device, torch.float32).contiguous()
+        if int(sr_in) == int(sr_out) or wav_n.numel() == 0:
+            return wav_n
+        key = (int(sr_in), int(sr_out))
+        if key not in self._banks:
+            bank, left, orig, new = audio.sinc_resample_bank(*key)
+            self._banks[key] = (torch.from_numpy(bank).to(self.device), left, orig, new)
+        bank, left, orig, new = self._banks[key]
+        n = int(wav_n.numel())
+        n_blk = n // orig + 1  # torchaudio pads (width, width + orig): floor((n + orig - orig) / orig) + 1 blocks
+        out = torch.empty(n_blk * new, device=self.device)
+        with self.on_stream():
+            hip.fir1(wav_n, bank, out, B=1, n_in=n, n_out=n_blk, C_=new, K=int(bank.shape[1]), stride=orig, left=left)
+        self.stream.synchronize()
+        return out[: -(-new * n // orig)].contiguous()
+
+    @torch.inference_mode()
+    def encode_waveform(self, wav: torch.Tensor) -> torch.Tensor:
+        """[N] / [1, N] / [B, N] waveform(s) at the codec rate -> codes [T, Q] (or [B, T, Q]), T = ceil(N / 1920).
+        HF:modeling_mimi.py MimiModel._encode_frame: SEANet encoder -> transformer -> stride-2 downsample ->
+        split residual VQ.  Every contraction runs in ``sopro_gemm_f32`` (strided convs = overlapping-row windows)."""
+        mc, w, dev, ws = self.mc, self.w, self.device, self.ws
+        if "enc.conv0.w" not in w:
+            raise hip.SoproHipError("this Mimi checkpoint was loaded without its encoder-side tensors")
+        squeeze = wav.dim() == 1
+        x = (wav.unsqueeze(0) if squeeze else wav.reshape(-1, wav.shape[-1])).to(dev, torch.float32).contiguous()
+        B, N = int(x.shape[0]), int(x.shape[1])
+        if N == 0:
+            raise ValueError("empty waveform")
+        HS, CD, V, Q = int(mc.hidden_size), int(mc.codebook_dim), int(mc.codebook_size), self.num_quantizers
+        ratios = [int(r) for r in reversed(mc.upsampling_ratios)]
+        k0, rk, lk = int(mc.kernel_size), int(mc.residual_kernel_size), int(mc.last_kernel_size)
+        s2 = int(mc.upsample_stride)
+        with self.on_stream():
+            ch, L = int(mc.num_filters), N
+            pad = max(ratios[0], rk - 1)
+            Lo = -(-L // ratios[0])
+            Hc = torch.zeros(B, pad + Lo * ratios[0], ch, device=dev)  # per-call: lengths vary freely
+            # first conv 1 -> 64, k = 7, causal
+            hip.fir1(x, w["enc.conv0.w"], Hc, B=B, n_in=N, n_out=N, C_=ch, K=k0, stride=1, left=k0 - 1, bias=w["enc.conv0.b"],
+                     o_off=pad * ch, o_seg_stride=int(Hc.shape[1]) * ch)
+            for si, r in enumerate(ratios):
+                seg_stride = int(Hc.shape[1]) * ch
+                hid = ch // int(mc.compress)
+                # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x))))
+                Y1 = torch.empty(B * L, hid, device=dev)
+                hip.gemm(Hc, w[f"enc.res{si}.c1.w"], Y1, M=B * L, N=hid, K=rk * ch, lda=ch, bias=w[f"enc.res{si}.c1.b"],
+                         prologue=hip.PRO_ELU, rows_per_seg=L, a_seg_stride=seg_stride, a_off=(pad - (rk - 1)) * ch)
+                hip.gemm(Y1, w[f"enc.res{si}.c2.w"], Hc, M=B * L, N=ch, K=hid, bias=w[f"enc.res{si}.c2.b"], prologue=hip.PRO_ELU,
+                         epilogue=hip.EPI_RES, R=Hc, rows_per_seg=L, c_off=pad * ch, r_off=pad * ch, c_seg_stride=seg_stride,
+                         r_seg_stride=seg_stride, ldc=ch, ldr=ch)
+                # ELU -> Conv1d(ch -> 2ch, k = 2r, stride r): frame j contracts rows j*r - r .. j*r + r - 1
+                Lo = -(-L // r)
+                last = si == len(ratios) - 1
+                if last:
+                    npad, ntail = lk - 1, 0
+                else:
+                    npad = max(ratios[si + 1], rk - 1)
+                    ntail = -(-Lo // ratios[si + 1]) * ratios[si + 1] - Lo
+                Hn = torch.zeros(B, npad + Lo + ntail, 2 * ch, device=dev)
+                hip.gemm(Hc, w[f"enc.down{si}.w"], Hn, M=B * Lo, N=2 * ch, K=2 * r * ch, lda=r * ch, bias=w[f"enc.down{si}.b"],
+                         prologue=hip.PRO_ELU, rows_per_seg=Lo, a_seg_stride=seg_stride, a_off=(pad - r) * ch, c_off=npad * 2 * ch,
+                         c_seg_stride=int(Hn.shape[1]) * 2 * ch, ldc=2 * ch)
+                Hc, ch, L, pad = Hn, 2 * ch, Lo, npad
+            # ELU -> last conv (k = 3) into the transformer stream, which carries the downsample conv's replicate pads
+            T25 = L
+            T = -(-T25 // s2)
+            pad_x, tail_x = s2, T * s2 - T25
+            xs_stride = (pad_x + T25 + tail_x) * HS
+            X = torch.empty(B, pad_x + T25 + tail_x, HS, device=dev)
+            hip.gemm(Hc, w["enc.final.w"], X, M=B * T25, N=HS, K=lk * ch, lda=ch, bias=w["enc.final.b"], prologue=hip.PRO_ELU,
+                     rows_per_seg=T25, a_seg_stride=int(Hc.shape[1]) * ch, c_off=pad_x * HS, c_seg_stride=xs_stride, ldc=HS)
+            self._transformer("etr", X, B, T25, pad_x, xs_stride)
+            # downsample: Conv1d(k = 2*s2, stride s2, no bias), replicate padding on both sides
+            X[:, :pad_x] = X[:, pad_x:pad_x + 1]
+            if tail_x:
+                X[:, pad_x + T25:] = X[:, pad_x + T25 - 1:pad_x + T25]
+            Dn = torch.empty(B * T, HS, device=dev)
+            hip.gemm(X, w["enc.ds.w"], Dn, M=B * T, N=HS, K=2 * s2 * HS, lda=s2 * HS, rows_per_seg=T, a_seg_stride=xs_stride)
+            # split residual VQ: semantic group (input_proj + ns layers), acoustic group (input_proj + the rest)
+            codes = torch.empty(B * T, Q, dtype=torch.int32, device=dev)
+            res = torch.empty(B * T, CD, device=dev)
+            scores = torch.empty(B * T, V, device=dev)
+            ns = int(mc.num_semantic_quantizers)
+            for grp, q0, q1 in (("sem", 0, ns), ("ac", ns, Q)):
+                hip.gemm(Dn, w[f"enc.inproj.{grp}.w"], res, M=B * T, N=CD, K=HS)
+                for q in range(q0, q1):
+                    hip.gemm(res, w["codebooks"][q * V:(q + 1) * V], scores, M=B * T, N=V, K=CD, bias=w["enc.cb_bias"][q * V:(q + 1) * V])
+                    hip.rvq_assign(scores, w["codebooks"], res, codes, rows=B * T, V=V, D=CD, ldc=Q, t_off=q * V * CD, c_off=q)
+        self.stream.synchronize()
+        out = codes.view(B, T, Q).long()
+        return out[0] if squeeze else out
 
     @torch.inference_mode()
     def decode_full(self, codes_tq: torch.Tensor) -> torch.Tensor:
@@ -105,8 +218,6 @@ class MimiCodec:
             return torch.zeros(B, 0, device=dev)
         HS, CD = int(mc.hidden_size), int(mc.codebook_dim)
         N2 = 2 * T
-        H, dh = int(mc.num_attention_heads), int(mc.head_dim)
-        win = int(mc.sliding_window)
         PADX = int(mc.kernel_size) - 1  # 6 zero rows in front of the first SEANet conv's input
         with self.on_stream():
             tok = codes_btq.to(dev).to(torch.int32).contiguous().view(B * T, Q)
@@ -121,51 +232,9 @@ class MimiCodec:
             X = ws.get("tr.x", (B, PADX + N2, HS), zero=True)
             hip.upsample2(q, w["upsample.w"], X, B=B, T=T, C_=HS, y_seg_stride=xs_stride, y_off=PADX * HS)
             # ---- transformer
-            past = 0
-            if state is not None:
-                if B != 1:
-                    raise ValueError("streaming decode state is single-utterance")
-                past = state.pos
-            cos_t, sin_t = self._rope_tables(past + N2)
-            y = ws.get("tr.y", (B * N2, HS))
-            qkv = ws.get("tr.qkv", (B * N2, 3 * HS))
-            ao = ws.get("tr.ao", (B * N2, HS))
-            hd = ws.get("tr.hd", (B * N2, int(mc.intermediate_size)))
-            seg = dict(rows_per_seg=N2)
-            new_kv: List[torch.Tensor] = []
-            for li in range(int(mc.num_hidden_layers)):
-                p = f"tr.{li}"
-                self._ln_stream(X, y, w[p + ".ln1.w"], w[p + ".ln1.b"], B, N2, PADX, HS)
-                hip.gemm(y, w[p + ".qkv.w"], qkv, M=B * N2, N=3 * HS, K=HS)
-                hip.rope(qkv, cos_t, sin_t, rows=B * N2, rows_per_seg=N2, pos0=past, H=H, dh=dh, ldx=3 * HS)
-                hip.rope(qkv, cos_t, sin_t, rows=B * N2, rows_per_seg=N2, pos0=past, H=H, dh=dh, ldx=3 * HS, x_off=HS)
-                if state is None:
-                    hip.attention(qkv, qkv, qkv, ao, B=B, H=H, dh=dh, Tq=N2, Tk=N2, ldq=3 * HS, ldk=3 * HS, ldv=3 * HS, ldo=HS,
-                                  q_bstride=N2 * 3 * HS, k_bstride=N2 * 3 * HS, v_bstride=N2 * 3 * HS, o_bstride=N2 * HS,
-                                  causal=True, window=win, k_off=HS, v_off=2 * HS)
-                else:
-                    # keys/values of earlier calls (post-RoPE) followed by this call's
-                    cur = qkv[:, HS:].contiguous()  # [N2, 2*HS] = (k | v)
-                    if state.kv is not None and state.kv_len > 0:
-                        allkv = torch.cat([state.kv[li], cur], dim=0)
-                    else:
-                        allkv = cur
-                    Tk = int(allkv.shape[0])
-                    hip.attention(qkv, allkv, allkv, ao, B=1, H=H, dh=dh, Tq=N2, Tk=Tk, ldq=3 * HS, ldk=2 * HS, ldv=2 * HS, ldo=HS,
-                                  q_bstride=0, k_bstride=0, v_bstride=0, o_bstride=0, causal=True, window=win, q_pos0=past,
-                                  k_pos0=past + N2 - Tk, v_off=HS)
-                    # DynamicSlidingWindowLayer keeps the last window-1 positions (installed transformers 5.x)
-                    new_kv.append(allkv[-(win - 1):].clone())
-                hip.gemm(ao, w[p + ".o.w"], X, M=B * N2, N=HS, K=HS, epilogue=hip.EPI_RES, R=X, scale=w[p + ".ls1"],
-                         c_off=PADX * HS, r_off=PADX * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
-                self._ln_stream(X, y, w[p + ".ln2.w"], w[p + ".ln2.b"], B, N2, PADX, HS)
-                hip.gemm(y, w[p + ".fc1.w"], hd, M=B * N2, N=int(mc.intermediate_size), K=HS, epilogue=hip.EPI_GELU)
-                hip.gemm(hd, w[p + ".fc2.w"], X, M=B * N2, N=HS, K=int(mc.intermediate_size), epilogue=hip.EPI_RES, R=X,
-                         scale=w[p + ".ls2"], c_off=PADX * HS, r_off=PADX * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
-            if state is not None:
-                state.kv = new_kv
-                state.kv_len = int(new_kv[0].shape[0])
-                state.pos = past + N2
+            if state is not None and B != 1:
+                raise ValueError("streaming decode state is single-utterance")
+            self._transformer("tr", X, B, N2, PADX, xs_stride, state)
             # ---- SEANet decoder (HF:modeling_mimi.py:931-961)
             ch = int(mc.num_filters) * (2 ** len(mc.upsampling_ratios))  # 1024
             rows = N2
@@ -206,10 +275,60 @@ class MimiCodec:
         self.stream.synchronize()
         return wav
 
-    def _ln_stream(self, X: torch.Tensor, y: torch.Tensor, wt: torch.Tensor, bs: torch.Tensor, B: int, N2: int, pad: int, HS: int) -> None:
+    def _transformer(self, pre: str, X: torch.Tensor, B: int, n: int, pad: int, xs_stride: int,
+                     state: Optional[MimiDecodeState] = None) -> None:
+        """Pre-norm causal sliding-window RoPE transformer over the residual stream ``X`` [B, pad + n (+ tail), HS], in place
+        (HF:modeling_mimi.py MimiTransformerModel; ``pre`` = "tr" for the decoder side, "etr" for the encoder side)."""
+        mc, w, ws = self.mc, self.w, self.ws
+        HS, H, dh, win = int(mc.hidden_size), int(mc.num_attention_heads), int(mc.head_dim), int(mc.sliding_window)
+        inter = int(mc.intermediate_size)
+        past = state.pos if state is not None else 0
+        cos_t, sin_t = self._rope_tables(past + n)
+        y = ws.get("tr.y", (B * n, HS))
+        qkv = ws.get("tr.qkv", (B * n, 3 * HS))
+        ao = ws.get("tr.ao", (B * n, HS))
+        hd = ws.get("tr.hd", (B * n, inter))
+        seg = dict(rows_per_seg=n)
+        new_kv: List[torch.Tensor] = []
+        for li in range(int(mc.num_hidden_layers)):
+            p = f"{pre}.{li}"
+            self._ln_stream(X, y, w[p + ".ln1.w"], w[p + ".ln1.b"], B, n, pad, HS, xs_stride)
+            hip.gemm(y, w[p + ".qkv.w"], qkv, M=B * n, N=3 * HS, K=HS)
+            hip.rope(qkv, cos_t, sin_t, rows=B * n, rows_per_seg=n, pos0=past, H=H, dh=dh, ldx=3 * HS)
+            hip.rope(qkv, cos_t, sin_t, rows=B * n, rows_per_seg=n, pos0=past, H=H, dh=dh, ldx=3 * HS, x_off=HS)
+            if state is None:
+                hip.attention(qkv, qkv, qkv, ao, B=B, H=H, dh=dh, Tq=n, Tk=n, ldq=3 * HS, ldk=3 * HS, ldv=3 * HS, ldo=HS,
+                              q_bstride=n * 3 * HS, k_bstride=n * 3 * HS, v_bstride=n * 3 * HS, o_bstride=n * HS,
+                              causal=True, window=win, k_off=HS, v_off=2 * HS)
+            else:
+                # keys/values of earlier calls (post-RoPE) followed by this call's
+                cur = qkv[:, HS:].contiguous()  # [n, 2*HS] = (k | v)
+                if state.kv is not None and state.kv_len > 0:
+                    allkv = torch.cat([state.kv[li], cur], dim=0)
+                else:
+                    allkv = cur
+                Tk = int(allkv.shape[0])
+                hip.attention(qkv, allkv, allkv, ao, B=1, H=H, dh=dh, Tq=n, Tk=Tk, ldq=3 * HS, ldk=2 * HS, ldv=2 * HS, ldo=HS,
+                              q_bstride=0, k_bstride=0, v_bstride=0, o_bstride=0, causal=True, window=win, q_pos0=past,
+                              k_pos0=past + n - Tk, v_off=HS)
+                # DynamicSlidingWindowLayer keeps the last window-1 positions (installed transformers 5.x)
+                new_kv.append(allkv[-(win - 1):].clone())
+            hip.gemm(ao, w[p + ".o.w"], X, M=B * n, N=HS, K=HS, epilogue=hip.EPI_RES, R=X, scale=w[p + ".ls1"],
+                     c_off=pad * HS, r_off=pad * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
+            self._ln_stream(X, y, w[p + ".ln2.w"], w[p + ".ln2.b"], B, n, pad, HS, xs_stride)
+            hip.gemm(y, w[p + ".fc1.w"], hd, M=B * n, N=inter, K=HS, epilogue=hip.EPI_GELU)
+            hip.gemm(hd, w[p + ".fc2.w"], X, M=B * n, N=HS, K=inter, epilogue=hip.EPI_RES, R=X,
+                     scale=w[p + ".ls2"], c_off=pad * HS, r_off=pad * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
+        if state is not None:
+            state.kv = new_kv
+            state.kv_len = int(new_kv[0].shape[0])
+            state.pos = past + n
+
+    def _ln_stream(self, X: torch.Tensor, y: torch.Tensor, wt: torch.Tensor, bs: torch.Tensor, B: int, N2: int, pad: int, HS: int,
+                   xs_stride: int) -> None:
         """LayerNorm of the zero-padded residual stream into a dense [B*N2, HS] buffer."""
         hip.norm(X, y, wt, rows=B * N2, C_=HS, eps=float(self.mc.norm_eps), kind=hip.NORM_LN, b=bs, rows_per_seg=N2,
-                 x_off=pad * HS, x_seg_stride=(pad + N2) * HS)
+                 x_off=pad * HS, x_seg_stride=xs_stride)
 
 
 class MimiStreamDecoder:

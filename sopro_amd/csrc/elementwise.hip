@@ -221,6 +221,64 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Mimi encode side: single-channel FIR bank (first SEANet conv, polyphase resampler) and the
+// residual-VQ assignment step
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fir1_kernel(const float* __restrict__ x, int64_t x_seg_stride, int n_in,
+                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                   float* __restrict__ out, int64_t ldo, int64_t o_seg_stride, int n_out, int C,
+                                                   int K, int stride, int left) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_out * C) return;
+  const int c = (int)(i % C);
+  const int t = (int)(i / C);
+  const float* xb = x + (int64_t)blockIdx.y * x_seg_stride;
+  const float* wc = w + (int64_t)c * K;
+  const int s0 = t * stride - left;
+  float acc = 0.0f;  // taps in ascending order, one fma each
+  for (int k = 0; k < K; ++k) {
+    const int s = s0 + k;
+    const float xv = (s >= 0 && s < n_in) ? xb[s] : 0.0f;
+    acc = fmaf(wc[k], xv, acc);
+  }
+  out[(int64_t)blockIdx.y * o_seg_stride + (int64_t)t * ldo + c] = acc + (bias ? bias[c] : 0.0f);
+}
+
+// one 256-thread workgroup per row: first maximum of the score row -> code; residual -= codebook row
+__global__ __launch_bounds__(256) void rvq_assign_kernel(const float* __restrict__ scores, int64_t lds_, int V,
+                                                         const float* __restrict__ table, float* __restrict__ res, int64_t ldr,
+                                                         int D, int* __restrict__ codes, int64_t ldc) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int row = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* xr = scores + (int64_t)row * lds_;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int n = threadIdx.x; n < V; n += 256) {
+    const float v = xr[n];
+    if (v > best || (v == best && n < bi)) { best = v; bi = n; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  best = sv[0]; bi = si[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+  if (bi == 0x7fffffff) bi = 0;  // all-NaN row
+  if (threadIdx.x == 0) codes[(int64_t)row * ldc] = bi;
+  const float* e = table + (int64_t)bi * D;
+  float* r = res + (int64_t)row * ldr;
+  for (int d = threadIdx.x; d < D; d += 256) r[d] -= e[d];
+}
+
+// ---------------------------------------------------------------------------------------------
 // RoPE (rotate-half), Mimi upsample, last SEANet conv
 // ---------------------------------------------------------------------------------------------
 __global__ void rope_kernel(float* __restrict__ x, int64_t ldx, const float* __restrict__ cos_t,
@@ -420,6 +478,23 @@ int sopro_text_embed_f32(const int32_t* ids, const int32_t* lens, const float* t
 int sopro_argmax_rows_f32(const float* x, int64_t ldx, int32_t* out, int64_t ldo, int32_t rows, int32_t N, void* stream) {
   SOPRO_CHECK_ARG(x && out && rows > 0 && N > 0, "bad pointers or sizes");
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(nblk(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, rows, N);
+  SOPRO_LAUNCH_CHECK();
+}
+
+int sopro_fir1_f32(const float* x, int64_t x_seg_stride, int32_t n_in, const float* w, const float* bias, float* out, int64_t ldo,
+                   int64_t o_seg_stride, int32_t B, int32_t n_out, int32_t C, int32_t K, int32_t stride, int32_t left, void* stream) {
+  SOPRO_CHECK_ARG(x && w && out, "NULL pointer");
+  SOPRO_CHECK_ARG(B > 0 && B <= 65535 && n_in > 0 && n_out > 0 && C > 0 && K > 0 && stride > 0 && left >= 0 && ldo >= C, "bad sizes");
+  hipLaunchKernelGGL(fir1_kernel, dim3(nblk((int64_t)n_out * C, 256), B), dim3(256), 0, (hipStream_t)stream, x, x_seg_stride, n_in, w,
+                     bias, out, ldo, o_seg_stride, n_out, C, K, stride, left);
+  SOPRO_LAUNCH_CHECK();
+}
+
+int sopro_rvq_assign_f32(const float* scores, int64_t lds, int32_t V, const float* table, float* res, int64_t ldr, int32_t D,
+                         int32_t* codes, int64_t ldc, int32_t rows, void* stream) {
+  SOPRO_CHECK_ARG(scores && table && res && codes, "NULL pointer");
+  SOPRO_CHECK_ARG(rows > 0 && V > 0 && D > 0 && lds >= V && ldr >= D && ldc > 0, "bad sizes");
+  hipLaunchKernelGGL(rvq_assign_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, scores, lds, V, table, res, ldr, D, codes, ldc);
   SOPRO_LAUNCH_CHECK();
 }
 

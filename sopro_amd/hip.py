@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -86,6 +86,8 @@ SYMBOLS = {
     "sopro_codebook_sum_f32": (C.c_int, [_p, _i32, _p, _p, _p, _i32, _p, _i64, _p, _f32, _f32, _p, _i64, _i64, _i32, _i32, _i32, _p]),
     "sopro_text_embed_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "sopro_argmax_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _p]),
+    "sopro_fir1_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "sopro_rvq_assign_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _i32, _p, _i64, _i32, _p]),
     "sopro_attention_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
     "sopro_attn_decode_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
     "sopro_xattn_step_f32": (C.c_int, [C.POINTER(XattnArgs), _p]),
@@ -300,6 +302,21 @@ def argmax_rows(x: torch.Tensor, out: torch.Tensor, *, rows: int, N: int, ldx: O
                 o_off: int = 0) -> None:
     _check(load().sopro_argmax_rows_f32(ptr(x), N if ldx is None else ldx, ptr(out, torch.int32) + 4 * o_off, ldo, rows, N,
                                         _stream()), "sopro_argmax_rows_f32")
+
+
+def fir1(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, B: int, n_in: int, n_out: int, C_: int, K: int, stride: int,
+         left: int, bias: Optional[torch.Tensor] = None, ldo: Optional[int] = None, x_seg_stride: Optional[int] = None,
+         o_seg_stride: Optional[int] = None, o_off: int = 0) -> None:
+    ldo = C_ if ldo is None else ldo
+    _check(load().sopro_fir1_f32(ptr(x), n_in if x_seg_stride is None else x_seg_stride, n_in, ptr(w), ptr(bias) if bias is not None else None,
+                                 ptr(out) + 4 * o_off, ldo, n_out * ldo if o_seg_stride is None else o_seg_stride, B, n_out, C_, K,
+                                 stride, left, _stream()), "sopro_fir1_f32")
+
+
+def rvq_assign(scores: torch.Tensor, table: torch.Tensor, res: torch.Tensor, codes: torch.Tensor, *, rows: int, V: int, D: int,
+               ldc: int, t_off: int = 0, c_off: int = 0) -> None:
+    _check(load().sopro_rvq_assign_f32(ptr(scores), V, V, ptr(table) + 4 * t_off, ptr(res), D, D, ptr(codes, torch.int32) + 4 * c_off,
+                                       ldc, rows, _stream()), "sopro_rvq_assign_f32")
 
 
 def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor, *, B: int, H: int, dh: int, Tq: int,

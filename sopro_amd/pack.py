@@ -165,16 +165,11 @@ def pack_mimi(weights: Dict[str, "np.ndarray"], mc: MimiDecoderConfig) -> Dict[s
     pac = w["quantizer.acoustic_residual_vector_quantizer.output_proj.weight"].squeeze(-1)
     out["rvq_proj.w"] = torch.cat([psem, pac], dim=1).contiguous()  # [512, 256 sem | 256 ac]
     out["upsample.w"] = w["upsample.conv.weight"].squeeze(1).contiguous()  # [512, 4]
-    for li in range(int(mc.num_hidden_layers)):
-        p = f"decoder_transformer.layers.{li}"
-        out[f"tr.{li}.qkv.w"] = torch.cat([w[p + f".self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], dim=0).contiguous()
-        out[f"tr.{li}.o.w"] = w[p + ".self_attn.o_proj.weight"]
-        out[f"tr.{li}.fc1.w"] = w[p + ".mlp.fc1.weight"]
-        out[f"tr.{li}.fc2.w"] = w[p + ".mlp.fc2.weight"]
-        out[f"tr.{li}.ln1.w"], out[f"tr.{li}.ln1.b"] = w[p + ".input_layernorm.weight"], w[p + ".input_layernorm.bias"]
-        out[f"tr.{li}.ln2.w"], out[f"tr.{li}.ln2.b"] = w[p + ".post_attention_layernorm.weight"], w[p + ".post_attention_layernorm.bias"]
-        out[f"tr.{li}.ls1"] = w[p + ".self_attn_layer_scale.scale"]
-        out[f"tr.{li}.ls2"] = w[p + ".mlp_layer_scale.scale"]
+    for pre, name in (("tr", "decoder_transformer"), ("etr", "encoder_transformer")):
+        if f"{name}.layers.0.mlp.fc1.weight" in w:
+            _pack_transformer(out, w, pre, name, int(mc.num_hidden_layers))
+    if "encoder.layers.0.conv.weight" in w:
+        _pack_mimi_encoder(out, w, mc)
     out["sea.conv0.w"] = pack_conv1d(w["decoder.layers.0.conv.weight"])
     out["sea.conv0.b"] = w["decoder.layers.0.conv.bias"]
     li = 1
@@ -193,6 +188,45 @@ def pack_mimi(weights: Dict[str, "np.ndarray"], mc: MimiDecoderConfig) -> Dict[s
     out["sea.final.w"] = fw[0].t().contiguous()  # [3, 64]
     out["sea.final.b"] = w[f"decoder.layers.{li}.conv.bias"].reshape(1)
     return {k: v.contiguous() for k, v in out.items()}
+
+
+def _pack_mimi_encoder(out: Dict[str, torch.Tensor], w: Dict[str, torch.Tensor], mc: MimiDecoderConfig) -> None:
+    """Encode side (HF:modeling_mimi.py MimiEncoder, downsample, RVQ input projections).  Strided convs keep the
+    [Cout, tap*Cin + ci] layout: with stride r and k = 2r, output frame j contracts 2r consecutive channels-last rows."""
+    out["enc.conv0.w"] = w["encoder.layers.0.conv.weight"].squeeze(1).contiguous()  # [64, 7]
+    out["enc.conv0.b"] = w["encoder.layers.0.conv.bias"]
+    li = 1
+    for si, _r in enumerate(reversed(mc.upsampling_ratios)):
+        p = f"encoder.layers.{li}.block"
+        out[f"enc.res{si}.c1.w"] = pack_conv1d(w[p + ".1.conv.weight"])
+        out[f"enc.res{si}.c1.b"] = w[p + ".1.conv.bias"]
+        out[f"enc.res{si}.c2.w"] = pack_conv1d(w[p + ".3.conv.weight"])
+        out[f"enc.res{si}.c2.b"] = w[p + ".3.conv.bias"]
+        li += 2
+        out[f"enc.down{si}.w"] = pack_conv1d(w[f"encoder.layers.{li}.conv.weight"])
+        out[f"enc.down{si}.b"] = w[f"encoder.layers.{li}.conv.bias"]
+        li += 1
+    li += 1
+    out["enc.final.w"] = pack_conv1d(w[f"encoder.layers.{li}.conv.weight"])
+    out["enc.final.b"] = w[f"encoder.layers.{li}.conv.bias"]
+    out["enc.ds.w"] = pack_conv1d(w["downsample.conv.weight"])  # [512, 4*512], no bias
+    out["enc.inproj.sem.w"] = w["quantizer.semantic_residual_vector_quantizer.input_proj.weight"].squeeze(-1).contiguous()
+    out["enc.inproj.ac.w"] = w["quantizer.acoustic_residual_vector_quantizer.input_proj.weight"].squeeze(-1).contiguous()
+    # nearest code = argmax_e (r.e - |e|^2 / 2)
+    out["enc.cb_bias"] = (-0.5 * (out["codebooks"].double() ** 2).sum(dim=1)).float()
+
+
+def _pack_transformer(out: Dict[str, torch.Tensor], w: Dict[str, torch.Tensor], pre: str, name: str, n_layers: int) -> None:
+    for li in range(n_layers):
+        p = f"{name}.layers.{li}"
+        out[f"{pre}.{li}.qkv.w"] = torch.cat([w[p + f".self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], dim=0).contiguous()
+        out[f"{pre}.{li}.o.w"] = w[p + ".self_attn.o_proj.weight"]
+        out[f"{pre}.{li}.fc1.w"] = w[p + ".mlp.fc1.weight"]
+        out[f"{pre}.{li}.fc2.w"] = w[p + ".mlp.fc2.weight"]
+        out[f"{pre}.{li}.ln1.w"], out[f"{pre}.{li}.ln1.b"] = w[p + ".input_layernorm.weight"], w[p + ".input_layernorm.bias"]
+        out[f"{pre}.{li}.ln2.w"], out[f"{pre}.{li}.ln2.b"] = w[p + ".post_attention_layernorm.weight"], w[p + ".post_attention_layernorm.bias"]
+        out[f"{pre}.{li}.ls1"] = w[p + ".self_attn_layer_scale.scale"]
+        out[f"{pre}.{li}.ls2"] = w[p + ".mlp_layer_scale.scale"]
 
 
 def sinusoid_table(n: int, d: int) -> torch.Tensor:

@@ -202,6 +202,49 @@ def mimi_decoder_weight_spec(mc: MimiDecoderConfig) -> Spec:
     return spec
 
 
+def mimi_encoder_weight_spec(mc: MimiDecoderConfig) -> Spec:
+    """Encode-side tensors of HF ``MimiModel.state_dict()``: SEANet encoder (modeling_mimi.py MimiEncoder), encoder
+    transformer, downsample conv and the RVQ input projections (the codebooks are shared with the decode side)."""
+    spec: Spec = {}
+    nf, hs, cd = int(mc.num_filters), int(mc.hidden_size), int(mc.codebook_dim)
+    k0, rk, lk = int(mc.kernel_size), int(mc.residual_kernel_size), int(mc.last_kernel_size)
+    spec["encoder.layers.0.conv.weight"] = ((nf, 1, k0), "lin_w", k0 / 3.0)
+    spec["encoder.layers.0.conv.bias"] = ((nf,), "lin_b", k0)
+    li, ch = 1, nf
+    for r in reversed(mc.upsampling_ratios):
+        hd = ch // int(mc.compress)
+        p = f"encoder.layers.{li}.block"
+        spec[p + ".1.conv.weight"] = ((hd, ch, rk), "lin_w", ch * rk / 3.0)
+        spec[p + ".1.conv.bias"] = ((hd,), "lin_b", ch * rk)
+        spec[p + ".3.conv.weight"] = ((ch, hd, 1), "lin_w", hd / 3.0)
+        spec[p + ".3.conv.bias"] = ((ch,), "lin_b", hd)
+        li += 2  # residual block, ELU
+        k = 2 * int(r)
+        spec[f"encoder.layers.{li}.conv.weight"] = ((2 * ch, ch, k), "lin_w", ch * k / 3.0)
+        spec[f"encoder.layers.{li}.conv.bias"] = ((2 * ch,), "lin_b", ch * k)
+        li += 1
+        ch *= 2
+    li += 1  # ELU
+    spec[f"encoder.layers.{li}.conv.weight"] = ((hs, ch, lk), "lin_w", ch * lk / 3.0)
+    spec[f"encoder.layers.{li}.conv.bias"] = ((hs,), "lin_b", ch * lk)
+    inter = int(mc.intermediate_size)
+    for i in range(int(mc.num_hidden_layers)):
+        p = f"encoder_transformer.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            spec[f"{p}.self_attn.{n}.weight"] = ((hs, hs), "lin_w", hs)
+        spec[f"{p}.mlp.fc1.weight"] = ((inter, hs), "lin_w", hs)
+        spec[f"{p}.mlp.fc2.weight"] = ((hs, inter), "lin_w", inter)
+        for n in ("input_layernorm", "post_attention_layernorm"):
+            spec[f"{p}.{n}.weight"] = ((hs,), "norm_w", 0.0)
+            spec[f"{p}.{n}.bias"] = ((hs,), "norm_b", 0.0)
+        spec[f"{p}.self_attn_layer_scale.scale"] = ((hs,), "scale", 0.25)
+        spec[f"{p}.mlp_layer_scale.scale"] = ((hs,), "scale", 0.25)
+    spec["downsample.conv.weight"] = ((hs, hs, 2 * int(mc.upsample_stride)), "lin_w", hs * 2 * int(mc.upsample_stride) / 3.0)
+    for group in ("semantic", "acoustic"):
+        spec[f"quantizer.{group}_residual_vector_quantizer.input_proj.weight"] = ((cd, hs, 1), "lin_w", hs / 3.0)
+    return spec
+
+
 # ----------------------------------------------------------------------------
 # synthetic tensors
 # ----------------------------------------------------------------------------
@@ -249,8 +292,12 @@ def synth_sopro_weights(
     return w
 
 
-def synth_mimi_weights(mc: MimiDecoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
-    return synth_tensors(mimi_decoder_weight_spec(mc), seed)
+def synth_mimi_weights(mc: MimiDecoderConfig, seed: int = 0, *, with_encoder: bool = False) -> Dict[str, np.ndarray]:
+    """Decode-side tensors; ``with_encoder`` adds the encode side (reference audio -> tokens)."""
+    w = synth_tensors(mimi_decoder_weight_spec(mc), seed)
+    if with_encoder:
+        w.update(synth_tensors(mimi_encoder_weight_spec(mc), seed))
+    return w
 
 
 # ----------------------------------------------------------------------------

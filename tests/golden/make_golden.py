@@ -195,6 +195,35 @@ def main():
     np.savez_compressed(os.path.join(HERE, "mimi.npz"), tok8=tok8, tok32=tok32, rvq=emb.numpy(), upsample=up.numpy(),
                         transformer=tr.numpy(), wav8=wav8.numpy(), wav32=wav32.numpy())
 
+    # ---- Mimi encode (reference audio -> tokens) + host audio helpers ------------
+    from transformers import MimiConfig, MimiModel
+    from sopro.audio import center_crop_audio, trim_silence_energy
+
+    rng_e = np.random.default_rng(4321)  # own stream: the fixtures above keep their draws
+    mwe = synth_mimi_weights(mc, SEED, with_encoder=True)
+    mme = MimiModel(MimiConfig(num_quantizers=int(mc.num_quantizers))).eval()
+    print("mimi encoder load:", mme.load_state_dict({k: torch.from_numpy(v) for k, v in mwe.items()}, strict=True))
+    N = 24000 + 777
+    ewav = torch.from_numpy((0.3 * rng_e.standard_normal(N)).astype(np.float32)).view(1, 1, N)
+    with torch.inference_mode():
+        eemb = mme.encoder(ewav)
+        etr = mme.encoder_transformer(eemb.transpose(1, 2), return_dict=True)[0].transpose(1, 2)
+        eds = mme.downsample(etr)
+        ecodes = mme.encode(ewav, return_dict=True).audio_codes
+    etaps = {}
+    ocodes = O.mimi_encode(ewav, O.to_torch(mwe), mc, etaps)
+    print("mimi encode: seanet", maxdiff(eemb, etaps["enc_seanet"]), "tr", maxdiff(etr, etaps["enc_transformer"]), "ds",
+          maxdiff(eds, etaps["enc_downsample"]), "codes equal", float((ecodes == ocodes).float().mean()), tuple(ecodes.shape))
+    # silence | burst | silence at 16 kHz for the trim rule
+    sr16 = 16000
+    tw = 1e-4 * rng_e.standard_normal(int(1.6 * sr16)).astype(np.float32)
+    tw[int(0.41 * sr16):int(1.23 * sr16)] += (0.2 * np.sin(np.arange(int(1.23 * sr16) - int(0.41 * sr16)) * 0.07)).astype(np.float32)
+    trimmed = trim_silence_energy(torch.from_numpy(tw), sr16)
+    cropped = center_crop_audio(torch.from_numpy(tw)[None], 9999)
+    np.savez_compressed(os.path.join(HERE, "mimi_encode.npz"), wav=ewav.numpy()[0, 0], codes=ecodes[0].permute(1, 0).numpy(),
+                        enc_seanet_head=eemb.numpy()[:, :, :4], enc_downsample=eds.numpy(), trim_in=tw, trim_sr=sr16,
+                        trim_out=trimmed.numpy(), crop_out=cropped.numpy()[0])
+
     # ---- end-to-end synthesize + stream (greedy) --------------------------------
     tok.table["hello"] = ids.tolist()
     with torch.inference_mode():

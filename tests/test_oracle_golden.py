@@ -119,3 +119,71 @@ def test_repeated_tail_and_sampling_distribution():
     sp, si, _ = O.sampling_distribution(lg, [0], top_p=1.0, temperature=1.0, repetition_penalty=2.0)
     p = torch.softmax(torch.tensor([1.0, 1.0, 0.0, -1.0]), 0)
     assert torch.allclose(sp.sort(descending=True).values, p.sort(descending=True).values, atol=1e-6)
+
+
+def test_mimi_encode(mc):
+    """Oracle encoder (SEANet -> transformer -> downsample -> RVQ) against HF MimiModel.encode on the stored waveform."""
+    from sopro_amd.weights import synth_mimi_weights
+    from conftest import SEED
+
+    g = golden("mimi_encode")
+    mwe = O.to_torch(synth_mimi_weights(mc, SEED, with_encoder=True))
+    taps = {}
+    codes = O.mimi_encode(_t(g["wav"]).view(1, 1, -1), mwe, mc, taps)
+    assert torch.allclose(taps["enc_seanet"][:, :, :4], _t(g["enc_seanet_head"]), atol=1e-4)
+    assert torch.allclose(taps["enc_downsample"], _t(g["enc_downsample"]), atol=5e-4)
+    assert torch.equal(codes[0].permute(1, 0), _t(g["codes"]))
+
+
+def test_audio_helpers_match_reference():
+    """Host trim/crop rules (sopro_amd.audio) and their oracle restatements against the reference's outputs."""
+    from sopro_amd import audio
+
+    g = golden("mimi_encode")
+    sr = int(g["trim_sr"])
+    assert np.array_equal(audio.trim_silence_energy(g["trim_in"], sr), g["trim_out"])
+    assert torch.equal(O.trim_silence_energy(_t(g["trim_in"]), sr), _t(g["trim_out"]))
+    assert np.array_equal(audio.center_crop_audio(g["trim_in"], 9999), g["crop_out"])
+    assert torch.equal(O.center_crop_audio(_t(g["trim_in"]), 9999), _t(g["crop_out"]))
+    assert audio.trim_silence_energy(g["trim_in"][:100], sr).shape[0] == 100  # shorter than 0.1 s: untouched
+
+
+def test_resample_bank_matches_oracle_restatement():
+    """The polyphase bank applied by sopro_fir1_f32 == the oracle's conv1d restatement of torchaudio's resampler."""
+    from sopro_amd import audio
+
+    rng = np.random.default_rng(5)
+    for sr_in, sr_out in ((16000, 24000), (44100, 24000), (48000, 24000), (22050, 24000)):
+        x = rng.standard_normal(3000).astype(np.float32)
+        bank, left, orig, new = audio.sinc_resample_bank(sr_in, sr_out)
+        n = x.shape[0]
+        n_blk = n // orig + 1
+        xp = np.concatenate([np.zeros(left, np.float32), x, np.zeros(left + orig + bank.shape[1], np.float32)])
+        y = np.stack([bank @ xp[i * orig:i * orig + bank.shape[1]] for i in range(n_blk)]).reshape(-1)[: -(-new * n // orig)]
+        ref = O.sinc_resample(_t(x), sr_in, sr_out).numpy()
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() < 1e-5
+
+
+def test_load_audio_file_formats(tmp_path):
+    import struct
+    import wave
+
+    from sopro_amd import audio
+
+    rng = np.random.default_rng(9)
+    x = (rng.uniform(-0.9, 0.9, size=(1000, 2))).astype(np.float32)
+    p16 = str(tmp_path / "a16.wav")
+    with wave.open(p16, "wb") as f:
+        f.setnchannels(2), f.setsampwidth(2), f.setframerate(22050)
+        f.writeframes((x * 32767).astype("<i2").tobytes())
+    w16, sr = audio.load_audio_file(p16)
+    assert sr == 22050 and w16.shape == (1000,)
+    assert np.abs(w16 - ((x * 32767).astype(np.int16) / 32768.0).mean(axis=1)).max() < 1e-6
+    pf = str(tmp_path / "af.wav")
+    body = x[:, 0].astype("<f4").tobytes()
+    with open(pf, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, 24000, 96000, 4, 32))
+        f.write(b"data" + struct.pack("<I", len(body)) + body)
+    wf, sr = audio.load_audio_file(pf)
+    assert sr == 24000 and np.array_equal(wf, x[:, 0])
