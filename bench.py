@@ -112,7 +112,9 @@ def main() -> None:
     ap.add_argument("--cpu-utts", type=int, default=6)
     ap.add_argument("--ttfa-runs", type=int, default=20)
     ap.add_argument("--lanes", type=int, default=2, help="engines pipelined on one GPU (1 = strictly sequential batches)")
-    ap.add_argument("--ar-cus", type=int, default=64, help="CUs reserved for the latency-bound AR phase when lanes > 1")
+    ap.add_argument("--ar-cus", type=int, default=64, help="CUs of each AR partition (latency-bound phase) when lanes > 1")
+    ap.add_argument("--ar-shared", type=int, default=0, help="1: the AR partitions are one CU range used by --ar-parts AR phases at once")
+    ap.add_argument("--ar-parts", type=int, default=1, help="independent AR partitions (concurrent AR phases) when lanes > 1")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -159,7 +161,7 @@ def main() -> None:
         from sopro_amd.pipeline import PipelinedSynthesizer
 
         try:
-            pipe = PipelinedSynthesizer(tts, lanes=args.lanes, ar_cus=args.ar_cus)
+            pipe = PipelinedSynthesizer(tts, lanes=args.lanes, ar_cus=args.ar_cus, ar_parts=args.ar_parts, ar_shared=bool(args.ar_shared))
         except Exception as e:  # noqa: BLE001  (e.g. a device without CU-mask support): fall back to sequential batches
             log(f"pipelining unavailable ({e!r}); running sequential batches")
             pipe, args.lanes = None, 1
@@ -208,7 +210,7 @@ def main() -> None:
     if "gemm_f32_kernel" in fam:
         f = fam["gemm_f32_kernel"]
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-        share = (256 - args.ar_cus) / 256.0 if args.lanes > 1 else 1.0  # CUs this kernel may run on (CU-masked bulk stream)
+        share = (256 - args.ar_cus * (1 if args.ar_shared else args.ar_parts)) / 256.0 if args.lanes > 1 else 1.0  # CUs this kernel may run on (CU-masked bulk stream)
         roof = {"kernel": "gemm_f32_kernel (all tile shapes; v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": round(ach, 3),
                 "peak": round(PEAK_F32_MFMA_TFLOPS * share, 2), "unit": "TFLOP/s", "frac": round(ach / (PEAK_F32_MFMA_TFLOPS * share), 5),
                 "cu_share": share, "peak_full_chip": PEAK_F32_MFMA_TFLOPS, "frac_full_chip": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
@@ -277,8 +279,8 @@ def main() -> None:
                                    "top_p=0.9 T=1.05 anti_loop (reference defaults), synthetic weights with EOS suppressed",
                        "batch_per_gpu": BATCH, "frames": FRAMES, "parallelism": f"replicas x{world} (utterance sharding, no collective)",
                        "lanes_per_gpu": args.lanes,
-                       "pipelining": (f"{args.lanes} engines per GPU share the weights: AR phase of batch k+1 on a {args.ar_cus}-CU stream while NAR+Mimi of "
-                                      f"batch k run on the other {256 - args.ar_cus} CUs (hipExtStreamCreateWithCUMask)") if args.lanes > 1 else "none"},
+                       "pipelining": (f"{args.lanes} engines per GPU share the weights: AR phases on {args.ar_parts} partition(s) of {args.ar_cus} CUs while NAR+Mimi of "
+                                      f"earlier batches run on the other {256 - args.ar_cus * args.ar_parts} CUs (hipExtStreamCreateWithCUMask)") if args.lanes > 1 else "none"},
             "phase_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phases.items()},
             "kernel_families": families,
             "ttfa_ms_p50": None if ttfa is None else round(ttfa, 3),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 6
+#define SOPRO_ABI_VERSION 8
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -82,6 +82,26 @@ typedef struct sopro_gemm_args {
 int sopro_gemm_f32(const sopro_gemm_args* args, void* stream);
 /* developer probe: force a tile shape (0 = heuristic, 1: 128x128, 2: 64x128, 3: 256x64, 4: 256x32, 5: 64x64) */
 int sopro_gemm_set_tile_override(int cfg);
+
+/* The same contraction at bf16 matrix-core rate for paths whose contract is a waveform tolerance (Mimi decoder:
+ * HF:modeling_mimi.py MimiConv1d / MimiConvTranspose1d / MimiTransformerModel): operands are split x = hi + lo into two
+ * bf16 halves (16 mantissa bits, round-to-nearest) and accumulated in fp32 as lo*hi + hi*lo + hi*hi with
+ * v_mfma_f32_32x32x16_bf16.  `a->W`/`a->ldw` are ignored: the weight comes pre-split in MFMA fragment order from
+ * sopro_pack_w_bf16x3 (device pointers; `packed` holds sopro_packed_w_bytes(N, K) bytes, 16-byte aligned).
+ * Epilogues NONE / GELU / RES; prologues NONE / ELU.  `ext` (may be NULL = all zero) selects "split form" tensors:
+ * every aligned group of 32 channels (128 bytes as fp32) is stored as [32 hi bf16 | 32 lo bf16], so an element stays in
+ * its 128-byte line and every fp32 stride / offset keeps its meaning (rows must start on 128-byte boundaries).  A
+ * producer writes ELU(x) in that form (c_mode 1), optionally next to the raw fp32 tensor (c_mode 2), and the consumer
+ * (a_format 1) stages it with plain 16-byte copies: no activation or split work is left in its main loop. */
+typedef struct sopro_gemm_split_ext {
+  int32_t a_format; /* 0: A is fp32 rows; 1: split form (prologue must be NONE) */
+  int32_t c_mode;   /* 0: fp32 to C; 1: ELU + split form to C; 2: fp32 to C and ELU + split form to C2 */
+  float* C2; int64_t ldc2; int64_t c2_seg_stride; /* c_mode 2; strides in 4-byte units like ldc / c_seg_stride */
+} sopro_gemm_split_ext;
+int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
+int sopro_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K, void* packed, void* stream);
+int64_t sopro_packed_w_bytes(int32_t N, int32_t K);
+int sopro_gemm_bf16x3_set_tile_override(int cfg); /* developer probe */
 
 /* Batch-of-at-most-a-few-dozen-rows contraction for the autoregressive step
  * (src/sopro/nn/generator.py:98-130): Y[b, n] = epi( rs[b] * sum_k Xin[b, k] * W[n, k] + bias[n] ),

@@ -52,7 +52,28 @@ class MimiCodec:
         self.ws = Workspace(self.device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.num_quantizers = int(self.mc.num_quantizers)
+        self.use_graph = os.environ.get("SOPRO_NO_BULK_GRAPH", "0") != "1"
+        self._graphs = hip.GraphCache("mimi_graph")  # recorded decode launch sequences per (B, T)
         self.fuse_tail = os.environ.get("SOPRO_UNFUSED_TAIL", "0") != "1"
+        # Decoder contractions run on the split-bf16 matrix-core path (16 mantissa bits per operand, fp32 accumulate:
+        # waveform error ~1e-5 of peak, inside the 1e-4 contract); SOPRO_MIMI_F32=1 keeps them on the fp32 MFMA kernel.
+        self.split_bf16 = os.environ.get("SOPRO_MIMI_F32", "0") != "1"
+        # SOPRO_MIMI_SPLIT_FORM=1: keep SEANet activations in split form between convolutions (producer-side ELU + split);
+        # measured slower than splitting while staging with the current kernel, so it is off by default.
+        self.split_form = os.environ.get("SOPRO_MIMI_SPLIT_FORM", "0") == "1"
+        self.wd: Dict[str, object] = {}
+        if self.split_bf16:
+            with torch.cuda.device(self.device):
+                for k, v in self.w.items():
+                    if v.dim() == 2 and k.endswith(".w") and (k.startswith(("tr.", "sea.conv0", "sea.up", "sea.res", "rvq_proj")))\
+                            and int(v.shape[0]) >= 64 and int(v.shape[1]) % 32 == 0:
+                        self.wd[k] = hip.pack_w_bf16x3(v)
+                torch.cuda.synchronize(self.device)
+            n_st = len(self.mc.upsampling_ratios)
+            need = ["rvq_proj.w", "sea.conv0.w"] + [f"sea.up{i}.w" for i in range(n_st)] + \
+                   [f"sea.res{i}.c{j}.w" for i in range(n_st - 1) for j in (1, 2)]
+            if any(k not in self.wd for k in need):  # unusual channel counts: stay on the fp32 kernels
+                self.split_bf16, self.wd = False, {}
         self._rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._rope_n = 0
         self._banks: Dict[Tuple[int, int], tuple] = {}
@@ -73,6 +94,7 @@ class MimiCodec:
         other = copy.copy(self)
         other.ws = Workspace(self.device)
         other.stream = torch.cuda.Stream(device=self.device)
+        other._graphs = hip.GraphCache("mimi_graph")
         return other
 
     def _rope_tables(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -211,6 +233,7 @@ class MimiCodec:
         """[B, T, Q] integer codes -> [B, T*1920] fp32 waveform.  With ``state`` (B == 1) the transformer
         attends over the cached keys/values of earlier calls, as MimiModel.decode(decoder_past_key_values=...)."""
         mc, w, dev, ws = self.mc, self.w, self.device, self.ws
+        gw = self._gw
         B, T, Q = codes_btq.shape
         if Q != self.num_quantizers:
             raise ValueError(f"expected {self.num_quantizers} codebooks, got {Q}")
@@ -219,67 +242,146 @@ class MimiCodec:
         HS, CD = int(mc.hidden_size), int(mc.codebook_dim)
         N2 = 2 * T
         PADX = int(mc.kernel_size) - 1  # 6 zero rows in front of the first SEANet conv's input
+        if state is not None and B != 1:
+            raise ValueError("streaming decode state is single-utterance")
         with self.on_stream():
-            tok = codes_btq.to(dev).to(torch.int32).contiguous().view(B * T, Q)
-            # ---- RVQ decode + output projections (HF:modeling_mimi.py:1128-1137)
-            emb = ws.get("rvq.emb", (B * T, 2 * CD))
-            hip.codebook_sum(tok, Q, *self._sem, w["codebooks"], emb, rows=B * T, D=CD, ldo=2 * CD)
-            hip.codebook_sum(tok, Q, *self._ac, w["codebooks"], emb, rows=B * T, D=CD, ldo=2 * CD, o_off=CD)
-            q = ws.get("rvq.q", (B * T, HS))
-            hip.gemm(emb, w["rvq_proj.w"], q, M=B * T, N=HS, K=2 * CD)
-            # ---- upsample into the (zero-padded) transformer stream
-            xs_stride = (PADX + N2) * HS
-            X = ws.get("tr.x", (B, PADX + N2, HS), zero=True)
-            hip.upsample2(q, w["upsample.w"], X, B=B, T=T, C_=HS, y_seg_stride=xs_stride, y_off=PADX * HS)
-            # ---- transformer
-            if state is not None and B != 1:
-                raise ValueError("streaming decode state is single-utterance")
-            self._transformer("tr", X, B, N2, PADX, xs_stride, state)
-            # ---- SEANet decoder (HF:modeling_mimi.py:931-961)
-            ch = int(mc.num_filters) * (2 ** len(mc.upsampling_ratios))  # 1024
-            rows = N2
-            # first conv k=7: window = 7 consecutive rows starting 6 rows before (the zero pad)
-            Hc = ws.get("sea.h0", (B, 1 + rows, ch), zero=True)  # 1 zero row: x[t-1] of the transposed conv
-            hip.gemm(X, w["sea.conv0.w"], Hc, M=B * rows, N=ch, K=int(mc.kernel_size) * HS, lda=HS, bias=w["sea.conv0.b"],
-                     rows_per_seg=rows, a_seg_stride=xs_stride, c_off=ch, c_seg_stride=(1 + rows) * ch, ldc=ch)
-            pad_in = 1
-            for si, r in enumerate(mc.upsampling_ratios):
-                r = int(r)
-                co = ch // 2
-                orow = rows * r
-                Ho = ws.get(f"sea.h{si + 1}", (B, 2 + orow, co), zero=True)  # 2 zero rows: left pad of the k=3 conv
-                # ELU -> ConvTranspose1d(ch -> co, k=2r, s=r): row t of A = [x[t-1] | x[t]]
-                hip.gemm(Hc, w[f"sea.up{si}.w"], Ho, M=B * rows, N=r * co, K=2 * ch, lda=ch, bias=w[f"sea.up{si}.b"],
-                         prologue=hip.PRO_ELU, rows_per_seg=rows, a_seg_stride=(pad_in + rows) * ch, a_off=(pad_in - 1) * ch,
-                         c_off=2 * co, c_seg_stride=(2 + orow) * co, ldc=r * co)
-                hid = co // int(mc.compress)
-                last = si == len(mc.upsampling_ratios) - 1
-                if last and self.fuse_tail and co == 64 and hid == 32 and int(mc.residual_kernel_size) == 3 and int(mc.last_kernel_size) == 3:
-                    # last residual block + last conv in one kernel: the 64-channel 24 kHz activation is read once
-                    wav = torch.empty(B, orow, device=dev)
+            # codes land in a persistent buffer so that the launch sequence of a (B, T) shape can be recorded once
+            tok = ws.get("rvq.tok", (B * T, Q), dtype=torch.int32)
+            tok.copy_(codes_btq.to(dev).reshape(B * T, Q))
+            if state is None and self.use_graph:
+                self._graphs.run((B, T), lambda: self._decode_issue(B, T, tok, None))
+            else:
+                self._decode_issue(B, T, tok, state)
+            wav = ws.get("sea.wav", (B, T * int(mc.frame_samples))).clone()  # the caller owns its result
+        self.stream.synchronize()
+        return wav
+
+    def _decode_issue(self, B: int, T: int, tok: torch.Tensor, state: Optional[MimiDecodeState]) -> None:
+        """The decoder's launch sequence for [B*T, Q] int32 codes -> ws["sea.wav"]: launches only (recordable when
+        ``state`` is None)."""
+        mc, w, ws = self.mc, self.w, self.ws
+        gw = self._gw
+        Q = self.num_quantizers
+        HS, CD = int(mc.hidden_size), int(mc.codebook_dim)
+        N2 = 2 * T
+        PADX = int(mc.kernel_size) - 1  # 6 zero rows in front of the first SEANet conv's input
+        # ---- RVQ decode + output projections (HF:modeling_mimi.py:1128-1137)
+        emb = ws.get("rvq.emb", (B * T, 2 * CD))
+        hip.codebook_sum(tok, Q, *self._sem, w["codebooks"], emb, rows=B * T, D=CD, ldo=2 * CD)
+        hip.codebook_sum(tok, Q, *self._ac, w["codebooks"], emb, rows=B * T, D=CD, ldo=2 * CD, o_off=CD)
+        q = ws.get("rvq.q", (B * T, HS))
+        hip.gemm(emb, gw("rvq_proj.w"), q, M=B * T, N=HS, K=2 * CD)
+        # ---- upsample into the (zero-padded) transformer stream
+        xs_stride = (PADX + N2) * HS
+        X = ws.get("tr.x", (B, PADX + N2, HS), zero=True)
+        hip.upsample2(q, w["upsample.w"], X, B=B, T=T, C_=HS, y_seg_stride=xs_stride, y_off=PADX * HS)
+        # ---- transformer
+        self._transformer("tr", X, B, N2, PADX, xs_stride, state)
+        # ---- SEANet decoder (HF:modeling_mimi.py:931-961)
+        wav = ws.get("sea.wav", (B, T * int(mc.frame_samples)))
+        if self.split_bf16 and self.split_form:
+            self._seanet_split(X, B, N2, xs_stride, wav)
+        else:
+            self._seanet_f32(X, B, N2, xs_stride, wav)
+
+    def _seanet_f32(self, X: torch.Tensor, B: int, N2: int, xs_stride: int, wav: torch.Tensor) -> None:
+        """SEANet decoder with fp32 activations and ELU as a GEMM prologue: on the split-bf16 kernel (operands split while
+        they are staged) or, with SOPRO_MIMI_F32=1, on the fp32 MFMA kernel."""
+        mc, w, dev, ws = self.mc, self.w, self.device, self.ws
+        HS = int(mc.hidden_size)
+        gwf = self._gw
+        ch = int(mc.num_filters) * (2 ** len(mc.upsampling_ratios))  # 1024
+        rows = N2
+        # first conv k=7: window = 7 consecutive rows starting 6 rows before (the zero pad)
+        Hc = ws.get("sea.h0", (B, 1 + rows, ch), zero=True)  # 1 zero row: x[t-1] of the transposed conv
+        hip.gemm(X, gwf("sea.conv0.w"), Hc, M=B * rows, N=ch, K=int(mc.kernel_size) * HS, lda=HS, bias=w["sea.conv0.b"],
+                 rows_per_seg=rows, a_seg_stride=xs_stride, c_off=ch, c_seg_stride=(1 + rows) * ch, ldc=ch)
+        pad_in = 1
+        for si, r in enumerate(mc.upsampling_ratios):
+            r = int(r)
+            co = ch // 2
+            orow = rows * r
+            Ho = ws.get(f"sea.h{si + 1}", (B, 2 + orow, co), zero=True)  # 2 zero rows: left pad of the k=3 conv
+            # ELU -> ConvTranspose1d(ch -> co, k=2r, s=r): row t of A = [x[t-1] | x[t]]
+            hip.gemm(Hc, gwf(f"sea.up{si}.w"), Ho, M=B * rows, N=r * co, K=2 * ch, lda=ch, bias=w[f"sea.up{si}.b"],
+                     prologue=hip.PRO_ELU, rows_per_seg=rows, a_seg_stride=(pad_in + rows) * ch, a_off=(pad_in - 1) * ch,
+                     c_off=2 * co, c_seg_stride=(2 + orow) * co, ldc=r * co)
+            hid = co // int(mc.compress)
+            last = si == len(mc.upsampling_ratios) - 1
+            if last and self.fuse_tail and co == 64 and hid == 32 and int(mc.residual_kernel_size) == 3 and int(mc.last_kernel_size) == 3:
+                # last residual block + last conv in one kernel: the 64-channel 24 kHz activation is read once
+                hip.seanet_tail(Ho, w[f"sea.res{si}.c1.w"], w[f"sea.res{si}.c1.b"], w[f"sea.res{si}.c2.w"], w[f"sea.res{si}.c2.b"],
+                                w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
+                Hc, ch, rows, pad_in = Ho, co, orow, 2
+                break
+            # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x))))
+            Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
+            hip.gemm(Ho, gwf(f"sea.res{si}.c1.w"), Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"],
+                     prologue=hip.PRO_ELU, rows_per_seg=orow, a_seg_stride=(2 + orow) * co)
+            hip.gemm(Y1, gwf(f"sea.res{si}.c2.w"), Ho, M=B * orow, N=co, K=hid, bias=w[f"sea.res{si}.c2.b"], prologue=hip.PRO_ELU,
+                     epilogue=hip.EPI_RES, R=Ho, rows_per_seg=orow, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co,
+                     r_seg_stride=(2 + orow) * co, ldc=co, ldr=co)
+            Hc, ch, rows, pad_in = Ho, co, orow, 2
+        else:
+            hip.final_conv(Hc, w["sea.final.w"], self.final_bias, wav, B=B, T=rows, h_seg_stride=(2 + rows) * ch, wav_seg_stride=rows)
+
+    def _seanet_split(self, X: torch.Tensor, B: int, N2: int, xs_stride: int, wav: torch.Tensor) -> None:
+        """SEANet decoder on the split-bf16 matrix-core path.  Between convolutions an activation lives as ELU(x) in
+        split form (every 32 channels = [32 hi bf16 | 32 lo bf16], same bytes, lines and strides as fp32), written by the producer's
+        epilogue, so the consumer's main loop stages it with plain copies.  The raw fp32 tensor is written next to it
+        only where the residual block needs it as its skip operand (transposed-conv outputs)."""
+        mc, w, dev, ws = self.mc, self.w, self.device, self.ws
+        gw = self._gw
+        HS = int(mc.hidden_size)
+        ratios = [int(r) for r in mc.upsampling_ratios]
+        ch = int(mc.num_filters) * (2 ** len(ratios))  # 1024
+        rows = N2
+        # first conv k=7 over the fp32 transformer stream -> ELU, split planes; 1 zero row = x[t-1] of the transposed conv
+        He = ws.get("sea.e0", (B, 1 + rows, ch), zero=True)
+        hip.gemm(X, gw("sea.conv0.w"), He, M=B * rows, N=ch, K=int(mc.kernel_size) * HS, lda=HS, bias=w["sea.conv0.b"],
+                 rows_per_seg=rows, a_seg_stride=xs_stride, c_off=ch, c_seg_stride=(1 + rows) * ch, ldc=ch, c_mode=1)
+        pad_in = 1
+        for si, r in enumerate(ratios):
+            co, orow = ch // 2, rows * r
+            hid = co // int(mc.compress)
+            last = si == len(ratios) - 1
+            Ho = ws.get(f"sea.h{si + 1}", (B, 2 + orow, co), zero=True)  # raw fp32 (skip operand / tail input)
+            up = dict(M=B * rows, N=r * co, K=2 * ch, lda=ch, bias=w[f"sea.up{si}.b"], rows_per_seg=rows, a_seg_stride=(pad_in + rows) * ch,
+                      a_off=(pad_in - 1) * ch, a_split=True, c_off=2 * co, c_seg_stride=(2 + orow) * co, ldc=r * co)
+            if last:
+                # ConvTranspose1d -> raw fp32 only: the last stage runs in the fused tail (or on the fp32 kernels)
+                hip.gemm(He, gw(f"sea.up{si}.w"), Ho, **up)
+                if self.fuse_tail and co == 64 and hid == 32 and int(mc.residual_kernel_size) == 3 and int(mc.last_kernel_size) == 3:
                     hip.seanet_tail(Ho, w[f"sea.res{si}.c1.w"], w[f"sea.res{si}.c1.b"], w[f"sea.res{si}.c2.w"], w[f"sea.res{si}.c2.b"],
                                     w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
-                    Hc, ch, rows, pad_in = Ho, co, orow, 2
-                    break
-                # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x))))
+                    return
                 Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
                 hip.gemm(Ho, w[f"sea.res{si}.c1.w"], Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"],
                          prologue=hip.PRO_ELU, rows_per_seg=orow, a_seg_stride=(2 + orow) * co)
                 hip.gemm(Y1, w[f"sea.res{si}.c2.w"], Ho, M=B * orow, N=co, K=hid, bias=w[f"sea.res{si}.c2.b"], prologue=hip.PRO_ELU,
                          epilogue=hip.EPI_RES, R=Ho, rows_per_seg=orow, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co,
                          r_seg_stride=(2 + orow) * co, ldc=co, ldr=co)
-                Hc, ch, rows, pad_in = Ho, co, orow, 2
-            else:
-                wav = torch.empty(B, rows, device=dev)
-                hip.final_conv(Hc, w["sea.final.w"], self.final_bias, wav, B=B, T=rows, h_seg_stride=(2 + rows) * ch, wav_seg_stride=rows)
-        self.stream.synchronize()
-        return wav
+                hip.final_conv(Ho, w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
+                return
+            # ELU -> ConvTranspose1d(ch -> co, k=2r, s=r): row t of A = [x[t-1] | x[t]]; raw to Ho, ELU split to Hn
+            Hn = ws.get(f"sea.e{si + 1}", (B, 2 + orow, co), zero=True)  # 2 zero rows: left pad of the k=3 conv
+            hip.gemm(He, gw(f"sea.up{si}.w"), Ho, c_mode=2, C2=Hn, ldc2=r * co, c2_seg_stride=(2 + orow) * co, c2_off=2 * co, **up)
+            # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x)))); its output is only ever read through ELU
+            Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
+            hip.gemm(Hn, gw(f"sea.res{si}.c1.w"), Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"], rows_per_seg=orow,
+                     a_seg_stride=(2 + orow) * co, a_split=True, c_mode=1)
+            hip.gemm(Y1, gw(f"sea.res{si}.c2.w"), Hn, M=B * orow, N=co, K=hid, bias=w[f"sea.res{si}.c2.b"], epilogue=hip.EPI_RES, R=Ho,
+                     rows_per_seg=orow, a_split=True, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co, r_seg_stride=(2 + orow) * co,
+                     ldc=co, ldr=co, c_mode=1)
+            He, ch, rows, pad_in = Hn, co, orow, 2
+        raise AssertionError("unreachable: the last stage returns")
 
     def _transformer(self, pre: str, X: torch.Tensor, B: int, n: int, pad: int, xs_stride: int,
                      state: Optional[MimiDecodeState] = None) -> None:
         """Pre-norm causal sliding-window RoPE transformer over the residual stream ``X`` [B, pad + n (+ tail), HS], in place
         (HF:modeling_mimi.py MimiTransformerModel; ``pre`` = "tr" for the decoder side, "etr" for the encoder side)."""
         mc, w, ws = self.mc, self.w, self.ws
+        gw = self._gw
         HS, H, dh, win = int(mc.hidden_size), int(mc.num_attention_heads), int(mc.head_dim), int(mc.sliding_window)
         inter = int(mc.intermediate_size)
         past = state.pos if state is not None else 0
@@ -293,7 +395,7 @@ class MimiCodec:
         for li in range(int(mc.num_hidden_layers)):
             p = f"{pre}.{li}"
             self._ln_stream(X, y, w[p + ".ln1.w"], w[p + ".ln1.b"], B, n, pad, HS, xs_stride)
-            hip.gemm(y, w[p + ".qkv.w"], qkv, M=B * n, N=3 * HS, K=HS)
+            hip.gemm(y, gw(p + ".qkv.w"), qkv, M=B * n, N=3 * HS, K=HS)
             hip.rope(qkv, cos_t, sin_t, rows=B * n, rows_per_seg=n, pos0=past, H=H, dh=dh, ldx=3 * HS)
             hip.rope(qkv, cos_t, sin_t, rows=B * n, rows_per_seg=n, pos0=past, H=H, dh=dh, ldx=3 * HS, x_off=HS)
             if state is None:
@@ -313,16 +415,20 @@ class MimiCodec:
                               k_pos0=past + n - Tk, v_off=HS)
                 # DynamicSlidingWindowLayer keeps the last window-1 positions (installed transformers 5.x)
                 new_kv.append(allkv[-(win - 1):].clone())
-            hip.gemm(ao, w[p + ".o.w"], X, M=B * n, N=HS, K=HS, epilogue=hip.EPI_RES, R=X, scale=w[p + ".ls1"],
+            hip.gemm(ao, gw(p + ".o.w"), X, M=B * n, N=HS, K=HS, epilogue=hip.EPI_RES, R=X, scale=w[p + ".ls1"],
                      c_off=pad * HS, r_off=pad * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
             self._ln_stream(X, y, w[p + ".ln2.w"], w[p + ".ln2.b"], B, n, pad, HS, xs_stride)
-            hip.gemm(y, w[p + ".fc1.w"], hd, M=B * n, N=inter, K=HS, epilogue=hip.EPI_GELU)
-            hip.gemm(hd, w[p + ".fc2.w"], X, M=B * n, N=HS, K=inter, epilogue=hip.EPI_RES, R=X,
+            hip.gemm(y, gw(p + ".fc1.w"), hd, M=B * n, N=inter, K=HS, epilogue=hip.EPI_GELU)
+            hip.gemm(hd, gw(p + ".fc2.w"), X, M=B * n, N=HS, K=inter, epilogue=hip.EPI_RES, R=X,
                      scale=w[p + ".ls2"], c_off=pad * HS, r_off=pad * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
         if state is not None:
             state.kv = new_kv
             state.kv_len = int(new_kv[0].shape[0])
             state.pos = past + n
+
+    def _gw(self, key: str):
+        """GEMM weight operand: the split-bf16 packed form where one was made, else the fp32 matrix."""
+        return self.wd.get(key) or self.w[key]
 
     def _ln_stream(self, X: torch.Tensor, y: torch.Tensor, wt: torch.Tensor, bs: torch.Tensor, B: int, N2: int, pad: int, HS: int,
                    xs_stride: int) -> None:

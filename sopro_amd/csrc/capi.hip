@@ -46,7 +46,7 @@ int sopro_capture_end(void* stream, void** graph_exec_out) {
   SOPRO_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (e != hipSuccess) {
     sopro_set_error("sopro_capture_end: hipGraphInstantiate failed: %s", hipGetErrorString(e));
     return -1;

@@ -47,6 +47,19 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // surrounding contractions is larger); expm1f's software expansion was the dominant VALU cost of the SEANet tail.
 __device__ __forceinline__ float eluf_(float v) { return v > 0.0f ? v : __expf(v) - 1.0f; }
 
+// fp32 -> two bf16 halves, x = hi + lo with hi = bf16(x), lo = bf16(x - hi), both round-to-nearest-even: |lo| <= 2^-9 |x|
+// with either sign, so products that drop lo*lo are 2^-18-relative and zero-mean (a truncated hi: 2^-14, one-signed).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_bf16(float x, float y, unsigned& hi, unsigned& lo) {
+  const f32x2_t v = {x, y};
+  const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+  hi = *reinterpret_cast<const unsigned*>(&h);
+  const f32x2_t r = {x - __uint_as_float(hi << 16), y - __uint_as_float(hi & 0xffff0000u)};  // exact
+  const bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
+  lo = *reinterpret_cast<const unsigned*>(&l);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1,0 +1,311 @@
+// fp32 contraction at bf16 matrix-core rate: every operand is split x = hi + lo into two bf16 halves (16 mantissa
+// bits together) and the product is accumulated in fp32 as lo*hi + hi*lo + hi*hi with v_mfma_f32_32x32x16_bf16
+// (three passes at 16x the fp32-MFMA rate; the dropped lo*lo term and the 16-bit truncation are ~2^-17 relative per
+// product).  Used where the contract is a waveform tolerance (Mimi decoder / encoder); token paths stay on gemm_f32.
+//
+// A (activations, fp32 in HBM, same segmented / overlapping-row addressing as gemm_f32) is split while it is staged
+// into LDS: row = [32 k hi | 32 k lo | 16 B pad] = 144 B, so the ds_read_b128 fragment reads of a 16-lane group hit 16
+// distinct 16-byte slots.  W is split ONCE on the device by sopro_pack_w_bf16x3 into MFMA fragment order
+// [n/32][k/16][plane][lane][8 bf16]; each wave streams its B fragments straight from L2 into registers with fully
+// coalesced dwordx4 loads (1 KB per instruction, every byte used once), so W never touches LDS.
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int AROW = 144;  // bytes per LDS row
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 as_frag(const uint4& v) { return *reinterpret_cast<const bf16x8*>(&v); }
+
+// AMODE: 0 = A is fp32 rows, split while staged; 1 = the same with ELU applied first; 2 = A is already in split form
+// (each 32-channel group = [32 hi | 32 lo] bf16, written by a producer's OUT = 1 / 2 epilogue): pure 16-byte copies.
+template <int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_kernel(const sopro_gemm_args g, const uint4* __restrict__ Wp,
+                                                                  int ksubs, const sopro_gemm_split_ext ext) {
+  constexpr bool ELU = AMODE == 1;
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int A_F4 = BM * 8 / NT;
+  constexpr int RSTEP = NT / 8;
+  extern __shared__ float4 smem4[];
+  unsigned char* As = reinterpret_cast<unsigned char*>(smem4);  // [2][BM][AROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = (g.N + BN - 1) / BN;
+  const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int lrow = tid >> 3, lc4 = tid & 7;
+  const int rps = g.rows_per_seg;
+
+  // Branch-free operand addressing: rows >= M and column tiles >= N are clamped onto valid ones (their accumulators
+  // are never stored) and the K tail re-reads the row's last in-range piece (W is zero-padded there), so the main loop
+  // is one basic block and the compiler can count its outstanding loads instead of draining them.
+  const float* ap[A_F4];
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    const int m = min(m0 + lrow + i * RSTEP, g.M - 1);
+    const int seg = m / rps;
+    const int r = m - seg * rps;
+    ap[i] = g.A + (int64_t)seg * g.a_seg_stride + (int64_t)r * g.lda;
+  }
+  const int ntiles = (g.N + 31) >> 5;
+  const uint4* bp[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int t = min((n0 >> 5) + wn * TN + j, ntiles - 1);
+    bp[j] = Wp + ((int64_t)t * ksubs * 2) * 64 + lane;
+  }
+  float biasv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    biasv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+  }
+
+  float4 ra[A_F4];
+  const int KT = (g.K + BK - 1) / BK;
+  const int klast = g.K - 4;
+
+  auto gload = [&](int kt) {  // split-form A has the fp32 addresses: a K-step is the same 128 bytes of the row
+    const int k = min(kt * BK + lc4 * 4, klast);
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i] + k);
+  };
+  auto bload = [&](int kt, uint4 (&rb)[TN][2][2]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) rb[j][s][p] = bp[j][((int64_t)(kt * 2 + s) * 2 + p) * 64];
+  };
+  auto lstore = [&](int buf) {
+    if (AMODE == 2) {  // pieces 0-3 of the 128-byte group are the hi halves, 4-7 the lo halves: the LDS row layout
+      unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 16;
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(a + i * RSTEP * AROW) = ra[i];
+      return;
+    }
+    if (ELU) {
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) {
+        ra[i].x = eluf_(ra[i].x); ra[i].y = eluf_(ra[i].y); ra[i].z = eluf_(ra[i].z); ra[i].w = eluf_(ra[i].w);
+      }
+    }
+    unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 8;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      uint2 h, l;
+      split2_bf16(ra[i].x, ra[i].y, h.x, l.x);
+      split2_bf16(ra[i].z, ra[i].w, h.y, l.y);
+      *reinterpret_cast<uint2*>(a + i * RSTEP * AROW) = h;
+      *reinterpret_cast<uint2*>(a + i * RSTEP * AROW + 64) = l;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fg = lane >> 5;
+  auto compute = [&](int buf, const uint4 (&rb)[TN][2][2]) {
+    const unsigned char* a = As + buf * BM * AROW + (wm * TM * 32 + frow) * AROW + fg * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 ah[TM], al[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const uint4*>(a + i * 32 * AROW + s * 32);
+        al[i] = *reinterpret_cast<const uint4*>(a + i * 32 * AROW + 64 + s * 32);
+      }
+      // small terms first; the three passes walk all accumulators so that consecutive MFMAs are independent
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(al[i]), as_frag(rb[j][s][0]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ah[i]), as_frag(rb[j][s][1]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ah[i]), as_frag(rb[j][s][0]), acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // Two K-steps per trip (register double buffer for the B fragments, LDS double buffer for A).  The prefetch of the
+  // step after the last one is clamped onto the last step: redundant but branch-free.
+  uint4 rb0[TN][2][2], rb1[TN][2][2];
+  gload(0);
+  bload(0, rb0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; kt += 2) {
+    const int k1 = min(kt + 1, KT - 1), k2 = min(kt + 2, KT - 1);
+    gload(k1);
+    bload(k1, rb1);
+    compute(0, rb0);
+    lstore(1);
+    __syncthreads();
+    if (kt + 1 >= KT) break;
+    gload(k2);
+    bload(k2, rb0);
+    compute(1, rb1);
+    lstore(0);
+    __syncthreads();
+  }
+  gemm_store_tile<WM, WN, TM, TN, EPI, OUT>(g, reinterpret_cast<float*>(smem4), acc, biasv, m0, n0, &ext);
+}
+
+// W [N, ldw] fp32 -> fragment-ordered (hi, lo) bf16 planes; one thread per 16-byte fragment piece
+__global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, uint4* __restrict__ out,
+                                                     int ksubs, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  const int p = (int)((i >> 6) & 1);
+  const int64_t tk = i >> 7;
+  const int ks = (int)(tk % ksubs);
+  const int t = (int)(tk / ksubs);
+  const int n = t * 32 + (lane & 31);
+  const int k0 = ks * 16 + (lane >> 5) * 8;
+  unsigned w[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = k0 + 2 * e;
+    const float x = (n < N && k < K) ? W[(int64_t)n * ldw + k] : 0.f;
+    const float y = (n < N && k + 1 < K) ? W[(int64_t)n * ldw + k + 1] : 0.f;
+    unsigned hi, lo;
+    split2_bf16(x, y, hi, lo);
+    w[e] = p ? lo : hi;
+  }
+  out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT>
+int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds_main = (size_t)2 * BM * AROW, lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static bool attr_done = false;
+  auto kern = gemm_bf16x3_kernel<WM, WN, TM, TN, EPI, AMODE, OUT>;
+  if (!attr_done) {
+    SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, g, wp, ksubs, ext);
+  SOPRO_LAUNCH_CHECK();
+}
+
+// The (epilogue, A format, output mode) combinations the Mimi decoder issues; anything else is refused.
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
+  const int amode = ext.a_format == 1 ? 2 : (g.prologue == SOPRO_PRO_ELU ? 1 : 0);
+  const int key = g.epilogue * 100 + amode * 10 + ext.c_mode;
+#define SOPRO_CASE(E, A, O) \
+  case (E) * 100 + (A) * 10 + (O): return launch_one<WM, WN, TM, TN, E, A, O>(g, wp, ksubs, ext, s)
+  switch (key) {
+    SOPRO_CASE(SOPRO_EPI_NONE, 0, 0);  // transformer qkv, RVQ output projections
+    SOPRO_CASE(SOPRO_EPI_GELU, 0, 0);  // transformer fc1
+    SOPRO_CASE(SOPRO_EPI_RES, 0, 0);   // transformer o / fc2 (+ layer scale)
+    SOPRO_CASE(SOPRO_EPI_NONE, 1, 0);  // fp32 activations with an ELU prologue (generic conv)
+    SOPRO_CASE(SOPRO_EPI_RES, 1, 0);
+    SOPRO_CASE(SOPRO_EPI_NONE, 0, 1);  // first SEANet conv: fp32 in, ELU + split out
+    SOPRO_CASE(SOPRO_EPI_NONE, 0, 2);
+    SOPRO_CASE(SOPRO_EPI_NONE, 2, 0);  // last transposed conv: split in, fp32 out (feeds the fused tail)
+    SOPRO_CASE(SOPRO_EPI_NONE, 2, 1);  // residual block conv k=3
+    SOPRO_CASE(SOPRO_EPI_NONE, 2, 2);  // transposed convs: raw fp32 (residual operand) + ELU split (next conv's input)
+    SOPRO_CASE(SOPRO_EPI_RES, 2, 1);   // residual block conv k=1 + skip
+    default: break;
+  }
+#undef SOPRO_CASE
+  sopro_set_error("sopro_gemm_bf16x3: (epilogue %d, prologue %d, a_format %d, c_mode %d) is not an available combination",
+                  g.epilogue, g.prologue, ext.a_format, ext.c_mode);
+  return -2;
+}
+
+}  // namespace
+
+static int g_tile_override = 0;  // developer probe: 1: 128x128, 2: 256x128, 3: 256x64, 4: 128x64, 5: 64x64
+extern "C" int sopro_gemm_bf16x3_set_tile_override(int cfg) {
+  g_tile_override = cfg;
+  return 0;
+}
+
+extern "C" int64_t sopro_packed_w_bytes(int32_t N, int32_t K) {
+  if (N <= 0 || K <= 0) return 0;
+  return (int64_t)((N + 31) / 32) * ((K + 31) / 32 * 2) * 2 * 64 * 16;
+}
+
+extern "C" int sopro_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K, void* packed, void* stream) {
+  SOPRO_CHECK_ARG(W && packed && N > 0 && K > 0 && ldw >= K, "bad pointers or sizes");
+  SOPRO_CHECK_ARG(aligned16(packed), "packed must be 16-byte aligned");
+  const int ksubs = (K + 31) / 32 * 2;
+  const int64_t total = (int64_t)((N + 31) / 32) * ksubs * 2 * 64;
+  hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K,
+                     reinterpret_cast<uint4*>(packed), ksubs, total);
+  SOPRO_LAUNCH_CHECK();
+}
+
+extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* x, void* stream) {
+  SOPRO_CHECK_ARG(a != nullptr, "args is NULL");
+  sopro_gemm_args g = *a;
+  sopro_gemm_split_ext ext;
+  memset(&ext, 0, sizeof(ext));
+  if (x) ext = *x;
+  if (g.a_seg_stride == 0) g.a_seg_stride = (int64_t)g.rows_per_seg * g.lda;
+  if (g.c_seg_stride == 0) g.c_seg_stride = (int64_t)g.rows_per_seg * g.ldc;
+  if (g.r_seg_stride == 0) g.r_seg_stride = (int64_t)g.rows_per_seg * g.ldr;
+  if (ext.c2_seg_stride == 0) ext.c2_seg_stride = (int64_t)g.rows_per_seg * ext.ldc2;
+  SOPRO_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0, "M, N, K must be positive");
+  SOPRO_CHECK_ARG((g.K & 3) == 0, "K must be a multiple of 4");
+  SOPRO_CHECK_ARG(g.rows_per_seg > 0, "rows_per_seg must be positive");
+  SOPRO_CHECK_ARG(g.A && packed_w && g.C, "A, packed_w, C must be non-NULL");
+  SOPRO_CHECK_ARG(aligned16(g.A) && aligned16(packed_w), "A and packed_w must be 16-byte aligned");
+  SOPRO_CHECK_ARG((g.lda & 3) == 0 && (g.a_seg_stride & 3) == 0, "lda, a_seg_stride must be multiples of 4");
+  SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ELU, "prologue must be NONE or ELU");
+  SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES,
+                  "epilogue must be NONE, GELU or RES");
+  SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_RES || g.R != nullptr, "EPI_RES needs R");
+  SOPRO_CHECK_ARG(ext.a_format == 0 || ext.a_format == 1, "a_format must be 0 (fp32) or 1 (split planes)");
+  if (ext.a_format == 1) {
+    SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE, "split-form A carries its activation already");
+    SOPRO_CHECK_ARG((g.K & 31) == 0 && (g.lda & 31) == 0 && (g.a_seg_stride & 31) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 127u) == 0,
+                    "split-form A: K, lda, a_seg_stride multiples of 32 and a 128-byte aligned base");
+  }
+  SOPRO_CHECK_ARG(ext.c_mode >= 0 && ext.c_mode <= 2, "c_mode must be 0, 1 or 2");
+  if (ext.c_mode != 0) {
+    SOPRO_CHECK_ARG((g.N & 3) == 0, "split-form output: N % 4 == 0");
+    float* d = ext.c_mode == 2 ? ext.C2 : g.C;
+    const int64_t ldd = ext.c_mode == 2 ? ext.ldc2 : g.ldc, dseg = ext.c_mode == 2 ? ext.c2_seg_stride : g.c_seg_stride;
+    SOPRO_CHECK_ARG(d && (reinterpret_cast<uintptr_t>(d) & 127u) == 0 && (ldd & 31) == 0 && (dseg & 31) == 0 && ldd >= g.N,
+                    "split-form output rows must start on 128-byte boundaries (ld, seg stride multiples of 32)");
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const uint4* wp = reinterpret_cast<const uint4*>(packed_w);
+  const int ksubs = (g.K + 31) / 32 * 2;
+  switch (g_tile_override) {
+    case 1: return launch_cfg<2, 2, 2, 2>(g, wp, ksubs, ext, s);
+    case 2: return launch_cfg<2, 2, 4, 2>(g, wp, ksubs, ext, s);
+    case 3: return launch_cfg<4, 1, 2, 2>(g, wp, ksubs, ext, s);
+    case 4: return launch_cfg<2, 2, 2, 1>(g, wp, ksubs, ext, s);
+    case 5: return launch_cfg<2, 2, 1, 1>(g, wp, ksubs, ext, s);
+    default: break;
+  }
+  if (g.N <= 64) return launch_cfg<2, 2, 1, 1>(g, wp, ksubs, ext, s);
+  return launch_cfg<2, 2, 2, 2>(g, wp, ksubs, ext, s);
+}

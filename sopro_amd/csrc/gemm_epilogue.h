@@ -1,0 +1,136 @@
+// Shared epilogue of the tiled contractions (gemm_f32.hip, gemm_bf16s.hip): bias, activation / residual, and the
+// transposition of the MFMA accumulator layout through LDS so that global traffic is coalesced dwordx4.
+#pragma once
+#include "common.h"
+
+// OUT: 0 = fp32 rows to C; 1 = ELU, then split-bf16 form to C; 2 = fp32 rows to C AND ELU + split form to ext.C2 (the raw
+// tensor stays available as a residual operand while the next contraction reads its activated form without any prologue
+// work).  Split form: every aligned group of 32 channels (128 bytes as fp32) becomes [32 hi bf16 | 32 lo bf16], so an
+// element keeps its 128-byte line and every fp32 stride / offset keeps its meaning.
+template <int WM, int WN, int TM, int TN, int EPI, int OUT = 0>
+__device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float* __restrict__ Cs, f32x16 (&acc)[TM][TN],
+                                                const float (&biasv)[TN], int m0, int n0,
+                                                const sopro_gemm_split_ext* __restrict__ ext = nullptr) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int rps = g.rows_per_seg;
+  // ---- epilogue through LDS.  The MFMA accumulator layout gives a lane ONE column of 16 rows, i.e. 4-byte
+  // stores/loads (measured: 26k of a workgroup's 119k cycles for a 128x128x256 tile).  The tile buffers are free
+  // now, so the accumulators are transposed through LDS and every thread streams whole 16-byte pieces of rows:
+  // residual loads and output stores are fully coalesced dwordx4 accesses.  Residual operands are loaded in
+  // batches BEFORE the stores of the same batch (R may alias C: in-place residual updates).
+  constexpr int CLD = BN + 4;
+  {
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          Cs[row * CLD + (wn * TN + j) * 32 + col] = acc[i][j][r] + biasv[j];
+        }
+  }
+  __syncthreads();
+  constexpr bool glu = EPI == SOPRO_EPI_GLU;
+  constexpr bool res = EPI == SOPRO_EPI_RES;
+  constexpr int TPR = BN / 4;          // threads per tile row (one float4 each)
+  constexpr int RPP = NT / TPR;        // rows per pass
+  constexpr int NPASS = BM / RPP;
+  const int prow = tid / TPR, pc4 = tid % TPR;
+  const int n_out_total = glu ? g.N / 2 : g.N;
+  // GLU: columns are packed per 64 as [32 value | 32 gate]; the thread that owns value columns c..c+3 also reads
+  // the gate columns c+32..c+35 and writes output columns (c/64)*32 + c%32 ..; threads on gate columns idle.
+  const int ncol = n0 + pc4 * 4;                       // first tile column of this thread (pre-activation index)
+  const int ocol = glu ? (ncol >> 6) * 32 + (ncol & 31) : ncol;
+  const bool col_ok = ocol < n_out_total && (!glu || ((pc4 * 4) & 32) == 0);
+  const bool vec_ok = ((n_out_total & 3) == 0) && ((g.ldc & 3) == 0) && ((g.c_seg_stride & 3) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(g.C) & 15u) == 0) &&
+                      (!res || (((g.ldr & 3) == 0) && ((g.r_seg_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.R) & 15u) == 0)));
+  float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (res && g.scale) {
+    sc4.x = ncol + 0 < g.N ? g.scale[ncol + 0] : 1.f; sc4.y = ncol + 1 < g.N ? g.scale[ncol + 1] : 1.f;
+    sc4.z = ncol + 2 < g.N ? g.scale[ncol + 2] : 1.f; sc4.w = ncol + 3 < g.N ? g.scale[ncol + 3] : 1.f;
+  }
+  // row walk: one division, then pointer increments; a segment wrap (rare) recomputes the pointers
+  int m = m0 + prow;
+  int seg = m / rps, rr = m - seg * rps;
+  float* cptr = g.C + (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc + ocol;
+  // split-form destination: the row walk of cptr, pointing at the 128-byte group of this thread's columns
+  float* const dbase = OUT == 2 ? ext->C2 : g.C;
+  const int64_t ldd = OUT == 2 ? ext->ldc2 : g.ldc, dseg = OUT == 2 ? ext->c2_seg_stride : g.c_seg_stride;
+  const int64_t dcol_bytes = (int64_t)(ocol >> 5) * 128 + (ocol & 31) * 2;
+  char* dptr = OUT != 0 ? reinterpret_cast<char*>(dbase + (int64_t)seg * dseg + (int64_t)rr * ldd) + dcol_bytes : nullptr;
+  const int64_t dstep = (int64_t)RPP * ldd * 4;
+  const float* rptr = res ? g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr + ocol : nullptr;
+  const int64_t cstep = (int64_t)RPP * g.ldc, rstep = (int64_t)RPP * g.ldr;
+  const float* csrc = Cs + prow * CLD + pc4 * 4;
+  constexpr int BATCH = NPASS < 8 ? NPASS : 8;
+#pragma unroll 1
+  for (int p0 = 0; p0 < NPASS; p0 += BATCH) {
+    float* cp[BATCH];
+    char* dp[BATCH];
+    float4 rv[BATCH];
+#pragma unroll
+    for (int q = 0; q < BATCH; ++q) {
+      const bool ok = col_ok && m < g.M;
+      cp[q] = ok ? cptr : nullptr;
+      dp[q] = dptr;
+      rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res && ok) {
+        if (vec_ok) {
+          rv[q] = *reinterpret_cast<const float4*>(rptr);
+        } else {
+          rv[q].x = rptr[0];
+          if (ocol + 1 < n_out_total) rv[q].y = rptr[1];
+          if (ocol + 2 < n_out_total) rv[q].z = rptr[2];
+          if (ocol + 3 < n_out_total) rv[q].w = rptr[3];
+        }
+      }
+      m += RPP; rr += RPP; cptr += cstep;
+      if (OUT != 0) dptr += dstep;
+      if (res) rptr += rstep;
+      if (rr >= rps) {
+        do { rr -= rps; ++seg; } while (rr >= rps);
+        cptr = g.C + (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc + ocol;
+        if (OUT != 0) dptr = reinterpret_cast<char*>(dbase + (int64_t)seg * dseg + (int64_t)rr * ldd) + dcol_bytes;
+        if (res) rptr = g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr + ocol;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < BATCH; ++q) {
+      if (!cp[q]) continue;
+      float4 v = *reinterpret_cast<const float4*>(csrc + (p0 + q) * RPP * CLD);
+      if (glu) {
+        const float4 gt = *reinterpret_cast<const float4*>(csrc + (p0 + q) * RPP * CLD + 32);
+        v.x *= sigmoidf_(gt.x); v.y *= sigmoidf_(gt.y); v.z *= sigmoidf_(gt.z); v.w *= sigmoidf_(gt.w);
+      } else if (EPI == SOPRO_EPI_GELU) {
+        v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+      } else if (EPI == SOPRO_EPI_TANH) {
+        v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+      } else if (res) {
+        v.x = rv[q].x + sc4.x * v.x; v.y = rv[q].y + sc4.y * v.y; v.z = rv[q].z + sc4.z * v.z; v.w = rv[q].w + sc4.w * v.w;
+      }
+      if (OUT != 0) {  // host guarantees N % 4 == 0 and 128-byte aligned rows
+        uint2 h, l;
+        split2_bf16(eluf_(v.x), eluf_(v.y), h.x, l.x);
+        split2_bf16(eluf_(v.z), eluf_(v.w), h.y, l.y);
+        *reinterpret_cast<uint2*>(dp[q]) = h;
+        *reinterpret_cast<uint2*>(dp[q] + 64) = l;
+        if (OUT == 1) continue;
+      }
+      if (vec_ok) {
+        *reinterpret_cast<float4*>(cp[q]) = v;
+      } else {
+        cp[q][0] = v.x;
+        if (ocol + 1 < n_out_total) cp[q][1] = v.y;
+        if (ocol + 2 < n_out_total) cp[q][2] = v.z;
+        if (ocol + 3 < n_out_total) cp[q][3] = v.w;
+      }
+    }
+  }
+}

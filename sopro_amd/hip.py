@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 8
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -31,6 +31,10 @@ class GemmArgs(C.Structure):
                 ("C", _p), ("ldc", _i64), ("c_seg_stride", _i64), ("R", _p), ("ldr", _i64), ("r_seg_stride", _i64),
                 ("scale", _p), ("pro_vec", _p), ("dbg", _p), ("M", _i32), ("N", _i32), ("K", _i32), ("rows_per_seg", _i32),
                 ("prologue", _i32), ("epilogue", _i32)]
+
+
+class SplitExt(C.Structure):
+    _fields_ = [("a_format", _i32), ("c_mode", _i32), ("C2", _p), ("ldc2", _i64), ("c2_seg_stride", _i64)]
 
 
 class SkinnyArgs(C.Structure):
@@ -73,6 +77,10 @@ SYMBOLS = {
     "sopro_stream_create_cu_range": (C.c_int, [C.c_int, C.c_int, C.POINTER(_p)]),
     "sopro_stream_destroy": (C.c_int, [_p]),
     "sopro_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), _p]),
+    "sopro_gemm_bf16x3": (C.c_int, [_p, _p, _p, _p]),
+    "sopro_pack_w_bf16x3": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
+    "sopro_packed_w_bytes": (C.c_int64, [_i32, _i32]),
+    "sopro_gemm_bf16x3_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_gemm_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_skinny_f32": (C.c_int, [C.POINTER(SkinnyArgs), _p]),
     "sopro_norm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32, _p]),
@@ -186,19 +194,26 @@ def ptr(t: Optional[torch.Tensor], dtype: torch.dtype = torch.float32) -> Option
 # ------------------------------------------------------------------------------------------
 # op wrappers (thin: argument marshalling only)
 # ------------------------------------------------------------------------------------------
-def gemm(A: torch.Tensor, W: torch.Tensor, Cout: torch.Tensor, *, M: int, N: int, K: int, lda: Optional[int] = None,
+def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda: Optional[int] = None,
          ldc: Optional[int] = None, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
          prologue: int = PRO_NONE, R: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
          scale: Optional[torch.Tensor] = None, pro_vec: Optional[torch.Tensor] = None, rows_per_seg: Optional[int] = None,
          a_seg_stride: int = 0, c_seg_stride: int = 0, r_seg_stride: int = 0, a_off: int = 0, c_off: int = 0,
-         r_off: int = 0, ldw: Optional[int] = None, dbg: Optional[torch.Tensor] = None) -> None:
-    """C = epi(pro(A) @ W^T + bias); offsets are in elements from the tensors' first element."""
+         r_off: int = 0, ldw: Optional[int] = None, dbg: Optional[torch.Tensor] = None, a_split: bool = False, c_mode: int = 0,
+         C2: Optional[torch.Tensor] = None, ldc2: Optional[int] = None, c2_seg_stride: int = 0,
+         c2_off: int = 0) -> None:
+    """C = epi(pro(A) @ W^T + bias); offsets are in elements from the tensors' first element.  With a ``PackedW`` weight the
+    contraction runs on the split-bf16 path, where ``a_split`` says A is in split form and ``c_mode`` 1 / 2 writes
+    ELU(C) in split form (to C, or to C2 next to the fp32 C): see sopro_gemm_split_ext in include/sopro_hip.h."""
     n_out = N // 2 if epilogue == EPI_GLU else N
     g = GemmArgs()
     g.A = ptr(A) + 4 * a_off
     g.lda = K if lda is None else lda
     g.a_seg_stride = a_seg_stride
-    g.W = ptr(W)
+    packed = isinstance(W, PackedW)
+    if packed and (W.N != N or W.K != K or epilogue == EPI_GLU):
+        raise SoproHipError(f"packed weight is [{W.N}, {W.K}], the call wants [{N}, {K}] (GLU is fp32-only)")
+    g.W = None if packed else ptr(W)
     g.ldw = K if ldw is None else ldw
     g.bias = ptr(bias)
     g.C = ptr(Cout) + 4 * c_off
@@ -214,9 +229,38 @@ def gemm(A: torch.Tensor, W: torch.Tensor, Cout: torch.Tensor, *, M: int, N: int
     g.rows_per_seg = M if rows_per_seg is None else rows_per_seg
     g.prologue, g.epilogue = prologue, epilogue
     e0 = _prof.begin() if _prof is not None else None
-    _check(load().sopro_gemm_f32(C.byref(g), _stream()), "sopro_gemm_f32")
+    if packed:
+        x = SplitExt()
+        x.a_format, x.c_mode = int(bool(a_split)), c_mode
+        x.C2 = (ptr(C2) + 4 * c2_off) if C2 is not None else None
+        x.ldc2, x.c2_seg_stride = (n_out if ldc2 is None else ldc2), c2_seg_stride
+        _check(load().sopro_gemm_bf16x3(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_bf16x3")
+    elif a_split or c_mode:
+        raise SoproHipError("split-plane operands need a PackedW weight (the fp32 kernel reads and writes fp32 rows)")
+    else:
+        _check(load().sopro_gemm_f32(C.byref(g), _stream()), "sopro_gemm_f32")
     if e0 is not None:
-        _prof.end("gemm_f32_kernel", 2.0 * M * N * K, e0)
+        _prof.end("gemm_bf16x3_kernel" if packed else "gemm_f32_kernel", 2.0 * M * N * K, e0)
+
+
+class PackedW:
+    """A weight matrix [N, K] split into bf16 (hi, lo) planes in MFMA fragment order (sopro_pack_w_bf16x3)."""
+
+    __slots__ = ("data", "N", "K")
+
+    def __init__(self, data: torch.Tensor, N: int, K: int):
+        self.data, self.N, self.K = data, N, K
+
+
+def pack_w_bf16x3(W: torch.Tensor) -> PackedW:
+    """[N, K] fp32 device matrix -> the operand of ``gemm`` on the split-bf16 matrix-core path."""
+    if W.dim() != 2 or not W.is_contiguous():
+        raise SoproHipError("pack_w_bf16x3 wants a contiguous [N, K] matrix")
+    N, K = int(W.shape[0]), int(W.shape[1])
+    lib = load()
+    data = torch.empty(int(lib.sopro_packed_w_bytes(N, K)) // 4, dtype=torch.int32, device=W.device)
+    _check(lib.sopro_pack_w_bf16x3(ptr(W), K, N, K, ptr(data, torch.int32), _stream()), "sopro_pack_w_bf16x3")
+    return PackedW(data, N, K)
 
 
 def skinny(X: torch.Tensor, W: torch.Tensor, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: Optional[int] = None,
@@ -388,14 +432,15 @@ def ar_sample(st: ArState, logits: torch.Tensor, ld: int) -> None:
 class Graph:
     """A recorded launch sequence (hipGraphExec) replayable on any stream."""
 
-    def __init__(self, handle: int):
+    def __init__(self, handle: int, family: str = "ar_step_graph"):
         self.handle = handle
+        self.family = family
 
     def launch(self) -> None:
         e0 = _prof.begin() if _prof is not None else None
         _check(load().sopro_graph_launch(self.handle, _stream()), "sopro_graph_launch")
         if e0 is not None:
-            _prof.end("ar_step_graph", 0.0, e0)
+            _prof.end(self.family, 0.0, e0)
 
     def __del__(self):
         try:
@@ -403,6 +448,47 @@ class Graph:
                 _lib.sopro_graph_destroy(self.handle)
         except Exception:
             pass
+
+
+def profiling() -> bool:
+    """True while bench.py's per-launch event timing is attached (recorded graphs would hide the launches from it)."""
+    return _prof is not None
+
+
+class GraphCache:
+    """Recorded launch sequences keyed by problem shape, for host code whose launches depend only on that shape.
+    A shape is run eagerly the first time (scratch buffers get allocated), recorded the second time, replayed after."""
+
+    def __init__(self, family: str, cap: int = 8):
+        self.family, self.cap = family, cap
+        self.graphs: dict = {}
+        self.seen: dict = {}
+
+    def run(self, key, issue) -> None:
+        """``issue()`` enqueues the launches on the current stream; it must not allocate, synchronise or touch the host."""
+        g = self.graphs.get(key)
+        if g is not None:
+            g.launch()
+            return
+        n = self.seen.get(key, 0)
+        self.seen[key] = n + 1
+        if n == 0 or profiling():
+            issue()
+            return
+        capture_begin()
+        try:
+            issue()
+        finally:
+            g = capture_end()
+        g.family = self.family
+        if len(self.graphs) >= self.cap:
+            self.graphs.pop(next(iter(self.graphs)))
+        self.graphs[key] = g
+        g.launch()
+
+    def clear(self) -> None:
+        self.graphs.clear()
+        self.seen.clear()
 
 
 def capture_begin() -> None:

@@ -93,7 +93,9 @@ class SoproTTSModel:
         self.ws = Workspace(self.device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.bulk_stream = self.stream  # throughput-bound phase (NAR); a pipeline may point it at another CU partition
+        self.prep_stream = self.stream
         self._ar_cache: Dict[Tuple[int, int, int], "_ARPlan"] = {}
+        self._nar_graphs = hip.GraphCache("nar_graph")  # recorded NAR launch sequences per (B, T)
         self._ones: Dict[int, torch.Tensor] = {}
         sc = cfg.stage_codebooks()
         self._stage_cbs = [(s, sc[s]) for s in cfg.stage_order()]
@@ -101,9 +103,11 @@ class SoproTTSModel:
         self._adapter: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None
 
     # ------------------------------------------------------------------ helpers
-    def on_stream(self, bulk: bool = False):
-        """Context: run on the engine's stream, ordered after whatever the caller queued so far."""
-        s = self.bulk_stream if bulk else self.stream
+    def on_stream(self, bulk: bool = False, prep: bool = False):
+        """Context: run on the engine's stream, ordered after whatever the caller queued so far.  ``prep`` = the stream of the
+        per-batch preparation (conditioning, text K/V folding): the AR stream itself unless a pipeline moved it to the
+        throughput partition (these are GEMM-shaped and crawl on a small latency partition)."""
+        s = self.bulk_stream if bulk else (self.prep_stream if prep else self.stream)
         s.wait_stream(torch.cuda.current_stream(self.device))
         return torch.cuda.stream(s)
 
@@ -115,7 +119,9 @@ class SoproTTSModel:
         other.ws = Workspace(self.device)
         other.stream = torch.cuda.Stream(device=self.device)
         other.bulk_stream = other.stream
+        other.prep_stream = other.stream
         other._ar_cache = {}
+        other._nar_graphs = hip.GraphCache("nar_graph")
         return other
 
     def rf_ar(self) -> int:
@@ -228,7 +234,7 @@ class SoproTTSModel:
         ids = torch.zeros(B, S, dtype=torch.int32)
         for b, x in enumerate(ids_list):
             ids[b, : lens_h[b]] = x.detach().to("cpu", torch.int32).view(-1)
-        with self.on_stream():
+        with self.on_stream(prep=True):
             ids = ids.to(dev)
             lens = _i32(lens_h, dev)
             ragged = min(lens_h) != S
@@ -289,7 +295,7 @@ class SoproTTSModel:
                 hip.gemm(am, w[p + ".o.w"], cond, M=B * Tar, N=D, K=D, epilogue=hip.EPI_RES, R=cond, scale=w[p + ".gate_scale"])
             cond_ar = torch.empty(B, Tar, D, device=dev)
             hip.norm(cond, cond_ar, w["cond_norm.weight"], rows=B * Tar, C_=D, eps=RMS_EPS)
-        self.stream.synchronize()
+        self.prep_stream.synchronize()
         return {"txt_seq": txt_seq, "text_lens": lens, "text_lens_host": lens_h, "txt_pool": txt_pool, "sv_ref": sv,
                 "cond_ar": cond_ar}
 
@@ -386,39 +392,52 @@ class SoproTTSModel:
         cfg, w, dev, D, V, Q = self.cfg, self.w, self.device, self.D, self.V, self.Q
         B, T, _ = cond_seq.shape
         M = B * T
+        lens_l = [T] * B if lens is None else [int(n) for n in lens]
         with self.on_stream(bulk=True):
-            cond = cond_seq.to(dev).float().contiguous().view(M, D)
-            toks = torch.zeros(M, Q, dtype=torch.int32, device=dev)
-            toks[:, 0] = tokens_A_1xT.to(dev).reshape(M).to(torch.int32)
-            lens_d = _i32(lens, dev) if lens is not None and min(lens) != T else None
+            # inputs land in persistent buffers so that the launch sequence of a (B, T) shape can be recorded once
+            cond = self.ws.get("nar.cond", (M, D))
+            cond.view(B, T, D).copy_(cond_seq.to(dev).float())
+            toks = self.ws.get("nar.toks", (M, Q), dtype=torch.int32)
+            toks.view(B, T, Q)[:, :, 0] = tokens_A_1xT.to(dev).reshape(B, T).to(torch.int32)
+            lens_d = self.ws.get("nar.lens", (B,), dtype=torch.int32)
+            lens_d.copy_(torch.tensor(lens_l, dtype=torch.int32), non_blocking=False)
             adapters = self._adapter_coeffs()
-            xa = self.ws.get("nar.xa", (M, D))
-            xb = self.ws.get("nar.xb", (M, D))
-            z = self.ws.get("nar.z", (M, int(cfg.nar_head_dim)))
-            logits = self.ws.get("nar.logits", (M, V))
-            HD = int(cfg.nar_head_dim)
-            for sid, (stage, cbs) in enumerate(self._stage_cbs):
-                # prev = sum_j softmax(w[known])_j * E[cb_j*V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
-                nc = self._nar_const[sid]
-                hip.codebook_sum(toks, Q, nc["cols"], nc["offs"], nc["cw"], w["cb_embed"], xa,
-                                 rows=M, D=D, base=cond, alpha=nc["mix0"], beta=nc["mix1"])
-                mul, add = adapters[sid]
-                hip.norm(xa, xb, w["nar.adapter.norm.weight"], rows=M, C_=D, eps=RMS_EPS, mul=mul, add=add, rows_per_seg=M)
-                xa, xb = xb, xa
-                for i, dil in enumerate(cfg.nar_dilations):
-                    self._ssm_block_seq(xa, xb, f"nar.blocks.{i}", B=B, T=T, ksize=int(cfg.nar_kernel_size), dil=int(dil),
-                                        causal=False, lens=lens_d)
-                    xa, xb = xb, xa
-                hip.norm(xa, xb, w["nar.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
-                hip.gemm(xb, w["nar.pre.w"], z, M=M, N=HD, K=D, bias=w["nar.pre.b"])
-                hid = w[f"nar.head_id_emb.{stage}"]
-                for j, cb in enumerate(cbs):
-                    hip.gemm(z, w[f"nar.heads.{stage}.{j}.w"], logits, M=M, N=V, K=HD, bias=w[f"nar.heads.{stage}.{j}.b"],
-                             prologue=hip.PRO_ADDVEC, pro_vec=hid[j])
-                    hip.argmax_rows(logits, toks, rows=M, N=V, ldo=Q, o_off=cb)
+            if self.use_graph:
+                self._nar_graphs.run((B, T), lambda: self._nar_issue(B, T, cond, toks, lens_d, adapters))
+            else:
+                self._nar_issue(B, T, cond, toks, lens_d, adapters)
             out = toks.view(B, T, Q).long()
         self.bulk_stream.synchronize()
         return out
+
+    def _nar_issue(self, B: int, T: int, cond: torch.Tensor, toks: torch.Tensor, lens_d: torch.Tensor, adapters) -> None:
+        """The NAR launch sequence for a [B, T] batch: launches only (recordable)."""
+        cfg, w, D, V, Q = self.cfg, self.w, self.D, self.V, self.Q
+        M = B * T
+        xa = self.ws.get("nar.xa", (M, D))
+        xb = self.ws.get("nar.xb", (M, D))
+        z = self.ws.get("nar.z", (M, int(cfg.nar_head_dim)))
+        logits = self.ws.get("nar.logits", (M, V))
+        HD = int(cfg.nar_head_dim)
+        for sid, (stage, cbs) in enumerate(self._stage_cbs):
+            # prev = sum_j softmax(w[known])_j * E[cb_j*V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
+            nc = self._nar_const[sid]
+            hip.codebook_sum(toks, Q, nc["cols"], nc["offs"], nc["cw"], w["cb_embed"], xa,
+                             rows=M, D=D, base=cond, alpha=nc["mix0"], beta=nc["mix1"])
+            mul, add = adapters[sid]
+            hip.norm(xa, xb, w["nar.adapter.norm.weight"], rows=M, C_=D, eps=RMS_EPS, mul=mul, add=add, rows_per_seg=M)
+            xa, xb = xb, xa
+            for i, dil in enumerate(cfg.nar_dilations):
+                self._ssm_block_seq(xa, xb, f"nar.blocks.{i}", B=B, T=T, ksize=int(cfg.nar_kernel_size), dil=int(dil),
+                                    causal=False, lens=lens_d)
+                xa, xb = xb, xa
+            hip.norm(xa, xb, w["nar.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
+            hip.gemm(xb, w["nar.pre.w"], z, M=M, N=HD, K=D, bias=w["nar.pre.b"])
+            hid = w[f"nar.head_id_emb.{stage}"]
+            for j, cb in enumerate(cbs):
+                hip.gemm(z, w[f"nar.heads.{stage}.{j}.w"], logits, M=M, N=V, K=HD, bias=w[f"nar.heads.{stage}.{j}.b"],
+                         prologue=hip.PRO_ADDVEC, pro_vec=hid[j])
+                hip.argmax_rows(logits, toks, rows=M, N=V, ldo=Q, o_off=cb)
 
     # ------------------------------------------------------------------ text + reference -> tokens
     @torch.inference_mode()
@@ -614,7 +633,7 @@ class _ARRun:
         self.m = m
         self.plan = plan = m._ar_plan(B, S_cap, Tar)
         min_gen = int(min_gen_frames if min_gen_frames is not None else cfg.min_gen_frames)
-        with m.on_stream():
+        with m.on_stream(prep=True):
             plan.cond.copy_(cond_ar.to(dev).float())
             if text_lens is None:
                 plan.klens.fill_(S)
@@ -640,6 +659,7 @@ class _ARRun:
             plan.params.copy_(torch.tensor([float(top_p), float(temperature), 1.0 if anti_loop else 0.0, 0.85, 1.2, 1.1, 50.0,
                                             float(min_gen)], dtype=torch.float32), non_blocking=False)
             hip.ar_init(plan.state)
+        m.stream.wait_stream(m.prep_stream)
         plan.ensure_graph()
 
     def advance(self, n: int) -> None:

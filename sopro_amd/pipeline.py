@@ -21,24 +21,35 @@ from . import hip
 
 
 class PipelinedSynthesizer:
-    def __init__(self, tts, lanes: int = 2, ar_cus: int = 64):
+    def __init__(self, tts, lanes: int = 2, ar_cus: int = 64, ar_parts: int = 1, ar_shared: bool = False):
+        """``ar_parts`` AR partitions of ``ar_cus`` CUs each (the AR phase is launch-latency bound, so independent
+        partitions generate independent batches concurrently); the remaining CUs form the one bulk partition.
+        Lane i generates on partition i % ar_parts.  With ``ar_shared`` the partitions are ONE CU range of ``ar_cus`` CUs
+        that ``ar_parts`` AR phases use at the same time (their short kernels interleave on the same CUs)."""
         self.device = tts.device
         total = hip.device_info(self.device.index or 0)["cus"]
-        if not (0 < ar_cus < total):
-            raise ValueError("ar_cus must leave CUs for the bulk phase")
+        ar_parts = max(1, int(ar_parts))
+        n_ar = ar_cus if ar_shared else ar_cus * ar_parts
+        if not (0 < n_ar < total):
+            raise ValueError("the AR partitions must leave CUs for the bulk phase")
         self.lanes = []
-        self._saved = (tts.model.stream, tts.model.bulk_stream, tts.codec.stream)
+        self._saved = (tts.model.stream, tts.model.bulk_stream, tts.codec.stream, tts.model.prep_stream)
         self._streams = []
+        bulk0 = n_ar
         for i in range(int(lanes)):
             lane = tts if i == 0 else tts.clone_lane()
-            lane.model.stream = hip.cu_range_stream(0, ar_cus, self.device)
-            lane.model.bulk_stream = hip.cu_range_stream(ar_cus, total - ar_cus, self.device)
+            lane.model.stream = hip.cu_range_stream(0 if ar_shared else (i % ar_parts) * ar_cus, ar_cus, self.device)
+            lane.model.bulk_stream = hip.cu_range_stream(bulk0, total - bulk0, self.device)
+            lane.model.prep_stream = lane.model.bulk_stream  # idle while this lane generates; GEMM-shaped preparation belongs there
             self._streams += [lane.model.stream, lane.model.bulk_stream]
             lane.codec.stream = lane.model.bulk_stream
             lane.model._ar_cache.clear()  # recorded graphs belong to the stream they were captured on
+            lane.model._nar_graphs.clear()
+            lane.codec._graphs.clear()
             self.lanes.append(lane)
-        self.ar_lock, self.bulk_lock = threading.Lock(), threading.Lock()
-        self.ar_cus, self.bulk_cus = ar_cus, total - ar_cus
+        self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
+        self.bulk_lock = threading.Lock()
+        self.ar_cus, self.ar_parts, self.bulk_cus = ar_cus, ar_parts, total - bulk0
 
     def close(self) -> None:
         """Drop the extra lanes, destroy the CU-masked streams (and the graphs recorded on them) and give lane 0
@@ -48,10 +59,12 @@ class PipelinedSynthesizer:
         torch.cuda.synchronize(self.device)
         for lane in self.lanes:
             lane.model._ar_cache.clear()  # hipGraphExecDestroy now, not at interpreter shutdown
+            lane.model._nar_graphs.clear()
+            lane.codec._graphs.clear()
             lane.model.ws.clear()
             lane.codec.ws.clear()
         lane0 = self.lanes[0]
-        lane0.model.stream, lane0.model.bulk_stream, lane0.codec.stream = self._saved
+        lane0.model.stream, lane0.model.bulk_stream, lane0.codec.stream, lane0.model.prep_stream = self._saved
         self.lanes = []
         torch.cuda.synchronize(self.device)
         for st in self._streams:
@@ -65,7 +78,7 @@ class PipelinedSynthesizer:
         nxt = [0]
         pick = threading.Lock()
 
-        def worker(lane):
+        def worker(lane, ar_lock):
             # the worker's current stream is the lane's own (never the NULL stream, which would serialise the lanes)
             with torch.cuda.stream(lane.model.stream):
                 while True:
@@ -75,16 +88,22 @@ class PipelinedSynthesizer:
                     if i >= len(jobs) or errors:
                         return
                     try:
-                        results[i] = lane.synthesize_batch(phase_locks=(self.ar_lock, self.bulk_lock), timings=timings, **jobs[i])
+                        results[i] = lane.synthesize_batch(phase_locks=(ar_lock, self.bulk_lock), timings=timings, **jobs[i])
                     except BaseException as e:  # noqa: BLE001
                         errors.append(e)
                         return
 
-        threads = [threading.Thread(target=worker, args=(lane,)) for lane in self.lanes[: max(1, min(len(self.lanes), len(jobs)))]]
+        n_run = max(1, min(len(self.lanes), len(jobs)))
+        import sys
+
+        swi = sys.getswitchinterval()
+        sys.setswitchinterval(2e-4)  # lanes hand the interpreter over between launches; 5 ms hand-over stalls a whole AR poll
+        threads = [threading.Thread(target=worker, args=(lane, self.ar_locks[i % self.ar_parts])) for i, lane in enumerate(self.lanes[:n_run])]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
+        sys.setswitchinterval(swi)
         if errors:
             raise errors[0]
         return results

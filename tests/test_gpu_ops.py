@@ -99,6 +99,132 @@ def test_gemm_causal_conv_and_convtranspose_through_row_windows():
         close(out[:, 2:], ref, 5e-5, f"conv transpose stride {s}")
 
 
+
+# ----------------------------------------------------------------------- split-bf16 GEMM (Mimi decoder path)
+def _split_bound(A, W, b=None):
+    """|err| <= 2^-15 * (|A| |W|^T): two bf16 halves keep 16 mantissa bits per operand, products accumulate in fp32."""
+    mag = A.double().abs() @ W.double().abs().t()
+    return mag * 2.0 ** -15 + 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (129, 64, 64), (1000, 96, 192), (70, 33, 192), (5, 384, 384), (257, 2048, 256),
+                                   (640, 640, 512), (256, 128, 36)])
+def test_gemm_bf16x3_plain_bias(M, N, K):
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    Wp = hip.pack_w_bf16x3(dev(W))
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().t() + b.double()
+    err = (C.cpu().double() - ref).abs()
+    assert bool((err <= _split_bound(A, W)).all()), f"{M}x{N}x{K}: worst {float((err / _split_bound(A, W)).max()):.2f} of the bound"
+    with pytest.raises(hip.SoproHipError):
+        hip.gemm(dev(A), Wp, C, M=M, N=N + 1, K=K)
+
+
+def test_gemm_bf16x3_epilogues_prologue_and_row_windows():
+    M, N, K = 200, 256, 128
+    A, W, b = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=K ** -0.5), rnd(N, seed=6)
+    R, sc = rnd(M, N, seed=7), rnd(N, seed=8)
+    Wp = hip.pack_w_bf16x3(dev(W))
+    ref = A @ W.t() + b
+    C = torch.empty(M, N, device=DEV)
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_GELU)
+    close(C, F.gelu(ref), 2e-4, "gelu")
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_RES, R=dev(R), scale=dev(sc))
+    close(C, R + sc * ref, 3e-4, "res+scale")
+    Rd = dev(R)
+    hip.gemm(dev(A), Wp, Rd, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_RES, R=Rd)  # in place
+    close(Rd, R + ref, 2e-4, "res in place")
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), prologue=hip.PRO_ELU)
+    close(C, F.elu(A) @ W.t() + b, 2e-4, "elu prologue")
+    # causal conv / transposed conv through segmented overlapping rows, as the Mimi decoder issues them
+    B, T, ci, co, k = 3, 37, 64, 96, 7
+    x = rnd(B, T, ci, seed=10)
+    w, bb = rnd(co, ci, k, seed=11, scale=(ci * k) ** -0.5), rnd(co, seed=12)
+    ref = F.conv1d(F.pad(F.elu(x).transpose(1, 2), (k - 1, 0)), w, bb).transpose(1, 2)
+    buf = torch.zeros(B, k - 1 + T, ci)
+    buf[:, k - 1:] = x
+    out = torch.zeros(B, 2 + T, co, device=DEV)
+    hip.gemm(dev(buf), hip.pack_w_bf16x3(dev(pack.pack_conv1d(w))), out, M=B * T, N=co, K=k * ci, lda=ci, bias=dev(bb),
+             prologue=hip.PRO_ELU, rows_per_seg=T, a_seg_stride=(k - 1 + T) * ci, c_off=2 * co, c_seg_stride=(2 + T) * co, ldc=co)
+    close(out[:, 2:], ref, 2e-4, "causal conv1d")
+    assert float(out[:, :2].abs().max()) == 0.0
+    s_ = 5
+    wt, bt = rnd(ci, co, 2 * s_, seed=18, scale=(2 * ci) ** -0.5), rnd(co, seed=14)
+    y = F.conv_transpose1d(x.transpose(1, 2), wt, bt, stride=s_)
+    ref = y[..., : y.shape[-1] - s_].transpose(1, 2)
+    wp, bp = pack.pack_convtr1d(wt, bt, s_)
+    buf = torch.zeros(B, 1 + T, ci)
+    buf[:, 1:] = x
+    out = torch.zeros(B, 2 + T * s_, co, device=DEV)
+    hip.gemm(dev(buf), hip.pack_w_bf16x3(dev(wp)), out, M=B * T, N=s_ * co, K=2 * ci, lda=ci, bias=dev(bp), rows_per_seg=T,
+             a_seg_stride=(1 + T) * ci, c_off=2 * co, c_seg_stride=(2 + T * s_) * co, ldc=s_ * co)
+    close(out[:, 2:], ref, 2e-4, "conv transpose stride 5")
+
+
+def _planes(t, P):
+    """Split-form rows [.., P floats] (every 32 channels = [32 hi | 32 lo] bf16) -> the fp32 values hi + lo they encode."""
+    b = t.contiguous().view(torch.bfloat16).view(*t.shape[:-1], P // 32, 2, 32).float()
+    return (b[..., 0, :] + b[..., 1, :]).reshape(*t.shape[:-1], P)
+
+
+def test_gemm_bf16x3_split_plane_producer_and_consumer():
+    """c_mode 1 / 2 write ELU(C) in split form; a_split consumes it through overlapping row windows."""
+    B, T, ci, co, r = 2, 19, 64, 64, 4
+    x = rnd(B, T, ci, seed=21)
+    wt, bt = rnd(ci, co, 2 * r, seed=22, scale=(2 * ci) ** -0.5), rnd(co, seed=23)
+    wp, bp = pack.pack_convtr1d(wt, bt, r)
+    y = F.conv_transpose1d(x.transpose(1, 2), wt, bt, stride=r)
+    raw_ref = y[..., : y.shape[-1] - r].transpose(1, 2).contiguous()  # [B, T*r, co]
+    buf = torch.zeros(B, 1 + T, ci)
+    buf[:, 1:] = x
+    raw = torch.zeros(B, 2 + T * r, co, device=DEV)
+    act = torch.zeros(B, 2 + T * r, co, device=DEV)
+    hip.gemm(dev(buf), hip.pack_w_bf16x3(dev(wp)), raw, M=B * T, N=r * co, K=2 * ci, lda=ci, bias=dev(bp), rows_per_seg=T,
+             a_seg_stride=(1 + T) * ci, c_off=2 * co, c_seg_stride=(2 + T * r) * co, ldc=r * co, c_mode=2, C2=act,
+             ldc2=r * co, c2_seg_stride=(2 + T * r) * co, c2_off=2 * co)
+    close(raw[:, 2:], raw_ref, 2e-4, "raw fp32 output")
+    close(_planes(act[:, 2:], co), F.elu(raw[:, 2:].cpu()), 4e-5, "ELU split planes")
+    assert float(raw[:, :2].abs().max()) == 0.0 and float(_planes(act[:, :2], co).abs().max()) == 0.0
+    # consumer: causal conv k=3 over the split planes (+ ELU split output), then k=1 conv with the raw skip operand
+    hid = 32
+    w1, b1 = rnd(hid, co, 3, seed=24, scale=(3 * co) ** -0.5), rnd(hid, seed=25)
+    w2, b2 = rnd(co, hid, 1, seed=26, scale=hid ** -0.5), rnd(co, seed=27)
+    h = raw[:, 2:].cpu()
+    y1_ref = F.conv1d(F.pad(F.elu(h).transpose(1, 2), (2, 0)), w1, b1).transpose(1, 2)
+    out_ref = F.elu(h + F.conv1d(F.elu(y1_ref).transpose(1, 2), w2, b2).transpose(1, 2))
+    M2 = B * T * r
+    y1 = torch.zeros(M2, hid, device=DEV)
+    hip.gemm(act, hip.pack_w_bf16x3(dev(pack.pack_conv1d(w1))), y1, M=M2, N=hid, K=3 * co, lda=co, bias=dev(b1), rows_per_seg=T * r,
+             a_seg_stride=(2 + T * r) * co, a_split=True, c_mode=1)
+    close(_planes(y1, hid), F.elu(y1_ref).reshape(M2, hid), 2e-4, "conv k=3 on split planes")
+    hip.gemm(y1, hip.pack_w_bf16x3(dev(pack.pack_conv1d(w2))), act, M=M2, N=co, K=hid, bias=dev(b2), epilogue=hip.EPI_RES, R=raw,
+             rows_per_seg=T * r, a_split=True, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + T * r) * co, r_seg_stride=(2 + T * r) * co,
+             ldc=co, ldr=co, c_mode=1)
+    close(_planes(act[:, 2:], co), out_ref, 3e-4, "residual block output, ELU split")
+    with pytest.raises(hip.SoproHipError):  # split operands are a property of the packed path
+        hip.gemm(act, dev(pack.pack_conv1d(w1)), y1, M=M2, N=hid, K=3 * co, lda=co, a_split=True)
+
+
+def test_mimi_decode_split_bf16_vs_f32_paths(mc, mimi_np):
+    """The decoder on the split-bf16 path against the same decoder on fp32 MFMA: 1e-5-of-peak class."""
+    import os
+
+    from sopro_amd.codec import MimiCodec
+
+    tok = torch.from_numpy(np.random.default_rng(3).integers(0, 2048, size=(2, 24, 32)))
+    a = MimiCodec(mimi_np, mc, device=DEV)
+    assert a.split_bf16 and len(a.wd) > 40
+    os.environ["SOPRO_MIMI_F32"] = "1"
+    try:
+        b = MimiCodec(mimi_np, mc, device=DEV)
+    finally:
+        del os.environ["SOPRO_MIMI_F32"]
+    assert not b.split_bf16 and not b.wd
+    ya, yb = a.decode_batch(tok), b.decode_batch(tok)
+    assert float((ya - yb).abs().max()) < 5e-5 * float(yb.abs().max())
+
 # ------------------------------------------------------------------------------------------- skinny
 @pytest.mark.parametrize("B", [1, 7, 16, 32, 40])
 def test_skinny_norm_head(B):
