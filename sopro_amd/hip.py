@@ -466,13 +466,16 @@ class GraphCache:
 
     def run(self, key, issue) -> None:
         """``issue()`` enqueues the launches on the current stream; it must not allocate, synchronise or touch the host."""
+        if profiling():  # per-launch event timing wants to see the launches one by one
+            issue()
+            return
         g = self.graphs.get(key)
         if g is not None:
             g.launch()
             return
         n = self.seen.get(key, 0)
         self.seen[key] = n + 1
-        if n == 0 or profiling():
+        if n == 0:
             issue()
             return
         capture_begin()
