@@ -231,6 +231,19 @@ def main() -> None:
                       "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2),
                       "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"])),
                       "note": "achieved = algorithmic (fp32-equivalent) flops / launch time; each product costs three bf16 MFMA passes"}
+    roof_x6 = None
+    if "gemm_bf16x6_kernel" in fam:
+        f = fam["gemm_bf16x6_kernel"]
+        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        roof_x6 = {"kernel": "gemm_bf16x6_kernel (NAR contractions; v_mfma_f32_32x32x16_bf16, 6 passes per product, 24-bit operands)",
+                   "bound": "mfma", "achieved": round(ach, 3), "peak": round(PEAK_BF16_MFMA_TFLOPS * share, 2), "unit": "TFLOP/s",
+                   "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS * share), 5), "cu_share": share,
+                   "peak_six_pass": round(PEAK_BF16_MFMA_TFLOPS * share / 6.0, 2),
+                   "frac_six_pass": round(ach / (PEAK_BF16_MFMA_TFLOPS * share / 6.0), 5),
+                   "traffic": pmc.get("gemm_bf16x6_kernel", {}).get("traffic_bytes_per_launch"), "launches": f["launches"],
+                   "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2),
+                   "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"])),
+                   "note": "achieved = algorithmic (fp32-equivalent) flops / launch time; each product costs six bf16 MFMA passes"}
     if "gemm_f32_kernel" in fam:
         f = fam["gemm_f32_kernel"]
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
@@ -254,7 +267,8 @@ def main() -> None:
                    "traffic": tr, "launches": f["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
                    "algorithmic_bytes_per_launch": bytes_step}
     # `roofline` = the compute kernel family with the largest share of a step; the others follow as roofline_more
-    cands = [(fam[k]["ms"], r) for k, r in (("gemm_f32_kernel", roof), ("gemm_bf16x3_kernel", roof_split)) if r is not None]
+    cands = [(fam[k]["ms"], r) for k, r in (("gemm_f32_kernel", roof), ("gemm_bf16x3_kernel", roof_split),
+                                                 ("gemm_bf16x6_kernel", roof_x6)) if r is not None]
     cands.sort(key=lambda t: -t[0])
     roof = cands[0][1] if cands else None
     roof_more = [r for _, r in cands[1:]] + ([roof_ar] if roof_ar is not None else [])
@@ -312,8 +326,8 @@ def main() -> None:
                                       f"{'one shared partition' if args.ar_shared else 'partitions'} of {args.ar_cus} CUs while conditioning, NAR and Mimi "
                                       f"decode of other batches run on the other {int(round(256 * share))} CUs (hipExtStreamCreateWithCUMask); NAR and Mimi "
                                       "launch sequences are recorded hipGraphs") if args.lanes > 1 else "none"},
-            "dtype_detail": "token path (conditioning, AR, NAR) fp32 on v_mfma_f32_*_f32; Mimi decoder contractions fp32 operands split into two "
-                            "bf16 halves (16 mantissa bits), fp32 accumulate",
+            "dtype_detail": "fp32 tensors and accumulation everywhere; conditioning + AR on v_mfma_f32_*_f32; NAR contractions with operands split into "
+                            "three bf16 pieces (24 mantissa bits, 6 MFMA passes); Mimi decoder contractions with two pieces (16 bits, 3 passes)",
             "phase_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phases.items()},
             "kernel_families": families,
             "ttfa_ms_p50": None if ttfa is None else round(ttfa, 3),

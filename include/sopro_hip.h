@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 8
+#define SOPRO_ABI_VERSION 9
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -87,7 +87,7 @@ int sopro_gemm_set_tile_override(int cfg);
  * HF:modeling_mimi.py MimiConv1d / MimiConvTranspose1d / MimiTransformerModel): operands are split x = hi + lo into two
  * bf16 halves (16 mantissa bits, round-to-nearest) and accumulated in fp32 as lo*hi + hi*lo + hi*hi with
  * v_mfma_f32_32x32x16_bf16.  `a->W`/`a->ldw` are ignored: the weight comes pre-split in MFMA fragment order from
- * sopro_pack_w_bf16x3 (device pointers; `packed` holds sopro_packed_w_bytes(N, K) bytes, 16-byte aligned).
+ * sopro_pack_w_bf16 with pieces = 2 (device pointers).
  * Epilogues NONE / GELU / RES; prologues NONE / ELU.  `ext` (may be NULL = all zero) selects "split form" tensors:
  * every aligned group of 32 channels (128 bytes as fp32) is stored as [32 hi bf16 | 32 lo bf16], so an element stays in
  * its 128-byte line and every fp32 stride / offset keeps its meaning (rows must start on 128-byte boundaries).  A
@@ -99,9 +99,16 @@ typedef struct sopro_gemm_split_ext {
   float* C2; int64_t ldc2; int64_t c2_seg_stride; /* c_mode 2; strides in 4-byte units like ldc / c_seg_stride */
 } sopro_gemm_split_ext;
 int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
-int sopro_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K, void* packed, void* stream);
-int64_t sopro_packed_w_bytes(int32_t N, int32_t K);
-int sopro_gemm_bf16x3_set_tile_override(int cfg); /* developer probe */
+/* Six-pass variant for token paths (NAR refinement, conditioning: src/sopro/nn/nar.py, blocks.py): operands split into
+ * THREE bf16 pieces (24 mantissa bits), products p2*p0 + p0*p2 + p1*p1 + p1*p0 + p0*p1 + p0*p0; the dropped terms are
+ * <= 2^-25 relative, i.e. the accuracy class of an fp32 fma chain, at 16/6 of the fp32-MFMA rate.  fp32 rows in and out;
+ * prologues NONE / ADDVEC, epilogues NONE / GELU / RES / GLU.  The weight must have been packed with pieces = 3. */
+int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w, void* stream);
+/* W [N, ldw] fp32 (device) -> `pieces` (2: bf16x3, 3: bf16x6) bf16 planes in MFMA fragment order
+ * [n/32][k/16][piece][lane][8]; `packed` holds sopro_packed_w_bytes(N, K, pieces) bytes, 16-byte aligned. */
+int sopro_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t pieces, void* packed, void* stream);
+int64_t sopro_packed_w_bytes(int32_t N, int32_t K, int32_t pieces);
+int sopro_gemm_bf16_set_tile_override(int cfg); /* developer probe */
 
 /* Batch-of-at-most-a-few-dozen-rows contraction for the autoregressive step
  * (src/sopro/nn/generator.py:98-130): Y[b, n] = epi( rs[b] * sum_k Xin[b, k] * W[n, k] + bias[n] ),

@@ -1,12 +1,15 @@
-// fp32 contraction at bf16 matrix-core rate: every operand is split x = hi + lo into two bf16 halves (16 mantissa
-// bits together) and the product is accumulated in fp32 as lo*hi + hi*lo + hi*hi with v_mfma_f32_32x32x16_bf16
-// (three passes at 16x the fp32-MFMA rate; the dropped lo*lo term and the 16-bit truncation are ~2^-17 relative per
-// product).  Used where the contract is a waveform tolerance (Mimi decoder / encoder); token paths stay on gemm_f32.
+// fp32 contraction at bf16 matrix-core rate: every operand is split into NPL bf16 pieces (x = p0 + p1 [+ p2], each the
+// round-to-nearest bf16 of what the previous pieces left) and the product is accumulated in fp32 with
+// v_mfma_f32_32x32x16_bf16 over the piece pairs that matter:
+//   NPL = 2 ("bf16x3"): p1*p0 + p0*p1 + p0*p0             16 mantissa bits per operand, ~2^-17 relative per product.
+//                       For paths whose contract is a waveform tolerance (Mimi decoder).
+//   NPL = 3 ("bf16x6"): + p1*p1 + p2*p0 + p0*p2            24 mantissa bits per operand, dropped terms <= 2^-25: the
+//                       accuracy class of an fp32 fma chain, at 16/6 of the fp32-MFMA rate.  For token paths (NAR).
 //
 // A (activations, fp32 in HBM, same segmented / overlapping-row addressing as gemm_f32) is split while it is staged
-// into LDS: row = [32 k hi | 32 k lo | 16 B pad] = 144 B, so the ds_read_b128 fragment reads of a 16-lane group hit 16
-// distinct 16-byte slots.  W is split ONCE on the device by sopro_pack_w_bf16x3 into MFMA fragment order
-// [n/32][k/16][plane][lane][8 bf16]; each wave streams its B fragments straight from L2 into registers with fully
+// into LDS: row = NPL x [32 k of one piece, 64 B] + 16 B pad (144 / 208 B), so the ds_read_b128 fragment reads of a
+// 16-lane group hit 16 distinct 16-byte slots.  W is split ONCE on the device by sopro_pack_w_bf16 into MFMA fragment
+// order [n/32][k/16][piece][lane][8 bf16]; each wave streams its B fragments straight from L2 into registers with fully
 // coalesced dwordx4 loads (1 KB per instruction, every byte used once), so W never touches LDS.
 #include "common.h"
 #include "gemm_epilogue.h"
@@ -14,18 +17,31 @@
 namespace {
 
 constexpr int BK = 32;
-constexpr int AROW = 144;  // bytes per LDS row
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ bf16x8 as_frag(const uint4& v) { return *reinterpret_cast<const bf16x8*>(&v); }
 
+// two fp32 values -> NPL packed bf16 pairs (piece p of x in the low half, of y in the high half)
+template <int NPL>
+__device__ __forceinline__ void split_pair(float x, float y, unsigned (&pc)[NPL]) {
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) {
+    const f32x2_t v = {x, y};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    pc[p] = *reinterpret_cast<const unsigned*>(&h);
+    x -= __uint_as_float(pc[p] << 16);  // exact
+    y -= __uint_as_float(pc[p] & 0xffff0000u);
+  }
+}
+
 // AMODE: 0 = A is fp32 rows, split while staged; 1 = the same with ELU applied first; 2 = A is already in split form
-// (each 32-channel group = [32 hi | 32 lo] bf16, written by a producer's OUT = 1 / 2 epilogue): pure 16-byte copies.
-template <int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_kernel(const sopro_gemm_args g, const uint4* __restrict__ Wp,
-                                                                  int ksubs, const sopro_gemm_split_ext ext) {
-  constexpr bool ELU = AMODE == 1;
+// (NPL == 2 only: each 32-channel group = [32 hi | 32 lo] bf16, written by a producer's OUT = 1 / 2 epilogue): pure
+// 16-byte copies; 3 = fp32 rows + pro_vec[k] (PRO_ADDVEC).
+template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gemm_args g, const uint4* __restrict__ Wp,
+                                                                 int ksubs, const sopro_gemm_split_ext ext) {
+  constexpr int AROW = NPL * 64 + 16;  // bytes per LDS row
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -58,7 +74,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_kernel(const sopro_ge
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int t = min((n0 >> 5) + wn * TN + j, ntiles - 1);
-    bp[j] = Wp + ((int64_t)t * ksubs * 2) * 64 + lane;
+    bp[j] = Wp + ((int64_t)t * ksubs * NPL) * 64 + lane;
   }
   float biasv[TN];
 #pragma unroll
@@ -68,6 +84,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_kernel(const sopro_ge
   }
 
   float4 ra[A_F4];
+  float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
   const int KT = (g.K + BK - 1) / BK;
   const int klast = g.K - 4;
 
@@ -75,14 +92,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_kernel(const sopro_ge
     const int k = min(kt * BK + lc4 * 4, klast);
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i] + k);
+    if (AMODE == 3) pv = *reinterpret_cast<const float4*>(g.pro_vec + k);
   };
-  auto bload = [&](int kt, uint4 (&rb)[TN][2][2]) {
+  auto bload = [&](int kt, uint4 (&rb)[TN][2][NPL]) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) rb[j][s][p] = bp[j][((int64_t)(kt * 2 + s) * 2 + p) * 64];
+        for (int p = 0; p < NPL; ++p) rb[j][s][p] = bp[j][((int64_t)(kt * 2 + s) * NPL + p) * 64];
   };
   auto lstore = [&](int buf) {
     if (AMODE == 2) {  // pieces 0-3 of the 128-byte group are the hi halves, 4-7 the lo halves: the LDS row layout
@@ -91,20 +109,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_kernel(const sopro_ge
       for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(a + i * RSTEP * AROW) = ra[i];
       return;
     }
-    if (ELU) {
+    if (AMODE == 1) {
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
         ra[i].x = eluf_(ra[i].x); ra[i].y = eluf_(ra[i].y); ra[i].z = eluf_(ra[i].z); ra[i].w = eluf_(ra[i].w);
       }
+    } else if (AMODE == 3) {
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) { ra[i].x += pv.x; ra[i].y += pv.y; ra[i].z += pv.z; ra[i].w += pv.w; }
     }
     unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 8;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      uint2 h, l;
-      split2_bf16(ra[i].x, ra[i].y, h.x, l.x);
-      split2_bf16(ra[i].z, ra[i].w, h.y, l.y);
-      *reinterpret_cast<uint2*>(a + i * RSTEP * AROW) = h;
-      *reinterpret_cast<uint2*>(a + i * RSTEP * AROW + 64) = l;
+      unsigned c0[NPL], c1[NPL];
+      split_pair<NPL>(ra[i].x, ra[i].y, c0);
+      split_pair<NPL>(ra[i].z, ra[i].w, c1);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(a + i * RSTEP * AROW + p * 64) = make_uint2(c0[p], c1[p]);
     }
   };
 
@@ -117,38 +138,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_kernel(const sopro_ge
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frow = lane & 31, fg = lane >> 5;
-  auto compute = [&](int buf, const uint4 (&rb)[TN][2][2]) {
+  // piece pairs (A piece, B piece), smallest terms first
+  constexpr int NPAIR = NPL == 2 ? 3 : 6;
+  constexpr int PA[6] = {NPL == 2 ? 1 : 2, 0, NPL == 2 ? 0 : 1, 1, 0, 0};
+  constexpr int PB[6] = {0, NPL == 2 ? 1 : 2, NPL == 2 ? 0 : 1, 0, 1, 0};
+  auto compute = [&](int buf, const uint4 (&rb)[TN][2][NPL]) {
     const unsigned char* a = As + buf * BM * AROW + (wm * TM * 32 + frow) * AROW + fg * 16;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      uint4 ah[TM], al[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const uint4*>(a + i * 32 * AROW + s * 32);
-        al[i] = *reinterpret_cast<const uint4*>(a + i * 32 * AROW + 64 + s * 32);
-      }
-      // small terms first; the three passes walk all accumulators so that consecutive MFMAs are independent
+      uint4 af[TM][NPL];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(al[i]), as_frag(rb[j][s][0]), acc[i][j], 0, 0, 0);
+        for (int p = 0; p < NPL; ++p) af[i][p] = *reinterpret_cast<const uint4*>(a + i * 32 * AROW + p * 64 + s * 32);
+      // each pass walks all accumulators so that consecutive MFMAs are independent
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int q = 0; q < NPAIR; ++q)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ah[i]), as_frag(rb[j][s][1]), acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ah[i]), as_frag(rb[j][s][0]), acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af[i][PA[q]]), as_frag(rb[j][s][PB[q]]), acc[i][j], 0, 0, 0);
     }
   };
 
   // Two K-steps per trip (register double buffer for the B fragments, LDS double buffer for A).  The prefetch of the
   // step after the last one is clamped onto the last step: redundant but branch-free.
-  uint4 rb0[TN][2][2], rb1[TN][2][2];
+  uint4 rb0[TN][2][NPL], rb1[TN][2][NPL];
   gload(0);
   bload(0, rb0);
   lstore(0);
@@ -170,14 +186,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16x3_kernel(const sopro_ge
   gemm_store_tile<WM, WN, TM, TN, EPI, OUT>(g, reinterpret_cast<float*>(smem4), acc, biasv, m0, n0, &ext);
 }
 
-// W [N, ldw] fp32 -> fragment-ordered (hi, lo) bf16 planes; one thread per 16-byte fragment piece
+// W [N, ldw] fp32 -> fragment-ordered bf16 pieces; one thread per 16-byte fragment piece
+template <int NPL>
 __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, uint4* __restrict__ out,
                                                      int ksubs, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int lane = (int)(i & 63);
-  const int p = (int)((i >> 6) & 1);
-  const int64_t tk = i >> 7;
+  const int64_t pk = i >> 6;
+  const int p = (int)(pk % NPL);
+  const int64_t tk = pk / NPL;
   const int ks = (int)(tk % ksubs);
   const int t = (int)(tk / ksubs);
   const int n = t * 32 + (lane & 31);
@@ -188,20 +206,20 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W
     const int k = k0 + 2 * e;
     const float x = (n < N && k < K) ? W[(int64_t)n * ldw + k] : 0.f;
     const float y = (n < N && k + 1 < K) ? W[(int64_t)n * ldw + k + 1] : 0.f;
-    unsigned hi, lo;
-    split2_bf16(x, y, hi, lo);
-    w[e] = p ? lo : hi;
+    unsigned pc[NPL];
+    split_pair<NPL>(x, y, pc);
+    w[e] = pc[p];
   }
   out[i] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT>
+template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT>
 int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr size_t lds_main = (size_t)2 * BM * AROW, lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds_main = (size_t)2 * BM * (NPL * 64 + 16), lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr_done = false;
-  auto kern = gemm_bf16x3_kernel<WM, WN, TM, TN, EPI, AMODE, OUT>;
+  auto kern = gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT>;
   if (!attr_done) {
     SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -211,25 +229,29 @@ int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro
   SOPRO_LAUNCH_CHECK();
 }
 
-// The (epilogue, A format, output mode) combinations the Mimi decoder issues; anything else is refused.
+inline int amode_of(const sopro_gemm_args& g, const sopro_gemm_split_ext& ext) {
+  if (ext.a_format == 1) return 2;
+  return g.prologue == SOPRO_PRO_ELU ? 1 : (g.prologue == SOPRO_PRO_ADDVEC ? 3 : 0);
+}
+
+// The (epilogue, A format, output mode) combinations the engine issues; anything else is refused.
 template <int WM, int WN, int TM, int TN>
-int launch_cfg(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
-  const int amode = ext.a_format == 1 ? 2 : (g.prologue == SOPRO_PRO_ELU ? 1 : 0);
-  const int key = g.epilogue * 100 + amode * 10 + ext.c_mode;
+int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
+  const int key = g.epilogue * 100 + amode_of(g, ext) * 10 + ext.c_mode;
 #define SOPRO_CASE(E, A, O) \
-  case (E) * 100 + (A) * 10 + (O): return launch_one<WM, WN, TM, TN, E, A, O>(g, wp, ksubs, ext, s)
+  case (E) * 100 + (A) * 10 + (O): return launch_one<2, WM, WN, TM, TN, E, A, O>(g, wp, ksubs, ext, s)
   switch (key) {
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 0);  // transformer qkv, RVQ output projections
     SOPRO_CASE(SOPRO_EPI_GELU, 0, 0);  // transformer fc1
     SOPRO_CASE(SOPRO_EPI_RES, 0, 0);   // transformer o / fc2 (+ layer scale)
-    SOPRO_CASE(SOPRO_EPI_NONE, 1, 0);  // fp32 activations with an ELU prologue (generic conv)
+    SOPRO_CASE(SOPRO_EPI_NONE, 1, 0);  // fp32 activations with an ELU prologue (SEANet convs)
     SOPRO_CASE(SOPRO_EPI_RES, 1, 0);
-    SOPRO_CASE(SOPRO_EPI_NONE, 0, 1);  // first SEANet conv: fp32 in, ELU + split out
+    SOPRO_CASE(SOPRO_EPI_NONE, 0, 1);  // split-form activation flow (SOPRO_MIMI_SPLIT_FORM): fp32 in, ELU + split out
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 2);
-    SOPRO_CASE(SOPRO_EPI_NONE, 2, 0);  // last transposed conv: split in, fp32 out (feeds the fused tail)
-    SOPRO_CASE(SOPRO_EPI_NONE, 2, 1);  // residual block conv k=3
-    SOPRO_CASE(SOPRO_EPI_NONE, 2, 2);  // transposed convs: raw fp32 (residual operand) + ELU split (next conv's input)
-    SOPRO_CASE(SOPRO_EPI_RES, 2, 1);   // residual block conv k=1 + skip
+    SOPRO_CASE(SOPRO_EPI_NONE, 2, 0);
+    SOPRO_CASE(SOPRO_EPI_NONE, 2, 1);
+    SOPRO_CASE(SOPRO_EPI_NONE, 2, 2);
+    SOPRO_CASE(SOPRO_EPI_RES, 2, 1);
     default: break;
   }
 #undef SOPRO_CASE
@@ -238,35 +260,27 @@ int launch_cfg(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro
   return -2;
 }
 
-}  // namespace
-
-static int g_tile_override = 0;  // developer probe: 1: 128x128, 2: 256x128, 3: 256x64, 4: 128x64, 5: 64x64
-extern "C" int sopro_gemm_bf16x3_set_tile_override(int cfg) {
-  g_tile_override = cfg;
-  return 0;
+template <int WM, int WN, int TM, int TN>
+int launch_cfg6(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
+  const int key = g.epilogue * 10 + amode_of(g, ext);
+#define SOPRO_CASE(E, A) \
+  case (E) * 10 + (A): return launch_one<3, WM, WN, TM, TN, E, A, 0>(g, wp, ksubs, ext, s)
+  switch (key) {
+    SOPRO_CASE(SOPRO_EPI_NONE, 0);  // plain projections
+    SOPRO_CASE(SOPRO_EPI_GELU, 0);  // FF1
+    SOPRO_CASE(SOPRO_EPI_RES, 0);   // FF2 + skip
+    SOPRO_CASE(SOPRO_EPI_NONE, 3);  // NAR heads: z + head-id embedding
+    default: break;
+  }
+#undef SOPRO_CASE
+  if constexpr (WN * TN * 32 >= 64) {
+    if (key == SOPRO_EPI_GLU * 10) return launch_one<3, WM, WN, TM, TN, SOPRO_EPI_GLU, 0, 0>(g, wp, ksubs, ext, s);
+  }
+  sopro_set_error("sopro_gemm_bf16x6: (epilogue %d, prologue %d) is not an available combination", g.epilogue, g.prologue);
+  return -2;
 }
 
-extern "C" int64_t sopro_packed_w_bytes(int32_t N, int32_t K) {
-  if (N <= 0 || K <= 0) return 0;
-  return (int64_t)((N + 31) / 32) * ((K + 31) / 32 * 2) * 2 * 64 * 16;
-}
-
-extern "C" int sopro_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K, void* packed, void* stream) {
-  SOPRO_CHECK_ARG(W && packed && N > 0 && K > 0 && ldw >= K, "bad pointers or sizes");
-  SOPRO_CHECK_ARG(aligned16(packed), "packed must be 16-byte aligned");
-  const int ksubs = (K + 31) / 32 * 2;
-  const int64_t total = (int64_t)((N + 31) / 32) * ksubs * 2 * 64;
-  hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K,
-                     reinterpret_cast<uint4*>(packed), ksubs, total);
-  SOPRO_LAUNCH_CHECK();
-}
-
-extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* x, void* stream) {
-  SOPRO_CHECK_ARG(a != nullptr, "args is NULL");
-  sopro_gemm_args g = *a;
-  sopro_gemm_split_ext ext;
-  memset(&ext, 0, sizeof(ext));
-  if (x) ext = *x;
+int check_common(sopro_gemm_args& g, sopro_gemm_split_ext& ext, const void* packed_w) {
   if (g.a_seg_stride == 0) g.a_seg_stride = (int64_t)g.rows_per_seg * g.lda;
   if (g.c_seg_stride == 0) g.c_seg_stride = (int64_t)g.rows_per_seg * g.ldc;
   if (g.r_seg_stride == 0) g.r_seg_stride = (int64_t)g.rows_per_seg * g.ldr;
@@ -277,11 +291,50 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
   SOPRO_CHECK_ARG(g.A && packed_w && g.C, "A, packed_w, C must be non-NULL");
   SOPRO_CHECK_ARG(aligned16(g.A) && aligned16(packed_w), "A and packed_w must be 16-byte aligned");
   SOPRO_CHECK_ARG((g.lda & 3) == 0 && (g.a_seg_stride & 3) == 0, "lda, a_seg_stride must be multiples of 4");
+  SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_RES || g.R != nullptr, "EPI_RES needs R");
+  SOPRO_CHECK_ARG(g.prologue != SOPRO_PRO_ADDVEC || (g.pro_vec && aligned16(g.pro_vec)), "PRO_ADDVEC needs an aligned pro_vec");
+  SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_GLU || (g.N % 64) == 0, "EPI_GLU needs N % 64 == 0 (packed value/gate blocks)");
+  return 0;
+}
+
+}  // namespace
+
+static int g_tile_override = 0;  // developer probe: 1: 128x128, 2: 256x128, 4: 128x64 (x6: 64x128), 5: 64x64
+extern "C" int sopro_gemm_bf16_set_tile_override(int cfg) {
+  g_tile_override = cfg;
+  return 0;
+}
+
+extern "C" int64_t sopro_packed_w_bytes(int32_t N, int32_t K, int32_t pieces) {
+  if (N <= 0 || K <= 0 || (pieces != 2 && pieces != 3)) return 0;
+  return (int64_t)((N + 31) / 32) * ((K + 31) / 32 * 2) * pieces * 64 * 16;
+}
+
+extern "C" int sopro_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t pieces, void* packed, void* stream) {
+  SOPRO_CHECK_ARG(W && packed && N > 0 && K > 0 && ldw >= K, "bad pointers or sizes");
+  SOPRO_CHECK_ARG(pieces == 2 || pieces == 3, "pieces must be 2 (bf16x3) or 3 (bf16x6)");
+  SOPRO_CHECK_ARG(aligned16(packed), "packed must be 16-byte aligned");
+  const int ksubs = (K + 31) / 32 * 2;
+  const int64_t total = (int64_t)((N + 31) / 32) * ksubs * pieces * 64;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (pieces == 2)
+    hipLaunchKernelGGL(pack_w_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, reinterpret_cast<uint4*>(packed), ksubs, total);
+  else
+    hipLaunchKernelGGL(pack_w_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, reinterpret_cast<uint4*>(packed), ksubs, total);
+  SOPRO_LAUNCH_CHECK();
+}
+
+extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* x, void* stream) {
+  SOPRO_CHECK_ARG(a != nullptr, "args is NULL");
+  sopro_gemm_args g = *a;
+  sopro_gemm_split_ext ext;
+  memset(&ext, 0, sizeof(ext));
+  if (x) ext = *x;
+  if (int rc = check_common(g, ext, packed_w)) return rc;
   SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ELU, "prologue must be NONE or ELU");
   SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES,
                   "epilogue must be NONE, GELU or RES");
-  SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_RES || g.R != nullptr, "EPI_RES needs R");
-  SOPRO_CHECK_ARG(ext.a_format == 0 || ext.a_format == 1, "a_format must be 0 (fp32) or 1 (split planes)");
+  SOPRO_CHECK_ARG(ext.a_format == 0 || ext.a_format == 1, "a_format must be 0 (fp32) or 1 (split form)");
   if (ext.a_format == 1) {
     SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE, "split-form A carries its activation already");
     SOPRO_CHECK_ARG((g.K & 31) == 0 && (g.lda & 31) == 0 && (g.a_seg_stride & 31) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 127u) == 0,
@@ -299,13 +352,35 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
   const uint4* wp = reinterpret_cast<const uint4*>(packed_w);
   const int ksubs = (g.K + 31) / 32 * 2;
   switch (g_tile_override) {
-    case 1: return launch_cfg<2, 2, 2, 2>(g, wp, ksubs, ext, s);
-    case 2: return launch_cfg<2, 2, 4, 2>(g, wp, ksubs, ext, s);
-    case 3: return launch_cfg<4, 1, 2, 2>(g, wp, ksubs, ext, s);
-    case 4: return launch_cfg<2, 2, 2, 1>(g, wp, ksubs, ext, s);
-    case 5: return launch_cfg<2, 2, 1, 1>(g, wp, ksubs, ext, s);
+    case 1: return launch_cfg3<2, 2, 2, 2>(g, wp, ksubs, ext, s);
+    case 2: return launch_cfg3<2, 2, 4, 2>(g, wp, ksubs, ext, s);
+    case 4: return launch_cfg3<2, 2, 2, 1>(g, wp, ksubs, ext, s);
+    case 5: return launch_cfg3<2, 2, 1, 1>(g, wp, ksubs, ext, s);
     default: break;
   }
-  if (g.N <= 64) return launch_cfg<2, 2, 1, 1>(g, wp, ksubs, ext, s);
-  return launch_cfg<2, 2, 2, 2>(g, wp, ksubs, ext, s);
+  if (g.N <= 64) return launch_cfg3<2, 2, 1, 1>(g, wp, ksubs, ext, s);
+  return launch_cfg3<2, 2, 2, 2>(g, wp, ksubs, ext, s);
+}
+
+extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w, void* stream) {
+  SOPRO_CHECK_ARG(a != nullptr, "args is NULL");
+  sopro_gemm_args g = *a;
+  sopro_gemm_split_ext ext;
+  memset(&ext, 0, sizeof(ext));
+  if (int rc = check_common(g, ext, packed_w)) return rc;
+  SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ADDVEC, "prologue must be NONE or ADDVEC");
+  SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES || g.epilogue == SOPRO_EPI_GLU,
+                  "epilogue must be NONE, GELU, RES or GLU");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const uint4* wp = reinterpret_cast<const uint4*>(packed_w);
+  const int ksubs = (g.K + 31) / 32 * 2;
+  switch (g_tile_override) {
+    case 1: return launch_cfg6<2, 2, 2, 2>(g, wp, ksubs, ext, s);
+    case 4: return launch_cfg6<2, 2, 1, 2>(g, wp, ksubs, ext, s);
+    case 5: if (g.epilogue != SOPRO_EPI_GLU) return launch_cfg6<2, 2, 1, 1>(g, wp, ksubs, ext, s); break;
+    default: break;
+  }
+  // measured on the NAR shapes (tools/gemm_x6_probe.py): a few thousand rows, K <= 1536 -> the small tiles win
+  if (g.epilogue == SOPRO_EPI_GLU) return launch_cfg6<2, 2, 1, 2>(g, wp, ksubs, ext, s);
+  return launch_cfg6<2, 2, 1, 1>(g, wp, ksubs, ext, s);
 }

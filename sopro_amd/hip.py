@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -78,9 +78,10 @@ SYMBOLS = {
     "sopro_stream_destroy": (C.c_int, [_p]),
     "sopro_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "sopro_gemm_bf16x3": (C.c_int, [_p, _p, _p, _p]),
-    "sopro_pack_w_bf16x3": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
-    "sopro_packed_w_bytes": (C.c_int64, [_i32, _i32]),
-    "sopro_gemm_bf16x3_set_tile_override": (C.c_int, [C.c_int]),
+    "sopro_gemm_bf16x6": (C.c_int, [_p, _p, _p]),
+    "sopro_pack_w_bf16": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
+    "sopro_packed_w_bytes": (C.c_int64, [_i32, _i32, _i32]),
+    "sopro_gemm_bf16_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_gemm_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_skinny_f32": (C.c_int, [C.POINTER(SkinnyArgs), _p]),
     "sopro_norm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32, _p]),
@@ -211,8 +212,8 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     g.lda = K if lda is None else lda
     g.a_seg_stride = a_seg_stride
     packed = isinstance(W, PackedW)
-    if packed and (W.N != N or W.K != K or epilogue == EPI_GLU):
-        raise SoproHipError(f"packed weight is [{W.N}, {W.K}], the call wants [{N}, {K}] (GLU is fp32-only)")
+    if packed and (W.N != N or W.K != K):
+        raise SoproHipError(f"packed weight is [{W.N}, {W.K}], the call wants [{N}, {K}]")
     g.W = None if packed else ptr(W)
     g.ldw = K if ldw is None else ldw
     g.bias = ptr(bias)
@@ -229,7 +230,11 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     g.rows_per_seg = M if rows_per_seg is None else rows_per_seg
     g.prologue, g.epilogue = prologue, epilogue
     e0 = _prof.begin() if _prof is not None else None
-    if packed:
+    if packed and W.pieces == 3:
+        if a_split or c_mode:
+            raise SoproHipError("split-form operands belong to the three-pass (pieces = 2) path")
+        _check(load().sopro_gemm_bf16x6(C.byref(g), ptr(W.data, torch.int32), _stream()), "sopro_gemm_bf16x6")
+    elif packed:
         x = SplitExt()
         x.a_format, x.c_mode = int(bool(a_split)), c_mode
         x.C2 = (ptr(C2) + 4 * c2_off) if C2 is not None else None
@@ -240,27 +245,36 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     else:
         _check(load().sopro_gemm_f32(C.byref(g), _stream()), "sopro_gemm_f32")
     if e0 is not None:
-        _prof.end("gemm_bf16x3_kernel" if packed else "gemm_f32_kernel", 2.0 * M * N * K, e0)
+        _prof.end(("gemm_bf16x6_kernel" if W.pieces == 3 else "gemm_bf16x3_kernel") if packed else "gemm_f32_kernel", 2.0 * M * N * K, e0)
 
 
 class PackedW:
-    """A weight matrix [N, K] split into bf16 (hi, lo) planes in MFMA fragment order (sopro_pack_w_bf16x3)."""
+    """A weight matrix [N, K] split into 2 or 3 bf16 pieces in MFMA fragment order (sopro_pack_w_bf16)."""
 
-    __slots__ = ("data", "N", "K")
+    __slots__ = ("data", "N", "K", "pieces")
 
-    def __init__(self, data: torch.Tensor, N: int, K: int):
-        self.data, self.N, self.K = data, N, K
+    def __init__(self, data: torch.Tensor, N: int, K: int, pieces: int):
+        self.data, self.N, self.K, self.pieces = data, N, K, pieces
+
+
+def pack_w_bf16(W: torch.Tensor, pieces: int) -> PackedW:
+    """[N, K] fp32 device matrix -> the operand of ``gemm`` on the split-bf16 matrix-core paths
+    (pieces = 2: three passes, 16 mantissa bits; pieces = 3: six passes, 24 mantissa bits)."""
+    if W.dim() != 2 or not W.is_contiguous():
+        raise SoproHipError("pack_w_bf16 wants a contiguous [N, K] matrix")
+    N, K = int(W.shape[0]), int(W.shape[1])
+    lib = load()
+    data = torch.empty(int(lib.sopro_packed_w_bytes(N, K, pieces)) // 4, dtype=torch.int32, device=W.device)
+    _check(lib.sopro_pack_w_bf16(ptr(W), K, N, K, pieces, ptr(data, torch.int32), _stream()), "sopro_pack_w_bf16")
+    return PackedW(data, N, K, pieces)
 
 
 def pack_w_bf16x3(W: torch.Tensor) -> PackedW:
-    """[N, K] fp32 device matrix -> the operand of ``gemm`` on the split-bf16 matrix-core path."""
-    if W.dim() != 2 or not W.is_contiguous():
-        raise SoproHipError("pack_w_bf16x3 wants a contiguous [N, K] matrix")
-    N, K = int(W.shape[0]), int(W.shape[1])
-    lib = load()
-    data = torch.empty(int(lib.sopro_packed_w_bytes(N, K)) // 4, dtype=torch.int32, device=W.device)
-    _check(lib.sopro_pack_w_bf16x3(ptr(W), K, N, K, ptr(data, torch.int32), _stream()), "sopro_pack_w_bf16x3")
-    return PackedW(data, N, K)
+    return pack_w_bf16(W, 2)
+
+
+def pack_w_bf16x6(W: torch.Tensor) -> PackedW:
+    return pack_w_bf16(W, 3)
 
 
 def skinny(X: torch.Tensor, W: torch.Tensor, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: Optional[int] = None,

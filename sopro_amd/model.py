@@ -10,6 +10,8 @@ recorded once into a hipGraph and replayed.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass
 from typing import Any, Dict, Iterator, List, Optional, Sequence, Tuple
@@ -96,6 +98,16 @@ class SoproTTSModel:
         self.prep_stream = self.stream
         self._ar_cache: Dict[Tuple[int, int, int], "_ARPlan"] = {}
         self._nar_graphs = hip.GraphCache("nar_graph")  # recorded NAR launch sequences per (B, T)
+        # NAR contractions on the six-pass split-bf16 matrix-core path (24 mantissa bits per operand: the accuracy class of
+        # the fp32 MFMA kernel at ~1.5x its speed on these shapes); SOPRO_NAR_F32=1 keeps the fp32 kernel.
+        self.wx: Dict[str, hip.PackedW] = {}
+        if os.environ.get("SOPRO_NAR_F32", "0") != "1":
+            with torch.cuda.device(self.device):
+                for k, v in self.w.items():
+                    if k.startswith("nar.") and v.dim() == 2 and k.endswith(".w") and int(v.shape[1]) % 32 == 0 and int(v.shape[0]) >= 64 \
+                            and not k.startswith("nar.adapter"):
+                        self.wx[k] = hip.pack_w_bf16x6(v)
+                torch.cuda.synchronize(self.device)
         self._ones: Dict[int, torch.Tensor] = {}
         sc = cfg.stage_codebooks()
         self._stage_cbs = [(s, sc[s]) for s in cfg.stage_order()]
@@ -139,13 +151,14 @@ class SoproTTSModel:
         x1 = ws.get("ssm.x1", (M, D))
         u = ws.get("ssm.u", (M, 4 * D))
         hip.norm(x, nrm, w[p + ".norm.weight"], rows=M, C_=D, eps=RMS_EPS)
-        hip.gemm(nrm, w[p + ".glu.w"], h, M=M, N=2 * D, K=D, bias=w[p + ".glu.b"], epilogue=hip.EPI_GLU)
+        gw = lambda k: self.wx.get(k) or w[k]  # noqa: E731
+        hip.gemm(nrm, gw(p + ".glu.w"), h, M=M, N=2 * D, K=D, bias=w[p + ".glu.b"], epilogue=hip.EPI_GLU)
         total = (ksize - 1) * dil
         left = total if causal else total // 2
         hip.dwconv(h, w[p + ".dw.w"], w[p + ".dw.b"], x1, B=B, T=T, C_=D, ksize=ksize, dil=dil, left=left, mode=1, res=x, lens=lens)
         hip.norm(x1, nrm, w[p + ".ff.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
-        hip.gemm(nrm, w[p + ".ff1.w"], u, M=M, N=4 * D, K=D, bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
-        hip.gemm(u, w[p + ".ff2.w"], out, M=M, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=x1)
+        hip.gemm(nrm, gw(p + ".ff1.w"), u, M=M, N=4 * D, K=D, bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
+        hip.gemm(u, gw(p + ".ff2.w"), out, M=M, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=x1)
 
     # ------------------------------------------------------------------ per-voice preparation
     @torch.inference_mode()
@@ -432,10 +445,10 @@ class SoproTTSModel:
                                     causal=False, lens=lens_d)
                 xa, xb = xb, xa
             hip.norm(xa, xb, w["nar.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
-            hip.gemm(xb, w["nar.pre.w"], z, M=M, N=HD, K=D, bias=w["nar.pre.b"])
+            hip.gemm(xb, self.wx.get("nar.pre.w") or w["nar.pre.w"], z, M=M, N=HD, K=D, bias=w["nar.pre.b"])
             hid = w[f"nar.head_id_emb.{stage}"]
             for j, cb in enumerate(cbs):
-                hip.gemm(z, w[f"nar.heads.{stage}.{j}.w"], logits, M=M, N=V, K=HD, bias=w[f"nar.heads.{stage}.{j}.b"],
+                hip.gemm(z, self.wx.get(f"nar.heads.{stage}.{j}.w") or w[f"nar.heads.{stage}.{j}.w"], logits, M=M, N=V, K=HD, bias=w[f"nar.heads.{stage}.{j}.b"],
                          prologue=hip.PRO_ADDVEC, pro_vec=hid[j])
                 hip.argmax_rows(logits, toks, rows=M, N=V, ldo=Q, o_off=cb)
 

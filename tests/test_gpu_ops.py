@@ -163,6 +163,40 @@ def test_gemm_bf16x3_epilogues_prologue_and_row_windows():
     close(out[:, 2:], ref, 2e-4, "conv transpose stride 5")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (129, 64, 64), (70, 33, 192), (257, 2048, 256), (640, 384, 1536)])
+def test_gemm_bf16x6_is_fp32_class(M, N, K):
+    """Six passes over three bf16 pieces per operand: errors of the fp32-MFMA kernel's size (bound: 2^-21 |A||W|)."""
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(dev(A), hip.pack_w_bf16x6(dev(W)), C, M=M, N=N, K=K, bias=dev(b))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().t() + b.double()
+    bound = (A.double().abs() @ W.double().abs().t() + b.double().abs()) * 2.0 ** -21
+    err = (C.cpu().double() - ref).abs()
+    assert bool((err <= bound).all()), f"{M}x{N}x{K}: worst {float((err / bound).max()):.2f} of the bound"
+
+
+def test_gemm_bf16x6_epilogues_and_addvec():
+    M, N, K = 200, 256, 128
+    A, W, b = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=K ** -0.5), rnd(N, seed=6)
+    R, pv = rnd(M, N, seed=7), rnd(K, seed=9)
+    Wp = hip.pack_w_bf16x6(dev(W))
+    ref = A @ W.t() + b
+    C = torch.empty(M, N, device=DEV)
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_GELU)
+    close(C, F.gelu(ref), 3e-5, "gelu")
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_RES, R=dev(R))
+    close(C, R + ref, 5e-5, "res")
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), prologue=hip.PRO_ADDVEC, pro_vec=dev(pv))
+    close(C, (A + pv) @ W.t() + b, 5e-5, "addvec prologue")
+    wg, bg = pack.pack_glu(W, b)
+    G = torch.empty(M, N // 2, device=DEV)
+    hip.gemm(dev(A), hip.pack_w_bf16x6(dev(wg)), G, M=M, N=N, K=K, bias=dev(bg), epilogue=hip.EPI_GLU)
+    close(G, ref[:, : N // 2] * torch.sigmoid(ref[:, N // 2:]), 3e-5, "glu")
+    with pytest.raises(hip.SoproHipError):
+        hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, prologue=hip.PRO_ELU)
+
+
 def _planes(t, P):
     """Split-form rows [.., P floats] (every 32 channels = [32 hi | 32 lo] bf16) -> the fp32 values hi + lo they encode."""
     b = t.contiguous().view(torch.bfloat16).view(*t.shape[:-1], P // 32, 2, 32).float()

@@ -46,7 +46,7 @@ for name, M, N, K, epi, pro in shapes:
     for cfg in cfgs:
         if cfg == 3 and N < 64:
             continue
-        lib.sopro_gemm_bf16x3_set_tile_override(cfg)
+        lib.sopro_gemm_bf16_set_tile_override(cfg)
         for _ in range(2):
             hip.gemm(A, Wp, Cc, M=M, N=N, K=K, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -58,7 +58,7 @@ for name, M, N, K, epi, pro in shapes:
         us = e0.elapsed_time(e1) / 5 * 1e3
         err = float("nan") if split else float(((Cc[:256].double() - ref).abs() / mag).max())
         res.append(f"c{cfg}:{us:8.1f}us {2.0 * M * N * K / us / 1e6:6.1f}TF e={err:.1e}")
-    lib.sopro_gemm_bf16x3_set_tile_override(0)
+    lib.sopro_gemm_bf16_set_tile_override(0)
     for _ in range(2):
         hip.gemm(A, W, Cc, M=M, N=N, K=K, bias=b, epilogue=epi, prologue=pro, R=R)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
