@@ -95,7 +95,8 @@ int sopro_gemm_set_tile_override(int cfg);
  * (a_format 1) stages it with plain 16-byte copies: no activation or split work is left in its main loop. */
 typedef struct sopro_gemm_split_ext {
   int32_t a_format; /* 0: A is fp32 rows; 1: split form (prologue must be NONE) */
-  int32_t c_mode;   /* 0: fp32 to C; 1: ELU + split form to C; 2: fp32 to C and ELU + split form to C2 */
+  int32_t c_mode;   /* 0: fp32 to C; 1: ELU + split form to C; 2: fp32 to C and ELU + split form to C2;
+                     * 3: ELU(C) as fp32 to C; 4: fp32 to C and ELU(C) as fp32 to C2 */
   float* C2; int64_t ldc2; int64_t c2_seg_stride; /* c_mode 2; strides in 4-byte units like ldc / c_seg_stride */
 } sopro_gemm_split_ext;
 int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);

@@ -61,6 +61,9 @@ class MimiCodec:
         # SOPRO_MIMI_SPLIT_FORM=1: keep SEANet activations in split form between convolutions (producer-side ELU + split);
         # measured slower than splitting while staging with the current kernel, so it is off by default.
         self.split_form = os.environ.get("SOPRO_MIMI_SPLIT_FORM", "0") == "1"
+        # Activated-copy flow (default): a producer's epilogue writes ELU(x) as fp32 next to / instead of x, so the consumer's
+        # main loop has no activation work (measured: 4.9k -> 2.9k cycles per K-step); SOPRO_MIMI_ELU_PROLOGUE=1 disables it.
+        self.act_copy = os.environ.get("SOPRO_MIMI_ELU_PROLOGUE", "0") != "1"
         self.wd: Dict[str, object] = {}
         if self.split_bf16:
             with torch.cuda.device(self.device):
@@ -281,6 +284,8 @@ class MimiCodec:
         wav = ws.get("sea.wav", (B, T * int(mc.frame_samples)))
         if self.split_bf16 and self.split_form:
             self._seanet_split(X, B, N2, xs_stride, wav)
+        elif self.split_bf16 and self.act_copy:
+            self._seanet_act(X, B, N2, xs_stride, wav)
         else:
             self._seanet_f32(X, B, N2, xs_stride, wav)
 
@@ -324,6 +329,56 @@ class MimiCodec:
             Hc, ch, rows, pad_in = Ho, co, orow, 2
         else:
             hip.final_conv(Hc, w["sea.final.w"], self.final_bias, wav, B=B, T=rows, h_seg_stride=(2 + rows) * ch, wav_seg_stride=rows)
+
+    def _seanet_act(self, X: torch.Tensor, B: int, N2: int, xs_stride: int, wav: torch.Tensor) -> None:
+        """SEANet decoder on the split-bf16 kernel with the activation applied ONCE, by the producer: every convolution
+        input is stored as ELU(x) (fp32) by the epilogue that made it; the raw tensor is written too only where the
+        residual block needs it as its skip operand (transposed-conv outputs)."""
+        mc, w, ws = self.mc, self.w, self.ws
+        gw = self._gw
+        HS = int(mc.hidden_size)
+        ratios = [int(r) for r in mc.upsampling_ratios]
+        ch = int(mc.num_filters) * (2 ** len(ratios))  # 1024
+        rows = N2
+        # first conv k=7 -> ELU; 1 zero row in front = x[t-1] of the transposed conv
+        He = ws.get("sea.e0", (B, 1 + rows, ch), zero=True)
+        hip.gemm(X, gw("sea.conv0.w"), He, M=B * rows, N=ch, K=int(mc.kernel_size) * HS, lda=HS, bias=w["sea.conv0.b"],
+                 rows_per_seg=rows, a_seg_stride=xs_stride, c_off=ch, c_seg_stride=(1 + rows) * ch, ldc=ch, c_mode=3)
+        pad_in = 1
+        for si, r in enumerate(ratios):
+            co, orow = ch // 2, rows * r
+            hid = co // int(mc.compress)
+            last = si == len(ratios) - 1
+            Ho = ws.get(f"sea.h{si + 1}", (B, 2 + orow, co), zero=True)  # raw fp32 (skip operand / tail input)
+            up = dict(M=B * rows, N=r * co, K=2 * ch, lda=ch, bias=w[f"sea.up{si}.b"], rows_per_seg=rows, a_seg_stride=(pad_in + rows) * ch,
+                      a_off=(pad_in - 1) * ch, c_off=2 * co, c_seg_stride=(2 + orow) * co, ldc=r * co)
+            if last:
+                # ConvTranspose1d -> raw fp32 only: the last stage runs in the fused tail (or on the fp32 kernels)
+                hip.gemm(He, gw(f"sea.up{si}.w"), Ho, **up)
+                if self.fuse_tail and co == 64 and hid == 32 and int(mc.residual_kernel_size) == 3 and int(mc.last_kernel_size) == 3:
+                    hip.seanet_tail(Ho, w[f"sea.res{si}.c1.w"], w[f"sea.res{si}.c1.b"], w[f"sea.res{si}.c2.w"], w[f"sea.res{si}.c2.b"],
+                                    w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
+                    return
+                Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
+                hip.gemm(Ho, w[f"sea.res{si}.c1.w"], Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"],
+                         prologue=hip.PRO_ELU, rows_per_seg=orow, a_seg_stride=(2 + orow) * co)
+                hip.gemm(Y1, w[f"sea.res{si}.c2.w"], Ho, M=B * orow, N=co, K=hid, bias=w[f"sea.res{si}.c2.b"], prologue=hip.PRO_ELU,
+                         epilogue=hip.EPI_RES, R=Ho, rows_per_seg=orow, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co,
+                         r_seg_stride=(2 + orow) * co, ldc=co, ldr=co)
+                hip.final_conv(Ho, w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
+                return
+            # ConvTranspose1d(ch -> co, k=2r, s=r): row t of A = [x[t-1] | x[t]] of the activated input; raw to Ho, ELU to Hn
+            Hn = ws.get(f"sea.e{si + 1}", (B, 2 + orow, co), zero=True)  # 2 zero rows: left pad of the k=3 conv
+            hip.gemm(He, gw(f"sea.up{si}.w"), Ho, c_mode=4, C2=Hn, ldc2=r * co, c2_seg_stride=(2 + orow) * co, c2_off=2 * co, **up)
+            # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x)))); its output is only ever read through ELU
+            Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
+            hip.gemm(Hn, gw(f"sea.res{si}.c1.w"), Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"], rows_per_seg=orow,
+                     a_seg_stride=(2 + orow) * co, c_mode=3)
+            hip.gemm(Y1, gw(f"sea.res{si}.c2.w"), Hn, M=B * orow, N=co, K=hid, bias=w[f"sea.res{si}.c2.b"], epilogue=hip.EPI_RES, R=Ho,
+                     rows_per_seg=orow, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co, r_seg_stride=(2 + orow) * co,
+                     ldc=co, ldr=co, c_mode=3)
+            He, ch, rows, pad_in = Hn, co, orow, 2
+        raise AssertionError("unreachable: the last stage returns")
 
     def _seanet_split(self, X: torch.Tensor, B: int, N2: int, xs_stride: int, wav: torch.Tensor) -> None:
         """SEANet decoder on the split-bf16 matrix-core path.  Between convolutions an activation lives as ELU(x) in

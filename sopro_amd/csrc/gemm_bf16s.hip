@@ -57,6 +57,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   const int m0 = mt * BM, n0 = nt * BN;
   const int lrow = tid >> 3, lc4 = tid & 7;
   const int rps = g.rows_per_seg;
+  long long* dbg = g.dbg ? g.dbg + (int64_t)blockIdx.x * 8 : nullptr;  // developer probe: shader-clock stamps
+  if (dbg && tid == 0) dbg[0] = clock64();
 
   // Branch-free operand addressing: rows >= M and column tiles >= N are clamped onto valid ones (their accumulators
   // are never stored) and the K tail re-reads the row's last in-range piece (W is zero-padded there), so the main loop
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   bload(0, rb0);
   lstore(0);
   __syncthreads();
+  if (dbg && tid == 0) dbg[1] = clock64();
   for (int kt = 0; kt < KT; kt += 2) {
     const int k1 = min(kt + 1, KT - 1), k2 = min(kt + 2, KT - 1);
     gload(k1);
@@ -183,7 +186,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     lstore(0);
     __syncthreads();
   }
+  if (dbg && tid == 0) dbg[2] = clock64();
   gemm_store_tile<WM, WN, TM, TN, EPI, OUT>(g, reinterpret_cast<float*>(smem4), acc, biasv, m0, n0, &ext);
+  if (dbg && tid == 0) dbg[3] = clock64();
 }
 
 // W [N, ldw] fp32 -> fragment-ordered bf16 pieces; one thread per 16-byte fragment piece
@@ -246,6 +251,9 @@ int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
     SOPRO_CASE(SOPRO_EPI_RES, 0, 0);   // transformer o / fc2 (+ layer scale)
     SOPRO_CASE(SOPRO_EPI_NONE, 1, 0);  // fp32 activations with an ELU prologue (SEANet convs)
     SOPRO_CASE(SOPRO_EPI_RES, 1, 0);
+    SOPRO_CASE(SOPRO_EPI_NONE, 0, 3);  // activated-copy flow of the SEANet decoder: ELU applied once, by the producer
+    SOPRO_CASE(SOPRO_EPI_NONE, 0, 4);
+    SOPRO_CASE(SOPRO_EPI_RES, 0, 3);
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 1);  // split-form activation flow (SOPRO_MIMI_SPLIT_FORM): fp32 in, ELU + split out
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 2);
     SOPRO_CASE(SOPRO_EPI_NONE, 2, 0);
@@ -340,13 +348,18 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
     SOPRO_CHECK_ARG((g.K & 31) == 0 && (g.lda & 31) == 0 && (g.a_seg_stride & 31) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 127u) == 0,
                     "split-form A: K, lda, a_seg_stride multiples of 32 and a 128-byte aligned base");
   }
-  SOPRO_CHECK_ARG(ext.c_mode >= 0 && ext.c_mode <= 2, "c_mode must be 0, 1 or 2");
+  SOPRO_CHECK_ARG(ext.c_mode >= 0 && ext.c_mode <= 4, "c_mode must be 0..4");
   if (ext.c_mode != 0) {
-    SOPRO_CHECK_ARG((g.N & 3) == 0, "split-form output: N % 4 == 0");
-    float* d = ext.c_mode == 2 ? ext.C2 : g.C;
-    const int64_t ldd = ext.c_mode == 2 ? ext.ldc2 : g.ldc, dseg = ext.c_mode == 2 ? ext.c2_seg_stride : g.c_seg_stride;
-    SOPRO_CHECK_ARG(d && (reinterpret_cast<uintptr_t>(d) & 127u) == 0 && (ldd & 31) == 0 && (dseg & 31) == 0 && ldd >= g.N,
-                    "split-form output rows must start on 128-byte boundaries (ld, seg stride multiples of 32)");
+    SOPRO_CHECK_ARG((g.N & 3) == 0, "activated output: N % 4 == 0");
+    const bool second = ext.c_mode == 2 || ext.c_mode == 4;
+    float* d = second ? ext.C2 : g.C;
+    const int64_t ldd = second ? ext.ldc2 : g.ldc, dseg = second ? ext.c2_seg_stride : g.c_seg_stride;
+    if (ext.c_mode <= 2)
+      SOPRO_CHECK_ARG(d && (reinterpret_cast<uintptr_t>(d) & 127u) == 0 && (ldd & 31) == 0 && (dseg & 31) == 0 && ldd >= g.N,
+                      "split-form output rows must start on 128-byte boundaries (ld, seg stride multiples of 32)");
+    else
+      SOPRO_CHECK_ARG(d && aligned16(d) && (ldd & 3) == 0 && (dseg & 3) == 0 && ldd >= g.N,
+                      "activated output rows must be 16-byte aligned (ld, seg stride multiples of 4)");
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const uint4* wp = reinterpret_cast<const uint4*>(packed_w);

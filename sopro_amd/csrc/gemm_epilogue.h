@@ -3,6 +3,8 @@
 #pragma once
 #include "common.h"
 
+// OUT: 3 = ELU(C) as fp32 rows to C; 4 = fp32 rows to C AND ELU(C) as fp32 rows to ext.C2 (the consumer then needs no
+// activation prologue; host guarantees N % 4 == 0 and 16-byte aligned rows).
 // OUT: 0 = fp32 rows to C; 1 = ELU, then split-bf16 form to C; 2 = fp32 rows to C AND ELU + split form to ext.C2 (the raw
 // tensor stays available as a residual operand while the next contraction reads its activated form without any prologue
 // work).  Split form: every aligned group of 32 channels (128 bytes as fp32) becomes [32 hi bf16 | 32 lo bf16], so an
@@ -61,9 +63,11 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
   int seg = m / rps, rr = m - seg * rps;
   float* cptr = g.C + (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc + ocol;
   // split-form destination: the row walk of cptr, pointing at the 128-byte group of this thread's columns
-  float* const dbase = OUT == 2 ? ext->C2 : g.C;
-  const int64_t ldd = OUT == 2 ? ext->ldc2 : g.ldc, dseg = OUT == 2 ? ext->c2_seg_stride : g.c_seg_stride;
-  const int64_t dcol_bytes = (int64_t)(ocol >> 5) * 128 + (ocol & 31) * 2;
+  constexpr bool second = OUT == 2 || OUT == 4;  // the activated tensor goes to C2, the raw one to C
+  constexpr bool split_out = OUT == 1 || OUT == 2;
+  float* const dbase = second ? ext->C2 : g.C;
+  const int64_t ldd = second ? ext->ldc2 : g.ldc, dseg = second ? ext->c2_seg_stride : g.c_seg_stride;
+  const int64_t dcol_bytes = split_out ? (int64_t)(ocol >> 5) * 128 + (ocol & 31) * 2 : (int64_t)ocol * 4;
   char* dptr = OUT != 0 ? reinterpret_cast<char*>(dbase + (int64_t)seg * dseg + (int64_t)rr * ldd) + dcol_bytes : nullptr;
   const int64_t dstep = (int64_t)RPP * ldd * 4;
   const float* rptr = res ? g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr + ocol : nullptr;
@@ -115,13 +119,16 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
       } else if (res) {
         v.x = rv[q].x + sc4.x * v.x; v.y = rv[q].y + sc4.y * v.y; v.z = rv[q].z + sc4.z * v.z; v.w = rv[q].w + sc4.w * v.w;
       }
-      if (OUT != 0) {  // host guarantees N % 4 == 0 and 128-byte aligned rows
+      if (split_out) {  // host guarantees N % 4 == 0 and 128-byte aligned rows
         uint2 h, l;
         split2_bf16(eluf_(v.x), eluf_(v.y), h.x, l.x);
         split2_bf16(eluf_(v.z), eluf_(v.w), h.y, l.y);
         *reinterpret_cast<uint2*>(dp[q]) = h;
         *reinterpret_cast<uint2*>(dp[q] + 64) = l;
         if (OUT == 1) continue;
+      } else if (OUT != 0) {
+        *reinterpret_cast<float4*>(dp[q]) = make_float4(eluf_(v.x), eluf_(v.y), eluf_(v.z), eluf_(v.w));
+        if (OUT == 3) continue;
       }
       if (vec_ok) {
         *reinterpret_cast<float4*>(cp[q]) = v;

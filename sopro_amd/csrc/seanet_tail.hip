@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restric
   }
   __syncthreads();
 
-  // ---- conv k=1, 32 -> 64 on the ELU'd intermediate, + residual, written back over the h tile (rows 2..129)
+  // ---- conv k=1, 32 -> 64 on the ELU'd intermediate, + residual; ELU(h') is written back over the h tile (rows 2..129):
+  // the last convolution reads every row three times, so its activation is applied once here
   {
     f32x16 acc2[2];
 #pragma unroll
@@ -117,13 +118,13 @@ __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         float* p = hs + (mr + 2) * HLD + j * 32 + frow;
-        *p = real ? *p + (acc2[j][r] + b2v[j]) : 0.f;
+        *p = real ? eluf_(*p + (acc2[j][r] + b2v[j])) : 0.f;
       }
     }
   }
   __syncthreads();
 
-  // ---- last conv k=3, 64 -> 1 on ELU(h'): output i (sample s0+i) reads LDS rows i+2 .. i+4; two threads per output
+  // ---- last conv k=3, 64 -> 1 on the stored ELU(h'): output i (sample s0+i) reads LDS rows i+2 .. i+4; two threads per output
   {
     const int i = tid >> 1, half = tid & 1;  // half: channels 0..31 / 32..63
     float s = 0.f;
@@ -132,9 +133,8 @@ __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restric
       for (int j = 0; j < 3; ++j) {
 #pragma unroll
         for (int c4 = 0; c4 < 8; ++c4) {
-          float4 v = *reinterpret_cast<const float4*>(hs + (i + 2 + j) * HLD + half * 32 + c4 * 4);
+          const float4 v = *reinterpret_cast<const float4*>(hs + (i + 2 + j) * HLD + half * 32 + c4 * 4);
           const float4 wv = *reinterpret_cast<const float4*>(wf + j * 64 + half * 32 + c4 * 4);
-          v.x = eluf_(v.x); v.y = eluf_(v.y); v.z = eluf_(v.z); v.w = eluf_(v.w);
           s += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
         }
       }

@@ -336,13 +336,18 @@ class SoproTTSModel:
             raise ValueError("cond_ar must have max_frames+1 rows")
         run = _ARRun(self, cond_ar, txt_seq, text_lens, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
                      min_gen_frames=min_gen_frames)
+        # The stop poll trails the launches by one chunk: chunk k+1 is enqueued before the host looks at chunk k's counter, so
+        # the GPU never waits for the host round trip (rows that have stopped are masked on the device; the extra frames of
+        # a batch that turns out to be finished are discarded below).
         steps = 0
+        pending = None
         while steps < Tar:
             n = min(int(poll_every), Tar - steps)
             run.advance(n)
             steps += n
-            if run.n_stopped(stop_on_first_eos) >= B:
+            if pending is not None and pending() >= B:
                 break
+            pending = run.poll_async(stop_on_first_eos)
         hist, first_eos = run.history(steps)
         lens = [int(f) if f >= 0 else steps for f in first_eos]
         return hist, lens
@@ -476,11 +481,18 @@ class SoproTTSModel:
         ev.mark("nar")
         return toks
 
-    def phase_ar(self, ids_list, refs, *, max_frames, top_p, temperature, anti_loop, style_strength, min_gen_frames, ev=None):
-        """Latency-bound half of generate_tokens_batch: conditioning + the AR graph replay."""
+    def phase_cond(self, ids_list, refs, *, max_frames, style_strength, ev=None):
+        """Per-batch conditioning (GEMM-shaped; runs on the preparation stream, needs no generation slot)."""
         prep = self.prepare_conditioning_batch(ids_list, refs, max_frames=max_frames, style_strength=style_strength)
         if ev is not None:
             ev.mark("cond")
+        return prep
+
+    def phase_ar(self, ids_list, refs, *, max_frames, top_p, temperature, anti_loop, style_strength, min_gen_frames, ev=None,
+                 prep=None):
+        """Latency-bound half of generate_tokens_batch: (conditioning +) the AR graph replay."""
+        if prep is None:
+            prep = self.phase_cond(ids_list, refs, max_frames=max_frames, style_strength=style_strength, ev=ev)
         hist, lens = self.ar_generate_batch(prep["cond_ar"], prep["txt_seq"], prep["text_lens"], max_frames=max_frames,
                                             top_p=top_p, temperature=temperature, anti_loop=anti_loop,
                                             min_gen_frames=min_gen_frames)
@@ -687,6 +699,24 @@ class _ARRun:
             else:
                 v = int(self.plan.ctr[2].item())
         return v
+
+    def poll_async(self, first_eos: bool = False):
+        """Enqueue a copy of the stop counter behind the launches issued so far; the returned callable waits for it."""
+        plan = self.plan
+        with torch.cuda.stream(self.m.stream):
+            slot = plan.poll_slot = (getattr(plan, "poll_slot", 0) + 1) & 1
+            if not hasattr(plan, "poll_host"):
+                plan.poll_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+                plan.poll_ev = [torch.cuda.Event() for _ in range(2)]
+            src = (plan.first_eos >= 0).sum().to(torch.int32).view(1) if first_eos else plan.ctr[2:3]
+            plan.poll_host[slot].copy_(src, non_blocking=True)
+            plan.poll_ev[slot].record(self.m.stream)
+
+        def wait() -> int:
+            plan.poll_ev[slot].synchronize()
+            return int(plan.poll_host[slot][0])
+
+        return wait
 
     def tokens_host(self, t0: int, t1: int) -> List[int]:
         with torch.cuda.stream(self.m.stream):

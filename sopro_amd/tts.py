@@ -129,12 +129,14 @@ class SoproTTS:
         ids = list(text_ids) if text_ids is not None else [self.encode_text(t) for t in texts]
         ar_lock, bulk_lock = phase_locks if phase_locks is not None else (contextlib.nullcontext(), contextlib.nullcontext())
         ss = float(style_strength if style_strength is not None else self.cfg.style_strength)
-        with ar_lock:  # latency-bound phase: conditioning + AR graph replay
-            from .model import _PhaseTimer
+        from .model import _PhaseTimer
 
+        # conditioning needs no generation slot: it overlaps with whatever the other engines are doing
+        prep = self.model.phase_cond(ids, refs, max_frames=max_frames, style_strength=ss, ev=_PhaseTimer(self.model.prep_stream, timings))
+        with ar_lock:  # latency-bound phase: AR graph replay
             ev = _PhaseTimer(self.model.stream, timings)
             state = self.model.phase_ar(ids, refs, max_frames=max_frames, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-                                        style_strength=ss, min_gen_frames=min_gen_frames, ev=ev)
+                                        style_strength=ss, min_gen_frames=min_gen_frames, ev=ev, prep=prep)
         with bulk_lock:  # throughput-bound phase: NAR refinement + Mimi decode
             t0 = time.perf_counter()
             toks = self.model.phase_nar(state)

@@ -241,6 +241,22 @@ def test_gemm_bf16x3_split_plane_producer_and_consumer():
         hip.gemm(act, dev(pack.pack_conv1d(w1)), y1, M=M2, N=hid, K=3 * co, lda=co, a_split=True)
 
 
+def test_gemm_bf16x3_activated_copy_outputs():
+    """c_mode 3: ELU(C) as fp32 to C; c_mode 4: C to C and ELU(C) to C2 (SEANet decoder's producer-side activation)."""
+    M, N, K = 300, 192, 128
+    A, W, b, R = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5), rnd(N, seed=33), rnd(M, N, seed=34)
+    Wp = hip.pack_w_bf16x3(dev(W))
+    ref = A @ W.t() + b
+    C, C2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), c_mode=3)
+    close(C, F.elu(ref), 2e-4, "elu out")
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), c_mode=4, C2=C2)
+    close(C, ref, 2e-4, "raw out")
+    close(C2, F.elu(ref), 2e-4, "elu copy")
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_RES, R=dev(R), c_mode=3)
+    close(C, F.elu(R + ref), 3e-4, "elu(res) out")
+
+
 def test_mimi_decode_split_bf16_vs_f32_paths(mc, mimi_np):
     """The decoder on the split-bf16 path against the same decoder on fp32 MFMA: 1e-5-of-peak class."""
     import os
@@ -498,7 +514,7 @@ def test_attention_cross(H, dh, Tq, Tk):
     close(out, ref, 2e-5, "cross attention")
 
 
-@pytest.mark.parametrize("N,win,past", [(100, 250, 0), (400, 250, 0), (16, 250, 300), (300, 17, 5)])
+@pytest.mark.parametrize("N,win,past", [(100, 250, 0), (400, 250, 0), (16, 250, 300), (300, 17, 5), (33, 250, 0), (7, 250, 40), (95, 40, 1000)])
 def test_attention_causal_sliding_window_with_cache(N, win, past):
     """Mimi decoder attention incl. the cached-keys form (HF:modeling_mimi.py:657-726, 882-888)."""
     B, H, dh = (2 if past == 0 else 1), 8, 64
