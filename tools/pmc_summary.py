@@ -10,6 +10,12 @@ import sys
 
 
 def fam(name: str) -> str:
+    if "gemm_bf16s_kernel<2" in name:
+        return "gemm_bf16x3_kernel"
+    if "gemm_bf16s_kernel<3" in name:
+        return "gemm_bf16x6_kernel"
+    if "attn_window_mfma_kernel" in name:
+        return "attention_kernel"
     for k in ("gemm_f32_kernel", "skinny_kernel", "xattn_step_kernel", "ar_sample_kernel", "seanet_tail_kernel", "attention_kernel"):
         if k in name:
             return k
@@ -31,7 +37,7 @@ for k in f:
     n = f[k][0]
     out[k] = {"launches": n, "fetch_kib_raw": round(f[k][1]), "write_kib": round(w.get(k, [0, 0])[1]),
               "traffic_bytes_per_launch": round((2 * f[k][1] + w.get(k, [0, 0])[1]) * 1024 / max(1, n))}
-json.dump({"command": "python bench.py --steps 1 --warmup 1 --no-cpu-baseline --ttfa-runs 0 (2 passes of the step: warm-up + timed)",
+json.dump({"command": "python bench.py --lanes 1 --steps 1 --warmup 2 --profile-steps 0 --no-cpu-baseline --ttfa-runs 0 (3 passes of the step)",
            "correction": "read side doubled (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16 B/lane reads)", "families": out},
           open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
