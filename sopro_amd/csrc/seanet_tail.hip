@@ -3,129 +3,161 @@
 //     wav = Conv1d(64->1, k=3)(ELU(h'))                                       (last layer)
 // h is the 64-channel activation written by the last transposed convolution: 3.1 GB for 32 x 200 frames.
 // Unfused this level moves ~19 GB through HBM (h is read three times and rewritten once, the 32-channel
-// intermediate makes a round trip); fused, h is read once and only the waveform (1/64 of it) is written.
+// intermediate makes a round trip); fused, h is read once (plus one L2-resident re-read for the skip operand)
+// and only the waveform (1/64 of it) is written.
 //
-// One workgroup = 126 output samples of one utterance.  The h tile (130 rows incl. the 4-sample halo the two
-// k=3 convolutions need) sits in LDS with rows padded to 68 floats, so the k=3 window of a sample is three
-// consecutive LDS rows and 16-lane ds_read_b128 fragment reads are conflict free.  Both convolutions run on
-// v_mfma_f32_32x32x2_f32 (exact fp32) with the small weight matrices held in registers as B fragments
-// (24 + 8 float4 per lane); ELU is applied on the operand read; the residual and the last 64->1 convolution
-// read the same LDS tile.  3 workgroups fit per CU (53 KB of LDS each).
+// One workgroup = 126 output samples of one utterance.  Both convolutions run on the split-bf16 matrix-core path of
+// the rest of the decoder (operands x = hi + lo in bf16, lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16, fp32
+// accumulate): ELU(h) is activated and split ONCE per element while the tile is staged into LDS (row = [64 hi | 64 lo]
+// bf16 + 16 B pad = 272 B, so the k=3 window of a sample is three consecutive rows and 16-lane ds_read_b128 fragment
+// reads are conflict free), the small weight matrices are split once per lane into register B fragments, the 32-channel
+// intermediate goes through LDS in the same split form, and ELU(h') is stored once (fp32, over the dead h tile) for the
+// last 64 -> 1 convolution, which reads every row three times.  2 workgroups per CU (54 KB of LDS each).
 #include "common.h"
 
 namespace {
 
 constexpr int TO = 126;        // output samples per workgroup
 constexpr int HR = TO + 4;     // h rows in LDS (samples s0-4 .. s0+TO-1)
-constexpr int HLD = 68;        // padded h row
+constexpr int EROW = 272;      // bytes per row of the split h tile: 64 hi | 64 lo | pad
 constexpr int YR = TO + 2;     // rows of the 32-channel intermediate (samples s0-2 .. s0+TO-1) == 128 == 4 MFMA row tiles
-constexpr int YLD = 36;
+constexpr int YROW = 144;      // bytes per row of the split intermediate: 32 hi | 32 lo | pad
+constexpr int HLD = 68;        // floats per row of the ELU(h') tile (written over the split h tile)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 frag(const uint4& v) { return *reinterpret_cast<const bf16x8*>(&v); }
+
+// 8 consecutive fp32 weights -> (hi, lo) fragments
+__device__ __forceinline__ void split8(const float* __restrict__ p, uint4& hi, uint4& lo) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  split2_bf16(a.x, a.y, hi.x, lo.x);
+  split2_bf16(a.z, a.w, hi.y, lo.y);
+  split2_bf16(b.x, b.y, hi.z, lo.z);
+  split2_bf16(b.z, b.w, hi.w, lo.w);
+}
 
 __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restrict__ h, int64_t h_seg_stride,
                                                           const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const float* __restrict__ w2, const float* __restrict__ b2,
                                                           const float* __restrict__ wf, float bf, float* __restrict__ wav,
                                                           int64_t wav_seg_stride, int T) {
-  __shared__ float hs[HR * HLD];
-  __shared__ float ys[YR * YLD];
+  __shared__ __attribute__((aligned(16))) unsigned char es[HR * EROW];  // split ELU(h); later ELU(h') as fp32 [HR][HLD]
+  __shared__ __attribute__((aligned(16))) unsigned char ys[YR * YROW];  // split ELU(intermediate)
+  static_assert(HR * HLD * 4 <= HR * EROW, "the fp32 ELU(h') tile must fit over the split h tile");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int s0 = blockIdx.x * TO;
-  const int frow = lane & 31, fk = (lane >> 5) * 4;
-
-  // ---- weights as B fragments (n = lane&31, the lane half picks k = 8c+4h .. +3), one memory round with the tile
-  float4 w1f[24];
-#pragma unroll
-  for (int c = 0; c < 24; ++c) w1f[c] = *reinterpret_cast<const float4*>(w1 + frow * 192 + c * 8 + fk);
-  float4 w2f[2][4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) w2f[j][c] = *reinterpret_cast<const float4*>(w2 + (j * 32 + frow) * 32 + c * 8 + fk);
-  const float b1v = b1[frow];
-  const float b2v[2] = {b2[frow], b2[32 + frow]};
+  const int frow = lane & 31, fg = lane >> 5;
 
   // ---- h tile: local row r holds sample s0-4+r, which is padded row s0-2+r of the buffer (2 zero rows in front)
   const float* hb = h + (int64_t)b * h_seg_stride;
-  {
-    float4 v[9];
+  float4 v[9];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const int idx = tid + q * 256;       // float4 index: 16 per row
-      const int r = idx >> 4, c4 = idx & 15;
-      const int p = s0 - 2 + r;            // padded row
-      v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < HR && p >= 0 && p < T + 2) v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)p * 64 + c4 * 4);
-    }
+  for (int q = 0; q < 9; ++q) {
+    const int idx = tid + q * 256;       // float4 index: 16 per row
+    const int r = idx >> 4, c4 = idx & 15;
+    const int p = s0 - 2 + r;            // padded row
+    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < HR && p >= 0 && p < T + 2) v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)p * 64 + c4 * 4);
+  }
+
+  // ---- weights as (hi, lo) B fragments: n = lane&31, k = 16*substep + 8*(lane>>5) .. +7  (one memory round with the tile)
+  uint4 w1h[12], w1l[12];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const int idx = tid + q * 256;
-      const int r = idx >> 4, c4 = idx & 15;
-      if (r < HR) *reinterpret_cast<float4*>(hs + r * HLD + c4 * 4) = v[q];
+  for (int s = 0; s < 12; ++s) split8(w1 + frow * 192 + s * 16 + fg * 8, w1h[s], w1l[s]);
+  uint4 w2h[2][2], w2l[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) split8(w2 + (j * 32 + frow) * 32 + s * 16 + fg * 8, w2h[j][s], w2l[j][s]);
+  const float b1v = b1[frow];
+  const float b2v[2] = {b2[frow], b2[32 + frow]};
+
+  // ELU + split once per element
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int idx = tid + q * 256;
+    const int r = idx >> 4, c4 = idx & 15;
+    if (r < HR) {
+      uint2 hi, lo;
+      split2_bf16(eluf_(v[q].x), eluf_(v[q].y), hi.x, lo.x);
+      split2_bf16(eluf_(v[q].z), eluf_(v[q].w), hi.y, lo.y);
+      *reinterpret_cast<uint2*>(es + r * EROW + c4 * 8) = hi;
+      *reinterpret_cast<uint2*>(es + r * EROW + 128 + c4 * 8) = lo;
     }
   }
   __syncthreads();
 
-  // ---- conv k=3, 64 -> 32 on ELU(h): intermediate row m (sample s0-2+m) reads LDS rows m, m+1, m+2; wave w owns rows 32w..32w+31
+  // ---- conv k=3, 64 -> 32: intermediate row m (sample s0-2+m) reads tile rows m, m+1, m+2; wave w owns rows 32w..32w+31.
+  // K index = tap*64 + channel; substep s covers tap s/4, channels 16*(s%4) .. +15
   {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int m = wave * 32 + frow;
+    const unsigned char* a = es + (wave * 32 + frow) * EROW + fg * 16;
 #pragma unroll
-    for (int c = 0; c < 24; ++c) {
-      const int j = c >> 3, cc = (c & 7) * 8 + fk;  // tap, channel
-      float4 a4 = *reinterpret_cast<const float4*>(hs + (m + j) * HLD + cc);
-      a4.x = eluf_(a4.x); a4.y = eluf_(a4.y); a4.z = eluf_(a4.z); a4.w = eluf_(a4.w);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, w1f[c].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, w1f[c].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, w1f[c].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, w1f[c].w, acc, 0, 0, 0);
+    for (int s = 0; s < 12; ++s) {
+      const unsigned char* p = a + (s >> 2) * EROW + (s & 3) * 32;
+      const uint4 ah = *reinterpret_cast<const uint4*>(p), al = *reinterpret_cast<const uint4*>(p + 128);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(al), frag(w1h[s]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah), frag(w1l[s]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah), frag(w1h[s]), acc, 0, 0, 0);
     }
-    // D[r]: row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
+    // D[r]: row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 -> ELU, split, one bf16 per plane
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      ys[mr * YLD + frow] = eluf_(acc[r] + b1v);
+    for (int r = 0; r < 16; r += 1) {
+      const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+      unsigned hi, lo;
+      split2_bf16(eluf_(acc[r] + b1v), 0.f, hi, lo);
+      *reinterpret_cast<unsigned short*>(ys + mr * YROW + frow * 2) = (unsigned short)(hi & 0xffffu);
+      *reinterpret_cast<unsigned short*>(ys + mr * YROW + 64 + frow * 2) = (unsigned short)(lo & 0xffffu);
     }
   }
-  __syncthreads();
+  __syncthreads();  // every wave is done with the split h tile: its memory becomes the ELU(h') tile below
 
-  // ---- conv k=1, 32 -> 64 on the ELU'd intermediate, + residual; ELU(h') is written back over the h tile (rows 2..129):
-  // the last convolution reads every row three times, so its activation is applied once here
+  // ---- conv k=1, 32 -> 64 on the intermediate, + skip operand (raw h, re-read: L2 resident), ELU(h') -> fp32 tile rows 2..129
   {
     f32x16 acc2[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
-    const int m = wave * 32 + frow;
+    const unsigned char* a = ys + (wave * 32 + frow) * YROW + fg * 16;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float4 a4 = *reinterpret_cast<const float4*>(ys + m * YLD + c * 8 + fk);
+    for (int s = 0; s < 2; ++s) {
+      const uint4 ah = *reinterpret_cast<const uint4*>(a + s * 32), al = *reinterpret_cast<const uint4*>(a + 64 + s * 32);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, w2f[j][c].x, acc2[j], 0, 0, 0);
-        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, w2f[j][c].y, acc2[j], 0, 0, 0);
-        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, w2f[j][c].z, acc2[j], 0, 0, 0);
-        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, w2f[j][c].w, acc2[j], 0, 0, 0);
+        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(al), frag(w2h[j][s]), acc2[j], 0, 0, 0);
+        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah), frag(w2l[j][s]), acc2[j], 0, 0, 0);
+        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah), frag(w2h[j][s]), acc2[j], 0, 0, 0);
       }
+    }
+    float* hs = reinterpret_cast<float*>(es);
+    float skip[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+      const int p = s0 + mr;  // padded row of sample s0-2+mr
+      const bool in = p >= 2 && p < T + 2;
+      const float* hp = hb + (int64_t)(in ? p : 2) * 64 + frow;
+      skip[0][r] = in ? hp[0] : 0.f;
+      skip[1][r] = in ? hp[32] : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
       const bool real = (s0 - 2 + mr) >= 0;  // samples before the utterance start are the zero padding of the last conv
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float* p = hs + (mr + 2) * HLD + j * 32 + frow;
-        *p = real ? eluf_(*p + (acc2[j][r] + b2v[j])) : 0.f;
-      }
+      for (int j = 0; j < 2; ++j)
+        hs[(mr + 2) * HLD + j * 32 + frow] = real ? eluf_(skip[j][r] + acc2[j][r] + b2v[j]) : 0.f;
     }
   }
   __syncthreads();
 
-  // ---- last conv k=3, 64 -> 1 on the stored ELU(h'): output i (sample s0+i) reads LDS rows i+2 .. i+4; two threads per output
+  // ---- last conv k=3, 64 -> 1 on the stored ELU(h'): output i (sample s0+i) reads tile rows i+2 .. i+4; two threads per output
   {
+    const float* hs = reinterpret_cast<const float*>(es);
     const int i = tid >> 1, half = tid & 1;  // half: channels 0..31 / 32..63
     float s = 0.f;
     if (i < TO) {
@@ -133,9 +165,9 @@ __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restric
       for (int j = 0; j < 3; ++j) {
 #pragma unroll
         for (int c4 = 0; c4 < 8; ++c4) {
-          const float4 v = *reinterpret_cast<const float4*>(hs + (i + 2 + j) * HLD + half * 32 + c4 * 4);
+          const float4 x = *reinterpret_cast<const float4*>(hs + (i + 2 + j) * HLD + half * 32 + c4 * 4);
           const float4 wv = *reinterpret_cast<const float4*>(wf + j * 64 + half * 32 + c4 * 4);
-          s += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+          s += x.x * wv.x + x.y * wv.y + x.z * wv.z + x.w * wv.w;
         }
       }
     }

@@ -580,7 +580,7 @@ def test_seanet_tail_fused_matches_unfused_layers():
     wav = torch.full((B, T), float("nan"), device=DEV)
     hip.seanet_tail(dev(hb), dev(pack.pack_conv1d(w1)), dev(b1), dev(pack.pack_conv1d(w2)), dev(b2), dev(wf[0].t()), bf, wav,
                     B=B, T=T, h_seg_stride=(2 + T) * 64, wav_seg_stride=T)
-    close(wav, ref, 3e-5, "fused SEANet tail")
+    close(wav, ref, 1e-4, "fused SEANet tail")  # split-bf16 contractions (16 mantissa bits per operand)
 
 
 # ------------------------------------------------------------------------------------------ sampler
