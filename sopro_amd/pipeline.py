@@ -47,6 +47,9 @@ class PipelinedSynthesizer:
             lane.model._nar_graphs.clear()
             lane.codec._graphs.clear()
             self.lanes.append(lane)
+        # An empty pipeline has nothing on the throughput partition yet: the first AR phases of a run use the whole chip
+        # (the recorded frame graph replays on any stream), which shortens the fill of the pipeline.
+        self._full = [torch.cuda.Stream(device=self.device) for _ in range(int(lanes))]
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
         self.bulk_lock = threading.Lock()
         self.ar_cus, self.ar_parts, self.bulk_cus = ar_cus, ar_parts, total - bulk0
@@ -78,7 +81,7 @@ class PipelinedSynthesizer:
         nxt = [0]
         pick = threading.Lock()
 
-        def worker(lane, ar_lock):
+        def worker(lane, ar_lock, lane_idx):
             # the worker's current stream is the lane's own (never the NULL stream, which would serialise the lanes)
             with torch.cuda.stream(lane.model.stream):
                 while True:
@@ -87,18 +90,23 @@ class PipelinedSynthesizer:
                         nxt[0] += 1
                     if i >= len(jobs) or errors:
                         return
+                    masked = lane.model.stream
+                    if i < self.ar_parts:
+                        lane.model.stream = self._full[lane_idx]
                     try:
                         results[i] = lane.synthesize_batch(phase_locks=(ar_lock, self.bulk_lock), timings=timings, **jobs[i])
                     except BaseException as e:  # noqa: BLE001
                         errors.append(e)
                         return
+                    finally:
+                        lane.model.stream = masked
 
         n_run = max(1, min(len(self.lanes), len(jobs)))
         import sys
 
         swi = sys.getswitchinterval()
         sys.setswitchinterval(2e-4)  # lanes hand the interpreter over between launches; 5 ms hand-over stalls a whole AR poll
-        threads = [threading.Thread(target=worker, args=(lane, self.ar_locks[i % self.ar_parts])) for i, lane in enumerate(self.lanes[:n_run])]
+        threads = [threading.Thread(target=worker, args=(lane, self.ar_locks[i % self.ar_parts], i)) for i, lane in enumerate(self.lanes[:n_run])]
         for t in threads:
             t.start()
         for t in threads:

@@ -224,6 +224,16 @@ def main():
                         enc_seanet_head=eemb.numpy()[:, :, :4], enc_downsample=eds.numpy(), trim_in=tw, trim_sr=sr16,
                         trim_out=trimmed.numpy(), crop_out=cropped.numpy()[0])
 
+    # ---- a PreparedReference cache file as the reference's demo server writes it (demo/server.py:69-112) ----
+    from sopro.model import PreparedReference as RefPR
+
+    gc = torch.Generator().manual_seed(5)
+    cache = RefPR(ref_tokens_btq=torch.randint(0, 2048, (1, 7, 32), generator=gc), sv_ref=torch.randn(1, 384, generator=gc),
+                  ref_seq=torch.randn(1, 7, 384, generator=gc),
+                  ref_kv_caches=[{"k": torch.randn(1, 2, 7, 192, generator=gc), "v": torch.randn(1, 2, 7, 192, generator=gc),
+                                  "key_padding_mask": None} for _ in range(3)])
+    torch.save(cache, os.path.join(HERE, "ref_cache_reference.pt"))
+
     # ---- end-to-end synthesize + stream (greedy) --------------------------------
     tok.table["hello"] = ids.tolist()
     with torch.inference_mode():
