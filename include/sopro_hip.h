@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 9
+#define SOPRO_ABI_VERSION 10
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -97,14 +97,24 @@ typedef struct sopro_gemm_split_ext {
   int32_t a_format; /* 0: A is fp32 rows; 1: split form (prologue must be NONE) */
   int32_t c_mode;   /* 0: fp32 to C; 1: ELU + split form to C; 2: fp32 to C and ELU + split form to C2;
                      * 3: ELU(C) as fp32 to C; 4: fp32 to C and ELU(C) as fp32 to C2 */
-  float* C2; int64_t ldc2; int64_t c2_seg_stride; /* c_mode 2; strides in 4-byte units like ldc / c_seg_stride */
+  float* C2; int64_t ldc2; int64_t c2_seg_stride; /* c_mode 2 / 4; strides in 4-byte units like ldc / c_seg_stride */
+  /* Split-K for problems with too few output tiles to fill the chip (a few rows: streaming chunks, batch 1): `ksplit`
+   * workgroups share a tile, each stores its raw accumulators into `ws`, the last to take the tile's ticket adds them in
+   * slice order (deterministic) and runs the epilogue.  ws: >= ksplit * tiles * tile_elems * 4 bytes (tiles are at most
+   * 128x128, at least 64x64); tickets: one zero-initialised int per tile, left zero by every launch.  Both belong to
+   * ONE stream at a time. */
+  int32_t ksplit;      /* 0 / 1: off */
+  int32_t n_tickets;
+  float* ws; int64_t ws_bytes;
+  int32_t* tickets;
 } sopro_gemm_split_ext;
 int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
 /* Six-pass variant for token paths (NAR refinement, conditioning: src/sopro/nn/nar.py, blocks.py): operands split into
  * THREE bf16 pieces (24 mantissa bits), products p2*p0 + p0*p2 + p1*p1 + p1*p0 + p0*p1 + p0*p0; the dropped terms are
  * <= 2^-25 relative, i.e. the accuracy class of an fp32 fma chain, at 16/6 of the fp32-MFMA rate.  fp32 rows in and out;
- * prologues NONE / ADDVEC, epilogues NONE / GELU / RES / GLU.  The weight must have been packed with pieces = 3. */
-int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w, void* stream);
+ * prologues NONE / ADDVEC, epilogues NONE / GELU / RES / GLU.  The weight must have been packed with pieces = 3; of `ext`
+ * (may be NULL) only the split-K fields apply. */
+int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
 /* W [N, ldw] fp32 (device) -> `pieces` (2: bf16x3, 3: bf16x6) bf16 planes in MFMA fragment order
  * [n/32][k/16][piece][lane][8]; `packed` holds sopro_packed_w_bytes(N, K, pieces) bytes, 16-byte aligned. */
 int sopro_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t pieces, void* packed, void* stream);

@@ -164,22 +164,32 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     }
   };
 
+  // Split-K (ext.ksplit > 1, for problems with too few tiles to fill the chip: a long K loop on a handful of workgroups
+  // is one memory latency per K-step): blockIdx.y picks a contiguous range of K-steps; every slice stores its raw
+  // accumulators, the LAST slice to arrive at the tile's ticket adds all of them IN SLICE ORDER (deterministic, whoever
+  // is last) and runs the epilogue.
+  const int KS = ext.ksplit > 1 ? ext.ksplit : 1;
+  const int per = (KT + KS - 1) / KS;
+  const int kt0 = (int)blockIdx.y * per;
+  const int nkt = max(0, min(KT, kt0 + per) - kt0);  // K-steps of this slice (0 for a trailing empty slice)
+  const int ktl = max(kt0, kt0 + nkt - 1);           // last valid step of the slice (prefetch clamp)
+
   // Two K-steps per trip (register double buffer for the B fragments, LDS double buffer for A).  The prefetch of the
   // step after the last one is clamped onto the last step: redundant but branch-free.
   uint4 rb0[TN][2][NPL], rb1[TN][2][NPL];
-  gload(0);
-  bload(0, rb0);
+  gload(min(kt0, KT - 1));
+  bload(min(kt0, KT - 1), rb0);
   lstore(0);
   __syncthreads();
   if (dbg && tid == 0) dbg[1] = clock64();
-  for (int kt = 0; kt < KT; kt += 2) {
-    const int k1 = min(kt + 1, KT - 1), k2 = min(kt + 2, KT - 1);
+  for (int it = 0; it < nkt; it += 2) {
+    const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl);
     gload(k1);
     bload(k1, rb1);
     compute(0, rb0);
     lstore(1);
     __syncthreads();
-    if (kt + 1 >= KT) break;
+    if (it + 1 >= nkt) break;
     gload(k2);
     bload(k2, rb0);
     compute(1, rb1);
@@ -187,6 +197,60 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     __syncthreads();
   }
   if (dbg && tid == 0) dbg[2] = clock64();
+  if (KS > 1) {
+    constexpr int PER_THREAD = TM * TN * 16;
+    const int tile = blockIdx.x, ntile = gridDim.x;
+    float* mine = ext.ws + ((int64_t)((int64_t)blockIdx.y * ntile + tile) * NT + tid) * PER_THREAD;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4)
+          *reinterpret_cast<float4*>(mine + (i * TN + j) * 16 + r) = make_float4(acc[i][j][r], acc[i][j][r + 1], acc[i][j][r + 2], acc[i][j][r + 3]);
+    __syncthreads();  // all partial stores of this workgroup are issued before its ticket
+    int* flag = reinterpret_cast<int*>(smem4);
+    if (tid == 0) {
+      __atomic_thread_fence(__ATOMIC_RELEASE);  // agent scope: partials visible before the ticket
+      const int old = __hip_atomic_fetch_add(ext.tickets + tile, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = old;
+      if (old == KS - 1) __hip_atomic_store(ext.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
+    if (*flag != KS - 1) return;  // whole workgroup
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    __syncthreads();  // the flag word is part of the epilogue's LDS tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // all slices of a 4-float piece are requested together (up to 16 loads in flight), then added in slice order
+    const int64_t sl_stride = (int64_t)ntile * NT * PER_THREAD;
+    const float* part0 = ext.ws + ((int64_t)tile * NT + tid) * PER_THREAD;
+    for (int s0 = 0; s0 < KS; s0 += 16) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; r += 4) {
+            f32x4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int sl = min(s0 + u, KS - 1);  // clamped: a repeated slice is read but not added
+              v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part0 + sl * sl_stride + (i * TN + j) * 16 + r));
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              if (s0 + u < KS) {
+                acc[i][j][r] += v[u][0]; acc[i][j][r + 1] += v[u][1]; acc[i][j][r + 2] += v[u][2]; acc[i][j][r + 3] += v[u][3];
+              }
+            }
+          }
+    }
+  }
   gemm_store_tile<WM, WN, TM, TN, EPI, OUT>(g, reinterpret_cast<float*>(smem4), acc, biasv, m0, n0, &ext);
   if (dbg && tid == 0) dbg[3] = clock64();
 }
@@ -230,7 +294,16 @@ int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro
     attr_done = true;
   }
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, g, wp, ksubs, ext);
+  const int ks = ext.ksplit > 1 ? ext.ksplit : 1;
+  if (ks > 1) {
+    const int64_t need = (int64_t)ks * ntm * ntn * BM * BN * (int64_t)sizeof(float);
+    if (!ext.ws || !ext.tickets || ext.ws_bytes < need || ext.n_tickets < ntm * ntn) {
+      sopro_set_error("split-K needs a %lld-byte workspace and %d tickets (got %lld, %d)", (long long)need, ntm * ntn,
+                      (long long)ext.ws_bytes, ext.n_tickets);
+      return -2;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, ks), dim3(WM * WN * 64), lds, s, g, wp, ksubs, ext);
   SOPRO_LAUNCH_CHECK();
 }
 
@@ -302,6 +375,8 @@ int check_common(sopro_gemm_args& g, sopro_gemm_split_ext& ext, const void* pack
   SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_RES || g.R != nullptr, "EPI_RES needs R");
   SOPRO_CHECK_ARG(g.prologue != SOPRO_PRO_ADDVEC || (g.pro_vec && aligned16(g.pro_vec)), "PRO_ADDVEC needs an aligned pro_vec");
   SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_GLU || (g.N % 64) == 0, "EPI_GLU needs N % 64 == 0 (packed value/gate blocks)");
+  SOPRO_CHECK_ARG(ext.ksplit >= 0 && ext.ksplit <= 64, "ksplit must be in 0..64");
+  SOPRO_CHECK_ARG(ext.ksplit <= 1 || g.dbg == nullptr, "the clock-stamp probe is for unsplit launches");
   return 0;
 }
 
@@ -371,15 +446,18 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
     case 5: return launch_cfg3<2, 2, 1, 1>(g, wp, ksubs, ext, s);
     default: break;
   }
-  if (g.N <= 64) return launch_cfg3<2, 2, 1, 1>(g, wp, ksubs, ext, s);
+  // few columns, or few rows (streaming chunks, batch 1: small tiles keep the split-K partial sums small): 64x64
+  if (g.N <= 64 || g.M <= 64) return launch_cfg3<2, 2, 1, 1>(g, wp, ksubs, ext, s);
   return launch_cfg3<2, 2, 2, 2>(g, wp, ksubs, ext, s);
 }
 
-extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w, void* stream) {
+extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* x, void* stream) {
   SOPRO_CHECK_ARG(a != nullptr, "args is NULL");
   sopro_gemm_args g = *a;
   sopro_gemm_split_ext ext;
   memset(&ext, 0, sizeof(ext));
+  if (x) ext = *x;
+  SOPRO_CHECK_ARG(ext.a_format == 0 && ext.c_mode == 0, "the six-pass path reads and writes fp32 rows (only the split-K fields of ext apply)");
   if (int rc = check_common(g, ext, packed_w)) return rc;
   SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ADDVEC, "prologue must be NONE or ADDVEC");
   SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES || g.epilogue == SOPRO_EPI_GLU,

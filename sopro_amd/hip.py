@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -34,7 +34,8 @@ class GemmArgs(C.Structure):
 
 
 class SplitExt(C.Structure):
-    _fields_ = [("a_format", _i32), ("c_mode", _i32), ("C2", _p), ("ldc2", _i64), ("c2_seg_stride", _i64)]
+    _fields_ = [("a_format", _i32), ("c_mode", _i32), ("C2", _p), ("ldc2", _i64), ("c2_seg_stride", _i64),
+                ("ksplit", _i32), ("n_tickets", _i32), ("ws", _p), ("ws_bytes", _i64), ("tickets", _p)]
 
 
 class SkinnyArgs(C.Structure):
@@ -78,7 +79,7 @@ SYMBOLS = {
     "sopro_stream_destroy": (C.c_int, [_p]),
     "sopro_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "sopro_gemm_bf16x3": (C.c_int, [_p, _p, _p, _p]),
-    "sopro_gemm_bf16x6": (C.c_int, [_p, _p, _p]),
+    "sopro_gemm_bf16x6": (C.c_int, [_p, _p, _p, _p]),
     "sopro_pack_w_bf16": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     "sopro_packed_w_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "sopro_gemm_bf16_set_tile_override": (C.c_int, [C.c_int]),
@@ -230,12 +231,18 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     g.rows_per_seg = M if rows_per_seg is None else rows_per_seg
     g.prologue, g.epilogue = prologue, epilogue
     e0 = _prof.begin() if _prof is not None else None
+    x = None
+    if packed:
+        x = SplitExt()
+        ks = _auto_ksplit(M, N, K, W.pieces, epilogue) if (dbg is None and _splitk_enabled) else 1
+        if ks > 1:
+            ws, tk = _splitk_buffers()
+            x.ksplit, x.n_tickets, x.ws, x.ws_bytes, x.tickets = ks, int(tk.numel()), ptr(ws), int(ws.numel()) * 4, ptr(tk, torch.int32)
     if packed and W.pieces == 3:
         if a_split or c_mode:
             raise SoproHipError("split-form operands belong to the three-pass (pieces = 2) path")
-        _check(load().sopro_gemm_bf16x6(C.byref(g), ptr(W.data, torch.int32), _stream()), "sopro_gemm_bf16x6")
+        _check(load().sopro_gemm_bf16x6(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_bf16x6")
     elif packed:
-        x = SplitExt()
         x.a_format, x.c_mode = int(bool(a_split)), c_mode
         x.C2 = (ptr(C2) + 4 * c2_off) if C2 is not None else None
         x.ldc2, x.c2_seg_stride = (n_out if ldc2 is None else ldc2), c2_seg_stride
@@ -246,6 +253,42 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
         _check(load().sopro_gemm_f32(C.byref(g), _stream()), "sopro_gemm_f32")
     if e0 is not None:
         _prof.end(("gemm_bf16x6_kernel" if W.pieces == 3 else "gemm_bf16x3_kernel") if packed else "gemm_f32_kernel", 2.0 * M * N * K, e0)
+
+
+_splitk_enabled = os.environ.get("SOPRO_NO_SPLITK", "0") != "1"
+_splitk_pool: dict = {}  # stream handle -> (workspace, tickets): split-K scratch belongs to one stream at a time
+_SPLITK_WS_BYTES = 32 << 20
+_SPLITK_TICKETS = 1024
+
+
+def _auto_ksplit(M: int, N: int, K: int, pieces: int, epilogue: int) -> int:
+    """K slices for a problem with too few output tiles to occupy the chip (streaming chunks, batch 1): its K loop
+    would otherwise run at one memory latency per 32-wide step on a handful of workgroups."""
+    if pieces == 3:
+        bm, bn = (64, 128) if epilogue == EPI_GLU else (64, 64)
+    else:
+        bm, bn = (64, 64) if (N <= 64 or M <= 64) else (128, 128)
+    tiles = -(-M // bm) * -(-N // bn)
+    kt = -(-K // 32)
+    # the split costs ~10 us (device-scope release / acquire around the ticket): it pays from ~32 K-steps (K >= 1024) up
+    if tiles >= 96 or kt < 32 or tiles > _SPLITK_TICKETS:
+        return 1
+    # a slice costs ~0.9 us per K-step, the reducing workgroup ~0.36 us per slice of a 64x64 tile: ks ~ sqrt(2.5 * kt)
+    ks = max(1, min(16, int(round((2.5 * kt) ** 0.5)), 512 // tiles))
+    while ks > 1 and ks * tiles * bm * bn * 4 > _SPLITK_WS_BYTES:
+        ks -= 1
+    return ks
+
+
+def _splitk_buffers():
+    key = _stream()
+    bufs = _splitk_pool.get(key)
+    if bufs is None:
+        dev = torch.cuda.current_device()
+        bufs = (torch.empty(_SPLITK_WS_BYTES // 4, dtype=torch.float32, device=f"cuda:{dev}"),
+                torch.zeros(_SPLITK_TICKETS, dtype=torch.int32, device=f"cuda:{dev}"))
+        _splitk_pool[key] = bufs
+    return bufs
 
 
 class PackedW:
@@ -522,11 +565,13 @@ def cu_range_stream(first_cu: int, n_cus: int, device: Optional[torch.device] = 
     """A torch-visible stream whose kernels are confined to CUs [first_cu, first_cu + n_cus).
     The owner must hand it back with ``destroy_stream`` (torch does not own external streams)."""
     out = _p()
-    _check(load().sopro_stream_create_cu_range(first_cu, n_cus, C.byref(out)), "sopro_stream_create_cu_range")
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):  # the C side creates it on the current device
+        _check(load().sopro_stream_create_cu_range(first_cu, n_cus, C.byref(out)), "sopro_stream_create_cu_range")
     return torch.cuda.ExternalStream(out.value, device=device)
 
 
 def destroy_stream(s: "torch.cuda.Stream") -> None:
+    _splitk_pool.pop(s.cuda_stream, None)
     _check(load().sopro_stream_destroy(s.cuda_stream), "sopro_stream_destroy")
 
 

@@ -197,6 +197,48 @@ def test_gemm_bf16x6_epilogues_and_addvec():
         hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, prologue=hip.PRO_ELU)
 
 
+@pytest.mark.parametrize("pieces,M,N,K,epi", [(3, 6, 384, 1536, "res"), (3, 6, 768, 1152, "glu"), (3, 12, 2048, 1024, "none"), (2, 12, 512, 2048, "res"),
+                                              (2, 12, 1024, 3584, "none"), (2, 33, 4096, 2048, "none"), (3, 1, 64, 1536, "gelu")])
+def test_gemm_split_k_small_m_is_exact_class_and_deterministic(pieces, M, N, K, epi):
+    """Few-row problems run split-K (last-arriver reduction in slice order): same accuracy class, bitwise repeatable."""
+    assert hip._auto_ksplit(M, N, K, pieces, hip.EPI_GLU if epi == "glu" else hip.EPI_NONE) > 1
+    A, W, b, R = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43), rnd(M, N, seed=44)
+    pre = A.double() @ W.double().t() + b.double()
+    mag = A.double().abs() @ W.double().abs().t() + b.double().abs()
+    kw, Wd, bd, nout = {}, W, b, N
+    if epi == "res":
+        ref, kw = pre + R.double(), dict(epilogue=hip.EPI_RES, R=dev(R))
+    elif epi == "gelu":
+        ref, kw = F.gelu(pre), dict(epilogue=hip.EPI_GELU)
+    elif epi == "glu":
+        Wd, bd = pack.pack_glu(W, b)
+        ref, mag, nout, kw = pre[:, : N // 2] * torch.sigmoid(pre[:, N // 2:]), mag[:, : N // 2], N // 2, dict(epilogue=hip.EPI_GLU)
+    else:
+        ref = pre
+    Wp = hip.pack_w_bf16(dev(Wd), pieces)
+    outs = []
+    for _ in range(3):
+        C = torch.full((M, nout), float("nan"), device=DEV)
+        hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(bd), **kw)
+        outs.append(C.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    bound = mag * (2.0 ** -21 if pieces == 3 else 2.0 ** -15) + 1e-6
+    err = (outs[0].double() - ref).abs()
+    assert bool((err <= bound).all()), f"worst {float((err / bound).max()):.2f} of the bound"
+    # two streams at once: each has its own split-K scratch
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    C1, C2 = torch.empty(M, nout, device=DEV), torch.empty(M, nout, device=DEV)
+    Ad, bdv = dev(A), dev(bd)
+    torch.cuda.synchronize()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            hip.gemm(Ad, Wp, C1, M=M, N=N, K=K, bias=bdv, **kw)
+        with torch.cuda.stream(s2):
+            hip.gemm(Ad, Wp, C2, M=M, N=N, K=K, bias=bdv, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(C1.cpu(), outs[0]) and torch.equal(C2.cpu(), outs[0])
+
+
 def _planes(t, P):
     """Split-form rows [.., P floats] (every 32 channels = [32 hi | 32 lo] bf16) -> the fp32 values hi + lo they encode."""
     b = t.contiguous().view(torch.bfloat16).view(*t.shape[:-1], P // 32, 2, 32).float()
