@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 10
+#define SOPRO_ABI_VERSION 11
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -199,8 +199,9 @@ int sopro_codebook_sum_f32(const int32_t* tok, int32_t ldt, const int32_t* col, 
 /* out[b, t, :] = table[ids[b, t], :] + pe[t, :]  (0 for t >= lens[b])   src/sopro/nn/text.py:31-33 */
 int sopro_text_embed_f32(const int32_t* ids, const int32_t* lens, const float* table, int64_t table_rows,
                          const float* pe, float* out, int32_t B, int32_t T, int32_t C, void* stream);
-/* argmax over each row of [rows, N] -> int32 written at out[r * ldo]  (src/sopro/model.py:340-343) */
-int sopro_argmax_rows_f32(const float* x, int64_t ldx, int32_t* out, int64_t ldo, int32_t rows, int32_t N,
+/* argmax over each row of [rows, N] -> int32 written at out[(r / inner) * ldo + r % inner]  (src/sopro/model.py:340-343;
+ * inner > 1: the `inner` heads of a NAR stage are consecutive rows of one logits matrix and fill consecutive codebooks) */
+int sopro_argmax_rows_f32(const float* x, int64_t ldx, int32_t* out, int64_t ldo, int32_t inner, int32_t rows, int32_t N,
                           void* stream);
 
 /* ---- Mimi encode side (reference audio -> tokens: src/sopro/codec/mimi.py:42-63) ---------------------- */

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__
 
 // first maximum wins (torch.argmax returns the first index on CPU for exact ties)
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int64_t ldx, int* __restrict__ out,
-                                                          int64_t ldo, int rows, int N) {
+                                                          int64_t ldo, int inner, int rows, int N) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
     const int oi = __shfl_xor(bi, o, 64);
     if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
   }
-  if (lane == 0) out[(int64_t)row * ldo] = (bi == 0x7fffffff) ? 0 : bi;
+  if (lane == 0) out[(int64_t)(row / inner) * ldo + row % inner] = (bi == 0x7fffffff) ? 0 : bi;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -475,9 +475,10 @@ int sopro_text_embed_f32(const int32_t* ids, const int32_t* lens, const float* t
   SOPRO_LAUNCH_CHECK();
 }
 
-int sopro_argmax_rows_f32(const float* x, int64_t ldx, int32_t* out, int64_t ldo, int32_t rows, int32_t N, void* stream) {
-  SOPRO_CHECK_ARG(x && out && rows > 0 && N > 0, "bad pointers or sizes");
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(nblk(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, rows, N);
+int sopro_argmax_rows_f32(const float* x, int64_t ldx, int32_t* out, int64_t ldo, int32_t inner, int32_t rows, int32_t N,
+                          void* stream) {
+  SOPRO_CHECK_ARG(x && out && rows > 0 && N > 0 && inner > 0, "bad pointers or sizes");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(nblk(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, inner, rows, N);
   SOPRO_LAUNCH_CHECK();
 }
 

@@ -38,7 +38,7 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned (&pc)[NPL]
 // AMODE: 0 = A is fp32 rows, split while staged; 1 = the same with ELU applied first; 2 = A is already in split form
 // (NPL == 2 only: each 32-channel group = [32 hi | 32 lo] bf16, written by a producer's OUT = 1 / 2 epilogue): pure
 // 16-byte copies; 3 = fp32 rows + pro_vec[k] (PRO_ADDVEC).
-template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT>
+template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT, bool SK>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gemm_args g, const uint4* __restrict__ Wp,
                                                                  int ksubs, const sopro_gemm_split_ext ext) {
   constexpr int AROW = NPL * 64 + 16;  // bytes per LDS row
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   // is one memory latency per K-step): blockIdx.y picks a contiguous range of K-steps; every slice stores its raw
   // accumulators, the LAST slice to arrive at the tile's ticket adds all of them IN SLICE ORDER (deterministic, whoever
   // is last) and runs the epilogue.
-  const int KS = ext.ksplit > 1 ? ext.ksplit : 1;
+  const int KS = SK ? ext.ksplit : 1;  // a separate instantiation: the reduction's registers must not weigh on the unsplit kernel
   const int per = (KT + KS - 1) / KS;
   const int kt0 = (int)blockIdx.y * per;
   const int nkt = max(0, min(KT, kt0 + per) - kt0);  // K-steps of this slice (0 for a trailing empty slice)
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     __syncthreads();
   }
   if (dbg && tid == 0) dbg[2] = clock64();
-  if (KS > 1) {
+  if constexpr (SK) {
     constexpr int PER_THREAD = TM * TN * 16;
     const int tile = blockIdx.x, ntile = gridDim.x;
     float* mine = ext.ws + ((int64_t)((int64_t)blockIdx.y * ntile + tile) * NT + tid) * PER_THREAD;
@@ -287,14 +287,14 @@ int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds_main = (size_t)2 * BM * (NPL * 64 + 16), lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  static bool attr_done = false;
-  auto kern = gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT>;
-  if (!attr_done) {
+  const int ks = ext.ksplit > 1 ? ext.ksplit : 1;
+  static bool attr_done[2] = {false, false};
+  auto kern = ks > 1 ? gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT, true> : gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT, false>;
+  if (!attr_done[ks > 1]) {
     SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    attr_done[ks > 1] = true;
   }
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  const int ks = ext.ksplit > 1 ? ext.ksplit : 1;
   if (ks > 1) {
     const int64_t need = (int64_t)ks * ntm * ntn * BM * BN * (int64_t)sizeof(float);
     if (!ext.ws || !ext.tickets || ext.ws_bytes < need || ext.n_tickets < ntm * ntn) {

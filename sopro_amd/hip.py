@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -95,7 +95,7 @@ SYMBOLS = {
     "sopro_dwconv_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "sopro_codebook_sum_f32": (C.c_int, [_p, _i32, _p, _p, _p, _i32, _p, _i64, _p, _f32, _f32, _p, _i64, _i64, _i32, _i32, _i32, _p]),
     "sopro_text_embed_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
-    "sopro_argmax_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _p]),
+    "sopro_argmax_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_fir1_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "sopro_rvq_assign_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _i32, _p, _i64, _i32, _p]),
     "sopro_attention_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
@@ -400,8 +400,9 @@ def text_embed(ids: torch.Tensor, lens: Optional[torch.Tensor], table: torch.Ten
 
 
 def argmax_rows(x: torch.Tensor, out: torch.Tensor, *, rows: int, N: int, ldx: Optional[int] = None, ldo: int = 1,
-                o_off: int = 0) -> None:
-    _check(load().sopro_argmax_rows_f32(ptr(x), N if ldx is None else ldx, ptr(out, torch.int32) + 4 * o_off, ldo, rows, N,
+                o_off: int = 0, inner: int = 1) -> None:
+    """out[(r // inner) * ldo + r % inner] = argmax(x[r, :N]): ``inner`` consecutive rows share one output row."""
+    _check(load().sopro_argmax_rows_f32(ptr(x), N if ldx is None else ldx, ptr(out, torch.int32) + 4 * o_off, ldo, inner, rows, N,
                                         _stream()), "sopro_argmax_rows_f32")
 
 

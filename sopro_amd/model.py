@@ -435,7 +435,7 @@ class SoproTTSModel:
         xa = self.ws.get("nar.xa", (M, D))
         xb = self.ws.get("nar.xb", (M, D))
         z = self.ws.get("nar.z", (M, int(cfg.nar_head_dim)))
-        logits = self.ws.get("nar.logits", (M, V))
+        logits = self.ws.get("nar.logits", (M, max(len(c) for _, c in self._stage_cbs) * V))
         HD = int(cfg.nar_head_dim)
         for sid, (stage, cbs) in enumerate(self._stage_cbs):
             # prev = sum_j softmax(w[known])_j * E[cb_j*V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
@@ -451,11 +451,11 @@ class SoproTTSModel:
                 xa, xb = xb, xa
             hip.norm(xa, xb, w["nar.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
             hip.gemm(xb, self.wx.get("nar.pre.w") or w["nar.pre.w"], z, M=M, N=HD, K=D, bias=w["nar.pre.b"])
-            hid = w[f"nar.head_id_emb.{stage}"]
-            for j, cb in enumerate(cbs):
-                hip.gemm(z, self.wx.get(f"nar.heads.{stage}.{j}.w") or w[f"nar.heads.{stage}.{j}.w"], logits, M=M, N=V, K=HD, bias=w[f"nar.heads.{stage}.{j}.b"],
-                         prologue=hip.PRO_ADDVEC, pro_vec=hid[j])
-                hip.argmax_rows(logits, toks, rows=M, N=V, ldo=Q, o_off=cb)
+            # all heads of the stage in one contraction (head-id embeddings live in the bias), one arg-max launch
+            nh = len(cbs)
+            hip.gemm(z, self.wx.get(f"nar.heads.{stage}.w") or w[f"nar.heads.{stage}.w"], logits, M=M, N=nh * V, K=HD,
+                     bias=w[f"nar.heads.{stage}.b"])
+            hip.argmax_rows(logits, toks, rows=M * nh, N=V, ldo=Q, o_off=cbs[0], inner=nh)
 
     # ------------------------------------------------------------------ text + reference -> tokens
     @torch.inference_mode()

@@ -134,9 +134,15 @@ def pack_sopro(weights: Dict[str, "np.ndarray"], cfg: SoproTTSConfig) -> Dict[st
         out[f"nar.adapter.{n}.w"], out[f"nar.adapter.{n}.b"] = w[f"nar.adapter.{n}.weight"], w[f"nar.adapter.{n}.bias"]
     sc = cfg.stage_codebooks()
     for s in cfg.stage_order():
+        # The heads of a stage become ONE projection [nh*V, HD]: logits_j = (z + e_j) W_j^T + b_j = z W_j^T + (b_j + W_j e_j)
+        # (src/sopro/nn/nar.py:100-116), the head-id embedding e_j folded into the bias in float64.
+        hid = w[f"nar.head_id_emb.{s}.weight"].double()
+        ws_, bs_ = [], []
         for j in range(len(sc[s])):
-            out[f"nar.heads.{s}.{j}.w"], out[f"nar.heads.{s}.{j}.b"] = w[f"nar.heads.{s}.{j}.weight"], w[f"nar.heads.{s}.{j}.bias"]
-        out[f"nar.head_id_emb.{s}"] = w[f"nar.head_id_emb.{s}.weight"]
+            wj, bj = w[f"nar.heads.{s}.{j}.weight"], w[f"nar.heads.{s}.{j}.bias"]
+            ws_.append(wj)
+            bs_.append((bj.double() + wj.double() @ hid[j]).float())
+        out[f"nar.heads.{s}.w"], out[f"nar.heads.{s}.b"] = torch.cat(ws_, dim=0).contiguous(), torch.cat(bs_, dim=0).contiguous()
         out[f"nar.mix.{s}"] = torch.softmax(w[f"nar.mix.{s}"].float(), dim=0)
     out["cond_norm.weight"] = w["cond_norm.weight"]
     # reference encoder + reference cross-attention
