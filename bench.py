@@ -107,7 +107,7 @@ def log(msg: str) -> None:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--profile-steps", type=int, default=4, help="instrumented repeat of the steps for the per-kernel roofline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -24,7 +24,6 @@ from .config import SoproTTSConfig
 from .pack import pack_sopro, sinusoid_table
 
 RMS_EPS = 1e-6  # reference: src/sopro/nn/blocks.py:27
-_PROBE_NOTAPS = __import__("os").environ.get("SOPRO_PROBE_NOTAPS") == "1"  # timing experiment only (wrong results)
 
 
 @dataclass
@@ -602,7 +601,7 @@ class _ARPlan:
             # RMSNorm -> GLU -> ring write -> dilated taps -> +x   (src/sopro/nn/blocks.py:150-157, 76-110)
             hip.skinny(base, w[p + ".glu.w"], out, B=B, N=2 * D, K=D, rms_norm=True, eps=RMS_EPS, bias=w[p + ".glu.b"],
                        epilogue=hip.EPI_GLU_DW, ring=self.rings[i], dw_w=w[p + ".dw.w"], dw_b=w[p + ".dw.b"], step=self.step_t,
-                       **(dict(ring_len=1, dil=1, ksize=1) if _PROBE_NOTAPS else dict(ring_len=(k - 1) * int(dil) + 1, dil=int(dil), ksize=k)),
+                       ring_len=(k - 1) * int(dil) + 1, dil=int(dil), ksize=k,
                        ring_bcap=B, **pend)
             # RMSNorm -> Linear -> GELU (blocks.py:158-160)
             hip.skinny(out, w[p + ".ff1.w"], self.u, B=B, N=4 * D, K=D, rms_norm=True, eps=RMS_EPS,
