@@ -52,8 +52,9 @@ class MimiCodec:
         self.ws = Workspace(self.device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.num_quantizers = int(self.mc.num_quantizers)
+        self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "32")) << 30  # scratch kept per batch shape, per engine
         self.use_graph = os.environ.get("SOPRO_NO_BULK_GRAPH", "0") != "1"
-        self._graphs = hip.GraphCache("mimi_graph")  # recorded decode launch sequences per (B, T)
+        self._graphs = hip.GraphCache("mimi_graph", cap=32)  # recorded decode launch sequences per (B, T)
         self.fuse_tail = os.environ.get("SOPRO_UNFUSED_TAIL", "0") != "1"
         # Decoder contractions run on the split-bf16 matrix-core path (16 mantissa bits per operand, fp32 accumulate:
         # waveform error ~1e-5 of peak, inside the 1e-4 contract); SOPRO_MIMI_F32=1 keeps them on the fp32 MFMA kernel.
@@ -97,7 +98,7 @@ class MimiCodec:
         other = copy.copy(self)
         other.ws = Workspace(self.device)
         other.stream = torch.cuda.Stream(device=self.device)
-        other._graphs = hip.GraphCache("mimi_graph")
+        other._graphs = hip.GraphCache("mimi_graph", cap=32)
         return other
 
     def _rope_tables(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -247,6 +248,10 @@ class MimiCodec:
         PADX = int(mc.kernel_size) - 1  # 6 zero rows in front of the first SEANet conv's input
         if state is not None and B != 1:
             raise ValueError("streaming decode state is single-utterance")
+        if ws.over(self.ws_budget) and (B, T) not in self._graphs.graphs:  # many batch shapes seen: start over
+            torch.cuda.synchronize(self.device)
+            self._graphs.clear()
+            ws.clear()
         with self.on_stream():
             # codes land in a persistent buffer so that the launch sequence of a (B, T) shape can be recorded once
             tok = ws.get("rvq.tok", (B * T, Q), dtype=torch.int32)

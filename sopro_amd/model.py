@@ -42,6 +42,7 @@ class Workspace:
     def __init__(self, device: torch.device):
         self.device = device
         self._bufs: Dict[Tuple[str, Tuple[int, ...], torch.dtype], torch.Tensor] = {}
+        self.bytes = 0
 
     def get(self, name: str, shape: Sequence[int], dtype: torch.dtype = torch.float32, zero: bool = False) -> torch.Tensor:
         key = (name, tuple(int(s) for s in shape), dtype)
@@ -50,10 +51,17 @@ class Workspace:
             # buffers whose padding rows must read as zero are zero-filled once; kernels never write the pads
             t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=self.device)
             self._bufs[key] = t
+            self.bytes += t.numel() * t.element_size()
         return t
 
     def clear(self) -> None:
         self._bufs.clear()
+        self.bytes = 0
+
+    def over(self, budget_bytes: int) -> bool:
+        """Buffers are kept per shape (recorded launch sequences point at them); a long-running process that sees many
+        batch shapes calls this between batches and drops everything (with its recorded graphs) past the budget."""
+        return self.bytes > budget_bytes
 
 
 def _i32(values, device) -> torch.Tensor:
@@ -96,7 +104,8 @@ class SoproTTSModel:
         self.bulk_stream = self.stream  # throughput-bound phase (NAR); a pipeline may point it at another CU partition
         self.prep_stream = self.stream
         self._ar_cache: Dict[Tuple[int, int, int], "_ARPlan"] = {}
-        self._nar_graphs = hip.GraphCache("nar_graph")  # recorded NAR launch sequences per (B, T)
+        self._nar_graphs = hip.GraphCache("nar_graph", cap=64)  # recorded NAR launch sequences per (B, T)
+        self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "16")) << 30  # scratch kept per batch shape, per engine
         # NAR contractions on the six-pass split-bf16 matrix-core path (24 mantissa bits per operand: the accuracy class of
         # the fp32 MFMA kernel at ~1.5x its speed on these shapes); SOPRO_NAR_F32=1 keeps the fp32 kernel.
         self.wx: Dict[str, hip.PackedW] = {}
@@ -132,7 +141,7 @@ class SoproTTSModel:
         other.bulk_stream = other.stream
         other.prep_stream = other.stream
         other._ar_cache = {}
-        other._nar_graphs = hip.GraphCache("nar_graph")
+        other._nar_graphs = hip.GraphCache("nar_graph", cap=64)
         return other
 
     def rf_ar(self) -> int:
@@ -410,6 +419,10 @@ class SoproTTSModel:
         B, T, _ = cond_seq.shape
         M = B * T
         lens_l = [T] * B if lens is None else [int(n) for n in lens]
+        if self.ws.over(self.ws_budget) and (B, T) not in self._nar_graphs.graphs:
+            torch.cuda.synchronize(self.device)
+            self._nar_graphs.clear()
+            self.ws.clear()
         with self.on_stream(bulk=True):
             # inputs land in persistent buffers so that the launch sequence of a (B, T) shape can be recorded once
             cond = self.ws.get("nar.cond", (M, D))
@@ -505,6 +518,8 @@ class SoproTTSModel:
         Tm = max(lens)
         if Tm <= 0:
             return [torch.zeros(0, self.Q, dtype=torch.long, device=self.device) for _ in range(B)]
+        # a few frames of padding keep the set of batch shapes (scratch + recorded graphs per shape) small
+        Tm = min(-(-Tm // 8) * 8, int(hist.shape[1]), int(state["cond_ar"].shape[1]))
         rvq1 = hist[:, :Tm].clamp(max=self.V - 1)  # rows past their own length are ignored below
         toks = self.nar_refine(state["cond_ar"][:, :Tm, :], rvq1, lens=[max(1, n) for n in lens])
         return [toks[b, : lens[b]] for b in range(B)]

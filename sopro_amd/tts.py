@@ -143,6 +143,8 @@ class SoproTTS:
             t1 = time.perf_counter()
             lens = [int(t.shape[0]) for t in toks]
             Tm = max(lens)
+            if Tm > 0:  # a few frames of padding keep the set of batch shapes (scratch + recorded graphs per shape) small
+                Tm = min(-(-Tm // 8) * 8, max(int(max_frames) + 1, Tm))
             B = len(toks)
             if Tm == 0:
                 return [torch.zeros(1, 1, 0, device=self.device) for _ in range(B)]
