@@ -60,6 +60,15 @@ __device__ __forceinline__ void split2_bf16(float x, float y, unsigned& hi, unsi
   lo = *reinterpret_cast<const unsigned*>(&l);
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own L2.  This maps
+// the workgroup index so that XCD x walks ONE contiguous range of tile indices: the tiles an L2 serves at the same time
+// share their A rows / W columns instead of every L2 fetching every operand.
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+  const int per = n >> 3, rem = n & 7;
+  const int x = b & 7, i = b >> 3;
+  return x * per + min(x, rem) + i;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int ntn = (g.N + BN - 1) / BN;
-  const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
+  const int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  const int mt = bid / ntn, nt = bid % ntn;
   const int m0 = mt * BM, n0 = nt * BN;
   const int lrow = tid >> 3, lc4 = tid & 7;
   const int rps = g.rows_per_seg;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   if (dbg && tid == 0) dbg[2] = clock64();
   if constexpr (SK) {
     constexpr int PER_THREAD = TM * TN * 16;
-    const int tile = blockIdx.x, ntile = gridDim.x;
+    const int tile = bid, ntile = gridDim.x;
     float* mine = ext.ws + ((int64_t)((int64_t)blockIdx.y * ntile + tile) * NT + tid) * PER_THREAD;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
