@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 11
+#define SOPRO_ABI_VERSION 12
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -294,12 +294,20 @@ typedef struct sopro_ar_state {
   const float* params;     /* [8] top_p, temperature, anti_loop, rec_top_p, rec_temperature, rep_penalty, top_k, min_gen */
   uint64_t seed;
   int32_t B, D, Tar, max_steps, V /* 2048, EOS id == V */, bos_row;
+  /* Slot mode (continuous batching; all three NULL = every row starts at frame 0 with the shared params): */
+  int32_t* start;          /* [bcap] global frame at which the row was admitted, -1 = free slot; row time = step - start */
+  const int32_t* row_max;  /* [bcap] frame budget of the row (rows of its cond block, <= Tar); NULL = Tar */
+  const float* row_params; /* [bcap, 8] per-row params; NULL = params */
 } sopro_ar_state;
 /* zero-step initialisation: step=0, flags reset, x_cur[b] = cond[b,0] + emb[bos_row]  (model.py:266-272) */
 int sopro_ar_init(const sopro_ar_state* st, void* stream);
 /* sample_token (src/sopro/sampling.py:24-93) + anti-loop policy (model.py:274-299) + EOS rule
  * (model.py:301-305) for every row, then x_cur[b] = cond[b, t+1] + emb[tok] and step += 1. */
 int sopro_ar_sample(const sopro_ar_state* st, const float* logits, int64_t ld_logits, void* stream);
+/* Slot mode: (re)start row `row` at the current global frame: x_cur = cond[row, 0] + emb[bos_row], flags and the recent
+ * window reset, start[row] = *step.  The caller has already written the row's cond block, its cross-attention operands
+ * and zeroed its ring-buffer columns, all on the same stream. */
+int sopro_ar_admit(const sopro_ar_state* st, int32_t row, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ __global__ void ar_init_kernel(const sopro_ar_state st) {
     st.first_eos[b] = -1;
     st.stop_t[b] = -1;
     for (int j = 0; j < 64; ++j) st.recent[(int64_t)b * 64 + j] = -1;
+    if (st.start) st.start[b] = -1;  // slot mode: every slot starts free
     if (b == 0) { *st.step = 0; *st.arrive = 0; *st.n_stopped = 0; }
   }
 }
@@ -91,10 +92,16 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   constexpr int PER = (2049 + SAMP_THREADS - 1) / SAMP_THREADS;
 
   // ---- the only up-front memory round: frame index, policy parameters, this row's logits, its recent tokens
-  const int t = *st.step;
-  const float p_top_p = st.params[0], p_temp = st.params[1], p_anti = st.params[2], p_rec_p = st.params[3];
-  const float p_rec_t = st.params[4], rep = st.params[5];
-  const int top_k = (int)st.params[6], min_gen = (int)st.params[7];
+  // Classic mode: every row started at global frame 0.  Slot mode (st.start != NULL, continuous batching): row b was
+  // admitted at global frame start[b] (-1 = free slot) with its own frame budget and parameters; its time is local.
+  const int tg = *st.step;
+  const int s0 = st.start ? st.start[b] : 0;
+  const int t = tg - s0;
+  const int tmax = (st.start && st.row_max) ? st.row_max[b] : st.Tar;
+  const float* prm = st.row_params ? st.row_params + (int64_t)b * 8 : st.params;
+  const float p_top_p = prm[0], p_temp = prm[1], p_anti = prm[2], p_rec_p = prm[3];
+  const float p_rec_t = prm[4], rep = prm[5];
+  const int top_k = (int)prm[6], min_gen = (int)prm[7];
   const float* lg = logits + (int64_t)b * ld;
   float xv[PER];
 #pragma unroll
@@ -104,10 +111,22 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   }
   int* recent = st.recent + (int64_t)b * RECENT;
   const int r_mine = (tid < RECENT) ? recent[tid] : -1;
-  if (t >= st.max_steps) return;  // uniform
+  if (!st.start && tg >= st.max_steps) return;  // classic mode, uniform over the grid: the loop is over
+  if (st.start && (s0 < 0 || t >= min(tmax, st.max_steps))) {
+    // free slot, or a row past its budget waiting to be harvested: nothing to sample, but the frame still needs its ticket
+    if (tid == 0) {
+      __threadfence();
+      const int old = atomicAdd(st.arrive, 1);
+      if (old == st.B - 1) {
+        *st.arrive = 0;
+        *st.step = tg + 1;
+      }
+    }
+    return;
+  }
   // next frame's conditioning row: address needs t only, consumed at the very end
   float cnext[2] = {0.f, 0.f};
-  if (t + 1 < st.Tar) {
+  if (t + 1 < tmax) {
     const float* c = st.cond + ((int64_t)b * st.Tar + (t + 1)) * st.D;
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   const int tok = sh_tok;
 
   // ---- bookkeeping: history, EOS rule (model.py:293-305), next input (model.py:266-272)
-  if (t + 1 < st.Tar) {
+  if (t + 1 < tmax) {
     const float* e = st.emb + (int64_t)tok * st.D;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -293,8 +312,21 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
     const int old = atomicAdd(st.arrive, 1);
     if (old == st.B - 1) {
       *st.arrive = 0;
-      *st.step = t + 1;
+      *st.step = tg + 1;
     }
+  }
+}
+
+// Slot mode: (re)start row `row` at the current global frame.  Stream-ordered between two frames, so *step is stable.
+__global__ void ar_admit_kernel(const sopro_ar_state st, int row) {
+  const int b = row;
+  for (int c = threadIdx.x; c < st.D; c += blockDim.x)
+    st.x_cur[(int64_t)b * st.D + c] = st.cond[((int64_t)b * st.Tar) * st.D + c] + st.emb[(int64_t)st.bos_row * st.D + c];
+  for (int j = threadIdx.x; j < 64; j += blockDim.x) st.recent[(int64_t)b * 64 + j] = -1;
+  if (threadIdx.x == 0) {
+    st.first_eos[b] = -1;
+    st.stop_t[b] = -1;
+    st.start[b] = *st.step;
   }
 }
 
@@ -315,6 +347,14 @@ static int check_state(const sopro_ar_state* st) {
 int sopro_ar_init(const sopro_ar_state* st, void* stream) {
   if (int rc = check_state(st)) return rc;
   hipLaunchKernelGGL(ar_init_kernel, dim3(st->B), dim3(128), 0, (hipStream_t)stream, *st);
+  SOPRO_LAUNCH_CHECK();
+}
+
+int sopro_ar_admit(const sopro_ar_state* st, int32_t row, void* stream) {
+  if (int rc = check_state(st)) return rc;
+  SOPRO_CHECK_ARG(st->start != nullptr, "sopro_ar_admit needs slot mode (state.start)");
+  SOPRO_CHECK_ARG(row >= 0 && row < st->B, "row out of range");
+  hipLaunchKernelGGL(ar_admit_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, *st, (int)row);
   SOPRO_LAUNCH_CHECK();
 }
 

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -63,7 +63,8 @@ class XattnArgs(C.Structure):
 class ArState(C.Structure):
     _fields_ = [("x_cur", _p), ("cond", _p), ("emb", _p), ("hist", _p), ("step", _p), ("arrive", _p),
                 ("first_eos", _p), ("stop_t", _p), ("n_stopped", _p), ("recent", _p), ("params", _p), ("seed", C.c_uint64),
-                ("B", _i32), ("D", _i32), ("Tar", _i32), ("max_steps", _i32), ("V", _i32), ("bos_row", _i32)]
+                ("B", _i32), ("D", _i32), ("Tar", _i32), ("max_steps", _i32), ("V", _i32), ("bos_row", _i32),
+                ("start", _p), ("row_max", _p), ("row_params", _p)]
 
 
 # every symbol declared in include/sopro_hip.h: name -> (restype, argtypes)
@@ -107,6 +108,7 @@ SYMBOLS = {
     "sopro_seanet_tail_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _f32, _p, _i64, _i32, _i32, _p]),
     "sopro_ar_init": (C.c_int, [C.POINTER(ArState), _p]),
     "sopro_ar_sample": (C.c_int, [C.POINTER(ArState), _p, _i64, _p]),
+    "sopro_ar_admit": (C.c_int, [C.POINTER(ArState), _i32, _p]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -481,6 +483,10 @@ def seanet_tail(h: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.T
 
 def ar_init(st: ArState) -> None:
     _check(load().sopro_ar_init(C.byref(st), _stream()), "sopro_ar_init")
+
+
+def ar_admit(st: ArState, row: int) -> None:
+    _check(load().sopro_ar_admit(C.byref(st), int(row), _stream()), "sopro_ar_admit")
 
 
 def ar_sample(st: ArState, logits: torch.Tensor, ld: int) -> None:

@@ -551,7 +551,7 @@ class _ARPlan:
     """Static buffers + the recorded per-frame launch sequence for (B rows, S_cap keys, Tar frames).
     reference step: src/sopro/nn/generator.py:98-130."""
 
-    def __init__(self, m: SoproTTSModel, B: int, S_cap: int, Tar: int):
+    def __init__(self, m: SoproTTSModel, B: int, S_cap: int, Tar: int, slots: bool = False):
         cfg, dev, D = m.cfg, m.device, m.D
         self.m, self.B, self.S_cap, self.Tar = m, B, S_cap, Tar
         self.max_steps = Tar
@@ -591,6 +591,11 @@ class _ARPlan:
         st.recent = self.recent.data_ptr()
         st.seed = m.seed
         st.B, st.D, st.Tar, st.max_steps, st.V, st.bos_row = B, D, Tar, self.max_steps, m.V, int(cfg.bos_row)
+        if slots:  # continuous batching: rows are admitted / released one by one (sopro_amd/continuous.py)
+            self.start = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            self.row_max = z(B, dt=torch.int32)
+            self.row_params = z(B, 8)
+            st.start, st.row_max, st.row_params = self.start.data_ptr(), self.row_max.data_ptr(), self.row_params.data_ptr()
         self.state = st
         self.step_t = self.ctr[0:1]
         self.graph: Optional[hip.Graph] = None
@@ -639,6 +644,31 @@ class _ARPlan:
         # the sampler writes the next frame's input into state.x_cur, which must be where block 0 reads
         hip.ar_sample(self.state, self.logits, m.V + 1)
         self.nlaunch = nl + 2
+
+    def load_row(self, row: int, cond_row: torch.Tensor, txt_row: torch.Tensor) -> None:
+        """Slot mode: install one utterance in row ``row`` (launches only, on the current stream): its conditioning rows
+        [T_r, D], the folded cross-attention operands of its text [S, D] (src/sopro/nn/text.py:75-83), zeroed ring columns."""
+        m, cfg, w, D = self.m, self.m.cfg, self.m.w, self.m.D
+        Tr, S = int(cond_row.shape[0]), int(txt_row.shape[0])
+        if Tr > self.Tar or S > self.S_cap:
+            raise ValueError(f"utterance needs {Tr} frames / {S} text positions, the plan holds {self.Tar} / {self.S_cap}")
+        self.cond[row, :Tr].copy_(cond_row)
+        self.klens[row:row + 1].fill_(S)
+        nkv = m.ws.get("ar.row.nkv", (S, D))
+        kvd = m.ws.get("ar.row.kvd", (S, 2 * D))
+        ts = txt_row.contiguous()
+        H, dh = 4, D // 4
+        for i in cfg.ar_xattn_layers:
+            pa = f"ar.x_attns.{i}"
+            hip.norm(ts, nkv, w[pa + ".nkv.weight"], rows=S, C_=D, eps=RMS_EPS)
+            hip.gemm(nkv, w[pa + ".kv.w"], kvd, M=S, N=2 * D, K=D)
+            seg = dict(M=S, N=D, K=dh, lda=2 * D, ldc=D)
+            for h in range(H):
+                off = (row * H + h) * self.S_cap * D
+                hip.gemm(kvd, w[pa + ".q.wT"][h], self.kp[i], a_off=h * dh, c_off=off, **seg)
+                hip.gemm(kvd, w[pa + ".o.w"][:, h * dh:], self.vp[i], a_off=D + h * dh, c_off=off, ldw=D, **seg)
+        for r in self.rings:
+            r[:, row].zero_()
 
     def ensure_graph(self) -> None:
         if self.graph is not None or not self.m.use_graph:
