@@ -670,10 +670,10 @@ class _ARPlan:
         for r in self.rings:
             r[:, row].zero_()
 
-    def ensure_graph(self) -> None:
+    def ensure_graph(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         if self.graph is not None or not self.m.use_graph:
             return
-        s = self.m.stream
+        s = stream if stream is not None else self.m.stream
         with torch.cuda.stream(s):
             hip.capture_begin()
             try:

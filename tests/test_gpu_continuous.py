@@ -45,5 +45,18 @@ def test_continuous_admission_matches_single_runs(cfg, sopro_np, mimi_np):
     again = eng.run(reqs[:5])
     for g, w in zip(again, want_wav[:5]):
         assert g.shape == w.shape and (w.numel() == 0 or float((g - w).abs().max()) <= 1e-4 * float(w.abs().max()))
-    # slot occupancy: the engine kept its slots busier than a static batch of the same requests would have
     assert eng.stats["slot_frames_used"] <= eng.stats["frames"] * 4
+    eng.close()
+    # the same with the chip partitioned (generation on 64 CUs, preparation / refinement / decoding on the rest)
+    eng2 = ContinuousSynthesizer(tts, slots=3, max_frames=40, max_text=64, poll_every=8, bulk_batch=4, prep_batch=3, ar_cus=64,
+                                 generators=2)
+    try:
+        got2 = eng2.run(reqs)
+    finally:
+        eng2.close()
+    for i, (g, w) in enumerate(zip(got2, want_wav)):
+        assert g.shape == w.shape and (w.numel() == 0 or float((g - w).abs().max()) <= 1e-4 * float(w.abs().max())), i
+    # the engine is whole again
+    t3 = tts.model.generate_tokens(reqs[0]["text_ids"], reqs[0]["ref"], style_strength=float(cfg.style_strength),
+                                   **{k: v for k, v in reqs[0].items() if k not in ("text_ids", "ref")})
+    assert torch.equal(t3, want_tok[0])
