@@ -20,6 +20,7 @@ from __future__ import annotations
 import queue
 import threading
 from collections import deque
+from concurrent.futures import Future
 from typing import Any, Dict, List, Optional, Sequence
 
 import torch
@@ -69,9 +70,22 @@ class ContinuousSynthesizer:
             self.gens.append({"plan": plan, "stream": st})
         self.plan = self.gens[0]["plan"]
         self.stats = {"frames": 0, "slot_frames_used": 0, "utterances": 0, "bulk_batches": 0, "prep_batches": 0}
+        self._sh: Optional[Dict[str, Any]] = None
+        self._threads: List[threading.Thread] = []
+        self._closed = False
 
     def close(self) -> None:
         m = self.model
+        if self._closed:
+            return
+        self._closed = True
+        if self._sh is not None:
+            self._sh["stop"] = True
+            for t in self._threads[1:]:
+                t.join()
+            self._sh["jobs"].put(None)
+            self._threads[0].join()
+            self._sh, self._threads = None, []
         torch.cuda.synchronize(m.device)
         for g in self.gens:
             g["plan"].graph = None
@@ -136,59 +150,71 @@ class ContinuousSynthesizer:
             plan.row_params[row].copy_(it["prm"], non_blocking=True)
             hip.ar_admit(plan.state, row)
 
-    # ------------------------------------------------------------------ the driver loop
-    @torch.inference_mode()
-    def run(self, requests: Sequence[Dict[str, Any]]) -> List[torch.Tensor]:
-        """Each request: dict(text_ids | text, ref, max_frames=…, top_p=…, temperature=…, anti_loop=…, style_strength=…,
-        min_gen_frames=…).  Returns the waveforms [1, 1, N] in request order."""
-        m, plan, cfg = self.model, self.plan, self.model.cfg
-        waiting: deque = deque()
-        for idx, rq in enumerate(requests):
-            ids = rq["text_ids"] if rq.get("text_ids") is not None else self.tts.encode_text(rq["text"])
-            if int(ids.numel()) > self.S_cap:
-                raise ValueError(f"text of {int(ids.numel())} positions exceeds max_text={self.S_cap}")
-            mf = min(int(rq.get("max_frames", self.max_frames)), self.max_frames)
-            ss = float(rq["style_strength"] if rq.get("style_strength") is not None else cfg.style_strength)
-            min_gen = int(rq["min_gen_frames"] if rq.get("min_gen_frames") is not None else cfg.min_gen_frames)
-            prm = torch.tensor([float(rq.get("top_p", 0.9)), float(rq.get("temperature", 1.05)), 1.0 if rq.get("anti_loop", True) else 0.0,
-                                0.85, 1.2, 1.1, 50.0, float(min_gen)], dtype=torch.float32).pin_memory()
-            waiting.append({"idx": idx, "ids": ids, "ref": rq["ref"], "mf": mf, "ss": ss, "prm": prm})
-        sh = {"waiting": waiting, "ready": deque(), "finished": [], "lock": threading.Lock(), "prep_lock": threading.Lock(),
-              "results": [None] * len(requests), "jobs": queue.Queue(), "errors": [], "live": len(self.gens)}
+    # ------------------------------------------------------------------ serving interface
+    def start(self) -> None:
+        """Spawn the generator threads and the refinement / decoding worker; they run until ``close``."""
+        if self._closed:
+            raise RuntimeError("engine is closed")
+        if self._sh is not None:
+            return
+        self._sh = sh = {"waiting": deque(), "ready": deque(), "finished": [], "lock": threading.Lock(), "prep_lock": threading.Lock(),
+                         "jobs": queue.Queue(), "errors": [], "stop": False}
 
         def bulk_worker():
-            with torch.cuda.stream(self.bulk_tts.model.bulk_stream):
+            with torch.inference_mode(), torch.cuda.stream(self.bulk_tts.model.bulk_stream):
                 while True:
                     batch = sh["jobs"].get()
                     if batch is None:
                         return
                     try:
                         for a, wav in zip(batch, self._bulk(batch)):
-                            sh["results"][a["idx"]] = wav
+                            a["future"].set_result(wav)
                     except BaseException as e:  # noqa: BLE001
                         sh["errors"].append(e)
-                        return
+                        for a in batch:
+                            if not a["future"].done():
+                                a["future"].set_exception(e)
 
-        worker = threading.Thread(target=bulk_worker, name="sopro-bulk")
-        worker.start()
-        try:
-            self._prepare_some(sh, self.slots * len(self.gens))  # the initial fill in one batch
-            threads = [threading.Thread(target=self._drive, args=(g, sh), name=f"sopro-gen{i}") for i, g in enumerate(self.gens)]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-            with sh["lock"]:
-                fin, sh["finished"] = sh["finished"], []
-            for s0 in range(0, len(fin), self.bulk_batch):
-                sh["jobs"].put(fin[s0:s0 + self.bulk_batch])
-        finally:
-            sh["jobs"].put(None)
-            worker.join()
-        if sh["errors"]:
-            raise sh["errors"][0]
+        self._threads = [threading.Thread(target=bulk_worker, name="sopro-bulk", daemon=True)]
+        self._threads += [threading.Thread(target=self._drive, args=(g, sh), name=f"sopro-gen{i}", daemon=True) for i, g in enumerate(self.gens)]
+        for t in self._threads:
+            t.start()
+
+    def _item(self, rq: Dict[str, Any]) -> Dict[str, Any]:
+        cfg = self.model.cfg
+        ids = rq["text_ids"] if rq.get("text_ids") is not None else self.tts.encode_text(rq["text"])
+        if int(ids.numel()) == 0 or int(ids.numel()) > self.S_cap:
+            raise ValueError(f"text of {int(ids.numel())} positions (this engine takes 1..{self.S_cap})")
+        mf = min(int(rq.get("max_frames", self.max_frames)), self.max_frames)
+        ss = float(rq["style_strength"] if rq.get("style_strength") is not None else cfg.style_strength)
+        min_gen = int(rq["min_gen_frames"] if rq.get("min_gen_frames") is not None else cfg.min_gen_frames)
+        prm = torch.tensor([float(rq.get("top_p", 0.9)), float(rq.get("temperature", 1.05)), 1.0 if rq.get("anti_loop", True) else 0.0,
+                            0.85, 1.2, 1.1, 50.0, float(min_gen)], dtype=torch.float32).pin_memory()
+        return {"ids": ids, "ref": rq["ref"], "mf": mf, "ss": ss, "prm": prm, "future": Future()}
+
+    def submit(self, **rq) -> "Future[torch.Tensor]":
+        """Queue one utterance: text_ids | text, ref, max_frames, top_p, temperature, anti_loop, style_strength,
+        min_gen_frames.  The future resolves to the waveform [1, 1, N] on the device."""
+        self.start()
+        if self._sh["stop"]:
+            raise RuntimeError("engine is closed")
+        it = self._item(rq)
+        with self._sh["lock"]:
+            self._sh["waiting"].append(it)
+        return it["future"]
+
+    @torch.inference_mode()
+    def run(self, requests: Sequence[Dict[str, Any]]) -> List[torch.Tensor]:
+        """All requests at once (each the keyword dict of ``submit``); waveforms come back in request order."""
+        self.start()
+        sh = self._sh
+        items = [self._item(rq) for rq in requests]
+        with sh["lock"]:
+            sh["waiting"].extend(items)
+        self._prepare_some(sh, self.slots * len(self.gens))  # the initial fill in one batch
+        out = [it["future"].result() for it in items]
         self.stats["utterances"] += len(requests)
-        return sh["results"]  # type: ignore[return-value]
+        return out
 
     def _prepare_some(self, sh: Dict[str, Any], limit: int) -> None:
         """Move up to ``limit`` waiting requests (one style strength per group) to the ready list; one thread at a time."""
@@ -217,8 +243,8 @@ class ContinuousSynthesizer:
         active: Dict[int, Dict[str, Any]] = {}
         gen["have_prev"], chunk = False, 0
         try:
-            with torch.cuda.stream(st):
-                while not sh["errors"]:
+            with torch.inference_mode(), torch.cuda.stream(st):
+                while True:
                     with sh["lock"]:
                         take = [sh["ready"].popleft() for _ in range(min(len(free), len(sh["ready"])))]
                     for it in take:
@@ -229,10 +255,14 @@ class ContinuousSynthesizer:
                     if not active:
                         with sh["lock"]:
                             idle = not sh["waiting"] and not sh["ready"]
-                        if idle:
+                            if idle and sh["finished"]:  # nobody will fill that batch soon: send what there is
+                                sh["jobs"].put(sh["finished"])
+                                sh["finished"] = []
+                        if idle and sh["stop"]:
                             return
-                        self._prepare_some(sh, self.prep_batch)  # nothing to step: help with (or wait for) the preparation
-                        time.sleep(0.0002)
+                        if not idle:
+                            self._prepare_some(sh, self.prep_batch)  # nothing to step: help with (or wait for) the preparation
+                        time.sleep(0.0002 if not idle else 0.001)
                         continue
                     # ---- a chunk of frames for every slot, then a snapshot of the slot states behind it.  The host looks at
                     # the snapshot of the PREVIOUS chunk (the GPU never waits for the round trip) and prepares the next
@@ -288,6 +318,11 @@ class ContinuousSynthesizer:
                                 sh["finished"] = sh["finished"][self.bulk_batch:]
         except BaseException as e:  # noqa: BLE001
             sh["errors"].append(e)
+            with sh["lock"]:
+                pend = list(active.values()) + list(sh["ready"]) + list(sh["waiting"]) + list(sh["finished"])
+            for it in pend:
+                if not it["future"].done():
+                    it["future"].set_exception(e)
 
     def _bulk(self, batch: List[Dict[str, Any]]) -> List[torch.Tensor]:
         bt = self.bulk_tts

@@ -46,7 +46,15 @@ def test_continuous_admission_matches_single_runs(cfg, sopro_np, mimi_np):
     for g, w in zip(again, want_wav[:5]):
         assert g.shape == w.shape and (w.numel() == 0 or float((g - w).abs().max()) <= 1e-4 * float(w.abs().max()))
     assert eng.stats["slot_frames_used"] <= eng.stats["frames"] * 4
+    # single requests while the engine keeps running
+    f1 = eng.submit(**reqs[7])
+    f2 = eng.submit(**reqs[2])
+    for f, i in ((f1, 7), (f2, 2)):
+        g = f.result(timeout=60)
+        assert g.shape == want_wav[i].shape and (want_wav[i].numel() == 0 or float((g - want_wav[i]).abs().max()) <= 1e-4 * float(want_wav[i].abs().max()))
     eng.close()
+    with pytest.raises(RuntimeError):
+        eng.submit(**reqs[0])
     # the same with the chip partitioned (generation on 64 CUs, preparation / refinement / decoding on the rest)
     eng2 = ContinuousSynthesizer(tts, slots=3, max_frames=40, max_text=64, poll_every=8, bulk_batch=4, prep_batch=3, ar_cus=64,
                                  generators=2)
