@@ -12,7 +12,7 @@ tts, cfg, mc, wn, mn = bench.build_engine("cuda:0")
 ids, ref_tq = bench.make_inputs(0)
 ref = tts.prepare_reference(ref_tokens_tq=ref_tq)
 rng = np.random.default_rng(5)
-N = 128
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 budgets = rng.integers(80, 401, size=N)
 reqs = [dict(text_ids=ids[i % 32], ref=ref, max_frames=int(b) - 1, top_p=0.9, temperature=1.05, anti_loop=True) for i, b in enumerate(budgets)]
 audio_s = float(budgets.sum()) * 0.08
@@ -51,11 +51,11 @@ def static_pipelined():
 
 
 dt = static_pipelined()
-print(f"{'static batches, 4-lane pipeline':34s}: {dt * 1e3:8.1f} ms for {audio_s:.0f} audio-s -> {audio_s / dt:8.1f} audio-s/s")
-eng = ContinuousSynthesizer(tts, slots=32, max_frames=400, max_text=64, poll_every=16, bulk_batch=32)
-eng64 = ContinuousSynthesizer(tts, slots=32, max_frames=400, max_text=64, poll_every=16, bulk_batch=32, ar_cus=64, generators=2)
-for name, fn in (("static batches of 32", static), ("frame-level admission, 32 slots", lambda: eng.run(reqs)),
-                 ("admission, 2 x 32 slots on a 64-CU partition", lambda: eng64.run(reqs))):
+print(f"{'static batches, 4-lane pipeline':46s}: {dt * 1e3:8.1f} ms for {audio_s:.0f} audio-s -> {audio_s / dt:8.1f} audio-s/s", flush=True)
+POLL = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+
+
+def timed(name, fn):
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -63,5 +63,15 @@ for name, fn in (("static batches of 32", static), ("frame-level admission, 32 s
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert all(o.shape[-1] == (r["max_frames"] + 1) * 1920 for o, r in zip(out, reqs))
-    print(f"{name:34s}: {dt * 1e3:8.1f} ms for {audio_s:.0f} audio-s -> {audio_s / dt:8.1f} audio-s/s")
-print("engine stats", eng.stats, eng64.stats)
+    print(f"{name:46s}: {dt * 1e3:8.1f} ms for {audio_s:.0f} audio-s -> {audio_s / dt:8.1f} audio-s/s", flush=True)
+
+
+timed("static batches of 32, one engine", static)
+for name, kw in (("frame-level admission, 32 slots, one engine", dict(slots=32)),
+                 ("admission, 2 x 32 slots on a 64-CU partition", dict(slots=32, ar_cus=64, generators=2))):
+    eng = ContinuousSynthesizer(tts, max_frames=400, max_text=64, poll_every=POLL, bulk_batch=32, **kw)
+    try:
+        timed(name, lambda: eng.run(reqs))
+        print("   stats", eng.stats, flush=True)
+    finally:
+        eng.close()
