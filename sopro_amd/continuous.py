@@ -37,6 +37,10 @@ class ContinuousSynthesizer:
         self.bulk_batch, self.prep_batch = int(bulk_batch), int(prep_batch)
         self.max_frames = int(max_frames)
         m = self.model
+        if getattr(m, "_driver", None) is not None:
+            raise RuntimeError("this engine is already driven by a " + type(m._driver).__name__ + " (close it first): "
+                               "the schedulers re-point the engine's streams at CU partitions")
+        m._driver = self
         self.S_cap = ((int(max_text) + 63) // 64) * 64
         self._own_streams: List[torch.cuda.Stream] = []
         self._saved = (m.stream, m.bulk_stream, m.prep_stream, tts.codec.stream)
@@ -94,6 +98,7 @@ class ContinuousSynthesizer:
         self.bulk_tts.model._nar_graphs.clear()
         self.bulk_tts.codec._graphs.clear()
         m.stream, m.bulk_stream, m.prep_stream, self.tts.codec.stream = self._saved
+        m._driver = None
         for s in self._own_streams:
             hip.destroy_stream(s)
         self._own_streams = []

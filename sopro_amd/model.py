@@ -103,6 +103,7 @@ class SoproTTSModel:
         self.stream = torch.cuda.Stream(device=self.device)
         self.bulk_stream = self.stream  # throughput-bound phase (NAR); a pipeline may point it at another CU partition
         self.prep_stream = self.stream
+        self._driver = None  # the scheduler (PipelinedSynthesizer / ContinuousSynthesizer) that currently owns the streams
         self._ar_cache: Dict[Tuple[int, int, int], "_ARPlan"] = {}
         self._nar_graphs = hip.GraphCache("nar_graph", cap=64)  # recorded NAR launch sequences per (B, T)
         self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "16")) << 30  # scratch kept per batch shape, per engine
@@ -140,6 +141,7 @@ class SoproTTSModel:
         other.stream = torch.cuda.Stream(device=self.device)
         other.bulk_stream = other.stream
         other.prep_stream = other.stream
+        other._driver = None
         other._ar_cache = {}
         other._nar_graphs = hip.GraphCache("nar_graph", cap=64)
         return other

@@ -27,6 +27,9 @@ class PipelinedSynthesizer:
         Lane i generates on partition i % ar_parts.  With ``ar_shared`` the partitions are ONE CU range of ``ar_cus`` CUs
         that ``ar_parts`` AR phases use at the same time (their short kernels interleave on the same CUs)."""
         self.device = tts.device
+        if getattr(tts.model, "_driver", None) is not None:
+            raise RuntimeError("this engine is already driven by a " + type(tts.model._driver).__name__ + " (close it first): "
+                               "the schedulers re-point the engine's streams at CU partitions")
         total = hip.device_info(self.device.index or 0)["cus"]
         ar_parts = max(1, int(ar_parts))
         n_ar = ar_cus if ar_shared else ar_cus * ar_parts
@@ -53,6 +56,7 @@ class PipelinedSynthesizer:
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
         self.bulk_lock = threading.Lock()
         self.ar_cus, self.ar_parts, self.bulk_cus = ar_cus, ar_parts, total - bulk0
+        tts.model._driver = self
 
     def close(self) -> None:
         """Drop the extra lanes, destroy the CU-masked streams (and the graphs recorded on them) and give lane 0
@@ -67,6 +71,7 @@ class PipelinedSynthesizer:
             lane.model.ws.clear()
             lane.codec.ws.clear()
         lane0 = self.lanes[0]
+        lane0.model._driver = None
         lane0.model.stream, lane0.model.bulk_stream, lane0.codec.stream, lane0.model.prep_stream = self._saved
         self.lanes = []
         torch.cuda.synchronize(self.device)
