@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 12
+#define SOPRO_ABI_VERSION 13
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -45,6 +45,11 @@ int sopro_graph_launch(void* graph_exec, void* stream);
 int sopro_graph_destroy(void* graph_exec);
 /* stream restricted to CUs [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask); destroy with sopro_stream_destroy */
 int sopro_stream_create_cu_range(int first_cu, int n_cus, void** stream_out);
+/* General form: one bit per CU (bit i of word i/32).  Measured on gfx950 (tools/micro/xcc_probe.hip): a mask with a single
+ * bit set still runs workgroups on all eight XCDs, i.e. the bits are dealt to the XCDs and an XCD whose bits are all clear is
+ * left unrestricted; a partition therefore has to keep some CUs on every XCD (contiguous ranges do: 1/8 of the range per
+ * XCD), and whole-XCD partitions cannot be expressed. */
+int sopro_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream_out);
 int sopro_stream_destroy(void* stream);
 
 /* ---- dense contraction ------------------------------------------------------------------ */

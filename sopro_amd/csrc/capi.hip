@@ -80,6 +80,20 @@ int sopro_stream_create_cu_range(int first_cu, int n_cus, void** stream_out) {
   return 0;
 }
 
+/* The general form: `mask` holds one bit per CU (bit i of word i/32), `words` 32-bit words. */
+int sopro_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out) {
+  SOPRO_CHECK_ARG(mask != nullptr && stream_out != nullptr && words > 0 && words <= 16, "bad CU mask");
+  uint32_t m[16];
+  memset(m, 0, sizeof(m));
+  bool any = false;
+  for (int i = 0; i < words; ++i) { m[i] = mask[i]; any = any || mask[i] != 0; }
+  SOPRO_CHECK_ARG(any, "empty CU mask");
+  hipStream_t s = nullptr;
+  SOPRO_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, m));
+  *stream_out = (void*)s;
+  return 0;
+}
+
 int sopro_stream_destroy(void* stream) {
   if (stream) SOPRO_HIP(hipStreamDestroy((hipStream_t)stream));
   return 0;

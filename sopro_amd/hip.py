@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -77,6 +77,7 @@ SYMBOLS = {
     "sopro_graph_launch": (C.c_int, [_p, _p]),
     "sopro_graph_destroy": (C.c_int, [_p]),
     "sopro_stream_create_cu_range": (C.c_int, [C.c_int, C.c_int, C.POINTER(_p)]),
+    "sopro_stream_create_cu_mask": (C.c_int, [_p, _i32, _p]),
     "sopro_stream_destroy": (C.c_int, [_p]),
     "sopro_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "sopro_gemm_bf16x3": (C.c_int, [_p, _p, _p, _p]),
@@ -574,6 +575,20 @@ def cu_range_stream(first_cu: int, n_cus: int, device: Optional[torch.device] = 
     out = _p()
     with torch.cuda.device(device if device is not None else torch.cuda.current_device()):  # the C side creates it on the current device
         _check(load().sopro_stream_create_cu_range(first_cu, n_cus, C.byref(out)), "sopro_stream_create_cu_range")
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
+def cu_mask_stream(cus, device: Optional[torch.device] = None) -> "torch.cuda.Stream":
+    """A torch-visible stream confined to the CUs whose mask bits are in ``cus`` (see sopro_stream_create_cu_mask for what
+    the bits mean on gfx950).  Hand it back with ``destroy_stream``."""
+    cus = sorted(set(int(c) for c in cus))
+    words = (max(cus) >> 5) + 1
+    arr = (C.c_uint32 * words)()
+    for c in cus:
+        arr[c >> 5] |= 1 << (c & 31)
+    out = _p()
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        _check(load().sopro_stream_create_cu_mask(arr, words, C.byref(out)), "sopro_stream_create_cu_mask")
     return torch.cuda.ExternalStream(out.value, device=device)
 
 
