@@ -193,7 +193,7 @@ def main() -> None:
     run_steps(args.steps, phases)
     fence()
     dt = time.perf_counter() - t0
-    log(f"timed region done: {dt:.3f} s for {args.steps} steps")
+    log(f"timed region done: {dt:.3f} s for {args.steps} steps; peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
