@@ -33,17 +33,32 @@ class _Request:
 
 class SynthesisService:
     def __init__(self, tts, *, max_batch: int = 32, max_wait_ms: float = 4.0, lanes: int = 4, ar_cus: int = 64, ar_parts: int = 2,
-                 ar_shared: bool = True):
+                 ar_shared: bool = True, mode: str = "batch", **continuous_kw):
+        """``mode="batch"``: requests with equal parameters are grouped into batches for the lanes of a PipelinedSynthesizer.
+        ``mode="continuous"``: frame-level admission (``ContinuousSynthesizer``; extra keywords go to it): parameters, frame
+        budgets and end-of-speech times may all differ between neighbouring slots."""
         from .pipeline import PipelinedSynthesizer
 
         self.tts = tts
+        self._closed = False
+        self.stats = {"requests": 0, "batches": 0, "rows": 0}
+        self.engine = None
+        if mode == "continuous":
+            from .continuous import ContinuousSynthesizer
+
+            kw = dict(slots=max_batch, ar_cus=ar_cus, generators=max(1, ar_parts))
+            kw.update(continuous_kw)
+            self.engine = ContinuousSynthesizer(tts, **kw)
+            self.engine.start()
+            self.pipe, self._threads = None, []
+            return
+        if mode != "batch":
+            raise ValueError("mode must be 'batch' or 'continuous'")
         self.max_batch, self.max_wait = int(max_batch), float(max_wait_ms) * 1e-3
         self.pipe = PipelinedSynthesizer(tts, lanes=lanes, ar_cus=ar_cus, ar_parts=ar_parts, ar_shared=ar_shared) if lanes > 1 else None
         self._lanes = self.pipe.lanes if self.pipe is not None else [tts]
         self._inbox: "queue.Queue[Optional[_Request]]" = queue.Queue()
         self._batches: "queue.Queue[Optional[List[_Request]]]" = queue.Queue(maxsize=2 * len(self._lanes))
-        self._closed = False
-        self.stats = {"requests": 0, "batches": 0, "rows": 0}
         self._threads = [threading.Thread(target=self._schedule, name="sopro-sched", daemon=True)]
         for i, lane in enumerate(self._lanes):
             self._threads.append(threading.Thread(target=self._work, args=(lane, i), name=f"sopro-lane{i}", daemon=True))
@@ -57,6 +72,10 @@ class SynthesisService:
         """Queue one utterance; the future resolves to the waveform ``[1, 1, N]`` on the device (``synthesize``'s result)."""
         if self._closed:
             raise RuntimeError("service is closed")
+        if self.engine is not None:
+            self.stats["requests"] += 1
+            return self.engine.submit(text=text, text_ids=text_ids, ref=ref, max_frames=max_frames, top_p=top_p, temperature=temperature,
+                                      anti_loop=anti_loop, style_strength=style_strength, min_gen_frames=min_gen_frames)
         ids = text_ids if text_ids is not None else self.tts.encode_text(text)
         if int(ids.numel()) == 0:
             raise ValueError("empty text")
@@ -73,6 +92,9 @@ class SynthesisService:
         if self._closed:
             return
         self._closed = True
+        if self.engine is not None:
+            self.engine.close()
+            return
         self._inbox.put(None)
         for t in self._threads:
             t.join()

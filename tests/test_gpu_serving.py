@@ -51,3 +51,24 @@ def test_service_batches_concurrent_requests_and_matches_single_calls(tts):
     assert sr == 24000 and pcm.shape[0] == got[0].shape[-1]
     with pytest.raises(RuntimeError):
         svc.submit("", refs[0], text_ids=reqs[0][0])
+
+
+def test_service_continuous_mode_mixed_parameters(tts):
+    """mode="continuous": every request may carry its own parameters and frame budget."""
+    from sopro_amd.serving import SynthesisService
+
+    rng = np.random.default_rng(33)
+    ref = tts.prepare_reference(ref_tokens_tq=torch.from_numpy(rng.integers(0, 2048, size=(30, 32))))
+    reqs = []
+    for i in range(7):
+        ids = torch.from_numpy(rng.integers(1, 500, size=int(rng.integers(5, 30))))
+        reqs.append((ids, dict(max_frames=8 + 3 * i, top_p=0.0, temperature=0.7 + 0.1 * i, anti_loop=False)))
+    want = [tts.codec.decode_full(tts.model.generate_tokens(ids, ref, style_strength=float(tts.cfg.style_strength), **kw)) for ids, kw in reqs]
+    svc = SynthesisService(tts, mode="continuous", max_batch=3, ar_parts=1, ar_cus=64, max_frames=40, max_text=64, poll_every=8, bulk_batch=2)
+    try:
+        futs = [svc.submit("", ref, text_ids=ids, **kw) for ids, kw in reqs]
+        got = [f.result(timeout=120) for f in futs]
+    finally:
+        svc.close()
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and float((g - w).abs().max()) <= 1e-4 * float(w.abs().max())
