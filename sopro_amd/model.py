@@ -107,14 +107,14 @@ class SoproTTSModel:
         self._ar_cache: Dict[Tuple[int, int, int], "_ARPlan"] = {}
         self._nar_graphs = hip.GraphCache("nar_graph", cap=64)  # recorded NAR launch sequences per (B, T)
         self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "16")) << 30  # scratch kept per batch shape, per engine
-        # NAR contractions on the six-pass split-bf16 matrix-core path (24 mantissa bits per operand: the accuracy class of
-        # the fp32 MFMA kernel at ~1.5x its speed on these shapes); SOPRO_NAR_F32=1 keeps the fp32 kernel.
+        # NAR and text / reference encoder contractions on the six-pass split-bf16 matrix-core path (24 mantissa bits per
+        # operand: the accuracy class of the fp32 MFMA kernel at ~1.5x its speed on these shapes); SOPRO_NAR_F32=1 keeps fp32.
         self.wx: Dict[str, hip.PackedW] = {}
         if os.environ.get("SOPRO_NAR_F32", "0") != "1":
             with torch.cuda.device(self.device):
                 for k, v in self.w.items():
-                    if k.startswith("nar.") and v.dim() == 2 and k.endswith(".w") and int(v.shape[1]) % 32 == 0 and int(v.shape[0]) >= 64 \
-                            and not k.startswith("nar.adapter"):
+                    if k.startswith(("nar.", "text_enc.layers.", "ref_enc_blocks.")) and v.dim() == 2 and k.endswith(".w") \
+                            and int(v.shape[1]) % 32 == 0 and int(v.shape[0]) >= 64 and not k.startswith("nar.adapter"):
                         self.wx[k] = hip.pack_w_bf16x6(v)
                 torch.cuda.synchronize(self.device)
         self._ones: Dict[int, torch.Tensor] = {}
