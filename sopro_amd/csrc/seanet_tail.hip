@@ -12,7 +12,8 @@
 // bf16 + 16 B pad = 272 B, so the k=3 window of a sample is three consecutive rows and 16-lane ds_read_b128 fragment
 // reads are conflict free), the small weight matrices are split once per lane into register B fragments, the 32-channel
 // intermediate goes through LDS in the same split form, and ELU(h') is stored once (fp32, over the dead h tile) for the
-// last 64 -> 1 convolution, which reads every row three times.  2 workgroups per CU (54 KB of LDS each).
+// last 64 -> 1 convolution, which reads every row three times.  The skip operand (an L2-resident re-read of h in the
+// accumulator layout) and the last layer's weights are requested in the tile's memory round.  2 workgroups per CU (55 KB LDS).
 #include "common.h"
 
 namespace {
@@ -72,6 +73,20 @@ __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restric
     for (int s = 0; s < 2; ++s) split8(w2 + (j * 32 + frow) * 32 + s * 16 + fg * 8, w2h[j][s], w2l[j][s]);
   const float b1v = b1[frow];
   const float b2v[2] = {b2[frow], b2[32 + frow]};
+  // skip operand of the residual block in the accumulator layout of the second convolution (row mr, column frow / 32+frow),
+  // and the last layer's weights: requested in the same memory round as the tile, consumed two phases later
+  float skip[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+    const int p = s0 + mr;  // padded row of sample s0-2+mr
+    const bool in = p >= 2 && p < T + 2;
+    const float* hp = hb + (int64_t)(in ? p : 2) * 64 + frow;
+    skip[0][r] = in ? hp[0] : 0.f;
+    skip[1][r] = in ? hp[32] : 0.f;
+  }
+  __shared__ __attribute__((aligned(16))) float wfs[192];
+  if (tid < 48) *reinterpret_cast<float4*>(wfs + tid * 4) = *reinterpret_cast<const float4*>(wf + tid * 4);
 
   // ELU + split once per element
 #pragma unroll
@@ -134,16 +149,6 @@ __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restric
       }
     }
     float* hs = reinterpret_cast<float*>(es);
-    float skip[2][16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
-      const int p = s0 + mr;  // padded row of sample s0-2+mr
-      const bool in = p >= 2 && p < T + 2;
-      const float* hp = hb + (int64_t)(in ? p : 2) * 64 + frow;
-      skip[0][r] = in ? hp[0] : 0.f;
-      skip[1][r] = in ? hp[32] : 0.f;
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restric
 #pragma unroll
         for (int c4 = 0; c4 < 8; ++c4) {
           const float4 x = *reinterpret_cast<const float4*>(hs + (i + 2 + j) * HLD + half * 32 + c4 * 4);
-          const float4 wv = *reinterpret_cast<const float4*>(wf + j * 64 + half * 32 + c4 * 4);
+          const float4 wv = *reinterpret_cast<const float4*>(wfs + j * 64 + half * 32 + c4 * 4);
           s += x.x * wv.x + x.y * wv.y + x.z * wv.z + x.w * wv.w;
         }
       }
