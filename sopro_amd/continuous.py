@@ -17,6 +17,7 @@ slot's arithmetic never depends on its neighbours.
 """
 from __future__ import annotations
 
+import atexit
 import queue
 import threading
 from collections import deque
@@ -83,6 +84,7 @@ class ContinuousSynthesizer:
         if self._closed:
             return
         self._closed = True
+        atexit.unregister(self.close)
         if self._sh is not None:
             self._sh["stop"] = True
             for t in self._threads[1:]:
@@ -184,6 +186,14 @@ class ContinuousSynthesizer:
         self._threads += [threading.Thread(target=self._drive, args=(g, sh), name=f"sopro-gen{i}", daemon=True) for i, g in enumerate(self.gens)]
         for t in self._threads:
             t.start()
+        atexit.register(self.close)  # worker threads must not be inside the HIP runtime when the interpreter tears it down
+
+    def __enter__(self):
+        self.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def _item(self, rq: Dict[str, Any]) -> Dict[str, Any]:
         cfg = self.model.cfg
@@ -232,8 +242,13 @@ class ContinuousSynthesizer:
                 while w and len(group) < limit and w[0]["ss"] == (group[0]["ss"] if group else w[0]["ss"]):
                     group.append(w.popleft())
             if group:
-                with torch.cuda.stream(self.model.prep_stream):  # not behind the frames the calling generator has queued
-                    self._prepare(group)
+                try:
+                    with torch.cuda.stream(self.model.prep_stream):  # not behind the frames the calling generator has queued
+                        self._prepare(group)
+                except BaseException as e:  # noqa: BLE001  (a bad request must not strand the others)
+                    for it in group:
+                        it["future"].set_exception(e)
+                    return
                 with sh["lock"]:
                     sh["ready"].extend(group)
         finally:

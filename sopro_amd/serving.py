@@ -10,6 +10,7 @@ voices and end-of-speech times may differ inside a batch.  Transport (HTTP, fram
 """
 from __future__ import annotations
 
+import atexit
 import queue
 import threading
 import time
@@ -64,6 +65,13 @@ class SynthesisService:
             self._threads.append(threading.Thread(target=self._work, args=(lane, i), name=f"sopro-lane{i}", daemon=True))
         for t in self._threads:
             t.start()
+        atexit.register(self.close)  # worker threads must not be inside the HIP runtime when the interpreter tears it down
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     # ------------------------------------------------------------------ client side
     def submit(self, text: str, ref: PreparedReference, *, max_frames: int = 400, top_p: float = 0.9, temperature: float = 1.05,
@@ -92,6 +100,7 @@ class SynthesisService:
         if self._closed:
             return
         self._closed = True
+        atexit.unregister(self.close)
         if self.engine is not None:
             self.engine.close()
             return
