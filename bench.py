@@ -129,6 +129,10 @@ def main() -> None:
                                       args.cpu_utts)), flush=True)
         return
 
+    if args.gpus > 1 and "RANK" not in os.environ:  # started by hand: re-launch as one rank per GPU, like the driver does
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                   "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"),
+                                   os.path.abspath(__file__), *sys.argv[1:]])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
