@@ -116,6 +116,7 @@ def main() -> None:
     ap.add_argument("--lanes", type=int, default=4, help="engines pipelined on one GPU (1 = strictly sequential batches)")
     ap.add_argument("--ar-cus", type=int, default=64, help="CUs of each AR partition (latency-bound phase) when lanes > 1")
     ap.add_argument("--ar-shared", type=int, default=1, help="1: the AR partitions are one CU range used by --ar-parts AR phases at once")
+    ap.add_argument("--bulk-slots", type=int, default=1, help="refinement / decoding phases allowed at the same time on the throughput partition")
     ap.add_argument("--ar-parts", type=int, default=2, help="independent AR partitions (concurrent AR phases) when lanes > 1")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -167,7 +168,7 @@ def main() -> None:
         from sopro_amd.pipeline import PipelinedSynthesizer
 
         try:
-            pipe = PipelinedSynthesizer(tts, lanes=args.lanes, ar_cus=args.ar_cus, ar_parts=args.ar_parts, ar_shared=bool(args.ar_shared))
+            pipe = PipelinedSynthesizer(tts, lanes=args.lanes, ar_cus=args.ar_cus, ar_parts=args.ar_parts, ar_shared=bool(args.ar_shared), bulk_slots=args.bulk_slots)
         except Exception as e:  # noqa: BLE001  (e.g. a device without CU-mask support): fall back to sequential batches
             log(f"pipelining unavailable ({e!r}); running sequential batches")
             pipe, args.lanes = None, 1

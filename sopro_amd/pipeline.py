@@ -21,7 +21,7 @@ from . import hip
 
 
 class PipelinedSynthesizer:
-    def __init__(self, tts, lanes: int = 2, ar_cus: int = 64, ar_parts: int = 1, ar_shared: bool = False):
+    def __init__(self, tts, lanes: int = 2, ar_cus: int = 64, ar_parts: int = 1, ar_shared: bool = False, bulk_slots: int = 1):
         """``ar_parts`` AR partitions of ``ar_cus`` CUs each (the AR phase is launch-latency bound, so independent
         partitions generate independent batches concurrently); the remaining CUs form the one bulk partition.
         Lane i generates on partition i % ar_parts.  With ``ar_shared`` the partitions are ONE CU range of ``ar_cus`` CUs
@@ -54,7 +54,7 @@ class PipelinedSynthesizer:
         # (the recorded frame graph replays on any stream), which shortens the fill of the pipeline.
         self._full = [torch.cuda.Stream(device=self.device) for _ in range(int(lanes))]
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
-        self.bulk_lock = threading.Lock()
+        self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))
         self.ar_cus, self.ar_parts, self.bulk_cus = ar_cus, ar_parts, total - bulk0
         tts.model._driver = self
 
