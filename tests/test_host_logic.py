@@ -1,0 +1,35 @@
+"""Host-side decisions that need no GPU: the split-K heuristic, the scratch budget, the style of batching keys."""
+import torch
+
+from sopro_amd import hip
+from sopro_amd.model import Workspace
+
+
+def test_auto_ksplit_only_for_few_tiles_and_long_k():
+    # whole batches fill the chip: never split
+    assert hip._auto_ksplit(12800, 1536, 512, 2, hip.EPI_NONE) == 1
+    assert hip._auto_ksplit(6400, 384, 1536, 3, hip.EPI_RES) == 1
+    # a streaming chunk: a handful of 64x64 tiles; split from K = 1024 up, not below (the release / acquire pair costs ~10 us)
+    assert hip._auto_ksplit(6, 384, 1536, 3, hip.EPI_RES) > 1
+    assert hip._auto_ksplit(12, 512, 2048, 2, hip.EPI_RES) > 1
+    assert hip._auto_ksplit(6, 768, 384, 3, hip.EPI_GLU) == 1
+    assert hip._auto_ksplit(12, 2048, 256, 3, hip.EPI_NONE) == 1
+    for (M, N, K, pieces, epi) in [(6, 384, 1536, 3, hip.EPI_RES), (12, 4096, 2048, 2, hip.EPI_NONE), (33, 4096, 2048, 2, hip.EPI_NONE),
+                                   (1, 64, 4096, 3, hip.EPI_GELU)]:
+        ks = hip._auto_ksplit(M, N, K, pieces, epi)
+        bm, bn = (64, 128) if (pieces == 3 and epi == hip.EPI_GLU) else ((64, 64) if (pieces == 3 or N <= 64 or M <= 64) else (128, 128))
+        tiles = -(-M // bm) * -(-N // bn)
+        assert 1 <= ks <= 16 and ks * tiles * bm * bn * 4 <= hip._SPLITK_WS_BYTES and tiles <= hip._SPLITK_TICKETS
+
+
+def test_workspace_keeps_one_buffer_per_shape_and_counts_bytes():
+    ws = Workspace(torch.device("cpu"))
+    a = ws.get("x", (4, 8))
+    assert ws.get("x", (4, 8)) is a and ws.bytes == 4 * 8 * 4
+    b = ws.get("x", (2, 8), zero=True)
+    assert b is not a and float(b.abs().sum()) == 0.0 and ws.bytes == (32 + 16) * 4
+    c = ws.get("i", (3,), dtype=torch.int32)
+    assert c.dtype == torch.int32 and ws.bytes == (32 + 16 + 3) * 4
+    assert ws.over(100) and not ws.over(1000)
+    ws.clear()
+    assert ws.bytes == 0 and ws.get("x", (4, 8)) is not a
