@@ -108,7 +108,7 @@ def _split_bound(A, W, b=None):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 96), (129, 64, 64), (1000, 96, 192), (70, 33, 192), (5, 384, 384), (257, 2048, 256),
-                                   (640, 640, 512), (256, 128, 36)])
+                                   (640, 640, 512), (256, 128, 36), (12, 1536, 512), (48, 512, 768), (7, 100, 64)])
 def test_gemm_bf16x3_plain_bias(M, N, K):
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
     C = torch.full((M, N), float("nan"), device=DEV)
@@ -163,7 +163,8 @@ def test_gemm_bf16x3_epilogues_prologue_and_row_windows():
     close(out[:, 2:], ref, 2e-4, "conv transpose stride 5")
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (129, 64, 64), (70, 33, 192), (257, 2048, 256), (640, 384, 1536)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (129, 64, 64), (70, 33, 192), (257, 2048, 256), (640, 384, 1536),
+                                   (6, 768, 384), (12, 2048, 256), (16, 1536, 384), (64, 384, 128), (1, 64, 64), (33, 96, 320)])
 def test_gemm_bf16x6_is_fp32_class(M, N, K):
     """Six passes over three bf16 pieces per operand: errors of the fp32-MFMA kernel's size (bound: 2^-21 |A||W|)."""
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
