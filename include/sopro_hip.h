@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 13
+#define SOPRO_ABI_VERSION 14
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -108,6 +108,9 @@ typedef struct sopro_gemm_split_ext {
    * slice order (deterministic) and runs the epilogue.  ws: >= ksplit * tiles * tile_elems * 4 bytes (tiles are at most
    * 128x128, at least 64x64); tickets: one zero-initialised int per tile, left zero by every launch.  Both belong to
    * ONE stream at a time. */
+  /* Fused RMSNorm of the A rows (six-pass path; src/sopro/nn/blocks.py:26-37): out = rsqrt(mean_k(a^2) + rms_eps) * (a W'^T)
+   * + bias, with the norm's weight vector folded into W' by the host.  K % 32 == 0, no split-K, no prologue. */
+  int32_t rms_norm; float rms_eps;
   int32_t ksplit;      /* 0 / 1: off */
   int32_t n_tickets;
   float* ws; int64_t ws_bytes;

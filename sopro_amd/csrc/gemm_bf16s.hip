@@ -37,7 +37,9 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned (&pc)[NPL]
 
 // AMODE: 0 = A is fp32 rows, split while staged; 1 = the same with ELU applied first; 2 = A is already in split form
 // (NPL == 2 only: each 32-channel group = [32 hi | 32 lo] bf16, written by a producer's OUT = 1 / 2 epilogue): pure
-// 16-byte copies; 3 = fp32 rows + pro_vec[k] (PRO_ADDVEC).
+// 16-byte copies; 3 = fp32 rows + pro_vec[k] (PRO_ADDVEC); 4 = fp32 rows whose RMSNorm is fused: the row's sum of squares is
+// accumulated while it is staged and rsqrt(mean + eps) scales the accumulator in the epilogue (the norm's weight vector is
+// folded into W by the host; needs K % 32 == 0 and no split-K: every workgroup sees its rows' whole K).
 template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT, bool SK>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gemm_args g, const uint4* __restrict__ Wp,
                                                                  int ksubs, const sopro_gemm_split_ext ext) {
@@ -87,6 +89,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   }
 
   float4 ra[A_F4];
+  float ssq[A_F4];
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) ssq[i] = 0.f;
   float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
   const int KT = (g.K + BK - 1) / BK;
   const int klast = g.K - 4;
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
 #pragma unroll
         for (int p = 0; p < NPL; ++p) rb[j][s][p] = bp[j][((int64_t)(kt * 2 + s) * NPL + p) * 64];
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, bool fresh = true) {  // fresh: not the clamped re-stage of the last step (RMSNorm sums count once)
     if (AMODE == 2) {  // pieces 0-3 of the 128-byte group are the hi halves, 4-7 the lo halves: the LDS row layout
       unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 16;
 #pragma unroll
@@ -120,6 +125,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     } else if (AMODE == 3) {
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) { ra[i].x += pv.x; ra[i].y += pv.y; ra[i].z += pv.z; ra[i].w += pv.w; }
+    }
+    if (AMODE == 4 && fresh) {
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i)
+        ssq[i] = fmaf(ra[i].x, ra[i].x, fmaf(ra[i].y, ra[i].y, fmaf(ra[i].z, ra[i].z, fmaf(ra[i].w, ra[i].w, ssq[i]))));
     }
     unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 8;
 #pragma unroll
@@ -188,13 +198,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     gload(k1);
     bload(k1, rb1);
     compute(0, rb0);
-    lstore(1);
+    lstore(1, it + 1 < nkt);
     __syncthreads();
     if (it + 1 >= nkt) break;
     gload(k2);
     bload(k2, rb0);
     compute(1, rb1);
-    lstore(0);
+    lstore(0, it + 2 < nkt);
     __syncthreads();
   }
   if (dbg && tid == 0) dbg[2] = clock64();
@@ -252,7 +262,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
           }
     }
   }
-  gemm_store_tile<WM, WN, TM, TN, EPI, OUT>(g, reinterpret_cast<float*>(smem4), acc, biasv, m0, n0, &ext);
+  const float* rs = nullptr;
+  if constexpr (AMODE == 4) {
+    // the 8 threads that staged a row hold its partial sums (consecutive lanes): reduce, publish one scale per tile row
+    // behind the epilogue tile
+    float* rsl = reinterpret_cast<float*>(smem4) + BM * (BN + 4);
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      float v = ssq[i];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      if (lc4 == 0) rsl[lrow + i * RSTEP] = rsqrtf(v / (float)g.K + ext.rms_eps);
+    }
+    __syncthreads();
+    rs = rsl;
+  }
+  gemm_store_tile<WM, WN, TM, TN, EPI, OUT>(g, reinterpret_cast<float*>(smem4), acc, biasv, m0, n0, &ext, rs);
   if (dbg && tid == 0) dbg[3] = clock64();
 }
 
@@ -286,7 +312,7 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W
 template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT>
 int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr size_t lds_main = (size_t)2 * BM * (NPL * 64 + 16), lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds_main = (size_t)2 * BM * (NPL * 64 + 16), lds_epi = (size_t)BM * (BN + 4 + (AMODE == 4 ? 1 : 0)) * sizeof(float);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   const int ks = ext.ksplit > 1 ? ext.ksplit : 1;
   static bool attr_done[2] = {false, false};
@@ -310,6 +336,7 @@ int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro
 
 inline int amode_of(const sopro_gemm_args& g, const sopro_gemm_split_ext& ext) {
   if (ext.a_format == 1) return 2;
+  if (ext.rms_norm) return 4;
   return g.prologue == SOPRO_PRO_ELU ? 1 : (g.prologue == SOPRO_PRO_ADDVEC ? 3 : 0);
 }
 
@@ -352,11 +379,14 @@ int launch_cfg6(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
     SOPRO_CASE(SOPRO_EPI_GELU, 0);  // FF1
     SOPRO_CASE(SOPRO_EPI_RES, 0);   // FF2 + skip
     SOPRO_CASE(SOPRO_EPI_NONE, 3);  // NAR heads: z + head-id embedding
+    SOPRO_CASE(SOPRO_EPI_GELU, 4);  // RMSNorm -> FF1 -> GELU
+    SOPRO_CASE(SOPRO_EPI_NONE, 4);
     default: break;
   }
 #undef SOPRO_CASE
   if constexpr (WN * TN * 32 >= 64) {
     if (key == SOPRO_EPI_GLU * 10) return launch_one<3, WM, WN, TM, TN, SOPRO_EPI_GLU, 0, 0>(g, wp, ksubs, ext, s);
+    if (key == SOPRO_EPI_GLU * 10 + 4) return launch_one<3, WM, WN, TM, TN, SOPRO_EPI_GLU, 4, 0>(g, wp, ksubs, ext, s);  // RMSNorm -> GLU
   }
   sopro_set_error("sopro_gemm_bf16x6: (epilogue %d, prologue %d) is not an available combination", g.epilogue, g.prologue);
   return -2;
@@ -419,6 +449,7 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
   SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES,
                   "epilogue must be NONE, GELU or RES");
   SOPRO_CHECK_ARG(ext.a_format == 0 || ext.a_format == 1, "a_format must be 0 (fp32) or 1 (split form)");
+  SOPRO_CHECK_ARG(!ext.rms_norm, "fused RMSNorm is a six-pass (sopro_gemm_bf16x6) feature");
   if (ext.a_format == 1) {
     SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE, "split-form A carries its activation already");
     SOPRO_CHECK_ARG((g.K & 31) == 0 && (g.lda & 31) == 0 && (g.a_seg_stride & 31) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 127u) == 0,
@@ -458,7 +489,9 @@ extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w,
   sopro_gemm_split_ext ext;
   memset(&ext, 0, sizeof(ext));
   if (x) ext = *x;
-  SOPRO_CHECK_ARG(ext.a_format == 0 && ext.c_mode == 0, "the six-pass path reads and writes fp32 rows (only the split-K fields of ext apply)");
+  SOPRO_CHECK_ARG(ext.a_format == 0 && ext.c_mode == 0, "the six-pass path reads and writes fp32 rows (only the split-K and RMSNorm fields of ext apply)");
+  SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f),
+                  "fused RMSNorm needs K % 32 == 0, no split-K, no prologue and eps > 0");
   if (int rc = check_common(g, ext, packed_w)) return rc;
   SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ADDVEC, "prologue must be NONE or ADDVEC");
   SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES || g.epilogue == SOPRO_EPI_GLU,

@@ -9,10 +9,13 @@
 // tensor stays available as a residual operand while the next contraction reads its activated form without any prologue
 // work).  Split form: every aligned group of 32 channels (128 bytes as fp32) becomes [32 hi bf16 | 32 lo bf16], so an
 // element keeps its 128-byte line and every fp32 stride / offset keeps its meaning.
+// rs (optional, LDS): one scale per tile row applied to the accumulator before the bias: the RMSNorm of the operand row
+// when its weight vector has been folded into W (out = rs * (x W'^T) + b).
 template <int WM, int WN, int TM, int TN, int EPI, int OUT = 0>
 __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float* __restrict__ Cs, f32x16 (&acc)[TM][TN],
                                                 const float (&biasv)[TN], int m0, int n0,
-                                                const sopro_gemm_split_ext* __restrict__ ext = nullptr) {
+                                                const sopro_gemm_split_ext* __restrict__ ext = nullptr,
+                                                const float* __restrict__ rs = nullptr) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -34,7 +37,7 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          Cs[row * CLD + (wn * TN + j) * 32 + col] = acc[i][j][r] + biasv[j];
+          Cs[row * CLD + (wn * TN + j) * 32 + col] = (rs ? acc[i][j][r] * rs[row] : acc[i][j][r]) + biasv[j];
         }
   }
   __syncthreads();

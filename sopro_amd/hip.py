@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -35,7 +35,8 @@ class GemmArgs(C.Structure):
 
 class SplitExt(C.Structure):
     _fields_ = [("a_format", _i32), ("c_mode", _i32), ("C2", _p), ("ldc2", _i64), ("c2_seg_stride", _i64),
-                ("ksplit", _i32), ("n_tickets", _i32), ("ws", _p), ("ws_bytes", _i64), ("tickets", _p)]
+                ("rms_norm", _i32), ("rms_eps", _f32), ("ksplit", _i32), ("n_tickets", _i32), ("ws", _p), ("ws_bytes", _i64),
+                ("tickets", _p)]
 
 
 class SkinnyArgs(C.Structure):
@@ -206,7 +207,7 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
          a_seg_stride: int = 0, c_seg_stride: int = 0, r_seg_stride: int = 0, a_off: int = 0, c_off: int = 0,
          r_off: int = 0, ldw: Optional[int] = None, dbg: Optional[torch.Tensor] = None, a_split: bool = False, c_mode: int = 0,
          C2: Optional[torch.Tensor] = None, ldc2: Optional[int] = None, c2_seg_stride: int = 0,
-         c2_off: int = 0) -> None:
+         c2_off: int = 0, rms_eps: float = 0.0) -> None:
     """C = epi(pro(A) @ W^T + bias); offsets are in elements from the tensors' first element.  With a ``PackedW`` weight the
     contraction runs on the split-bf16 path, where ``a_split`` says A is in split form and ``c_mode`` 1 / 2 writes
     ELU(C) in split form (to C, or to C2 next to the fp32 C): see sopro_gemm_split_ext in include/sopro_hip.h."""
@@ -237,7 +238,11 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     x = None
     if packed:
         x = SplitExt()
-        ks = _auto_ksplit(M, N, K, W.pieces, epilogue) if (dbg is None and _splitk_enabled) else 1
+        if rms_eps > 0.0:  # fused RMSNorm of the A rows (W must carry the norm's weight vector)
+            if W.pieces != 3:
+                raise SoproHipError("fused RMSNorm is a six-pass (pieces = 3) feature")
+            x.rms_norm, x.rms_eps = 1, float(rms_eps)
+        ks = _auto_ksplit(M, N, K, W.pieces, epilogue) if (dbg is None and _splitk_enabled and rms_eps <= 0.0) else 1
         if ks > 1:
             ws, tk = _splitk_buffers()
             x.ksplit, x.n_tickets, x.ws, x.ws_bytes, x.tickets = ks, int(tk.numel()), ptr(ws), int(ws.numel()) * 4, ptr(tk, torch.int32)

@@ -111,10 +111,21 @@ class SoproTTSModel:
         # operand: the accuracy class of the fp32 MFMA kernel at ~1.5x its speed on these shapes); SOPRO_NAR_F32=1 keeps fp32.
         self.wx: Dict[str, hip.PackedW] = {}
         if os.environ.get("SOPRO_NAR_F32", "0") != "1":
+            unfused = os.environ.get("SOPRO_NORM_UNFUSED", "0") == "1"
             with torch.cuda.device(self.device):
                 for k, v in self.w.items():
                     if k.startswith(("nar.", "text_enc.layers.", "ref_enc_blocks.")) and v.dim() == 2 and k.endswith(".w") \
                             and int(v.shape[1]) % 32 == 0 and int(v.shape[0]) >= 64 and not k.startswith("nar.adapter"):
+                        # the two RMSNorms of an SSMLite block are fused into the GEMMs they feed (sopro_gemm_split_ext.rms_norm):
+                        # their weight vectors are folded into the columns of W here, once
+                        nk = None
+                        if k.endswith(".glu.w"):
+                            nk = k[: -len("glu.w")] + "norm.weight"
+                        elif k.endswith(".ff1.w"):
+                            nk = k[: -len("ff1.w")] + "ff.norm.weight"
+                        if nk is not None and nk in self.w and not unfused:
+                            self.wx[k + "n"] = hip.pack_w_bf16x6((v * self.w[nk][None, :]).contiguous())
+                            continue
                         self.wx[k] = hip.pack_w_bf16x6(v)
                 torch.cuda.synchronize(self.device)
         self._ones: Dict[int, torch.Tensor] = {}
@@ -156,18 +167,26 @@ class SoproTTSModel:
                        causal: bool, lens: Optional[torch.Tensor]) -> None:
         """Full-sequence SSMLiteBlock over dense [B*T, D] rows (reference: src/sopro/nn/blocks.py:143-148)."""
         D, M, w, ws = self.D, B * T, self.w, self.ws
-        nrm = ws.get("ssm.nrm", (M, D))
         h = ws.get("ssm.h", (M, D))
         x1 = ws.get("ssm.x1", (M, D))
         u = ws.get("ssm.u", (M, 4 * D))
-        hip.norm(x, nrm, w[p + ".norm.weight"], rows=M, C_=D, eps=RMS_EPS)
         gw = lambda k: self.wx.get(k) or w[k]  # noqa: E731
-        hip.gemm(nrm, gw(p + ".glu.w"), h, M=M, N=2 * D, K=D, bias=w[p + ".glu.b"], epilogue=hip.EPI_GLU)
         total = (ksize - 1) * dil
         left = total if causal else total // 2
+        gn, fn = self.wx.get(p + ".glu.wn"), self.wx.get(p + ".ff1.wn")
+        if gn is not None:  # RMSNorm inside the GEMM (norm weight folded into W)
+            hip.gemm(x, gn, h, M=M, N=2 * D, K=D, bias=w[p + ".glu.b"], epilogue=hip.EPI_GLU, rms_eps=RMS_EPS)
+        else:
+            nrm = ws.get("ssm.nrm", (M, D))
+            hip.norm(x, nrm, w[p + ".norm.weight"], rows=M, C_=D, eps=RMS_EPS)
+            hip.gemm(nrm, gw(p + ".glu.w"), h, M=M, N=2 * D, K=D, bias=w[p + ".glu.b"], epilogue=hip.EPI_GLU)
         hip.dwconv(h, w[p + ".dw.w"], w[p + ".dw.b"], x1, B=B, T=T, C_=D, ksize=ksize, dil=dil, left=left, mode=1, res=x, lens=lens)
-        hip.norm(x1, nrm, w[p + ".ff.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
-        hip.gemm(nrm, gw(p + ".ff1.w"), u, M=M, N=4 * D, K=D, bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
+        if fn is not None:
+            hip.gemm(x1, fn, u, M=M, N=4 * D, K=D, bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU, rms_eps=RMS_EPS)
+        else:
+            nrm = ws.get("ssm.nrm", (M, D))
+            hip.norm(x1, nrm, w[p + ".ff.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
+            hip.gemm(nrm, gw(p + ".ff1.w"), u, M=M, N=4 * D, K=D, bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
         hip.gemm(u, gw(p + ".ff2.w"), out, M=M, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=x1)
 
     # ------------------------------------------------------------------ per-voice preparation

@@ -198,6 +198,36 @@ def test_gemm_bf16x6_epilogues_and_addvec():
         hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, prologue=hip.PRO_ELU)
 
 
+@pytest.mark.parametrize("M,K", [(6, 384), (200, 384), (1000, 384), (70, 64), (1, 32)])
+def test_gemm_bf16x6_fused_rmsnorm(M, K):
+    """RMSNorm inside the GEMM (ext.rms_norm; reference: src/sopro/nn/blocks.py:26-37 followed by the block's GLU / FF1
+    contraction): the norm's weight vector is folded into W, the row scale is applied to the accumulator."""
+    N, eps = 256, 1e-6
+    X, W, b, nw = rnd(M, K, seed=51, scale=3.0), rnd(N, K, seed=52, scale=K ** -0.5), rnd(N, seed=53), 1.0 + 0.3 * rnd(K, seed=54)
+    X[M // 2] *= 1e-3  # rows of very different energy
+    xn = (X.double() * torch.rsqrt((X.double() ** 2).mean(-1, keepdim=True) + eps)) * nw.double()
+    ref = (xn @ W.double().t() + b.double()).float()
+    Wf = (W * nw[None, :]).contiguous()
+    C = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(dev(X), hip.pack_w_bf16x6(dev(Wf)), C, M=M, N=N, K=K, bias=dev(b), rms_eps=eps)
+    close(C, ref, 2e-5, "rmsnorm+gemm")
+    hip.gemm(dev(X), hip.pack_w_bf16x6(dev(Wf)), C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_GELU, rms_eps=eps)
+    close(C, F.gelu(ref), 2e-5, "rmsnorm+gemm+gelu")
+    wg, bg = pack.pack_glu(Wf, b)
+    G = torch.full((M, N // 2), float("nan"), device=DEV)
+    hip.gemm(dev(X), hip.pack_w_bf16x6(dev(wg)), G, M=M, N=N, K=K, bias=dev(bg), epilogue=hip.EPI_GLU, rms_eps=eps)
+    close(G, ref[:, : N // 2] * torch.sigmoid(ref[:, N // 2:]), 2e-5, "rmsnorm+gemm+glu")
+    # the unfused pair of launches computes the same thing
+    nrm = torch.empty(M, K, device=DEV)
+    hip.norm(dev(X), nrm, dev(nw), rows=M, C_=K, eps=eps)
+    C2 = torch.empty(M, N, device=DEV)
+    hip.gemm(nrm, hip.pack_w_bf16x6(dev(W)), C2, M=M, N=N, K=K, bias=dev(b))
+    hip.gemm(dev(X), hip.pack_w_bf16x6(dev(Wf)), C, M=M, N=N, K=K, bias=dev(b), rms_eps=eps)
+    close(C, C2.cpu(), 2e-5, "fused vs unfused")
+    with pytest.raises(hip.SoproHipError):  # a two-piece weight has no fused norm
+        hip.gemm(dev(X), hip.pack_w_bf16x3(dev(Wf)), C, M=M, N=N, K=K, rms_eps=eps)
+
+
 @pytest.mark.parametrize("pieces,M,N,K,epi", [(3, 6, 384, 1536, "res"), (3, 6, 768, 1152, "glu"), (3, 12, 2048, 1024, "none"), (2, 12, 512, 2048, "res"),
                                               (2, 12, 1024, 3584, "none"), (2, 33, 4096, 2048, "none"), (3, 1, 64, 1536, "gelu")])
 def test_gemm_split_k_small_m_is_exact_class_and_deterministic(pieces, M, N, K, epi):
