@@ -84,7 +84,7 @@ def cpu_baseline(cfg, mc, wn, mn, n_utts: int):
         t0 = time.perf_counter()
         frames = 0
         for i in range(n_utts):
-            wav = O.synthesize(ids[i], ref, w, mw, cfg, mc, max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True)
+            wav = O.synthesize(ids[i % len(ids)], ref, w, mw, cfg, mc, max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True)
             frames += wav.shape[-1] // 1920
         dt = time.perf_counter() - t0
     return {"value": round(frames * FRAME_SEC / dt, 3), "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -105,6 +105,7 @@ def log(msg: str) -> None:
 
 
 def main() -> None:
+    global BATCH, FRAMES
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
@@ -118,8 +119,11 @@ def main() -> None:
     ap.add_argument("--ar-shared", type=int, default=1, help="1: the AR partitions are one CU range used by --ar-parts AR phases at once")
     ap.add_argument("--bulk-slots", type=int, default=1, help="refinement / decoding phases allowed at the same time on the throughput partition")
     ap.add_argument("--ar-parts", type=int, default=2, help="independent AR partitions (concurrent AR phases) when lanes > 1")
+    ap.add_argument("--batch", type=int, default=BATCH, help="utterances per step (default: BASELINE configs[1])")
+    ap.add_argument("--frames", type=int, default=FRAMES, help="frames per utterance (default: BASELINE configs[1]; 400 = the long-form case)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    BATCH, FRAMES = int(args.batch), int(args.frames)
 
     if args.cpu_baseline_only:  # child process of the N=1 run: CPU only, bounded by the parent's timeout
         from sopro_amd.config import MimiDecoderConfig, SoproTTSConfig
@@ -309,7 +313,8 @@ def main() -> None:
 
         log("cpu baseline (oracle, child process, <= 150 s)")
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-utts", str(args.cpu_utts)],
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-utts", str(args.cpu_utts), "--frames", str(FRAMES),
+                                "--batch", str(BATCH)],
                                capture_output=True, text=True, timeout=150, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
             cpu = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001  (a missing baseline must not void the GPU measurement)
@@ -322,7 +327,7 @@ def main() -> None:
             "metric": "audio_seconds_per_second", "value": round(audio_sec / dt, 2), "unit": "audio-s/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Sopro-135M synthesize, {BATCH} utterances x {FRAMES} frames per GPU (BASELINE configs[1]), "
+            "config": {"workload": f"Sopro-135M synthesize, {BATCH} utterances x {FRAMES} frames per GPU ({'BASELINE configs[1]' if (BATCH, FRAMES) == (32, 200) else 'non-default shape'}), "
                                    f"S={TEXT_LEN} text tokens, {REF_FRAMES}-frame reference voice prepared outside the timed region, "
                                    "top_p=0.9 T=1.05 anti_loop (reference defaults), synthetic weights with EOS suppressed",
                        "batch_per_gpu": BATCH, "frames": FRAMES, "parallelism": f"replicas x{world} (utterance sharding, no collective)",
