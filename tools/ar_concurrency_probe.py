@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Developer probe: how well do two AR phases (recorded frame graphs of two engines) overlap on one GPU?
+    python tools/ar_concurrency_probe.py [B] [steps]
+Cases: one phase alone / two at once, on ordinary streams (whole chip), on one shared CU-masked partition of 64 / 96 CUs,
+and on two disjoint partitions.  Prints us per frame of each phase (wall time of the pair / steps)."""
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from bench import build_engine, make_inputs
+from sopro_amd import hip
+from sopro_amd.model import _ARRun
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+tts, cfg, mc, wn, mn = build_engine("cuda:0")
+dev = tts.device
+ids, ref_tq = make_inputs(0)
+ref = tts.prepare_reference(ref_tokens_tq=ref_tq)
+lanes = [tts, tts.clone_lane()]
+kw = dict(top_p=0.9, temperature=1.05, anti_loop=True)
+preps = [l.model.prepare_conditioning_batch(ids[:B], [ref] * B, max_frames=steps - 1) for l in lanes]
+torch.cuda.synchronize()
+
+
+def phase(lane, prep, out, i):
+    with torch.cuda.stream(lane.model.stream):
+        run = _ARRun(lane.model, prep["cond_ar"], prep["txt_seq"], prep["text_lens"], min_gen_frames=None, **kw)
+        lane.model.stream.synchronize()
+        bar.wait()
+        t0 = time.perf_counter()
+        run.advance(steps)
+        lane.model.stream.synchronize()
+        out[i] = (time.perf_counter() - t0) / steps * 1e6
+
+
+def case(name, streams):
+    global bar
+    n = len(streams)
+    for l, s in zip(lanes, streams):
+        l.model.stream = l.model.prep_stream = l.model.bulk_stream = s
+        l.model._ar_cache.clear()
+    res = []
+    for rep in range(3):
+        out = [0.0] * n
+        bar = threading.Barrier(n)
+        th = [threading.Thread(target=phase, args=(lanes[i], preps[i], out, i)) for i in range(n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        res.append("/".join(f"{o:6.1f}" for o in out))
+    print(f"{name:44s} us/frame per phase: " + "   ".join(res), flush=True)
+
+
+S = lambda: torch.cuda.Stream(device=dev)  # noqa: E731
+M = lambda lo, n: hip.cu_range_stream(lo, n, dev)  # noqa: E731
+case("1 phase, whole chip", [S()])
+case("2 phases, whole chip, ordinary streams", [S(), S()])
+for n in (64, 96, 128):
+    case(f"1 phase, {n}-CU partition", [M(0, n)])
+    case(f"2 phases, one shared {n}-CU partition", [M(0, n), M(0, n)])
+case("2 phases, disjoint 64 + 64 CUs", [M(0, 64), M(64, 64)])
+case("2 phases, disjoint 128 + 128 CUs", [M(0, 128), M(128, 128)])

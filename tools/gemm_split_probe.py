@@ -17,6 +17,8 @@ shapes = [  # (name, M, N, K, epilogue, prologue)
     ("up2", 614400, 640, 512, E, EL), ("res2.c1", 3072000, 64, 384, E, EL), ("res2.c2", 3072000, 128, 64, R_, EL),
     ("up3", 3072000, 256, 256, E, EL),
 ]
+if os.environ.get("PROBE_NOELU", "0") == "1":  # the activated-copy flow: the producer applied ELU, the consumer reads fp32 rows as they are
+    shapes = [(n, M, N, K, e, 0) for (n, M, N, K, e, p) in shapes]
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 3, 4, 5]
 lib = hip.load()
 for name, M, N, K, epi, pro in shapes:
