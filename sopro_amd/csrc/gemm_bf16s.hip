@@ -476,9 +476,6 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
     case 2: return launch_cfg3<2, 2, 4, 2>(g, wp, ksubs, ext, s);
     case 4: return launch_cfg3<2, 2, 2, 1>(g, wp, ksubs, ext, s);
     case 5: return launch_cfg3<2, 2, 1, 1>(g, wp, ksubs, ext, s);
-    case 6: return launch_cfg3<1, 4, 4, 1>(g, wp, ksubs, ext, s);
-    case 7: return launch_cfg3<1, 4, 4, 2>(g, wp, ksubs, ext, s);
-    case 8: return launch_cfg3<1, 8, 4, 1>(g, wp, ksubs, ext, s);
     default: break;
   }
   // few columns, or few rows (streaming chunks, batch 1: small tiles keep the split-K partial sums small): 64x64
