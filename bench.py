@@ -225,6 +225,10 @@ def main() -> None:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["families"]
     except Exception:  # noqa: BLE001
         pmc = {}
+    try:  # matrix-core busy share from the SQ_VALU_MFMA_BUSY_CYCLES pass (tools/pmc_summary.py --mfma; whole chip per kernel)
+        busy = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_busy.json")))["families"]
+    except Exception:  # noqa: BLE001
+        busy = {}
     roof, roof_ar = None, None
     share = (256 - args.ar_cus * (1 if args.ar_shared else args.ar_parts)) / 256.0 if args.lanes > 1 else 1.0  # CUs of the bulk partition
     roof_split = None
@@ -237,6 +241,7 @@ def main() -> None:
                       "peak_three_pass": round(PEAK_BF16_MFMA_TFLOPS * share / 3.0, 2),
                       "frac_three_pass": round(ach / (PEAK_BF16_MFMA_TFLOPS * share / 3.0), 5),
                       "traffic": pmc.get("gemm_bf16x3_kernel", {}).get("traffic_bytes_per_launch"), "launches": f["launches"],
+                      "mfma_busy_pmc": busy.get("gemm_bf16x3_kernel", {}).get("mfma_busy_share_at_2p4ghz"),
                       "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2),
                       "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"])),
                       "note": "achieved = algorithmic (fp32-equivalent) flops / launch time; each product costs three bf16 MFMA passes"}
@@ -250,6 +255,7 @@ def main() -> None:
                    "peak_six_pass": round(PEAK_BF16_MFMA_TFLOPS * share / 6.0, 2),
                    "frac_six_pass": round(ach / (PEAK_BF16_MFMA_TFLOPS * share / 6.0), 5),
                    "traffic": pmc.get("gemm_bf16x6_kernel", {}).get("traffic_bytes_per_launch"), "launches": f["launches"],
+                   "mfma_busy_pmc": busy.get("gemm_bf16x6_kernel", {}).get("mfma_busy_share_at_2p4ghz"),
                    "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2),
                    "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"])),
                    "note": "achieved = algorithmic (fp32-equivalent) flops / launch time; each product costs six bf16 MFMA passes"}
