@@ -145,13 +145,19 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the Sopro engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # developer switch for a 1-GPU box: every rank on GPU 0, gloo for the barrier / MAX (exercises the launch and reduction path only)
+    share_gpu = os.environ.get("SOPRO_BENCH_SHARE_GPU", "0") == "1"
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     from sopro_amd import hip
 
@@ -194,7 +200,8 @@ def main() -> None:
 
     log("warmup")
     # every lane runs a shape eagerly once (scratch allocation) and records its launch sequences on the second pass
-    run_steps(max(args.warmup, 2 * args.lanes if pipe is not None else 2))
+    warm = max(args.warmup, 2 * args.lanes if pipe is not None else 2)
+    run_steps(warm)
     fence()
     log("timed steps")
     phases = {}
@@ -204,7 +211,7 @@ def main() -> None:
     dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f} s for {args.steps} steps; peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if share_gpu else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # ---- instrumented repeat of the same steps (same lanes, streams and CU partitions): HIP events around every GEMM /
@@ -331,7 +338,7 @@ def main() -> None:
         audio_sec = world * args.steps * BATCH * FRAMES * FRAME_SEC
         line = {
             "metric": "audio_seconds_per_second", "value": round(audio_sec / dt, 2), "unit": "audio-s/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "steps": args.steps, "warmup": args.warmup, "warmup_run": warm, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Sopro-135M synthesize, {BATCH} utterances x {FRAMES} frames per GPU ({'BASELINE configs[1]' if (BATCH, FRAMES) == (32, 200) else 'non-default shape'}), "
                                    f"S={TEXT_LEN} text tokens, {REF_FRAMES}-frame reference voice prepared outside the timed region, "
