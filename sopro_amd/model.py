@@ -321,18 +321,33 @@ class SoproTTSModel:
             q = torch.empty(B * Tar, D, device=dev)
             a = torch.empty(B * Tar, D, device=dev)
             am = torch.empty(B * Tar, D, device=dev)
-            Kb = torch.zeros(B, Tr, D, device=dev)
-            Vb = torch.zeros(B, Tr, D, device=dev)
+            # rows that share a voice (the same PreparedReference object) share its cached K / V: one dense copy per voice and
+            # layer; a single-voice batch reads it through a zero batch stride, a mixed one through one gather
+            order: List[PreparedReference] = []
+            seen: Dict[int, int] = {}
+            for r in refs:
+                if id(r) not in seen:
+                    seen[id(r)] = len(order)
+                    order.append(r)
+            row_u = [seen[id(r)] for r in refs]
+            U = len(order)
+            Ku = torch.zeros(U, Tr, D, device=dev)
+            Vu = torch.zeros(U, Tr, D, device=dev)
+            sel = None if U in (1, B) else torch.tensor(row_u, dtype=torch.long, device=dev)
+            kv_bstride = 0 if (U == 1 and B > 1) else Tr * D
             for i in range(int(cfg.ref_xattn_layers)):
                 p = f"ref_xattn.blocks.{i}"
-                for b, r in enumerate(refs):
+                for u, r in enumerate(order):
                     c = r.ref_kv_caches[i]
-                    Kb[b, : tr_h[b]] = c["k"].to(dev).permute(0, 2, 1, 3).reshape(tr_h[b], D)
-                    Vb[b, : tr_h[b]] = c["v"].to(dev).permute(0, 2, 1, 3).reshape(tr_h[b], D)
+                    tu = int(c["k"].shape[2])
+                    Ku[u, :tu] = c["k"].to(dev).permute(0, 2, 1, 3).reshape(tu, D)
+                    Vu[u, :tu] = c["v"].to(dev).permute(0, 2, 1, 3).reshape(tu, D)
+                Kb = Ku if sel is None else Ku.index_select(0, sel)
+                Vb = Vu if sel is None else Vu.index_select(0, sel)
                 hip.norm(cond, nq, w[p + ".nq.weight"], rows=B * Tar, C_=D, eps=RMS_EPS)
                 hip.gemm(nq, w[p + ".q.w"], q, M=B * Tar, N=D, K=D)
                 hip.attention(q, Kb, Vb, a, B=B, H=H, dh=dh, Tq=Tar, Tk=Tr, ldq=D, ldk=D, ldv=D, ldo=D, q_bstride=Tar * D,
-                              k_bstride=Tr * D, v_bstride=Tr * D, o_bstride=Tar * D, klens=klens)
+                              k_bstride=kv_bstride, v_bstride=kv_bstride, o_bstride=Tar * D, klens=klens)
                 hip.rms_match(a, cond, am, B * Tar, D)
                 hip.gemm(am, w[p + ".o.w"], cond, M=B * Tar, N=D, K=D, epilogue=hip.EPI_RES, R=cond, scale=w[p + ".gate_scale"])
             cond_ar = torch.empty(B, Tar, D, device=dev)

@@ -61,6 +61,20 @@ def test_prepare_conditioning_batch_ragged_matches_oracle(tts, cfg, w):
         assert _err(out["txt_seq"][b, : ids[b].numel()], op["txt_seq"][0]) < 5e-5, b
 
 
+def test_prepare_conditioning_batch_shared_voices(tts):
+    """Rows that pass the same PreparedReference share its cached K / V (zero batch stride for one voice, one gather for a
+    mix): same conditioning as with one private copy per row."""
+    rng = np.random.default_rng(6)
+    ids = [torch.from_numpy(rng.integers(0, 512, size=n)) for n in (9, 23, 14, 17)]
+    ra = tts.prepare_reference(ref_tokens_tq=torch.from_numpy(rng.integers(0, 2048, size=(20, 32))), ref_seconds=0)
+    rb = tts.prepare_reference(ref_tokens_tq=torch.from_numpy(rng.integers(0, 2048, size=(31, 32))), ref_seconds=0)
+    for refs in ([ra, ra, ra, ra], [ra, rb, ra, rb], [rb, rb, ra, rb]):
+        out = tts.model.prepare_conditioning_batch(ids, refs, max_frames=30, style_strength=1.0)
+        for b in range(4):
+            one = tts.model.prepare_conditioning_batch([ids[b]], [refs[b]], max_frames=30, style_strength=1.0)
+            assert _err(out["cond_ar"][b], one["cond_ar"][0]) < 1e-5, (b, [id(r) for r in refs])
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_ar_step_teacher_forced_logits_match_reference(tts, use_graph):
     """ARRVQ1Generator.step for B=2 with a ragged text mask (src/sopro/nn/generator.py:98-130)."""
