@@ -548,16 +548,21 @@ class SoproTTSModel:
             ev.mark("ar")
         return {"cond_ar": prep["cond_ar"], "hist": hist, "lens": lens, "B": len(ids_list)}
 
-    def phase_nar(self, state) -> List[torch.Tensor]:
-        """Throughput-bound half: NAR refinement of the generated codebook-0 tokens."""
+    def phase_nar(self, state, full: bool = False):
+        """Throughput-bound half: NAR refinement of the generated codebook-0 tokens -> one [T_b, Q] matrix per utterance, or with
+        ``full`` the whole padded [B, Tn, Q] batch (rows hold valid but meaningless codes past their own length)."""
         lens, hist, B = state["lens"], state["hist"], state["B"]
         Tm = max(lens)
         if Tm <= 0:
+            if full:
+                return torch.zeros(B, 0, self.Q, dtype=torch.long, device=self.device)
             return [torch.zeros(0, self.Q, dtype=torch.long, device=self.device) for _ in range(B)]
         # a few frames of padding keep the set of batch shapes (scratch + recorded graphs per shape) small
         Tm = min(-(-Tm // 8) * 8, int(hist.shape[1]), int(state["cond_ar"].shape[1]))
         rvq1 = hist[:, :Tm].clamp(max=self.V - 1)  # rows past their own length are ignored below
         toks = self.nar_refine(state["cond_ar"][:, :Tm, :], rvq1, lens=[max(1, n) for n in lens])
+        if full:
+            return toks
         return [toks[b, : lens[b]] for b in range(B)]
 
 

@@ -139,18 +139,15 @@ class SoproTTS:
                                         style_strength=ss, min_gen_frames=min_gen_frames, ev=ev, prep=prep)
         with bulk_lock:  # throughput-bound phase: NAR refinement + Mimi decode
             t0 = time.perf_counter()
-            toks = self.model.phase_nar(state)
+            full = self.model.phase_nar(state, full=True)  # [B, Tn, Q]
             t1 = time.perf_counter()
-            lens = [int(t.shape[0]) for t in toks]
-            Tm = max(lens)
-            if Tm > 0:  # a few frames of padding keep the set of batch shapes (scratch + recorded graphs per shape) small
-                Tm = min(-(-Tm // 8) * 8, max(int(max_frames) + 1, Tm))
-            B = len(toks)
-            if Tm == 0:
+            lens = [int(n) for n in state["lens"]]
+            B, Tn = int(full.shape[0]), int(full.shape[1])
+            if max(lens) == 0:
                 return [torch.zeros(1, 1, 0, device=self.device) for _ in range(B)]
-            codes = torch.zeros(B, Tm, int(self.cfg.num_codebooks), dtype=torch.long, device=self.device)
-            for b, t in enumerate(toks):
-                codes[b, : lens[b]] = t
+            # The padded batch goes to the decoder as it is: the decoder is causal, so the (valid, meaningless) codes a row holds
+            # past its own length never reach the samples that are returned.
+            codes = full
             wav = self.codec.decode_batch(codes)  # causal decoder: padding frames never reach earlier samples
             if timings is not None:
                 timings["nar"] = timings.get("nar", 0.0) + (t1 - t0)
