@@ -59,6 +59,19 @@ def case(name, streams):
 
 S = lambda: torch.cuda.Stream(device=dev)  # noqa: E731
 M = lambda lo, n: hip.cu_range_stream(lo, n, dev)  # noqa: E731
+if len(sys.argv) > 3 and sys.argv[3] == "masks":
+    # mask bit i = XCD i % 8, CU slot j = i // 8 of that XCD: which slots share a shader engine?
+    def K(pred):
+        bits = [i for i in range(256) if pred(i // 8)]
+        return lambda: hip.cu_mask_stream(bits, dev), len(bits)
+    layouts = {"slots 0-7 (range)": K(lambda j: j < 8), "slots j % 4 == 0": K(lambda j: j % 4 == 0),
+               "slots j % 2 == 0, j < 16": K(lambda j: j % 2 == 0 and j < 16), "slots j % 8 == 0 or 1": K(lambda j: j % 8 < 2),
+               "slots 0-11 (range)": K(lambda j: j < 12), "slots j % 4 == 0 + j % 8 == 1": K(lambda j: j % 4 == 0 or j % 8 == 1),
+               "slots j % 2 == 0": K(lambda j: j % 2 == 0), "slots 0-15 (range)": K(lambda j: j < 16)}
+    for name, (mk, n) in layouts.items():
+        case(f"1 phase, {n} CUs, {name}", [mk()])
+        case(f"2 phases shared, {n} CUs, {name}", [mk(), mk()])
+    sys.exit(0)
 case("1 phase, whole chip", [S()])
 case("2 phases, whole chip, ordinary streams", [S(), S()])
 for n in (64, 96, 128):
