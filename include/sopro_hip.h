@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 14
+#define SOPRO_ABI_VERSION 15
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -284,6 +284,7 @@ int sopro_final_conv_f32(const float* h, int64_t h_seg_stride, const float* w, f
 int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
                           const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
                           int32_t T, void* stream);
+int sopro_seanet_tail_set_tiles(int tiles); /* developer probe / tests: 126-sample tiles per workgroup, 0 = by size */
 
 /* ---- autoregressive driver state ----------------------------------------------------------- */
 /* Device-resident state of ar_stream (src/sopro/model.py:218-305) for up to `bcap` rows. All

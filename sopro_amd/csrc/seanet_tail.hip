@@ -6,7 +6,9 @@
 // intermediate makes a round trip); fused, h is read once (plus one L2-resident re-read for the skip operand)
 // and only the waveform (1/64 of it) is written.
 //
-// One workgroup = 126 output samples of one utterance.  Both convolutions run on the split-bf16 matrix-core path of
+// One workgroup = `tiles` consecutive tiles of 126 output samples of one utterance (the weight fragments - 128 registers per
+// lane, ~400 VALU instructions per wave to split - are prepared once and stay in registers for all of them; short inputs
+// keep one tile per workgroup so that streaming chunks still spread over the chip).  Both convolutions run on the split-bf16 matrix-core path of
 // the rest of the decoder (operands x = hi + lo in bf16, lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16, fp32
 // accumulate): ELU(h) is activated and split ONCE per element while the tile is staged into LDS (row = [64 hi | 64 lo]
 // bf16 + 16 B pad = 272 B, so the k=3 window of a sample is three consecutive rows and 16-lane ds_read_b128 fragment
@@ -18,7 +20,7 @@
 
 namespace {
 
-constexpr int TO = 126;        // output samples per workgroup
+constexpr int TO = 126;        // output samples per tile
 constexpr int HR = TO + 4;     // h rows in LDS (samples s0-4 .. s0+TO-1)
 constexpr int EROW = 272;      // bytes per row of the split h tile: 64 hi | 64 lo | pad
 constexpr int YR = TO + 2;     // rows of the 32-channel intermediate (samples s0-2 .. s0+TO-1) == 128 == 4 MFMA row tiles
@@ -37,32 +39,37 @@ __device__ __forceinline__ void split8(const float* __restrict__ p, uint4& hi, u
   split2_bf16(b.z, b.w, hi.w, lo.w);
 }
 
-__global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restrict__ h, int64_t h_seg_stride,
+template <bool LOOP>
+__global__ __launch_bounds__(256, 2) void seanet_tail_kernel(const float* __restrict__ h, int64_t h_seg_stride,
                                                           const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const float* __restrict__ w2, const float* __restrict__ b2,
                                                           const float* __restrict__ wf, float bf, float* __restrict__ wav,
-                                                          int64_t wav_seg_stride, int T) {
+                                                          int64_t wav_seg_stride, int T, int tiles_arg) {
+  const int tiles = LOOP ? tiles_arg : 1;
   __shared__ __attribute__((aligned(16))) unsigned char es[HR * EROW];  // split ELU(h); later ELU(h') as fp32 [HR][HLD]
   __shared__ __attribute__((aligned(16))) unsigned char ys[YR * YROW];  // split ELU(intermediate)
   static_assert(HR * HLD * 4 <= HR * EROW, "the fp32 ELU(h') tile must fit over the split h tile");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
-  const int s0 = blockIdx.x * TO;
   const int frow = lane & 31, fg = lane >> 5;
-
-  // ---- h tile: local row r holds sample s0-4+r, which is padded row s0-2+r of the buffer (2 zero rows in front)
   const float* hb = h + (int64_t)b * h_seg_stride;
-  float4 v[9];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const int idx = tid + q * 256;       // float4 index: 16 per row
-    const int r = idx >> 4, c4 = idx & 15;
-    const int p = s0 - 2 + r;            // padded row
-    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < HR && p >= 0 && p < T + 2) v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)p * 64 + c4 * 4);
-  }
 
-  // ---- weights as (hi, lo) B fragments: n = lane&31, k = 16*substep + 8*(lane>>5) .. +7  (one memory round with the tile)
+  // ---- h tile: local row r holds sample s0-4+r, which is padded row s0-2+r of the buffer (2 zero rows in front).  The first
+  // tile is requested before the weights (one memory round with them).
+  float4 v[9];
+  auto load_tile = [&](int s0) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int idx = tid + q * 256;       // float4 index: 16 per row
+      const int r = idx >> 4, c4 = idx & 15;
+      const int p = s0 - 2 + r;            // padded row
+      v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < HR && p >= 0 && p < T + 2) v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)p * 64 + c4 * 4);
+    }
+  };
+  if (!LOOP) load_tile((int)blockIdx.x * TO);  // looped variant: requested per tile (the weight fragments fill the registers here)
+
+  // ---- weights as (hi, lo) B fragments: n = lane&31, k = 16*substep + 8*(lane>>5) .. +7
   uint4 w1h[12], w1l[12];
 #pragma unroll
   for (int s = 0; s < 12; ++s) split8(w1 + frow * 192 + s * 16 + fg * 8, w1h[s], w1l[s]);
@@ -73,8 +80,16 @@ __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restric
     for (int s = 0; s < 2; ++s) split8(w2 + (j * 32 + frow) * 32 + s * 16 + fg * 8, w2h[j][s], w2l[j][s]);
   const float b1v = b1[frow];
   const float b2v[2] = {b2[frow], b2[32 + frow]};
+  __shared__ __attribute__((aligned(16))) float wfs[192];
+  if (tid < 48) *reinterpret_cast<float4*>(wfs + tid * 4) = *reinterpret_cast<const float4*>(wf + tid * 4);
+
+  for (int it = 0; it < tiles; ++it) {
+  const int s0 = ((int)blockIdx.x * tiles + it) * TO;
+  if (s0 >= T) break;  // uniform over the workgroup
+  if (it > 0) __syncthreads();  // the previous tile's last phase is done with the LDS tiles
+  if (LOOP) load_tile(s0);
   // skip operand of the residual block in the accumulator layout of the second convolution (row mr, column frow / 32+frow),
-  // and the last layer's weights: requested in the same memory round as the tile, consumed two phases later
+  // (an L2-resident re-read of rows the tile request brought in), consumed two phases later
   float skip[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -85,8 +100,6 @@ __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restric
     skip[0][r] = in ? hp[0] : 0.f;
     skip[1][r] = in ? hp[32] : 0.f;
   }
-  __shared__ __attribute__((aligned(16))) float wfs[192];
-  if (tid < 48) *reinterpret_cast<float4*>(wfs + tid * 4) = *reinterpret_cast<const float4*>(wf + tid * 4);
 
   // ELU + split once per element
 #pragma unroll
@@ -179,17 +192,31 @@ __global__ __launch_bounds__(256) void seanet_tail_kernel(const float* __restric
     s += __shfl_xor(s, 1, 64);
     if (half == 0 && i < TO && s0 + i < T) wav[(int64_t)b * wav_seg_stride + s0 + i] = s + bf;
   }
+  }  // tiles of this workgroup
 }
 
 }  // namespace
+
+static int g_tail_tiles = 0;  // developer probe / tests: tiles per workgroup, 0 = heuristic
+extern "C" int sopro_seanet_tail_set_tiles(int tiles) {
+  g_tail_tiles = tiles > 0 ? tiles : 0;
+  return 0;
+}
 
 extern "C" int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
                                       const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
                                       int32_t T, void* stream) {
   SOPRO_CHECK_ARG(h && w1 && b1 && w2 && b2 && wf && wav && B > 0 && T > 0, "bad pointers or sizes");
   SOPRO_CHECK_ARG(aligned16(h) && aligned16(w1) && aligned16(w2) && aligned16(wf) && (h_seg_stride & 3) == 0, "alignment");
-  dim3 grid((T + TO - 1) / TO, B);
-  hipLaunchKernelGGL(seanet_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, wf, bf, wav,
-                     wav_seg_stride, T);
+  const int ntile = (T + TO - 1) / TO;
+  // several tiles per workgroup once there are enough of them to keep every CU supplied (>= 8 workgroups per CU after the grouping)
+  const int tiles = g_tail_tiles > 0 ? g_tail_tiles : ((int64_t)ntile * B >= 16 * 2048 ? 16 : ((int64_t)ntile * B >= 8 * 1024 ? 8 : 1));
+  dim3 grid((ntile + tiles - 1) / tiles, B);
+  if (tiles > 1)
+    hipLaunchKernelGGL(seanet_tail_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, wf, bf, wav,
+                       wav_seg_stride, T, tiles);
+  else
+    hipLaunchKernelGGL(seanet_tail_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, wf, bf, wav,
+                       wav_seg_stride, T, 1);
   SOPRO_LAUNCH_CHECK();
 }

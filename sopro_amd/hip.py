@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -86,6 +86,7 @@ SYMBOLS = {
     "sopro_pack_w_bf16": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     "sopro_packed_w_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "sopro_gemm_bf16_set_tile_override": (C.c_int, [C.c_int]),
+    "sopro_seanet_tail_set_tiles": (C.c_int, [C.c_int]),
     "sopro_gemm_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_skinny_f32": (C.c_int, [C.POINTER(SkinnyArgs), _p]),
     "sopro_norm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32, _p]),

@@ -656,6 +656,30 @@ def test_seanet_tail_fused_matches_unfused_layers():
     close(wav, ref, 1e-4, "fused SEANet tail")  # split-bf16 contractions (16 mantissa bits per operand)
 
 
+def test_seanet_tail_tiles_per_workgroup_is_the_same_function():
+    """Large inputs give a workgroup several consecutive tiles (weight fragments prepared once): bit-identical samples."""
+    B, T = 3, 1000  # 8 tiles of 126 samples, the last one partial
+    hb = torch.zeros(B, 2 + T, 64)
+    hb[:, 2:] = rnd(B, T, 64, seed=710)
+    w1, b1 = rnd(32, 192, seed=711, scale=0.07), rnd(32, seed=712, scale=0.1)
+    w2, b2 = rnd(64, 32, seed=713, scale=0.17), rnd(64, seed=714, scale=0.1)
+    wf = rnd(3, 64, seed=715, scale=0.07)
+    args = [dev(x) for x in (hb, w1, b1, w2, b2, wf)]
+    lib, outs = hip.load(), []
+    try:
+        for tiles in (1, 3, 8, 16):
+            lib.sopro_seanet_tail_set_tiles(tiles)
+            wav = torch.full((B, T), float("nan"), device=DEV)
+            hip.seanet_tail(*args, 0.03, wav, B=B, T=T, h_seg_stride=(2 + T) * 64, wav_seg_stride=T)
+            torch.cuda.synchronize()
+            outs.append(wav.cpu())
+    finally:
+        lib.sopro_seanet_tail_set_tiles(0)
+    assert bool(torch.isfinite(outs[0]).all())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 # ------------------------------------------------------------------------------------------ sampler
 class _SamplerRig:
     def __init__(self, B, Tar=64, D=384, V=2048):
