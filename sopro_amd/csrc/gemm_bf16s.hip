@@ -88,15 +88,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     biasv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
   }
 
-  float4 ra[A_F4];
+  float4 raA[A_F4], raB[A_F4];  // A rows are requested TWO K-steps ahead (they come from HBM; W, one step ahead, from L2)
   float ssq[A_F4];
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) ssq[i] = 0.f;
-  float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pvA = make_float4(0.f, 0.f, 0.f, 0.f), pvB = pvA;
   const int KT = (g.K + BK - 1) / BK;
   const int klast = g.K - 4;
 
-  auto gload = [&](int kt) {  // split-form A has the fp32 addresses: a K-step is the same 128 bytes of the row
+  auto gload = [&](int kt, float4 (&ra)[A_F4], float4& pv) {  // split-form A has the fp32 addresses: a K-step is the same 128 bytes of the row
     const int k = min(kt * BK + lc4 * 4, klast);
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i] + k);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
 #pragma unroll
         for (int p = 0; p < NPL; ++p) rb[j][s][p] = bp[j][((int64_t)(kt * 2 + s) * NPL + p) * 64];
   };
-  auto lstore = [&](int buf, bool fresh = true) {  // fresh: not the clamped re-stage of the last step (RMSNorm sums count once)
+  auto lstore = [&](int buf, float4 (&ra)[A_F4], const float4& pv, bool fresh = true) {  // fresh: not the clamped re-stage of the last step (RMSNorm sums count once)
     if (AMODE == 2) {  // pieces 0-3 of the 128-byte group are the hi halves, 4-7 the lo halves: the LDS row layout
       unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 16;
 #pragma unroll
@@ -185,26 +185,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   const int nkt = max(0, min(KT, kt0 + per) - kt0);  // K-steps of this slice (0 for a trailing empty slice)
   const int ktl = max(kt0, kt0 + nkt - 1);           // last valid step of the slice (prefetch clamp)
 
-  // Two K-steps per trip (register double buffer for the B fragments, LDS double buffer for A).  The prefetch of the
-  // step after the last one is clamped onto the last step: redundant but branch-free.
+  // Two K-steps per trip (register double buffers for the B fragments and the A rows, LDS double buffer for the split A).
+  // Prefetches beyond the last step are clamped onto it: redundant but branch-free.
   uint4 rb0[TN][2][NPL], rb1[TN][2][NPL];
-  gload(min(kt0, KT - 1));
+  gload(min(kt0, KT - 1), raA, pvA);
   bload(min(kt0, KT - 1), rb0);
-  lstore(0);
+  gload(min(min(kt0 + 1, ktl), KT - 1), raB, pvB);
+  lstore(0, raA, pvA);
   __syncthreads();
   if (dbg && tid == 0) dbg[1] = clock64();
   for (int it = 0; it < nkt; it += 2) {
-    const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl);
-    gload(k1);
+    const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl), k3 = min(kt0 + it + 3, ktl);
+    gload(k2, raA, pvA);
     bload(k1, rb1);
     compute(0, rb0);
-    lstore(1, it + 1 < nkt);
+    lstore(1, raB, pvB, it + 1 < nkt);
     __syncthreads();
     if (it + 1 >= nkt) break;
-    gload(k2);
+    gload(k3, raB, pvB);
     bload(k2, rb0);
     compute(1, rb1);
-    lstore(0, it + 2 < nkt);
+    lstore(0, raA, pvA, it + 2 < nkt);
     __syncthreads();
   }
   if (dbg && tid == 0) dbg[2] = clock64();
