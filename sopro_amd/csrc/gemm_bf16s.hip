@@ -111,34 +111,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
         for (int p = 0; p < NPL; ++p) rb[j][s][p] = bp[j][((int64_t)(kt * 2 + s) * NPL + p) * 64];
   };
   auto lstore = [&](int buf, float4 (&ra)[A_F4], const float4& pv, bool fresh = true) {  // fresh: not the clamped re-stage of the last step (RMSNorm sums count once)
-    if (AMODE == 2) {  // pieces 0-3 of the 128-byte group are the hi halves, 4-7 the lo halves: the LDS row layout
+    if constexpr (AMODE == 2) {  // pieces 0-3 of the 128-byte group are the hi halves, 4-7 the lo halves: the LDS row layout
       unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 16;
 #pragma unroll
-      for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(a + i * RSTEP * AROW) = ra[i];
-      return;
-    }
-    if (AMODE == 1) {
+      for (int i = 0; i < A_F4; ++i)  // member-wise: whole-struct copies keep the array in scratch memory (no promotion to registers)
+        *reinterpret_cast<f32x4*>(a + i * RSTEP * AROW) = (f32x4){ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+    } else {
+      if constexpr (AMODE == 1) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+          ra[i].x = eluf_(ra[i].x); ra[i].y = eluf_(ra[i].y); ra[i].z = eluf_(ra[i].z); ra[i].w = eluf_(ra[i].w);
+        }
+      } else if constexpr (AMODE == 3) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) { ra[i].x += pv.x; ra[i].y += pv.y; ra[i].z += pv.z; ra[i].w += pv.w; }
+      }
+      if constexpr (AMODE == 4) {
+        if (fresh) {
+#pragma unroll
+          for (int i = 0; i < A_F4; ++i)
+            ssq[i] = fmaf(ra[i].x, ra[i].x, fmaf(ra[i].y, ra[i].y, fmaf(ra[i].z, ra[i].z, fmaf(ra[i].w, ra[i].w, ssq[i]))));
+        }
+      }
+      unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 8;
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
-        ra[i].x = eluf_(ra[i].x); ra[i].y = eluf_(ra[i].y); ra[i].z = eluf_(ra[i].z); ra[i].w = eluf_(ra[i].w);
+        unsigned c0[NPL], c1[NPL];
+        split_pair<NPL>(ra[i].x, ra[i].y, c0);
+        split_pair<NPL>(ra[i].z, ra[i].w, c1);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(a + i * RSTEP * AROW + p * 64) = make_uint2(c0[p], c1[p]);
       }
-    } else if (AMODE == 3) {
-#pragma unroll
-      for (int i = 0; i < A_F4; ++i) { ra[i].x += pv.x; ra[i].y += pv.y; ra[i].z += pv.z; ra[i].w += pv.w; }
-    }
-    if (AMODE == 4 && fresh) {
-#pragma unroll
-      for (int i = 0; i < A_F4; ++i)
-        ssq[i] = fmaf(ra[i].x, ra[i].x, fmaf(ra[i].y, ra[i].y, fmaf(ra[i].z, ra[i].z, fmaf(ra[i].w, ra[i].w, ssq[i]))));
-    }
-    unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 8;
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-      unsigned c0[NPL], c1[NPL];
-      split_pair<NPL>(ra[i].x, ra[i].y, c0);
-      split_pair<NPL>(ra[i].z, ra[i].w, c1);
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(a + i * RSTEP * AROW + p * 64) = make_uint2(c0[p], c1[p]);
     }
   };
 
@@ -188,21 +191,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   // Two K-steps per trip (register double buffers for the B fragments and the A rows, LDS double buffer for the split A).
   // Prefetches beyond the last step are clamped onto it: redundant but branch-free.
   uint4 rb0[TN][2][NPL], rb1[TN][2][NPL];
+  constexpr bool DEEP = true;  // A rows two K-steps ahead (false: one step ahead, one register set)
   gload(min(kt0, KT - 1), raA, pvA);
   bload(min(kt0, KT - 1), rb0);
-  gload(min(min(kt0 + 1, ktl), KT - 1), raB, pvB);
+  if (DEEP) gload(min(min(kt0 + 1, ktl), KT - 1), raB, pvB);
   lstore(0, raA, pvA);
   __syncthreads();
   if (dbg && tid == 0) dbg[1] = clock64();
   for (int it = 0; it < nkt; it += 2) {
     const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl), k3 = min(kt0 + it + 3, ktl);
-    gload(k2, raA, pvA);
+    if (DEEP) gload(k2, raA, pvA); else gload(k1, raA, pvA);
     bload(k1, rb1);
     compute(0, rb0);
-    lstore(1, raB, pvB, it + 1 < nkt);
+    if (DEEP) lstore(1, raB, pvB, it + 1 < nkt); else lstore(1, raA, pvA, it + 1 < nkt);
     __syncthreads();
     if (it + 1 >= nkt) break;
-    gload(k3, raB, pvB);
+    if (DEEP) gload(k3, raB, pvB); else gload(k2, raA, pvA);
     bload(k2, rb0);
     compute(1, rb1);
     lstore(0, raA, pvA, it + 2 < nkt);
