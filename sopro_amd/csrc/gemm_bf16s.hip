@@ -18,6 +18,14 @@ namespace {
 
 constexpr int BK = 32;
 
+// Developer ablation builds (tools/micro/build_ablate.sh, never the product library): bit 0 drops the MFMAs (fragment reads are
+// kept alive by a cheap fold), bit 1 the A path after the first tile (no global loads, no split, no LDS stores), bit 2 the W
+// loads after the first step, bit 3 the per-step barriers.  Results are meaningless; the time of what is left is the point.
+#ifndef SOPRO_ABLATE
+#define SOPRO_ABLATE 0
+#endif
+constexpr int ABL = SOPRO_ABLATE;
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ bf16x8 as_frag(const uint4& v) { return *reinterpret_cast<const bf16x8*>(&v); }
@@ -174,7 +182,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af[i][PA[q]]), as_frag(rb[j][s][PB[q]]), acc[i][j], 0, 0, 0);
+            if constexpr (ABL & 1)
+              acc[i][j][q & 15] += __uint_as_float((af[i][PA[q]].x ^ rb[j][s][PB[q]].y) & 0x3fffffffu);
+            else
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af[i][PA[q]]), as_frag(rb[j][s][PB[q]]), acc[i][j], 0, 0, 0);
     }
   };
 
@@ -200,17 +211,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   if (dbg && tid == 0) dbg[1] = clock64();
   for (int it = 0; it < nkt; it += 2) {
     const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl), k3 = min(kt0 + it + 3, ktl);
-    if (DEEP) gload(k2, raA, pvA); else gload(k1, raA, pvA);
-    bload(k1, rb1);
-    compute(0, rb0);
-    if (DEEP) lstore(1, raB, pvB, it + 1 < nkt); else lstore(1, raA, pvA, it + 1 < nkt);
-    __syncthreads();
+    if (!(ABL & 2)) { if (DEEP) gload(k2, raA, pvA); else gload(k1, raA, pvA); }
+    if (!(ABL & 4)) bload(k1, rb1);
+    compute(0, (ABL & 4) ? rb0 : rb0);
+    if (!(ABL & 2)) { if (DEEP) lstore(1, raB, pvB, it + 1 < nkt); else lstore(1, raA, pvA, it + 1 < nkt); }
+    if (!(ABL & 8)) __syncthreads();
     if (it + 1 >= nkt) break;
-    if (DEEP) gload(k3, raB, pvB); else gload(k2, raA, pvA);
-    bload(k2, rb0);
-    compute(1, rb1);
-    lstore(0, raA, pvA, it + 2 < nkt);
-    __syncthreads();
+    if (!(ABL & 2)) { if (DEEP) gload(k3, raB, pvB); else gload(k2, raA, pvA); }
+    if (!(ABL & 4)) bload(k2, rb0);
+    compute((ABL & 2) ? 0 : 1, (ABL & 4) ? rb0 : rb1);
+    if (!(ABL & 2)) lstore(0, raA, pvA, it + 2 < nkt);
+    if (!(ABL & 8)) __syncthreads();
   }
   if (dbg && tid == 0) dbg[2] = clock64();
   if constexpr (SK) {

@@ -126,11 +126,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SOPRO_HIP_LIB") or LIB_PATH  # developer override (ablation builds of tools/micro); same ABI checks
+    if not os.path.exists(path):
         raise SoproHipError(
-            f"{LIB_PATH} not found: the HIP kernel library is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: the HIP kernel library is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C sopro_amd/csrc`). There is no CPU / torch fallback for the Sopro hot path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
