@@ -312,7 +312,8 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
   const int klen = a.klens ? min(a.klens[b], a.S_cap) : a.S_cap;
   const float* Kb = a.Kp + ((int64_t)(b * a.H + h) * a.S_cap) * XD;
   const float* Vb = a.Vp + ((int64_t)(b * a.H + h) * a.S_cap) * XD;
-  const int key = tid >> 3, part = tid & 7;   // score mapping: 8 lanes share a key, 48 floats each
+  const int key = tid >> 3, part = tid & 7;   // score mapping: 8 lanes share a key; float4 f*8+part of its row each, so that one
+                                              // load instruction covers whole 128-byte lines (8 per wave instead of 64)
   const int vd4 = tid % 96, vg = tid / 96;    // P.V' mapping: float4 column, 16-key group (vg < 4)
 
   float m_run = -INFINITY, l_run = 0.f;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
 #pragma unroll
     for (int f = 0; f < 12; ++f) {
       kreg[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kin) kreg[f] = *reinterpret_cast<const float4*>(Kb + (int64_t)(k0 + key) * XD + part * 48 + f * 4);
+      if (kin) kreg[f] = *reinterpret_cast<const float4*>(Kb + (int64_t)(k0 + key) * XD + (f * 8 + part) * 4);
     }
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
     float s = 0.f;
 #pragma unroll
     for (int f = 0; f < 12; ++f) {
-      const float4 q4 = *reinterpret_cast<const float4*>(xn + part * 48 + f * 4);
+      const float4 q4 = *reinterpret_cast<const float4*>(xn + (f * 8 + part) * 4);
       s += q4.x * kreg[f].x + q4.y * kreg[f].y + q4.z * kreg[f].z + q4.w * kreg[f].w;
     }
     s += __shfl_xor(s, 1, 64);
