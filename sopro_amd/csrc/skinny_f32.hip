@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
   const float* wrow = a.W + (int64_t)w_row * a.ldw;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int srow = tid >> 4, spart = tid & 15;  // staging: row, 24-float part
+  const int srow = tid >> 4, spart = tid & 15;  // staging: row, float4 column within each 64-float group
   const int b_ld = min(bbase + srow, a.B - 1);
   unsigned slot0 = 0;  // ring slot of the oldest tap, (t + 1) mod L: one division, then increments
   float tapv[MAXTAPS - 1];
@@ -96,14 +96,15 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
     // ---- input slice (+ producer's partial sums, fixed order) -> LDS
     {
       float4 xv[SQ], pv[NP > 0 ? NP : 1][SQ];
-      const float* xp = a.X + (int64_t)b_ld * a.ldx + k0 + spart * 24;
+      // lane-contiguous: float4 q*16 + spart of the row, so that the 16 lanes of a row cover whole 128-byte lines per instruction
+      const float* xp = a.X + (int64_t)b_ld * a.ldx + k0 + spart * 4;
 #pragma unroll
-      for (int q = 0; q < SQ; ++q) xv[q] = *reinterpret_cast<const float4*>(xp + q * 4);
+      for (int q = 0; q < SQ; ++q) xv[q] = *reinterpret_cast<const float4*>(xp + q * 64);
 #pragma unroll
       for (int sidx = 0; sidx < NP; ++sidx) {
-        const float* pp = a.Xp + (int64_t)sidx * a.xp_stride + (int64_t)b_ld * a.ldx + k0 + spart * 24;
+        const float* pp = a.Xp + (int64_t)sidx * a.xp_stride + (int64_t)b_ld * a.ldx + k0 + spart * 4;
 #pragma unroll
-        for (int q = 0; q < SQ; ++q) pv[sidx][q] = *reinterpret_cast<const float4*>(pp + q * 4);
+        for (int q = 0; q < SQ; ++q) pv[sidx][q] = *reinterpret_cast<const float4*>(pp + q * 64);
       }
 #pragma unroll
       for (int sidx = 0; sidx < NP; ++sidx)
@@ -121,9 +122,9 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
         ss += __shfl_xor(ss, 8, 64);
         if (spart == 0) rstd_s[srow] = rsqrtf(ss / (float)KS + a.eps);
       }
-      float* dst = xs + srow * XLD + spart * 24;
+      float* dst = xs + srow * XLD + spart * 4;
 #pragma unroll
-      for (int q = 0; q < SQ; ++q) *reinterpret_cast<float4*>(dst + q * 4) = xv[q];
+      for (int q = 0; q < SQ; ++q) *reinterpret_cast<float4*>(dst + q * 64) = xv[q];
     }
     // ---- ring-buffer taps of earlier frames: addresses need the frame index; values are used in the epilogue
     if (GLU) {
