@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 15
+#define SOPRO_ABI_VERSION 16
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -160,8 +160,15 @@ typedef struct sopro_skinny_args {
   int32_t B, N, K, epilogue;
   int32_t ring_len, ring_bcap, dil, ksize;
   int32_t np, ksplit, rms_norm;
+  int32_t w_layout;       /* 0: W is [N, ldw] row-major; 1: W was laid out by sopro_pack_skinny_w (ldw unused) */
 } sopro_skinny_args;
 int sopro_skinny_f32(const sopro_skinny_args* args, void* stream);
+/* Fragment order for the AR-step weights: [column tile][K/32][2][64 lanes][4 floats] - lane (i = lane & 15, g = lane >> 4) of
+ * tile t holds k = 32*chunk + 8*g + 4*half .. +3 of weight row t*16 + i (glu = 0) or of the value row t*8 + (i & 7) (i < 8) /
+ * gate row N/2 + t*8 + (i & 7) (glu = 1: the packed value/gate pairing of EPI_GLU_DW), so that every load instruction of the
+ * kernel reads 1 KiB of consecutive memory.  Rows past N are zero.  `out` holds sopro_skinny_packed_floats(N, K, glu) floats. */
+int sopro_pack_skinny_w(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t glu, float* out, void* stream);
+int64_t sopro_skinny_packed_floats(int32_t N, int32_t K, int32_t glu);
 
 /* ---- normalisation / elementwise ------------------------------------------------------- */
 enum { SOPRO_NORM_RMS = 0, SOPRO_NORM_LN = 1 };

@@ -75,7 +75,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
     }
   }
 
-  const float* wrow = a.W + (int64_t)w_row * a.ldw;
+  // weight fragment addresses: row-major rows of W, or the fragment order of sopro_pack_skinny_w (1 KiB per load instruction)
+  const bool packed = a.w_layout == 1;
+  const int kchunks = a.K >> 5;
+  const float* wbase = packed ? a.W + ((int64_t)ntile * kchunks * 2) * 256 + lane * 4 : a.W + (int64_t)w_row * a.ldw + g * 8;
+  const int64_t w_chunk = packed ? 512 : 32, w_half = packed ? 256 : 4;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int srow = tid >> 4, spart = tid & 15;  // staging: row, float4 column within each 64-float group
@@ -89,9 +93,9 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
     float4 wf[3][2];
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc) {
-      const int kb = k0 + (wave * 3 + cc) * 32 + g * 8;
-      wf[cc][0] = *reinterpret_cast<const float4*>(wrow + kb);
-      wf[cc][1] = *reinterpret_cast<const float4*>(wrow + kb + 4);
+      const float* wp = wbase + (int64_t)((k0 >> 5) + wave * 3 + cc) * w_chunk;
+      wf[cc][0] = *reinterpret_cast<const float4*>(wp);
+      wf[cc][1] = *reinterpret_cast<const float4*>(wp + w_half);
     }
     // ---- input slice (+ producer's partial sums, fixed order) -> LDS
     {
@@ -199,6 +203,33 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
   if (dbg && tid == 0) dbg[5] = clock64();
 }
 
+// one thread per float4 of the packed image
+__global__ __launch_bounds__(256) void pack_skinny_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, int glu,
+                                                          float4* __restrict__ out, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63), half = (int)((idx >> 6) & 1);
+  const int64_t tc = idx >> 7;
+  const int kchunks = K >> 5;
+  const int chunk = (int)(tc % kchunks), t = (int)(tc / kchunks);
+  const int i = lane & 15, g = lane >> 4;
+  const int D = N / 2;
+  int row;
+  bool ok;
+  if (glu) {
+    const int n = t * 8 + (i & 7);
+    ok = n < D;
+    row = (i < 8) ? n : D + n;
+  } else {
+    row = t * 16 + i;
+    ok = row < N;
+  }
+  const int k = chunk * 32 + g * 8 + half * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) v = *reinterpret_cast<const float4*>(W + (int64_t)row * ldw + k);
+  out[idx] = v;
+}
+
 template <bool GLU, int NP, bool NORM>
 int launch(const sopro_skinny_args& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM>), grid, dim3(256), 0, s, a);
@@ -207,6 +238,22 @@ int launch(const sopro_skinny_args& a, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int64_t sopro_skinny_packed_floats(int32_t N, int32_t K, int32_t glu) {
+  if (N <= 0 || K <= 0 || (K & 31) || (glu && (N & 1))) return 0;
+  const int64_t tiles = glu ? (N / 2 + 7) / 8 : (N + 15) / 16;
+  return tiles * (K >> 5) * 512;
+}
+
+extern "C" int sopro_pack_skinny_w(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t glu, float* out, void* stream) {
+  SOPRO_CHECK_ARG(W && out && N > 0 && K > 0 && ldw >= K, "bad pointers or sizes");
+  SOPRO_CHECK_ARG((K & 31) == 0 && (ldw & 3) == 0 && aligned16(W) && aligned16(out), "K % 32 == 0, ldw % 4 == 0, 16-byte aligned W / out");
+  SOPRO_CHECK_ARG(!glu || (N & 1) == 0, "glu: N must be even");
+  const int64_t total = sopro_skinny_packed_floats(N, K, glu) / 4;
+  hipLaunchKernelGGL(pack_skinny_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, glu,
+                     reinterpret_cast<float4*>(out), total);
+  SOPRO_LAUNCH_CHECK();
+}
+
 extern "C" int sopro_skinny_f32(const sopro_skinny_args* p, void* stream) {
   SOPRO_CHECK_ARG(p != nullptr, "args is NULL");
   const sopro_skinny_args& a = *p;
@@ -214,6 +261,7 @@ extern "C" int sopro_skinny_f32(const sopro_skinny_args* p, void* stream) {
   SOPRO_CHECK_ARG((a.K % KS) == 0, "K must be a multiple of 384");
   SOPRO_CHECK_ARG(a.X && a.W && a.Y, "X, W, Y must be non-NULL");
   SOPRO_CHECK_ARG(aligned16(a.X) && aligned16(a.W) && (a.ldx & 3) == 0 && (a.ldw & 3) == 0, "X/W must be 16-byte aligned with ld % 4 == 0");
+  SOPRO_CHECK_ARG(a.w_layout == 0 || a.w_layout == 1, "w_layout must be 0 (row-major) or 1 (sopro_pack_skinny_w)");
   SOPRO_CHECK_ARG(!a.rms_norm || a.K == KS, "rms_norm needs K == 384");
   SOPRO_CHECK_ARG(a.epilogue != SOPRO_EPI_RES || a.R, "EPI_RES needs R");
   SOPRO_CHECK_ARG(a.epilogue != SOPRO_EPI_GLU, "EPI_GLU is not a skinny epilogue (use EPI_GLU_DW)");

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -45,7 +45,7 @@ class SkinnyArgs(C.Structure):
                 ("Xp", _p), ("xp_stride", _i64), ("y_part_stride", _i64), ("dbg", _p), ("eps", _f32),
                 ("B", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32),
                 ("ring_len", _i32), ("ring_bcap", _i32), ("dil", _i32), ("ksize", _i32),
-                ("np", _i32), ("ksplit", _i32), ("rms_norm", _i32)]
+                ("np", _i32), ("ksplit", _i32), ("rms_norm", _i32), ("w_layout", _i32)]
 
 
 class AttnArgs(C.Structure):
@@ -88,6 +88,8 @@ SYMBOLS = {
     "sopro_gemm_bf16_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_seanet_tail_set_tiles": (C.c_int, [C.c_int]),
     "sopro_gemm_set_tile_override": (C.c_int, [C.c_int]),
+    "sopro_pack_skinny_w": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
+    "sopro_skinny_packed_floats": (_i64, [_i32, _i32, _i32]),
     "sopro_skinny_f32": (C.c_int, [C.POINTER(SkinnyArgs), _p]),
     "sopro_norm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32, _p]),
     "sopro_rms_match_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
@@ -330,7 +332,28 @@ def pack_w_bf16x6(W: torch.Tensor) -> PackedW:
     return pack_w_bf16(W, 3)
 
 
-def skinny(X: torch.Tensor, W: torch.Tensor, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: Optional[int] = None,
+class SkinnyW:
+    """AR-step weights in the fragment order of ``sopro_pack_skinny_w`` (every load instruction reads 1 KiB of consecutive memory)."""
+
+    __slots__ = ("data", "N", "K", "glu")
+
+    def __init__(self, data: torch.Tensor, N: int, K: int, glu: bool):
+        self.data, self.N, self.K, self.glu = data, N, K, glu
+
+
+def pack_skinny_w(W: torch.Tensor, glu: bool = False) -> SkinnyW:
+    N, K = int(W.shape[0]), int(W.shape[1])
+    n = int(load().sopro_skinny_packed_floats(N, K, int(glu)))
+    if n <= 0:
+        raise SoproHipError(f"pack_skinny_w: unsupported shape {N}x{K} (K % 32 == 0; glu: N even)")
+    Wc = W.contiguous()
+    out = torch.empty(n, dtype=torch.float32, device=W.device)
+    with torch.cuda.device(W.device):
+        _check(load().sopro_pack_skinny_w(ptr(Wc), K, N, K, int(glu), ptr(out), _stream()), "sopro_pack_skinny_w")
+    return SkinnyW(out, N, K, bool(glu))
+
+
+def skinny(X: torch.Tensor, W, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: Optional[int] = None,
            ldy: Optional[int] = None, rms_norm: bool = False, eps: float = 1e-6, bias: Optional[torch.Tensor] = None,
            epilogue: int = EPI_NONE, R: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
            scale: Optional[torch.Tensor] = None, ring: Optional[torch.Tensor] = None, dw_w: Optional[torch.Tensor] = None,
@@ -340,7 +363,13 @@ def skinny(X: torch.Tensor, W: torch.Tensor, Y: torch.Tensor, *, B: int, N: int,
     """AR-step contraction.  With rms_norm the RMSNorm weight must already be folded into W (W * w_norm[None, :])."""
     a = SkinnyArgs()
     a.X, a.ldx = ptr(X), (K if ldx is None else ldx)
-    a.W, a.ldw, a.bias = ptr(W), K, ptr(bias)
+    if isinstance(W, SkinnyW):
+        if (W.N, W.K, W.glu) != (N, K, epilogue == EPI_GLU_DW):
+            raise SoproHipError(f"packed weight is {W.N}x{W.K} glu={W.glu}, the call says {N}x{K} glu={epilogue == EPI_GLU_DW}")
+        a.W, a.ldw, a.w_layout = ptr(W.data), K, 1
+    else:
+        a.W, a.ldw = ptr(W), K
+    a.bias = ptr(bias)
     n_out = N // 2 if epilogue == EPI_GLU_DW else N
     a.Y, a.ldy = ptr(Y), (n_out if ldy is None else ldy)
     a.R, a.ldr, a.scale = ptr(R), (n_out if ldr is None else ldr), ptr(scale)

@@ -128,6 +128,16 @@ class SoproTTSModel:
                             continue
                         self.wx[k] = hip.pack_w_bf16x6(v)
                 torch.cuda.synchronize(self.device)
+        # AR-step weights in the fragment order of the skinny kernel (1 KiB of consecutive memory per load instruction);
+        # SOPRO_AR_ROWMAJOR=1 keeps the row-major matrices.
+        self.wk: Dict[str, hip.SkinnyW] = {}
+        if os.environ.get("SOPRO_AR_ROWMAJOR", "0") != "1":
+            with torch.cuda.device(self.device):
+                for k, v in self.w.items():
+                    if (k.startswith("ar.blocks.") and k.endswith((".glu.w", ".ff1.w", ".ff2.w"))) or k == "ar.head.w":
+                        if v.dim() == 2 and int(v.shape[1]) % 32 == 0:
+                            self.wk[k] = hip.pack_skinny_w(v, glu=k.endswith(".glu.w"))
+                torch.cuda.synchronize(self.device)
         self._ones: Dict[int, torch.Tensor] = {}
         sc = cfg.stage_codebooks()
         self._stage_cbs = [(s, sc[s]) for s in cfg.stage_order()]
@@ -651,6 +661,7 @@ class _ARPlan:
         # while staging: the K-slices of a feed-forward output (slice 0 carries bias + residual) or the per-head
         # outputs of a cross-attention block (head 0 carries the residual).
         X0, XA, XB, _XC = self.x
+        wk = lambda key: m.wk.get(key) or w[key]  # noqa: E731  (fragment-ordered weights when packed)
         KS = 4 * D // 384  # FF2 K slices
         pk_ff = dict(Xp=self.part[1:], np_=KS - 1, xp_stride=B * D)
         pk_xa = dict(Xp=self.xp[1:], np_=H - 1, xp_stride=B * D)
@@ -660,15 +671,15 @@ class _ARPlan:
             p = f"ar.blocks.{i}"
             out = XA if i % 2 == 0 else XB
             # RMSNorm -> GLU -> ring write -> dilated taps -> +x   (src/sopro/nn/blocks.py:150-157, 76-110)
-            hip.skinny(base, w[p + ".glu.w"], out, B=B, N=2 * D, K=D, rms_norm=True, eps=RMS_EPS, bias=w[p + ".glu.b"],
+            hip.skinny(base, wk(p + ".glu.w"), out, B=B, N=2 * D, K=D, rms_norm=True, eps=RMS_EPS, bias=w[p + ".glu.b"],
                        epilogue=hip.EPI_GLU_DW, ring=self.rings[i], dw_w=w[p + ".dw.w"], dw_b=w[p + ".dw.b"], step=self.step_t,
                        ring_len=(k - 1) * int(dil) + 1, dil=int(dil), ksize=k,
                        ring_bcap=B, **pend)
             # RMSNorm -> Linear -> GELU (blocks.py:158-160)
-            hip.skinny(out, w[p + ".ff1.w"], self.u, B=B, N=4 * D, K=D, rms_norm=True, eps=RMS_EPS,
+            hip.skinny(out, wk(p + ".ff1.w"), self.u, B=B, N=4 * D, K=D, rms_norm=True, eps=RMS_EPS,
                        bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
             # Linear 4D -> D + residual as 4 K-slices on 4x the workgroups (blocks.py:161-162)
-            hip.skinny(self.u, w[p + ".ff2.w"], self.part, B=B, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=out,
+            hip.skinny(self.u, wk(p + ".ff2.w"), self.part, B=B, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=out,
                        ksplit=True, y_part_stride=B * D)
             base, pend = self.part[0], pk_ff
             nl += 3
@@ -681,7 +692,7 @@ class _ARPlan:
                 nl += 1
         cur = base
         hk = pend
-        hip.skinny(cur, w["ar.head.w"], self.logits, B=B, N=m.V + 1, K=D, rms_norm=True, eps=RMS_EPS, bias=w["ar.head.b"], **hk)
+        hip.skinny(cur, wk("ar.head.w"), self.logits, B=B, N=m.V + 1, K=D, rms_norm=True, eps=RMS_EPS, bias=w["ar.head.b"], **hk)
         # the sampler writes the next frame's input into state.x_cur, which must be where block 0 reads
         hip.ar_sample(self.state, self.logits, m.V + 1)
         self.nlaunch = nl + 2

@@ -680,6 +680,38 @@ def test_seanet_tail_tiles_per_workgroup_is_the_same_function():
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("N,K,glu", [(1536, 384, False), (384, 1536, False), (2049, 384, False), (768, 384, True)])
+def test_skinny_packed_weights_are_the_same_function(N, K, glu):
+    """sopro_pack_skinny_w only changes where the kernel finds a weight: bit-identical outputs (ragged last tile, K slices, GLU tail)."""
+    B, D = 19, 384
+    X, W, b = rnd(B, K, seed=801), rnd(N, K, seed=802, scale=K ** -0.5), rnd(N, seed=803)
+    Wd, Wp = dev(W), hip.pack_skinny_w(dev(W), glu=glu)
+    outs = []
+    for Wx in (Wd, Wp):
+        if glu:
+            L, k, dil = 5, 3, 2
+            ring = dev(rnd(L, B, D, seed=804))
+            step = torch.tensor([3], dtype=torch.int32, device=DEV)
+            Y = torch.full((B, D), float("nan"), device=DEV)
+            hip.skinny(dev(X), Wx, Y, B=B, N=N, K=K, rms_norm=True, eps=1e-6, bias=dev(b), epilogue=hip.EPI_GLU_DW, ring=ring,
+                       dw_w=dev(rnd(k, D, seed=805)), dw_b=dev(rnd(D, seed=806)), step=step, ring_len=L, dil=dil, ksize=k, ring_bcap=B)
+            outs.append((Y.cpu(), ring.cpu()))
+        elif K > 384:
+            Y = torch.full((K // 384, B, N), float("nan"), device=DEV)
+            R = dev(rnd(B, N, seed=807))
+            hip.skinny(dev(X), Wx, Y, B=B, N=N, K=K, bias=dev(b), epilogue=hip.EPI_RES, R=R, ksplit=True, y_part_stride=B * N)
+            outs.append((Y.cpu(),))
+        else:
+            Y = torch.full((B, N), float("nan"), device=DEV)
+            hip.skinny(dev(X), Wx, Y, B=B, N=N, K=K, rms_norm=True, eps=1e-6, bias=dev(b), epilogue=hip.EPI_GELU)
+            outs.append((Y.cpu(),))
+    torch.cuda.synchronize()
+    for a, c in zip(outs[0], outs[1]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, c)
+    with pytest.raises(hip.SoproHipError):  # a packed weight knows its shape
+        hip.skinny(dev(X), Wp, torch.empty(B, N, device=DEV), B=B, N=N + 16, K=K)
+
+
 # ------------------------------------------------------------------------------------------ sampler
 class _SamplerRig:
     def __init__(self, B, Tar=64, D=384, V=2048):
