@@ -115,7 +115,7 @@ def main() -> None:
     ap.add_argument("--cpu-utts", type=int, default=6)
     ap.add_argument("--ttfa-runs", type=int, default=20)
     ap.add_argument("--lanes", type=int, default=4, help="engines pipelined on one GPU (1 = strictly sequential batches)")
-    ap.add_argument("--ar-cus", type=int, default=96, help="CUs of each AR partition (latency-bound phase) when lanes > 1")
+    ap.add_argument("--ar-cus", type=int, default=64, help="CUs of each AR partition (latency-bound phase) when lanes > 1")
     ap.add_argument("--ar-shared", type=int, default=1, help="1: the AR partitions are one CU range used by --ar-parts AR phases at once")
     ap.add_argument("--bulk-slots", type=int, default=1, help="refinement / decoding phases allowed at the same time on the throughput partition")
     ap.add_argument("--ar-parts", type=int, default=2, help="independent AR partitions (concurrent AR phases) when lanes > 1")

@@ -33,7 +33,7 @@ class _Request:
 
 
 class SynthesisService:
-    def __init__(self, tts, *, max_batch: int = 32, max_wait_ms: float = 4.0, lanes: int = 4, ar_cus: int = 96, ar_parts: int = 2,
+    def __init__(self, tts, *, max_batch: int = 32, max_wait_ms: float = 4.0, lanes: int = 4, ar_cus: int = 64, ar_parts: int = 2,
                  ar_shared: bool = True, mode: str = "batch", **continuous_kw):
         """``mode="batch"``: requests with equal parameters are grouped into batches for the lanes of a PipelinedSynthesizer.
         ``mode="continuous"``: frame-level admission (``ContinuousSynthesizer``; extra keywords go to it): parameters, frame
