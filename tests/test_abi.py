@@ -72,6 +72,21 @@ def test_bad_arguments_are_refused_with_a_message():
     assert lib.sopro_capture_begin(None) == -2
 
 
+def test_packed_layout_sizes():
+    """Host-side size functions of the two packed weight layouts (no device needed)."""
+    lib = hip.load()
+    # split-bf16 GEMM weights: [n/32][k/16][piece][64 lanes][16 B], K padded to 32
+    assert lib.sopro_packed_w_bytes(64, 32, 2) == 2 * 2 * 2 * 64 * 16
+    assert lib.sopro_packed_w_bytes(65, 33, 3) == 3 * 4 * 3 * 64 * 16
+    assert lib.sopro_packed_w_bytes(64, 32, 4) == 0 and lib.sopro_packed_w_bytes(0, 32, 2) == 0
+    # AR-step weights: [column tile][K/32][512 floats]; GLU tiles pair 8 value rows with 8 gate rows
+    assert lib.sopro_skinny_packed_floats(1536, 384, 0) == 96 * 12 * 512
+    assert lib.sopro_skinny_packed_floats(2049, 384, 0) == 129 * 12 * 512
+    assert lib.sopro_skinny_packed_floats(768, 384, 1) == 48 * 12 * 512
+    assert lib.sopro_skinny_packed_floats(768, 100, 0) == 0 and lib.sopro_skinny_packed_floats(767, 384, 1) == 0
+    assert lib.sopro_pack_skinny_w(None, 0, 16, 32, 0, None, None) == -2
+
+
 def test_engine_refuses_to_run_without_the_hip_device():
     import torch
 
