@@ -107,11 +107,26 @@ __global__ __launch_bounds__(NTH) void gemm_ws_kernel(const float* __restrict__ 
     constexpr int NSET = PD + 1;
     f32x4 ra[NSET][4];
     u32x4 rb[NSET][4];
+    // The loads are opaque to the compiler (inline asm) and waited for with a COUNTED vmcnt: left to itself hipcc drains every
+    // outstanding load (vmcnt(0)) at the first use after the spin loop, which collapses the prefetch distance.
     auto gload = [&](int kt, int set) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ra[set][i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+      for (int i = 0; i < 4; ++i) {
+        const float* pa = ap[i] + kt * BK;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[set][i]) : "v"(pa) : "memory");
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rb[set][i] = bp[i][(int64_t)kt * 256];
+      for (int i = 0; i < 4; ++i) {
+        const u32x4* pb = bp[i] + (int64_t)kt * 256;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[set][i]) : "v"(pb) : "memory");
+      }
+    };
+    auto gwait = [&](int set) {  // the 8 loads of `set` are the oldest outstanding ones: PD * 8 younger loads may stay in flight
+      asm volatile("s_waitcnt vmcnt(%8)"
+                   : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(ra[set][2]), "+v"(ra[set][3]), "+v"(rb[set][0]), "+v"(rb[set][1]),
+                     "+v"(rb[set][2]), "+v"(rb[set][3])
+                   : "n"(PD * 8)
+                   : "memory");
     };
 #pragma unroll
     for (int d = 0; d < PD; ++d) gload(min(d, KT - 1), d);
@@ -131,6 +146,7 @@ __global__ __launch_bounds__(NTH) void gemm_ws_kernel(const float* __restrict__ 
         if (lane == 0) atomicExch(err, 1);
         return;
       }
+      gwait(set);
       unsigned char* a = smem + st * STAGE + lrow * AROW + lc4 * 8;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -161,7 +177,12 @@ __global__ __launch_bounds__(NTH) void gemm_ws_kernel(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // fragments of K-step kt+1 are requested from LDS before the MFMAs of K-step kt are issued (two register sets)
-  u32x4 af[2][2][2][2], bf[2][2][2][2];  // [set][s][i or j][piece]
+#ifdef CONSUMER_PREFETCH
+  constexpr int CSETS = 2;
+#else
+  constexpr int CSETS = 1;
+#endif
+  u32x4 af[CSETS][2][2][2], bf[CSETS][2][2][2];  // [set][s][i or j][piece]
   bool ok = true;
   auto fetch = [&](int kt, int set) {
     const int st = kt % NSTAGE, round = kt / NSTAGE;
@@ -198,6 +219,7 @@ __global__ __launch_bounds__(NTH) void gemm_ws_kernel(const float* __restrict__ 
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af[set][s][i][PA[q]]), as_frag(bf[set][s][j][PB[q]]), acc[i][j], 0, 0, 0);
   };
+#ifdef CONSUMER_PREFETCH   // fragments of K-step kt+1 requested before the MFMAs of kt (two register sets): measured, no gain
   fetch(0, 0);
   release(0);
   for (int kt = 0; kt < KT && ok; kt += 2) {
@@ -209,6 +231,14 @@ __global__ __launch_bounds__(NTH) void gemm_ws_kernel(const float* __restrict__ 
     mma(1);
     if (kt + 2 < KT && ok) release(kt + 2);
   }
+#else
+  for (int kt = 0; kt < KT && ok; ++kt) {
+    fetch(kt, 0);
+    if (!ok) break;
+    release(kt);
+    mma(0);
+  }
+#endif
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + frow;
