@@ -139,20 +139,29 @@ __global__ __launch_bounds__(NTH) void gemm_ws_kernel(const float* __restrict__ 
       constexpr int dummy = 0;
       (void)dummy;
       const int set = u;
+#ifndef ABL_NOLOAD
       gload(min(kt + PD, KT - 1), (u + PD) % NSET);
+#endif
       const int st = kt % NSTAGE, round = kt / NSTAGE;
       // the stage must have been drained `round` times by all four consumer waves
       if (round > 0 && !wait_ge(empty + st, 4 * round)) {
         if (lane == 0) atomicExch(err, 1);
         return;
       }
+#ifndef ABL_NOLOAD
       gwait(set);
+#endif
       unsigned char* a = smem + st * STAGE + lrow * AROW + lc4 * 8;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         unsigned c0[2], c1[2];
+#ifdef ABL_NOSPLIT
+        c0[0] = __float_as_uint(ra[set][i][0]); c0[1] = __float_as_uint(ra[set][i][1]);
+        c1[0] = __float_as_uint(ra[set][i][2]); c1[1] = __float_as_uint(ra[set][i][3]);
+#else
         split_pair2(ra[set][i][0], ra[set][i][1], c0);
         split_pair2(ra[set][i][2], ra[set][i][3], c1);
+#endif
 #pragma unroll
         for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x2*>(a + i * 32 * AROW + p * 64) = (u32x2){c0[p], c1[p]};
       }
@@ -236,7 +245,11 @@ __global__ __launch_bounds__(NTH) void gemm_ws_kernel(const float* __restrict__ 
     fetch(kt, 0);
     if (!ok) break;
     release(kt);
+#ifdef ABL_NOMMA
+    acc[0][0][0] += __uint_as_float((af[0][0][0][0][0] ^ bf[0][1][1][1][1]) & 0x3fffffffu);
+#else
     mma(0);
+#endif
   }
 #endif
 #pragma unroll
