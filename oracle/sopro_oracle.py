@@ -436,6 +436,56 @@ def nar_refine(cond_btd: torch.Tensor, rvq1_bt: torch.Tensor, w: W, cfg, *,
     return out
 
 
+def nar_audit(cond_btd: torch.Tensor, tokens_btq: torch.Tensor, w: W, cfg) -> Tuple[int, float]:
+    """Teacher-forced audit of a refined token matrix (test infrastructure for near-tie arg-maxes): every stage is run on
+    the embeddings of the GIVEN tokens of the codebooks decided before it (so one flipped near-tie does not make every later
+    decision look wrong), and each given token is compared with this oracle's arg-max.  Returns (number of positions where
+    they differ, the largest logit gap ``max - logit[given]`` among those): a correct engine differs only where the gap is
+    round-off sized.  Same arithmetic as nar_refine above (src/sopro/model.py:307-347)."""
+    B, T, Q = tokens_btq.shape
+    V = int(cfg.codebook_size)
+    known = [0]
+    E = w["cb_embed.emb.weight"]
+    sc = cfg.stage_codebooks()
+    n_off, worst = 0, 0.0
+    for sid, stage in enumerate(cfg.stage_order()):
+        cbs = sc[stage]
+        cw = torch.softmax(w["nar_prev_cb_weights"][torch.tensor(known)].float(), dim=0)
+        prev = torch.zeros(B, T, int(cfg.d_model))
+        for j, cb in enumerate(known):
+            prev = prev + cw[j] * E[cb * V + tokens_btq[:, :, cb]]
+        logits = nar_forward_stage(stage, sid, cond_btd, prev, w, cfg)
+        for j, cb in enumerate(cbs):
+            given = tokens_btq[:, :, cb]
+            gap = logits[j].max(dim=-1).values - logits[j].gather(-1, given.unsqueeze(-1)).squeeze(-1)
+            off = logits[j].argmax(dim=-1) != given
+            n_off += int(off.sum())
+            if bool(off.any()):
+                worst = max(worst, float(gap[off].max()))
+        known = known + cbs
+    return n_off, worst
+
+
+def ar_audit_greedy(prep: Dict[str, torch.Tensor], tokens: Sequence[int], w: W, cfg, *, temperature: float = 1.0,
+                    repetition_penalty: float = 1.1) -> Tuple[int, float]:
+    """Teacher-forced audit of a greedy codebook-0 token list: the loop of ar_generate fed with the GIVEN history; returns
+    (steps where the given token is not this oracle's arg-max of the penalised logits, largest gap among those)."""
+    cond = prep["cond_ar"]
+    V = int(cfg.codebook_size)
+    st = ar_init_state(1, prep["txt_seq"], prep["text_mask"], w, cfg)
+    E = w["cb_embed.emb.weight"]
+    hist: List[int] = []
+    n_off, worst = 0, 0.0
+    for t, tok in enumerate(tokens):
+        prev = E[int(cfg.num_codebooks) * V] if t == 0 else E[hist[-1]]
+        xs = penalised_logits(ar_step(cond[:, t, :] + prev.unsqueeze(0), st, w, cfg)[0], hist, temperature, repetition_penalty)
+        if int(xs.argmax()) != int(tok):
+            n_off += 1
+            worst = max(worst, float(xs.max() - xs[int(tok)]))
+        hist.append(int(tok))
+    return n_off, worst
+
+
 def generate_tokens(ids_1d: torch.Tensor, ref: OracleReference, w: W, cfg, *, max_frames: int, top_p: float = 0.9,
                     temperature: float = 1.05, anti_loop: bool = True, style_strength: float = 1.0,
                     min_gen_frames: Optional[int] = None, gen: Optional[torch.Generator] = None) -> torch.Tensor:
@@ -512,6 +562,7 @@ class MimiKV:
     k: List[Optional[torch.Tensor]] = field(default_factory=list)
     v: List[Optional[torch.Tensor]] = field(default_factory=list)
     seen: int = 0
+    evict: bool = True  # False once rebuilt through the legacy-cache API (plain layers: nothing is dropped, see decode_step)
 
 
 def mimi_transformer(x_bnc: torch.Tensor, mw: W, mc, cache: Optional[MimiKV] = None, prefix: str = "decoder_transformer") -> torch.Tensor:
@@ -540,7 +591,7 @@ def mimi_transformer(x_bnc: torch.Tensor, mw: W, mc, cache: Optional[MimiKV] = N
                 k = torch.cat([cache.k[li], k], dim=2)
                 v = torch.cat([cache.v[li], v], dim=2)
             # DynamicSlidingWindowLayer keeps the last (window-1) positions for the next call
-            cache.k[li], cache.v[li] = k[:, :, -(win - 1):], v[:, :, -(win - 1):]
+            cache.k[li], cache.v[li] = (k[:, :, -(win - 1):], v[:, :, -(win - 1):]) if cache.evict else (k, v)
             kpos = torch.arange(past + N - k.shape[2], past + N)
         s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)
         vis = (kpos[None, :] <= pos[:, None]) & (kpos[None, :] > pos[:, None] - win)
@@ -720,10 +771,15 @@ class StreamDecodeState:
     tail_codes_tq: Optional[torch.Tensor] = None
 
 
-def decode_step(codes_chunk_tq: torch.Tensor, st: StreamDecodeState, mw: W, mc, overlap_frames: int = 2
+def decode_step(codes_chunk_tq: torch.Tensor, st: StreamDecodeState, mw: W, mc, overlap_frames: int = 2, trim: str = "none"
                 ) -> Tuple[torch.Tensor, StreamDecodeState]:
-    """reference: src/sopro/codec/mimi.py:115-181 as it behaves with the installed transformers
-    (``drop_cache_tail`` finds no legacy-cache API and trims nothing: SURVEY.md Appendix C)."""
+    """reference: src/sopro/codec/mimi.py:115-181.  ``trim="none"``: as it behaves with the installed transformers 5.x
+    (``drop_cache_tail`` finds no legacy-cache API and trims nothing: SURVEY.md Appendix C).  ``trim="legacy"``: the
+    legacy branch of ``drop_cache_tail`` (:92-103, transformers 4.57.6 API): the last ``ov`` cached positions of every
+    layer are dropped, the cache is rebuilt as plain (k, v) layers - which never evict - and the positions of the next
+    call continue from the trimmed length (quirk Q6: ``ov`` frames are 2*ov positions, only ov are dropped)."""
+    if trim not in ("none", "legacy"):
+        raise ValueError("trim must be 'none' or 'legacy'")
     hop = int(mc.frame_samples)
     n_new = int(codes_chunk_tq.shape[0])
     if n_new == 0:
@@ -735,6 +791,11 @@ def decode_step(codes_chunk_tq: torch.Tensor, st: StreamDecodeState, mw: W, mc, 
         codes_in = torch.cat([st.tail_codes_tq[-ov:], codes_chunk_tq], dim=0)
     if st.cache is None:
         st.cache = MimiKV()
+    if trim == "legacy" and ov > 0 and st.cache.k and st.cache.k[0] is not None:
+        c = st.cache
+        c.k = [t[:, :, : max(0, t.shape[2] - ov)] for t in c.k]
+        c.v = [t[:, :, : max(0, t.shape[2] - ov)] for t in c.v]
+        c.seen, c.evict = int(c.k[0].shape[2]), False
     wav = mimi_decode(codes_in.permute(1, 0).unsqueeze(0).contiguous(), mw, mc, st.cache).reshape(1, -1)
     wav = wav[:, : (ov + n_new) * hop][:, ov * hop:]
     st.frames_seen += n_new
@@ -757,7 +818,7 @@ def synthesize(ids_1d: torch.Tensor, ref: OracleReference, w: W, mw: W, cfg, mc,
 def stream(ids_1d: torch.Tensor, ref: OracleReference, w: W, mw: W, cfg, mc, *, max_frames: int = 400,
            top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True, style_strength: Optional[float] = None,
            chunk_frames: int = 6, nar_context_frames: Optional[int] = None, min_gen_frames: Optional[int] = None,
-           gen: Optional[torch.Generator] = None) -> Iterator[torch.Tensor]:
+           gen: Optional[torch.Generator] = None, trim: str = "none") -> Iterator[torch.Tensor]:
     """reference: src/sopro/streaming.py:24-152 (stops at the first EOS, :114-115)."""
     prep = prepare_conditioning(ids_1d, ref, w, cfg, max_frames=max_frames,
                                 style_strength=float(style_strength if style_strength is not None else cfg.style_strength))
@@ -772,7 +833,7 @@ def stream(ids_1d: torch.Tensor, ref: OracleReference, w: W, mw: W, cfg, mc, *, 
             return None
         ws = max(0, emitted - nar_ctx)
         toks = nar_refine(prep["cond_ar"][:, ws:end, :], torch.tensor(hist[ws:end]).unsqueeze(0), w, cfg).squeeze(0)
-        wav, st = decode_step(toks[emitted - ws:, :], st, mw, mc)
+        wav, st = decode_step(toks[emitted - ws:, :], st, mw, mc, trim=trim)
         emitted = end
         return wav if wav.numel() > 0 else None
 

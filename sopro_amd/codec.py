@@ -34,7 +34,8 @@ class MimiDecodeState:
 
     kv: Optional[List[torch.Tensor]] = None  # per layer [len, 1024] rows of (k | v), post-RoPE
     kv_len: int = 0
-    pos: int = 0  # transformer positions consumed so far
+    pos: int = 0  # transformer position of the next row
+    evict: bool = True  # sliding-window layers drop all but the last window-1 rows; False after a legacy-policy trim
     frames_seen: int = 0
     samples_emitted: int = 0
     tail_codes_tq: Optional[torch.Tensor] = None
@@ -80,6 +81,7 @@ class MimiCodec:
                 self.split_bf16, self.wd = False, {}
         self._rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._rope_n = 0
+        self._rope_old: List[Tuple[torch.Tensor, torch.Tensor]] = []  # outgrown tables stay alive: recorded graphs point at them
         self._banks: Dict[Tuple[int, int], tuple] = {}
         Q, V = self.num_quantizers, int(self.mc.codebook_size)
         ns = int(self.mc.num_semantic_quantizers)
@@ -102,9 +104,14 @@ class MimiCodec:
         return other
 
     def _rope_tables(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """cos / sin rows for positions [0, n).  Allocated once for 8192 positions (2 MB; a 400-frame stream() reaches ~1100,
+        a 40 s reference ~1000); a table that is ever outgrown is kept alive next to its replacement, because the launch
+        sequences recorded for synthesize() hold raw pointers into it."""
         if self._rope is None or self._rope_n < n:
-            n2 = max(1024, 2 * n)
+            n2 = max(8192, 2 * n)
             c, s = rope_tables(n2, int(self.mc.head_dim), float(self.mc.rope_theta))
+            if self._rope is not None:
+                self._rope_old.append(self._rope)
             self._rope = (c.to(self.device), s.to(self.device))
             self._rope_n = n2
         return self._rope
@@ -473,8 +480,9 @@ class MimiCodec:
                 hip.attention(qkv, allkv, allkv, ao, B=1, H=H, dh=dh, Tq=n, Tk=Tk, ldq=3 * HS, ldk=2 * HS, ldv=2 * HS, ldo=HS,
                               q_bstride=0, k_bstride=0, v_bstride=0, o_bstride=0, causal=True, window=win, q_pos0=past,
                               k_pos0=past + n - Tk, v_off=HS)
-                # DynamicSlidingWindowLayer keeps the last window-1 positions (installed transformers 5.x)
-                new_kv.append(allkv[-(win - 1):].clone())
+                # DynamicSlidingWindowLayer keeps the last window-1 positions (installed transformers 5.x); the plain layers
+                # a legacy-policy trim rebuilds the cache from keep everything (the window then acts through the mask only)
+                new_kv.append((allkv[-(win - 1):] if state.evict else allkv).clone())
             hip.gemm(ao, gw(p + ".o.w"), X, M=B * n, N=HS, K=HS, epilogue=hip.EPI_RES, R=X, scale=w[p + ".ls1"],
                      c_off=pad * HS, r_off=pad * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
             self._ln_stream(X, y, w[p + ".ln2.w"], w[p + ".ln2.b"], B, n, pad, HS, xs_stride)
@@ -499,12 +507,20 @@ class MimiCodec:
 
 class MimiStreamDecoder:
     """Chunked decode with a 2-frame token overlap and a growing transformer cache
-    (reference: src/sopro/codec/mimi.py:83-181, as it behaves with the installed transformers 5.x:
-    ``drop_cache_tail`` trims nothing)."""
+    (reference: src/sopro/codec/mimi.py:83-181).  The reference's output depends on the installed transformers (quirk Q6):
+      * ``trim="none"`` (default) - transformers 5.x: ``drop_cache_tail`` finds no legacy-cache API and trims nothing
+        (SURVEY.md Appendix C); the sliding-window cache layers keep the last 249 positions;
+      * ``trim="legacy"`` - the lock-pinned 4.57.6: ``drop_cache_tail``'s legacy branch (:92-103) drops the last ``ov``
+        cached positions of every layer (``ov`` frames are 2*ov positions: only half of the overlap goes), rebuilds the
+        cache as plain layers that never evict, and the next call's positions continue from the trimmed length.
+    Both are pinned by reference-generated fixtures (tests/golden/stream160.npz, stream_legacy.npz)."""
 
-    def __init__(self, codec: MimiCodec, overlap_frames: int = 2):
+    def __init__(self, codec: MimiCodec, overlap_frames: int = 2, trim: str = "none"):
+        if trim not in ("none", "legacy"):
+            raise ValueError("trim must be 'none' or 'legacy'")
         self.codec = codec
         self.overlap_frames = int(overlap_frames)
+        self.trim = trim
 
     @torch.inference_mode()
     def decode_step(self, codes_chunk_tq: torch.Tensor, state: Optional[MimiDecodeState] = None
@@ -521,6 +537,10 @@ class MimiStreamDecoder:
         if self.overlap_frames > 0 and st.tail_codes_tq is not None and st.tail_codes_tq.numel() > 0:
             ov = min(self.overlap_frames, int(st.tail_codes_tq.shape[0]))
             codes_in = torch.cat([st.tail_codes_tq[-ov:], chunk], dim=0)
+        if self.trim == "legacy" and ov > 0 and st.kv is not None and st.kv_len > 0:
+            keep = max(0, st.kv_len - ov)
+            st.kv = [t[:keep] for t in st.kv]
+            st.kv_len, st.pos, st.evict = keep, keep, False
         wav = self.codec.decode_batch(codes_in.unsqueeze(0), state=st)
         wav = wav[:, : (ov + n_new) * hop][:, ov * hop:]
         st.frames_seen += n_new

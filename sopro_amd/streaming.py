@@ -20,13 +20,14 @@ from .model import PreparedReference
 class StreamConfig:
     chunk_frames: int = 16
     nar_context_frames: Optional[int] = None
+    cache_trim: str = "none"  # MimiStreamDecoder policy: "none" = transformers 5.x behaviour, "legacy" = 4.57.6 (quirk Q6)
 
 
 class SoproTTSStreamer:
     def __init__(self, tts, cfg: Optional[StreamConfig] = None):
         self.tts = tts
         self.cfg = cfg or StreamConfig()
-        self.mimi_stream = MimiStreamDecoder(tts.codec)
+        self.mimi_stream = MimiStreamDecoder(tts.codec, trim=self.cfg.cache_trim)
 
     @torch.inference_mode()
     def stream(self, text: str, *, ref_audio_path: Optional[str] = None, ref_tokens_tq: Optional[torch.Tensor] = None,
@@ -82,8 +83,8 @@ class SoproTTSStreamer:
 
 @torch.inference_mode()
 def stream(tts, text: str, *, ref_audio_path: Optional[str] = None, ref_tokens_tq: Optional[torch.Tensor] = None,
-           ref: Optional[PreparedReference] = None, chunk_frames: int = 6, **kwargs) -> Iterator[torch.Tensor]:
-    """reference: src/sopro/streaming.py:133-152"""
-    streamer = SoproTTSStreamer(tts, StreamConfig(chunk_frames=chunk_frames))
+           ref: Optional[PreparedReference] = None, chunk_frames: int = 6, cache_trim: str = "none", **kwargs) -> Iterator[torch.Tensor]:
+    """reference: src/sopro/streaming.py:133-152 (``cache_trim`` is new: see MimiStreamDecoder)"""
+    streamer = SoproTTSStreamer(tts, StreamConfig(chunk_frames=chunk_frames, cache_trim=cache_trim))
     return streamer.stream(text, ref_audio_path=ref_audio_path, ref_tokens_tq=ref_tokens_tq, ref=ref,
                            chunk_frames=chunk_frames, **kwargs)

@@ -83,3 +83,23 @@ def tts(cfg, sopro_np, mimi_np):
     """The engine under test on cuda:0 (gpu tests only)."""
     from sopro_amd import SoproTTS
     return SoproTTS.from_weights(cfg, sopro_np, mimi_np, FakeTok(), device="cuda:0")
+
+
+@pytest.fixture(scope="session")
+def sopro_np_noeos(cfg):
+    """The checkpoint of the full-size fixtures (tests/golden/make_golden_full.py): EOS logit biased away, fixed lengths."""
+    from sopro_amd.weights import synth_sopro_weights
+    return synth_sopro_weights(cfg, VOCAB, SEED, suppress_eos=True)
+
+
+@pytest.fixture(scope="session")
+def w_noeos(sopro_np_noeos):
+    from oracle import sopro_oracle as O
+    return O.to_torch(sopro_np_noeos)
+
+
+@pytest.fixture(scope="session")
+def tts_noeos(cfg, sopro_np_noeos, mimi_np):
+    """Engine with the EOS-suppressed checkpoint (gpu tests at the BASELINE shapes)."""
+    from sopro_amd import SoproTTS
+    return SoproTTS.from_weights(cfg, sopro_np_noeos, mimi_np, FakeTok(), device="cuda:0")

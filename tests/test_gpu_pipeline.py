@@ -174,8 +174,11 @@ def test_batch_with_rows_stopping_at_different_frames(cfg, sopro_np, mimi_np, w)
         want = O.generate_tokens(ids[b], oref, w2, cfg, style_strength=1.0, **kw)
         lens.append(int(want.shape[0]))
         assert tuple(got[b].shape) == tuple(want.shape), (b, tuple(got[b].shape), tuple(want.shape))
-        assert int((got[b].cpu() != want).sum()) <= 1, b  # codebook-0 exact; at most one NAR near-tie
         assert torch.equal(got[b][:, 0].cpu(), want[:, 0]), b
+        if not torch.equal(got[b].cpu(), want):  # a refined token may differ only where the oracle itself sees a near-tie
+            op = O.prepare_conditioning(ids[b], oref, w2, cfg, max_frames=40, style_strength=1.0)
+            n_off, gap = O.nar_audit(op["cond_ar"][:, : want.shape[0]], got[b].cpu().unsqueeze(0), w2, cfg)
+            assert gap < 1e-4, (b, n_off, gap)
     assert len(set(lens)) > 1, f"fixture is not ragged: {lens}"
 
 
@@ -196,11 +199,11 @@ def test_nar_refine_ragged_batch_matches_oracle(tts, cfg, w, ref_prep):
     cond = prep["cond_ar"][:, :40].repeat(3, 1, 1) * torch.tensor([1.0, 0.9, 1.1], device=prep["cond_ar"].device)[:, None, None]
     rvq1 = torch.from_numpy(rng.integers(0, 2048, size=(3, 40)))
     toks = tts.model.nar_refine(cond, rvq1, lens=lens)
-    bad = 0
     for b, n in enumerate(lens):
         want = O.nar_refine(cond[b: b + 1, :n].cpu(), rvq1[b: b + 1, :n], w, cfg)
-        bad += int((toks[b, :n].cpu() != want[0]).sum())
-    assert bad <= 2, f"{bad} token mismatches over {sum(lens) * 31}"  # near-tie argmaxes only
+        if not torch.equal(toks[b, :n].cpu(), want[0]):  # only audited near-ties may differ (no blanket mismatch budget)
+            n_off, gap = O.nar_audit(cond[b: b + 1, :n].cpu(), toks[b: b + 1, :n].cpu(), w, cfg)
+            assert gap < 1e-4, (b, n_off, gap)
 
 
 def test_mimi_decode_matches_hf_reference(tts):
