@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 16
+#define SOPRO_ABI_VERSION 17
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -314,6 +314,10 @@ typedef struct sopro_ar_state {
   int32_t* start;          /* [bcap] global frame at which the row was admitted, -1 = free slot; row time = step - start */
   const int32_t* row_max;  /* [bcap] frame budget of the row (rows of its cond block, <= Tar); NULL = Tar */
   const float* row_params; /* [bcap, 8] per-row params; NULL = params */
+  /* Per-row run nonce mixed into the sampler's Philox counter (t, row, nonce): the host bumps it for every run / slot
+   * admission so that two calls with the same text do not reuse one uniform sequence (the reference draws from torch's
+   * global generator, which advances between calls).  NULL = 0.  Device memory, so a recorded frame graph sees updates. */
+  const uint32_t* nonce;   /* [bcap] */
 } sopro_ar_state;
 /* zero-step initialisation: step=0, flags reset, x_cur[b] = cond[b,0] + emb[bos_row]  (model.py:266-272) */
 int sopro_ar_init(const sopro_ar_state* st, void* stream);

@@ -13,13 +13,36 @@ from typing import Tuple
 import numpy as np
 
 
+def _load_with_optional_decoders(path: str) -> Tuple[np.ndarray, int]:
+    """Anything that is not RIFF/WAVE (FLAC, OGG, MP3, ... - the demo server stores uploads under their own suffix,
+    demo/server.py:93-97) goes through the decoders the reference uses when they are installed, in its order
+    (src/sopro/audio.py:89-106): soundfile, then torchaudio."""
+    try:
+        import soundfile as sf  # noqa: PLC0415
+    except Exception:  # noqa: BLE001
+        sf = None
+    if sf is not None:
+        x, sr = sf.read(path, dtype="float32", always_2d=True)  # [N, channels]
+        return np.ascontiguousarray(x.mean(axis=1, dtype=np.float32) if x.shape[1] > 1 else x[:, 0], dtype=np.float32), int(sr)
+    try:
+        import torchaudio  # noqa: PLC0415
+    except Exception:  # noqa: BLE001
+        torchaudio = None
+    if torchaudio is not None:
+        w, sr = torchaudio.load(path)  # [channels, N]
+        w = w.float() / (2 ** 15) if str(w.dtype) == "torch.int16" else w.float()
+        return np.ascontiguousarray((w.mean(dim=0) if w.shape[0] > 1 else w[0]).numpy(), dtype=np.float32), int(sr)
+    raise ValueError(f"{path}: not a RIFF/WAVE file (install 'soundfile' or 'torchaudio' to read other formats)")
+
+
 def load_audio_file(path: str) -> Tuple[np.ndarray, int]:
-    """RIFF/WAVE -> (mono float32 [N] in [-1, 1), sample rate).  reference: src/sopro/audio.py:89-106
-    (soundfile ``dtype="float32"`` scaling: integer PCM / 2**(bits-1); channels averaged)."""
+    """Audio file -> (mono float32 [N] in [-1, 1), sample rate).  reference: src/sopro/audio.py:89-106
+    (soundfile ``dtype="float32"`` scaling: integer PCM / 2**(bits-1); channels averaged).  RIFF/WAVE is parsed here
+    (no dependency); other containers fall back to soundfile / torchaudio when present."""
     with open(path, "rb") as f:
         data = f.read()
     if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
-        raise ValueError(f"{path}: not a RIFF/WAVE file")
+        return _load_with_optional_decoders(path)
     pos, fmt, pcm = 12, None, None
     while pos + 8 <= len(data):
         cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]

@@ -155,6 +155,8 @@ class ContinuousSynthesizer:
                 r[:, row].zero_()
             plan.row_max[row:row + 1].fill_(Tr)
             plan.row_params[row].copy_(it["prm"], non_blocking=True)
+            nonce = self.model.next_nonce(it.get("seed"))  # a new take per admission unless the request pins its seed
+            plan.nonce[row:row + 1].fill_(nonce - (1 << 32) if nonce >= (1 << 31) else nonce)
             hip.ar_admit(plan.state, row)
 
     # ------------------------------------------------------------------ serving interface
@@ -205,11 +207,11 @@ class ContinuousSynthesizer:
         min_gen = int(rq["min_gen_frames"] if rq.get("min_gen_frames") is not None else cfg.min_gen_frames)
         prm = torch.tensor([float(rq.get("top_p", 0.9)), float(rq.get("temperature", 1.05)), 1.0 if rq.get("anti_loop", True) else 0.0,
                             0.85, 1.2, 1.1, 50.0, float(min_gen)], dtype=torch.float32).pin_memory()
-        return {"ids": ids, "ref": rq["ref"], "mf": mf, "ss": ss, "prm": prm, "future": Future()}
+        return {"ids": ids, "ref": rq["ref"], "mf": mf, "ss": ss, "prm": prm, "seed": rq.get("seed"), "future": Future()}
 
     def submit(self, **rq) -> "Future[torch.Tensor]":
         """Queue one utterance: text_ids | text, ref, max_frames, top_p, temperature, anti_loop, style_strength,
-        min_gen_frames.  The future resolves to the waveform [1, 1, N] on the device."""
+        min_gen_frames, seed.  The future resolves to the waveform [1, 1, N] on the device."""
         self.start()
         if self._sh["stop"]:
             raise RuntimeError("engine is closed")

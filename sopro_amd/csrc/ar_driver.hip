@@ -7,20 +7,24 @@
 
 namespace {
 
-constexpr int SAMP_THREADS = 256;
+constexpr int SAMP_THREADS = 256;  // four wavefronts per row
+
+typedef unsigned long long u64;
 
 __device__ __forceinline__ unsigned ord_f32(float v) {
   const unsigned u = __float_as_uint(v);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__device__ __forceinline__ float unord_f32(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
 
 __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
   const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
   const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
   c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
 }
-__device__ float philox_uniform(unsigned long long seed, unsigned t, unsigned b) {
-  unsigned c0 = t, c1 = b, c2 = 0x5090u, c3 = 0u;
+// counter = (frame, row, run nonce), key = seed: a new take per run / admission, reproducible for a given (seed, nonce)
+__device__ float philox_uniform(unsigned long long seed, unsigned t, unsigned b, unsigned nonce) {
+  unsigned c0 = t, c1 = b, c2 = 0x5090u, c3 = nonce;
   unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
   for (int i = 0; i < 10; ++i) {
     philox_round(c0, c1, c2, c3, k0, k1);
@@ -42,54 +46,73 @@ __global__ void ar_init_kernel(const sopro_ar_state st) {
   }
 }
 
-// wave-wide bitonic sort (descending) of one 64-bit key per lane
-__device__ __forceinline__ unsigned long long wave_sort_desc(unsigned long long key, int lane) {
+// ---- wave-wide all-reduce on the DPP data path (no LDS round trips): butterflies inside the quads (quad_perm) and the
+// rows of 16 lanes (row_ror), then the four row results through scalar registers.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_ROR4 = 0x124;   // row_ror:4
+constexpr int DPP_ROW_ROR8 = 0x128;   // row_ror:8
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, dpp_u32<DPP_QUAD_XOR1>(v));
+  v = max(v, dpp_u32<DPP_QUAD_XOR2>(v));
+  v = max(v, dpp_u32<DPP_ROW_ROR4>(v));
+  v = max(v, dpp_u32<DPP_ROW_ROR8>(v));
+  const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  return max(max(r0, r1), max(r2, r3));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __uint_as_float(dpp_u32<DPP_QUAD_XOR1>(__float_as_uint(v)));
+  v += __uint_as_float(dpp_u32<DPP_QUAD_XOR2>(__float_as_uint(v)));
+  v += __uint_as_float(dpp_u32<DPP_ROW_ROR4>(__float_as_uint(v)));
+  v += __uint_as_float(dpp_u32<DPP_ROW_ROR8>(__float_as_uint(v)));
+  const float r0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
+  const float r1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
+  const float r2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+  const float r3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+// the n-th largest (n >= 1) of the 64 lanes' values, built bit by bit from ballots: 32 scalar steps, no data movement
+__device__ __forceinline__ unsigned wave_nth_largest_u32(unsigned v, int n) {
+  unsigned r = 0u;
 #pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const unsigned long long other = __shfl_xor(key, j, 64);
-      const bool desc = (lane & k) == 0;
-      const bool lower = (lane & j) == 0;
-      const unsigned long long mx = key > other ? key : other, mn = key > other ? other : key;
-      key = (lower == desc) ? mx : mn;
-    }
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned c = r | (1u << bit);
+    if (__popcll(__ballot(v >= c)) >= n) r = c;
   }
-  return key;
+  return r;
 }
 
-// number of entries of a descending 64-entry array that are greater than x (binary search, <= 7 probes)
-__device__ __forceinline__ int count_greater64(const unsigned long long* arr, unsigned long long x) {
-  int lo = 0, hi = 64;  // invariant: arr[0..lo) > x >= arr[hi..64)
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (arr[mid] > x) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
+constexpr int RECENT = 64;   // rolling token window per row: slot j = token sampled j+1 frames ago (-1 = none)
+constexpr int PER = 9;       // logits per thread: ceil(2049 / 256), element q*256 + tid
+constexpr int MAXCAND = PER * SAMP_THREADS;
+constexpr int PAIRED = 128;  // candidates handled two threads apiece by the all-pairs stage
 
-constexpr int RECENT = 64;  // rolling token window per row: slot j = token sampled j+1 frames ago (-1 = none)
-constexpr int MAXCAND = 9 * 64;  // PER * max kk: the candidate bound of the scheme below
-
-// Top-k without a sort: the kk-th largest of the 256 per-thread maxima is a lower bound of the kk-th largest
-// logit, so "key >= that bound" keeps at most 9*kk candidates (all of the true top-kk among them); exact ranks
-// among the candidates come from an all-pairs count, which also lays them out in descending order.
+// sample_token (src/sopro/sampling.py:24-93) + the loop policy of src/sopro/model.py:274-305 for one row per workgroup.
+// Nothing is sorted.  What the reference does with sort / top-k / cumsum is done with counting:
+//   * top-k: every wave takes the ceil(kk/4)-th largest of its 64 per-thread maxima (32 ballot steps); the smallest of the
+//     four is a lower bound of the kk-th largest logit, so "logit >= bound" keeps a superset of the top kk (~1.4 kk
+//     entries), compacted with ballots;
+//   * an all-pairs pass gives every candidate its exact rank and the probability mass ahead of it (two threads per
+//     candidate) - i.e. its place in the sorted order and the cumulative sum the top-p rule needs - and the top kk land
+//     in rank order in one wave, which renormalises, cuts and draws with two wave reductions and two ballots.
+// Wave reductions run on the DPP path; five workgroup barriers in all (two of them only when a penalty applies).
 __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_state st, const float* __restrict__ logits,
                                                                  int64_t ld) {
   __shared__ float xs[2049 + 7];
-  __shared__ unsigned long long lmax[SAMP_THREADS];
-  __shared__ unsigned long long cand[MAXCAND];
-  __shared__ unsigned long long selk[64];
-  __shared__ float selp[64];
-  __shared__ float redf[4];
-  __shared__ int rs[RECENT];
-  __shared__ unsigned long long sh_thr, sh_best;
+  __shared__ u64 cand_k[MAXCAND];
+  __shared__ float cand_e[MAXCAND];
+  __shared__ u64 selk[64];
+  __shared__ float sele[64], selb[64];
+  __shared__ unsigned w_thr[4], w_best_v[4], w_best_i[4];
   __shared__ unsigned sh_cnt;
-  __shared__ int sh_tok;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const int V1 = st.V + 1;
-  constexpr int PER = (2049 + SAMP_THREADS - 1) / SAMP_THREADS;
 
   // ---- the only up-front memory round: frame index, policy parameters, this row's logits, its recent tokens
   // Classic mode: every row started at global frame 0.  Slot mode (st.start != NULL, continuous batching): row b was
@@ -102,15 +125,16 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   const float p_top_p = prm[0], p_temp = prm[1], p_anti = prm[2], p_rec_p = prm[3];
   const float p_rec_t = prm[4], rep = prm[5];
   const int top_k = (int)prm[6], min_gen = (int)prm[7];
+  const unsigned nonce = st.nonce ? st.nonce[b] : 0u;
   const float* lg = logits + (int64_t)b * ld;
   float xv[PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    const int i = tid + q * SAMP_THREADS;
+    const int i = q * SAMP_THREADS + tid;
     xv[q] = (i < V1) ? lg[i] : 0.f;
   }
   int* recent = st.recent + (int64_t)b * RECENT;
-  const int r_mine = (tid < RECENT) ? recent[tid] : -1;
+  const int r_mine = recent[lane];  // every wave holds the window: lane j = token sampled j+1 frames ago
   if (!st.start && tg >= st.max_steps) return;  // classic mode, uniform over the grid: the loop is over
   if (st.start && (s0 < 0 || t >= min(tmax, st.max_steps))) {
     // free slot, or a row past its budget waiting to be harvested: nothing to sample, but the frame still needs its ticket
@@ -124,182 +148,193 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
     }
     return;
   }
-  // next frame's conditioning row: address needs t only, consumed at the very end
-  float cnext[2] = {0.f, 0.f};
-  if (t + 1 < tmax) {
+  // next frame's conditioning row (wave 0 writes the next input): address needs t only, consumed at the very end
+  float cnext[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (wave == 0 && t + 1 < tmax) {
     const float* c = st.cond + ((int64_t)b * st.Tar + (t + 1)) * st.D;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if (tid + q * SAMP_THREADS < st.D) cnext[q] = c[tid + q * SAMP_THREADS];
+    for (int q = 0; q < 8; ++q)
+      if (q * 64 + lane < st.D) cnext[q] = c[q * 64 + lane];
   }
-  if (tid < RECENT) rs[tid] = r_mine;
   if (tid == 0) sh_cnt = 0u;
-  __syncthreads();
 
-  // ---- anti-loop policy (src/sopro/model.py:274-279, sampling.py:16-21): repeated tail of length 3..16, or 9 equal tokens
-  int loopy = 0;
+  // ---- anti-loop policy (src/sopro/model.py:274-279, sampling.py:16-21): repeated tail of length 3..16, or 9 equal
+  // tokens; evaluated by every wave on its own copy of the window (wave-uniform result, no exchange)
+  bool recover = false;
   if (p_anti != 0.f) {
-    if (tid >= 3 && tid <= 16) {
-      const int n = tid;
-      if (rs[2 * n - 1] >= 0) {
-        bool same = true;
-        for (int m2 = 0; m2 < n; ++m2) same = same && (rs[m2] == rs[m2 + n]);
-        loopy = same;
-      }
-    } else if (tid == 17 && rs[8] >= 0) {
-      bool same = true;
-      for (int m2 = 1; m2 < 9; ++m2) same = same && (rs[m2] == rs[0]);
-      loopy = same;
+    const u64 valid = __ballot(r_mine >= 0);
+#pragma unroll
+    for (int n = 3; n <= 16; ++n) {
+      const int other = __shfl_down(r_mine, n, 64);
+      const u64 same = __ballot(r_mine == other);
+      const u64 need = (1ull << n) - 1ull;
+      recover = recover || (((valid >> (2 * n - 1)) & 1ull) && (same & need) == need);
     }
+    const int newest = __builtin_amdgcn_readlane(r_mine, 0);
+    const u64 eq0 = __ballot(r_mine == newest);
+    recover = recover || (((valid >> 8) & 1ull) && (eq0 & 0x1FFull) == 0x1FFull);
   }
-  const bool recover = __syncthreads_or(loopy) != 0;
   const float top_p = recover ? p_rec_p : p_top_p;
   const float temp = recover ? p_rec_t : p_temp;
   // ---- nan_to_num, temperature (sampling.py:33-38)
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    const int i = tid + q * SAMP_THREADS;
     float v = xv[q];
     if (v != v) v = -1e9f;
     else if (v == INFINITY) v = 1e9f;
     else if (v == -INFINITY) v = -1e9f;
     if (temp != 0.f && temp != 1.0f) v = v / temp;
-    if (i < V1) xs[i] = v;
+    xv[q] = v;
   }
-  __syncthreads();
-  // ---- repetition penalty on the unique ids among the last 50 tokens (sampling.py:40-50)
-  if (rep != 1.0f && tid < 50) {
-    const int id = rs[tid];
-    if (id >= 0 && id < V1) {
-      bool first = true;
-      for (int j = 0; j < tid; ++j) first = first && (rs[j] != id);
-      if (first) {
-        const float v = xs[id];
-        xs[id] = v < 0.f ? v * rep : v / rep;
+  // ---- repetition penalty on the unique ids among the last 50 tokens (sampling.py:40-50): patched through LDS by id
+  const bool in_win = lane < 50 && r_mine >= 0 && r_mine < V1;
+  if (rep != 1.0f && __ballot(in_win) != 0ull) {  // workgroup-uniform: every wave sees the same window
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      if (q * SAMP_THREADS + tid < V1) xs[q * SAMP_THREADS + tid] = xv[q];
+    bool first = in_win;
+    if (wave == 0) {
+#pragma unroll 7
+      for (int j = 0; j < 49; ++j) {
+        const int other = __builtin_amdgcn_readlane(r_mine, j);
+        if (j < lane && other == r_mine) first = false;
       }
     }
+    __syncthreads();
+    if (wave == 0 && first) {
+      const float v = xs[r_mine];
+      xs[r_mine] = v < 0.f ? v * rep : v / rep;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      if (q * SAMP_THREADS + tid < V1) xv[q] = xs[q * SAMP_THREADS + tid];
   }
-  __syncthreads();
 
-  // 44-bit unique sort key: (order-preserving logit bits, 4095 - index): larger == better, ties -> lower index
-  unsigned long long key[PER];
-  unsigned long long lm = 0ull;
+  // ---- per-thread maximum as (order-preserving value bits, 4095 - index): larger == better, ties -> lower index
+  unsigned ov[PER];
+  unsigned tm_v = 0u, tm_i = 0u;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    const int i = tid + q * SAMP_THREADS;
-    key[q] = (i < V1) ? (((unsigned long long)ord_f32(xs[i]) << 12) | (unsigned long long)(4095 - i)) : 0ull;
-    lm = key[q] > lm ? key[q] : lm;
+    const int i = q * SAMP_THREADS + tid;
+    ov[q] = (i < V1) ? ord_f32(xv[q]) : 0u;  // padding sorts below every real logit (ord_f32 of a finite value is > 0)
+    const unsigned ii = (unsigned)(4095 - i);
+    const bool better = (i < V1) && (ov[q] > tm_v || (ov[q] == tm_v && ii > tm_i));
+    tm_v = better ? ov[q] : tm_v;
+    tm_i = better ? ii : tm_i;
   }
-  // per-wave sort of the 64 per-thread maxima, then each lane ranks its entry against the other three sorted lists
-  const unsigned long long lms = wave_sort_desc(lm, lane);  // lane i: i-th largest maximum of this wave
-  lmax[tid] = lms;
-  __syncthreads();
   const bool greedy = !(top_p > 0.f);
-  int kk = (top_k > 0) ? min(top_k, V1) : V1;
-  const bool head_only = greedy || kk > 64;  // top_k > 64 / "no top-k" is outside the reference policy (model.py:289)
+  const int kk = (top_k > 0) ? min(top_k, V1) : V1;
+  // top_p <= 0 keeps only the head of the sorted distribution == arg-max of the penalised logits.  top_k > 64 or "no
+  // top-k" is outside the reference policy (model.py:289) and refused by the host; here it degrades to the arg-max.
+  const bool sampling = !greedy && kk <= 64;
   {
-    int rank = lane;
-#pragma unroll
-    for (int w2 = 0; w2 < SAMP_THREADS / 64; ++w2)
-      if (w2 != wave) rank += count_greater64(lmax + w2 * 64, lms);
-    if (rank == 0) sh_best = lms;
-    if (!head_only && rank == kk - 1) sh_thr = lms;
+    const unsigned wv = wave_max_u32(tm_v);
+    const unsigned wi = wave_max_u32(tm_v == wv ? tm_i : 0u);
+    unsigned thr = 0u;
+    if (sampling) thr = wave_nth_largest_u32(tm_v, (kk + 3) >> 2);
+    if (lane == 0) { w_best_v[wave] = wv; w_best_i[wave] = wi; w_thr[wave] = thr; }
   }
   __syncthreads();
-  const int top_i = 4095 - (int)(sh_best & 4095ull);
-  if (head_only) {
-    // top_p <= 0 keeps only the head of the sorted distribution == arg-max of the penalised logits
-    if (tid == 0) sh_tok = top_i;
-  } else {
-    const unsigned long long thr = sh_thr;
-    const float xmax = xs[top_i];
-    float z = 0.f;
+  unsigned best_v = w_best_v[0], best_i = w_best_i[0], thr = w_thr[0];
+#pragma unroll
+  for (int w2 = 1; w2 < 4; ++w2) {
+    const unsigned v2 = w_best_v[w2], i2 = w_best_i[w2];
+    const bool better = v2 > best_v || (v2 == best_v && i2 > best_i);
+    best_v = better ? v2 : best_v;
+    best_i = better ? i2 : best_i;
+    thr = min(thr, w_thr[w2]);
+  }
+  const int top_i = 4095 - (int)best_i;
+  int tok = top_i;
+  if (sampling) {
+    // ---- candidates: every logit >= thr (at least kk of them), with exp(x - max) next to the key
+    const float xmax = unord_f32(best_v);
+    int nc = 0;
+    u64 masks[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      const int i = tid + q * SAMP_THREADS;
-      if (i < V1) {
-        z += expf(xs[i] - xmax);  // softmax denominator over the whole row (sampling.py:52)
-        if (key[q] >= thr) {
-          const unsigned slot = atomicAdd(&sh_cnt, 1u);
-          if (slot < (unsigned)MAXCAND) cand[slot] = key[q];
-        }
-      }
+      masks[q] = __ballot((q * SAMP_THREADS + tid < V1) && ov[q] >= thr);
+      nc += __popcll(masks[q]);
     }
-    z = wave_sum(z);
-    if (lane == 0) redf[wave] = z;
-    __syncthreads();
-    const int C = min((int)sh_cnt, MAXCAND);
-    const float Z = (redf[0] + redf[1]) + (redf[2] + redf[3]);
-    if (C <= 64) {
-      // usual case: one wave sorts the candidates directly (lane j ends up with the j-th largest)
-      if (wave == 0) {
-        const unsigned long long ks = wave_sort_desc(lane < C ? cand[lane] : 0ull, lane);
-        if (lane < kk) {
-          selk[lane] = ks;
-          selp[lane] = expf(xs[4095 - (int)(ks & 4095ull)] - xmax) / Z;
-        }
+    unsigned base = 0u;
+    if (lane == 0 && nc > 0) base = atomicAdd(&sh_cnt, (unsigned)nc);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      if ((masks[q] >> lane) & 1ull) {
+        const unsigned pos = base + (unsigned)__popcll(masks[q] & lt);
+        cand_k[pos] = ((u64)ov[q] << 12) | (u64)(4095 - (q * SAMP_THREADS + tid));
+        cand_e[pos] = expf(xv[q] - xmax);
       }
+      base += (unsigned)__popcll(masks[q]);
+    }
+    __syncthreads();
+    const int C = (int)sh_cnt;
+    // ---- all pairs: rank (entries ahead) and unnormalised mass ahead of every candidate
+    if (C <= PAIRED) {
+      const int c = tid >> 1, half = tid & 1;
+      const int j0 = half ? (C >> 1) : 0, j1 = half ? C : (C >> 1);
+      const u64 kc = c < C ? cand_k[c] : ~0ull;
+      int rank = 0;
+      float ahead = 0.f;
+      for (int j = j0; j < j1; ++j) {
+        const bool gt = cand_k[j] > kc;
+        rank += gt ? 1 : 0;
+        ahead += gt ? cand_e[j] : 0.f;
+      }
+      rank += __shfl_xor(rank, 1, 64);
+      ahead += __shfl_xor(ahead, 1, 64);
+      if (half == 0 && c < C && rank < kk) { selk[rank] = kc; sele[rank] = cand_e[c]; selb[rank] = ahead; }
     } else {
       for (int c = tid; c < C; c += SAMP_THREADS) {
-        const unsigned long long kc = cand[c];
+        const u64 kc = cand_k[c];
         int rank = 0;
-        for (int j = 0; j < C; ++j) rank += (cand[j] > kc) ? 1 : 0;
-        if (rank < kk) {
-          selk[rank] = kc;
-          selp[rank] = expf(xs[4095 - (int)(kc & 4095ull)] - xmax) / Z;
+        float ahead = 0.f;
+        for (int j = 0; j < C; ++j) {
+          const bool gt = cand_k[j] > kc;
+          rank += gt ? 1 : 0;
+          ahead += gt ? cand_e[j] : 0.f;
         }
+        if (rank < kk) { selk[rank] = kc; sele[rank] = cand_e[c]; selb[rank] = ahead; }
       }
     }
     __syncthreads();
     if (wave == 0) {
-      // top-k renormalisation, top-p cut and the draw on one wave (sampling.py:56-93): lane j owns sorted entry j
-      const float pj_raw = (lane < kk) ? selp[lane] : 0.f;
-      const float s = wave_sum(pj_raw);
-      int tok = top_i;
-      if (s > 1e-12f) {
-        const float pj = pj_raw / s;
-        float inc = pj;  // inclusive prefix sum over lanes
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const float u2 = __shfl_up(inc, o, 64);
-          if (lane >= o) inc += u2;
-        }
-        const float before = inc - pj;
-        // drop entry j when the cumulative mass *before* it already exceeds top_p; entry 0 always stays (sampling.py:68-76)
-        const bool keep = lane < kk && (lane == 0 || !(top_p < 1.0f && before > top_p));
-        const float kp = keep ? pj : 0.f;
-        const float kept = wave_sum(kp);
-        if (kept > 1e-12f) {
-          float kinc = kp;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const float u2 = __shfl_up(kinc, o, 64);
-            if (lane >= o) kinc += u2;
-          }
-          const float u = philox_uniform(st.seed, (unsigned)t, (unsigned)b) * kept;
-          const unsigned long long hit = __ballot(keep && u < kinc);
-          const unsigned long long kmask = __ballot(keep);
-          const int pick = hit ? (int)__ffsll((long long)hit) - 1 : 63 - __clzll((long long)kmask);
-          tok = 4095 - (int)(selk[pick] & 4095ull);
-        }
+      // top-k renormalisation, top-p cut and the draw (sampling.py:56-93): lane j owns sorted entry j.  The softmax
+      // denominator cancels in the renormalisation: p_j / sum_topk p = e_j / sum_topk e  (and sum_topk p >= 1/2049, so
+      // the reference's "mass <= 1e-12 -> arg-max" fallback cannot trigger on finite logits).
+      const float ej = (lane < kk) ? sele[lane] : 0.f;
+      const float S = wave_sum_dpp(ej);
+      const float pj = ej / S;
+      const float before = (lane < kk) ? selb[lane] / S : 0.f;
+      // drop entry j when the cumulative mass *before* it already exceeds top_p; entry 0 always stays (sampling.py:68-76)
+      const bool keep = lane < kk && (lane == 0 || !(top_p < 1.0f && before > top_p));
+      const float kept = wave_sum_dpp(keep ? pj : 0.f);
+      if (kept > 1e-12f) {
+        const float u = philox_uniform(st.seed, (unsigned)t, (unsigned)b, nonce) * kept;
+        const u64 hit = __ballot(keep && u < before + pj);
+        const u64 kmask = __ballot(keep);
+        const int pick = hit ? (int)__ffsll((long long)hit) - 1 : 63 - __clzll((long long)kmask);
+        tok = 4095 - (int)(selk[pick] & 4095ull);
       }
-      if (lane == 0) sh_tok = tok;
     }
   }
-  __syncthreads();
-  const int tok = sh_tok;
+  if (wave != 0) return;  // wave 0 holds the token (every wave does when it is the arg-max) and does the bookkeeping
 
   // ---- bookkeeping: history, EOS rule (model.py:293-305), next input (model.py:266-272)
   if (t + 1 < tmax) {
     const float* e = st.emb + (int64_t)tok * st.D;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int d = tid + q * SAMP_THREADS;
+    for (int q = 0; q < 8; ++q) {
+      const int d = q * 64 + lane;
       if (d < st.D) st.x_cur[(int64_t)b * st.D + d] = cnext[q] + e[d];
     }
   }
-  if (tid < RECENT) recent[tid] = (tid == 0) ? tok : rs[tid - 1];
-  if (tid == 0) {
+  const int older = __shfl_up(r_mine, 1, 64);
+  recent[lane] = (lane == 0) ? tok : older;
+  if (lane == 0) {
     st.hist[(int64_t)b * st.max_steps + t] = tok;
     if (tok == st.V) {
       if (st.first_eos[b] < 0) st.first_eos[b] = t;
@@ -308,7 +343,10 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
         atomicAdd(st.n_stopped, 1);
       }
     }
-    __threadfence();
+  }
+  // every lane's stores of this row are released before the row's ticket
+  __threadfence();
+  if (lane == 0) {
     const int old = atomicAdd(st.arrive, 1);
     if (old == st.B - 1) {
       *st.arrive = 0;

@@ -105,6 +105,7 @@ class SoproTTSModel:
         self.prep_stream = self.stream
         self._driver = None  # the scheduler (PipelinedSynthesizer / ContinuousSynthesizer) that currently owns the streams
         self._ar_cache: Dict[Tuple[int, int, int], "_ARPlan"] = {}
+        self._runs = [0]  # generation runs started so far (shared by the lanes of clone_lane): the sampler's default nonce
         self._nar_graphs = hip.GraphCache("nar_graph", cap=64)  # recorded NAR launch sequences per (B, T)
         self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "16")) << 30  # scratch kept per batch shape, per engine
         # NAR and text / reference encoder contractions on the six-pass split-bf16 matrix-core path (24 mantissa bits per
@@ -166,6 +167,16 @@ class SoproTTSModel:
         other._ar_cache = {}
         other._nar_graphs = hip.GraphCache("nar_graph", cap=64)
         return other
+
+    def next_nonce(self, seed: Optional[int] = None) -> int:
+        """Nonce of a generation run / slot admission, mixed into the sampler's Philox counter.  ``seed`` given: the run is
+        reproducible (same seed, same text, same voice -> same audio).  ``None``: a process-wide run counter, so that
+        every call is a new take - the reference draws from torch's global generator, which advances between calls
+        (src/sopro/sampling.py:81-86)."""
+        if seed is not None:
+            return int(seed) & 0xFFFFFFFF
+        self._runs[0] += 1
+        return (0x9E3779B9 * self._runs[0]) & 0xFFFFFFFF
 
     def rf_ar(self) -> int:
         return self.cfg.rf_ar()
@@ -368,20 +379,24 @@ class SoproTTSModel:
 
     # ------------------------------------------------------------------ autoregressive generation
     def _ar_plan(self, B: int, S_cap: int, Tar: int) -> "_ARPlan":
+        """The cached plan of a shape, or - while a suspended ar_stream / stream() generator of the same shape still owns
+        that one - a private plan for this run (the reference keeps its state local to each call, model.py:218-305)."""
         key = (B, S_cap, Tar)
         plan = self._ar_cache.get(key)
         if plan is None:
             if len(self._ar_cache) >= 8:
-                self._ar_cache.clear()
+                self._ar_cache.clear()  # plans still in use stay alive through their runs
             plan = _ARPlan(self, B, S_cap, Tar)
             self._ar_cache[key] = plan
+        elif plan.owner is not None and plan.owner() is not None and not plan.owner().done:
+            plan = _ARPlan(self, B, S_cap, Tar)  # not cached: dropped with its run
         return plan
 
     @torch.inference_mode()
     def ar_generate_batch(self, cond_ar: torch.Tensor, txt_seq: torch.Tensor, text_lens: Optional[torch.Tensor], *,
                           max_frames: int, top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True,
                           min_gen_frames: Optional[int] = None, stop_on_first_eos: bool = False,
-                          poll_every: int = 16) -> Tuple[torch.Tensor, List[int]]:
+                          poll_every: int = 16, seed: Optional[int] = None) -> Tuple[torch.Tensor, List[int]]:
         """Run the AR loop for B rows until every row has stopped or max_frames+1 steps were taken
         (reference loop: src/sopro/model.py:218-305, one row).  Returns (hist [B, steps] int32 on the
         device, per-row frame counts T_b following generate_tokens' cut at the FIRST EOS, model.py:385-390)."""
@@ -389,7 +404,7 @@ class SoproTTSModel:
         if Tar != int(max_frames) + 1:
             raise ValueError("cond_ar must have max_frames+1 rows")
         run = _ARRun(self, cond_ar, txt_seq, text_lens, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-                     min_gen_frames=min_gen_frames)
+                     min_gen_frames=min_gen_frames, seed=seed)
         # The stop poll trails the launches by one chunk: chunk k+1 is enqueued before the host looks at chunk k's counter, so
         # the GPU never waits for the host round trip (rows that have stopped are masked on the device; the extra frames of
         # a batch that turns out to be finished are discarded below).
@@ -403,6 +418,7 @@ class SoproTTSModel:
                 break
             pending = run.poll_async(stop_on_first_eos)
         hist, first_eos = run.history(steps)
+        run.done = True
         lens = [int(f) if f >= 0 else steps for f in first_eos]
         return hist, lens
 
@@ -411,29 +427,34 @@ class SoproTTSModel:
                   temperature: float = 1.05, anti_loop: bool = True, use_prefix: bool = False,
                   prefix_sec_fixed: Optional[float] = None, use_stop_head: Optional[bool] = None,
                   stop_patience: Optional[int] = None, stop_threshold: Optional[float] = None,
-                  min_gen_frames: Optional[int] = None, lookahead: int = 1) -> Iterator[Tuple[int, int, bool]]:
+                  min_gen_frames: Optional[int] = None, lookahead: int = 1, seed: Optional[int] = None
+                  ) -> Iterator[Tuple[int, int, bool]]:
         """Yields (t, token, is_eos) like the reference generator (src/sopro/model.py:218-305).
-        ``lookahead`` frames are generated per host round trip (new; 1 == token-by-token)."""
+        ``lookahead`` frames are generated per host round trip (new; 1 == token-by-token); ``seed`` (new) pins the
+        sampler's draws for this run."""
         cond = prep["cond_ar"]
         Tar = int(max_frames) + 1
         if cond.shape[1] != Tar:
             raise ValueError("prep['cond_ar'] must have max_frames+1 rows")
         min_gen = int(min_gen_frames if min_gen_frames is not None else self.cfg.min_gen_frames)
         run = _ARRun(self, cond, prep["txt_seq"], None, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-                     min_gen_frames=min_gen)
+                     min_gen_frames=min_gen, seed=seed)
         t = 0
         eos = self.V
-        while t < Tar:
-            n = min(max(1, int(lookahead)), Tar - t)
-            run.advance(n)
-            toks = run.tokens_host(t, t + n)
-            for j in range(n):
-                tok = int(toks[j])
-                is_eos = tok == eos
-                yield t + j, tok, is_eos
-                if is_eos and (t + j + 1) >= min_gen:
-                    return
-            t += n
+        try:
+            while t < Tar:
+                n = min(max(1, int(lookahead)), Tar - t)
+                run.advance(n)
+                toks = run.tokens_host(t, t + n)
+                for j in range(n):
+                    tok = int(toks[j])
+                    is_eos = tok == eos
+                    yield t + j, tok, is_eos
+                    if is_eos and (t + j + 1) >= min_gen:
+                        return
+                t += n
+        finally:
+            run.done = True  # also when the consumer abandons the generator: the plan is free again
 
     # ------------------------------------------------------------------ NAR refinement
     def _adapter_coeffs(self) -> List[Tuple[torch.Tensor, torch.Tensor]]:
@@ -521,20 +542,22 @@ class SoproTTSModel:
                         top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True, use_prefix: bool = False,
                         prefix_sec_fixed: Optional[float] = None, style_strength: float = 1.0,
                         use_stop_head: Optional[bool] = None, stop_patience: Optional[int] = None,
-                        stop_threshold: Optional[float] = None, min_gen_frames: Optional[int] = None) -> torch.Tensor:
+                        stop_threshold: Optional[float] = None, min_gen_frames: Optional[int] = None,
+                        seed: Optional[int] = None) -> torch.Tensor:
         """reference: src/sopro/model.py:349-401 -> [T, Q] int64 (``[0, Q]`` when EOS comes first)."""
         return self.generate_tokens_batch([text_ids], [ref], max_frames=max_frames, top_p=top_p, temperature=temperature,
-                                          anti_loop=anti_loop, style_strength=style_strength, min_gen_frames=min_gen_frames)[0]
+                                          anti_loop=anti_loop, style_strength=style_strength, min_gen_frames=min_gen_frames,
+                                          seed=seed)[0]
 
     @torch.inference_mode()
     def generate_tokens_batch(self, ids_list: Sequence[torch.Tensor], refs: Sequence[PreparedReference], *, max_frames: int,
                               top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True,
                               style_strength: float = 1.0, min_gen_frames: Optional[int] = None,
-                              timings: Optional[Dict[str, float]] = None) -> List[torch.Tensor]:
+                              timings: Optional[Dict[str, float]] = None, seed: Optional[int] = None) -> List[torch.Tensor]:
         """B utterances -> list of [T_b, Q] int64 token matrices (new, batched form of generate_tokens)."""
         ev = _PhaseTimer(self.stream, timings)
         state = self.phase_ar(ids_list, refs, max_frames=max_frames, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-                              style_strength=style_strength, min_gen_frames=min_gen_frames, ev=ev)
+                              style_strength=style_strength, min_gen_frames=min_gen_frames, ev=ev, seed=seed)
         toks = self.phase_nar(state)
         ev.mark("nar")
         return toks
@@ -547,13 +570,13 @@ class SoproTTSModel:
         return prep
 
     def phase_ar(self, ids_list, refs, *, max_frames, top_p, temperature, anti_loop, style_strength, min_gen_frames, ev=None,
-                 prep=None):
+                 prep=None, seed=None):
         """Latency-bound half of generate_tokens_batch: (conditioning +) the AR graph replay."""
         if prep is None:
             prep = self.phase_cond(ids_list, refs, max_frames=max_frames, style_strength=style_strength, ev=ev)
         hist, lens = self.ar_generate_batch(prep["cond_ar"], prep["txt_seq"], prep["text_lens"], max_frames=max_frames,
                                             top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-                                            min_gen_frames=min_gen_frames)
+                                            min_gen_frames=min_gen_frames, seed=seed)
         if ev is not None:
             ev.mark("ar")
         return {"cond_ar": prep["cond_ar"], "hist": hist, "lens": lens, "B": len(ids_list)}
@@ -628,6 +651,8 @@ class _ARPlan:
         self.stop_t = z(B, dt=torch.int32)
         self.params = z(8)
         self.recent = z(B, 64, dt=torch.int32)
+        self.nonce = z(B, dt=torch.int32)  # per-row run nonce of the sampler (device memory: the recorded graph reads it)
+        self.owner = None  # weakref to the _ARRun using this plan
         st = hip.ArState()
         st.x_cur = self.x[0].data_ptr()
         st.cond = self.cond.data_ptr()
@@ -640,6 +665,7 @@ class _ARPlan:
         st.stop_t = self.stop_t.data_ptr()
         st.params = self.params.data_ptr()
         st.recent = self.recent.data_ptr()
+        st.nonce = self.nonce.data_ptr()
         st.seed = m.seed
         st.B, st.D, st.Tar, st.max_steps, st.V, st.bos_row = B, D, Tar, self.max_steps, m.V, int(cfg.bos_row)
         if slots:  # continuous batching: rows are admitted / released one by one (sopro_amd/continuous.py)
@@ -743,16 +769,26 @@ class _ARPlan:
 class _ARRun:
     """One batch of utterances being generated on a plan."""
 
+    TOP_K = 50  # hard-coded by the reference's loop (src/sopro/model.py:289-290), like the repetition penalty 1.1
+
     def __init__(self, m: SoproTTSModel, cond_ar: torch.Tensor, txt_seq: torch.Tensor, text_lens: Optional[torch.Tensor], *,
-                 top_p: float, temperature: float, anti_loop: bool, min_gen_frames: Optional[int]):
+                 top_p: float, temperature: float, anti_loop: bool, min_gen_frames: Optional[int], seed: Optional[int] = None,
+                 top_k: Optional[int] = None):
+        import weakref
+
         cfg, w, dev, D = m.cfg, m.w, m.device, m.D
         if not bool(getattr(cfg, "use_bos", True)):
             raise RuntimeError("BOS embedding disabled")
+        top_k = self.TOP_K if top_k is None else int(top_k)
+        if not 1 <= top_k <= 64:
+            raise ValueError(f"top_k must be in [1, 64] (the reference uses 50), got {top_k}: the device sampler ranks at most 64 entries")
         B, Tar, _ = cond_ar.shape
         S = int(txt_seq.shape[1])
         S_cap = ((S + 63) // 64) * 64
         self.m = m
+        self.done = False
         self.plan = plan = m._ar_plan(B, S_cap, Tar)
+        plan.owner = weakref.ref(self)
         min_gen = int(min_gen_frames if min_gen_frames is not None else cfg.min_gen_frames)
         with m.on_stream(prep=True):
             plan.cond.copy_(cond_ar.to(dev).float())
@@ -777,8 +813,10 @@ class _ARRun:
             for r in plan.rings:
                 r.zero_()
             plan.hist.zero_()
-            plan.params.copy_(torch.tensor([float(top_p), float(temperature), 1.0 if anti_loop else 0.0, 0.85, 1.2, 1.1, 50.0,
+            plan.params.copy_(torch.tensor([float(top_p), float(temperature), 1.0 if anti_loop else 0.0, 0.85, 1.2, 1.1, float(top_k),
                                             float(min_gen)], dtype=torch.float32), non_blocking=False)
+            nonce = m.next_nonce(seed)
+            plan.nonce.fill_(nonce - (1 << 32) if nonce >= (1 << 31) else nonce)  # the uint32 bit pattern in an int32 tensor
             hip.ar_init(plan.state)
         m.stream.wait_stream(m.prep_stream)
         plan.ensure_graph()

@@ -35,7 +35,7 @@ class SoproTTSStreamer:
                temperature: float = 1.05, anti_loop: bool = True, style_strength: Optional[float] = None,
                ref_seconds: Optional[float] = None, chunk_frames: Optional[int] = None,
                nar_context_frames: Optional[int] = None, min_gen_frames: Optional[int] = None,
-               text_ids: Optional[torch.Tensor] = None) -> Iterator[torch.Tensor]:
+               text_ids: Optional[torch.Tensor] = None, seed: Optional[int] = None) -> Iterator[torch.Tensor]:
         tts = self.tts
         model = tts.model
         ids = text_ids if text_ids is not None else tts.encode_text(text)
@@ -67,7 +67,7 @@ class SoproTTSStreamer:
             return wav if wav.numel() > 0 else None
 
         for _t, tok, is_eos in model.ar_stream(prep, max_frames=max_frames, top_p=top_p, temperature=temperature,
-                                               anti_loop=anti_loop, min_gen_frames=min_gen_frames, lookahead=cf):
+                                               anti_loop=anti_loop, min_gen_frames=min_gen_frames, lookahead=cf, seed=seed):
             if is_eos:
                 break
             hist.append(int(tok))

@@ -105,15 +105,18 @@ class SoproTTS:
     def synthesize(self, text: str, *, ref: Optional[PreparedReference] = None, ref_audio_path: Optional[str] = None,
                    ref_tokens_tq: Optional[torch.Tensor] = None, max_frames: int = 400, top_p: float = 0.9,
                    temperature: float = 1.05, anti_loop: bool = True, style_strength: Optional[float] = None,
-                   ref_seconds: Optional[float] = None, min_gen_frames: Optional[int] = None) -> torch.Tensor:
-        """reference: src/sopro/model.py:531-575 -> waveform [1, 1, N] on ``self.device``."""
+                   ref_seconds: Optional[float] = None, min_gen_frames: Optional[int] = None,
+                   seed: Optional[int] = None) -> torch.Tensor:
+        """reference: src/sopro/model.py:531-575 -> waveform [1, 1, N] on ``self.device``.  ``seed`` (new) pins the sampler's
+        draws: the same seed, text and voice give the same audio; without it every call is a new take (the reference
+        draws from torch's global generator; its CLI seeds that once, src/sopro/cli.py:72-75)."""
         text_ids = self.encode_text(text)
         if ref is None:
             ref = self.prepare_reference(ref_audio_path=ref_audio_path, ref_tokens_tq=ref_tokens_tq, ref_seconds=ref_seconds)
         tokens = self.model.generate_tokens(
             text_ids, ref, max_frames=max_frames, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
             style_strength=float(style_strength if style_strength is not None else self.cfg.style_strength),
-            min_gen_frames=min_gen_frames)
+            min_gen_frames=min_gen_frames, seed=seed)
         return self.codec.decode_full(tokens)
 
     @torch.inference_mode()
@@ -121,7 +124,7 @@ class SoproTTS:
                          top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True,
                          style_strength: Optional[float] = None, min_gen_frames: Optional[int] = None,
                          timings: Optional[Dict[str, float]] = None, text_ids: Optional[Sequence[torch.Tensor]] = None,
-                         phase_locks: Optional[tuple] = None) -> List[torch.Tensor]:
+                         phase_locks: Optional[tuple] = None, seed: Optional[int] = None) -> List[torch.Tensor]:
         """New: B utterances in one pass (batched AR graph, NAR and Mimi decode) -> list of [1, 1, N_b]."""
         import contextlib
         import time
@@ -136,7 +139,7 @@ class SoproTTS:
         with ar_lock:  # latency-bound phase: AR graph replay
             ev = _PhaseTimer(self.model.stream, timings)
             state = self.model.phase_ar(ids, refs, max_frames=max_frames, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-                                        style_strength=ss, min_gen_frames=min_gen_frames, ev=ev, prep=prep)
+                                        style_strength=ss, min_gen_frames=min_gen_frames, ev=ev, prep=prep, seed=seed)
         with bulk_lock:  # throughput-bound phase: NAR refinement + Mimi decode
             t0 = time.perf_counter()
             full = self.model.phase_nar(state, full=True)  # [B, Tn, Q]

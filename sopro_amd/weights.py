@@ -306,13 +306,14 @@ def synth_mimi_weights(mc: MimiDecoderConfig, seed: int = 0, *, with_encoder: bo
 def save_sopro_checkpoint(path: str, weights: Dict[str, np.ndarray], cfg: SoproTTSConfig) -> None:
     from safetensors.numpy import save_file
 
-    save_file({k: np.ascontiguousarray(v) for k, v in weights.items()}, path, metadata={"cfg": cfg.to_json()})
+    # (np.ascontiguousarray would turn the 0-d gate scalars into shape (1,))
+    save_file({k: np.require(v, requirements="C") for k, v in weights.items()}, path, metadata={"cfg": cfg.to_json()})
 
 
 def load_cfg_from_safetensors(path: str) -> SoproTTSConfig:
     from safetensors import safe_open
 
-    with safe_open(path, framework="np") as f:
+    with safe_open(path, framework="pt") as f:
         meta = f.metadata() or {}
     if "cfg" not in meta:
         raise RuntimeError(f"No 'cfg' metadata found in {path}.")
@@ -320,16 +321,20 @@ def load_cfg_from_safetensors(path: str) -> SoproTTSConfig:
 
 
 def load_safetensors(path: str, names: Optional[Iterable[str]] = None) -> Dict[str, np.ndarray]:
+    """name -> numpy array; floating tensors of any width (fp16, bf16 - which numpy cannot represent -, fp64) come back as
+    float32, integer tensors unchanged.  reference: src/sopro/hub.py:30-52 (safetensors ``load_file`` + ``load_state_dict``)."""
+    import torch
     from safetensors import safe_open
 
     out: Dict[str, np.ndarray] = {}
-    with safe_open(path, framework="np") as f:
-        keys = list(f.keys()) if names is None else [k for k in names if k in set(f.keys())]
+    with safe_open(path, framework="pt", device="cpu") as f:
+        have = set(f.keys())
+        keys = sorted(have) if names is None else [k for k in names if k in have]
         for k in keys:
-            a = f.get_tensor(k)
-            if a.dtype != np.float32 and a.dtype.kind == "f":
-                a = a.astype(np.float32)
-            out[k] = a
+            t = f.get_tensor(k)
+            if t.is_floating_point() and t.dtype != torch.float32:
+                t = t.to(torch.float32)
+            out[k] = t.contiguous().numpy()
     return out
 
 

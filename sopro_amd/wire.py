@@ -90,27 +90,19 @@ def save_reference(path: str, ref: PreparedReference) -> None:
     torch.save(reference_to(ref, "cpu"), path)
 
 
-class _RefUnpickler(pickle.Unpickler):
-    def find_class(self, module, name):
-        if name == "PreparedReference" and module in ("sopro.model", "sopro_amd.model"):
-            return PreparedReference
-        if module.split(".")[0] in ("torch", "collections", "numpy", "_codecs", "builtins") or module == "torch._utils":
-            return super().find_class(module, name)
-        raise pickle.UnpicklingError(f"refusing to load {module}.{name} from a reference cache file")
-
-
-class _RefPickle:
-    Unpickler = _RefUnpickler
-    __name__ = "sopro_amd.wire._RefPickle"
-
-    @staticmethod
-    def load(f, **kw):
-        return _RefUnpickler(f, **kw).load()
-
-
 def load_reference(path: str, device="cpu") -> PreparedReference:
-    """A cache file written by this engine or by the reference (class ``sopro.model.PreparedReference``)."""
-    obj = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_RefPickle)
+    """A cache file written by this engine or by the reference (class ``sopro.model.PreparedReference``).
+
+    Loaded with ``weights_only=True`` like the reference does (demo/server.py:99,104): torch's restricted unpickler plus
+    an allow-list of exactly one extra global, the ``PreparedReference`` dataclass, under this package's name and under the
+    name the reference pickles it with (both resolve to the class of ``sopro_amd.model``: same fields, nothing is
+    imported).  Anything else in the file - ``builtins.eval``, ``torch.hub.load``, ... - is refused by torch."""
+    allowed = [PreparedReference, (PreparedReference, "sopro.model.PreparedReference")]
+    try:
+        with torch.serialization.safe_globals(allowed):
+            obj = torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        raise ValueError(f"{path}: refusing to load ({str(e).splitlines()[-1] if str(e) else e})") from e
     if not isinstance(obj, PreparedReference):
         raise ValueError(f"{path} does not hold a PreparedReference")
     return reference_to(obj, device)

@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header(tmp_path):
         "sopro_skinny_args": (hip.SkinnyArgs, ["X", "W", "Y", "scale", "ring", "step", "Xp", "y_part_stride", "dbg", "eps", "B", "epilogue", "ring_len", "ksize", "np", "ksplit", "rms_norm", "w_layout"]),
         "sopro_attn_args": (hip.AttnArgs, ["Q", "K", "V", "O", "klens", "B", "Tk", "causal", "window", "scale"]),
         "sopro_xattn_args": (hip.XattnArgs, ["X", "Xp", "norm_w", "Kp", "klens", "Y", "eps", "scale", "np", "S_cap"]),
-        "sopro_ar_state": (hip.ArState, ["x_cur", "emb", "hist", "recent", "params", "seed", "B", "bos_row", "start", "row_max", "row_params"]),
+        "sopro_ar_state": (hip.ArState, ["x_cur", "emb", "hist", "recent", "params", "seed", "B", "bos_row", "start", "row_max", "row_params", "nonce"]),
     }
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "sopro_hip.h"', "int main(void){"]
     for cname, (_cls, fields) in checks.items():

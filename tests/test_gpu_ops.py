@@ -721,7 +721,9 @@ class _SamplerRig:
         self.hist, self.ctr = z(B, Tar, dt=torch.int32), z(8, dt=torch.int32)
         self.first_eos, self.stop_t, self.params = z(B, dt=torch.int32), z(B, dt=torch.int32), z(8)
         self.recent = z(B, 64, dt=torch.int32)
+        self.nonce = z(B, dt=torch.int32)
         st = hip.ArState()
+        st.nonce = self.nonce.data_ptr()
         st.x_cur, st.cond, st.emb, st.hist = self.x.data_ptr(), self.cond.data_ptr(), self.emb.data_ptr(), self.hist.data_ptr()
         st.step, st.arrive, st.n_stopped = self.ctr.data_ptr(), self.ctr.data_ptr() + 4, self.ctr.data_ptr() + 8
         st.first_eos, st.stop_t, st.params = self.first_eos.data_ptr(), self.stop_t.data_ptr(), self.params.data_ptr()
@@ -729,8 +731,8 @@ class _SamplerRig:
         st.seed, st.B, st.D, st.Tar, st.max_steps, st.V, st.bos_row = 7, B, D, Tar, Tar, V, 2 * V
         self.st = st
 
-    def set_params(self, top_p, temp, anti, min_gen=12, rec_p=0.85, rec_t=1.2):
-        self.params.copy_(torch.tensor([top_p, temp, 1.0 if anti else 0.0, rec_p, rec_t, 1.1, 50.0, float(min_gen)]))
+    def set_params(self, top_p, temp, anti, min_gen=12, rec_p=0.85, rec_t=1.2, rep=1.1, top_k=50.0):
+        self.params.copy_(torch.tensor([top_p, temp, 1.0 if anti else 0.0, rec_p, rec_t, rep, float(top_k), float(min_gen)]))
 
 
 def test_sampler_greedy_penalty_temperature_and_bookkeeping():
@@ -787,6 +789,60 @@ def test_sampler_topk_topp_support_and_frequencies():
     n = B * steps
     p = expect / n
     assert abs(hits / n - p) < 5 * math.sqrt(p * (1 - p) / n) + 0.02, (hits / n, p)
+
+
+@pytest.mark.parametrize("top_p,temp,top_k,scale", [(0.9, 1.05, 50, 2.0), (0.6, 0.9, 50, 4.0), (1.0, 1.0, 8, 1.0), (0.97, 1.3, 64, 0.3),
+                                                     (0.9, 1.0, 50, -1.0)])
+def test_sampler_whole_distribution_matches_reference(top_p, temp, top_k, scale):
+    """Empirical distribution of ~6000 draws against sample_token's distribution (src/sopro/sampling.py:52-80), token by
+    token (5 sigma + 0.004), nothing outside the kept set; flat-ish logits put >64 candidates through the general ranking
+    path, top_k = 8 / 64 exercise the bound at both ends.  No repetition penalty here, so the distribution is fixed."""
+    B, V1, steps = 64, 2049, 96
+    rig = _SamplerRig(B, Tar=steps + 1)
+    rig.set_params(top_p, temp, False, rep=1.0, top_k=top_k)
+    rig.nonce.copy_(torch.arange(B, dtype=torch.int32) * 7919 + 13)
+    hip.ar_init(rig.st)
+    base = rnd(V1, seed=310, scale=abs(scale))
+    if scale < 0:  # a crowded head: 200 near-equal logits above the rest -> more than 128 candidates, the general ranking path
+        base[:200] = 10.0 - 1e-3 * torch.arange(200)
+    else:
+        base[7] = base[11] = float(base.max()) + 0.5  # an exact tie at the head: lower index first
+    lg = dev(base[None].repeat(B, 1))
+    for _ in range(steps):
+        hip.ar_sample(rig.st, lg, V1)
+    torch.cuda.synchronize()
+    got = rig.hist[:, :steps].cpu().reshape(-1)
+    sp, si, forced = O.sampling_distribution(base, [], top_p, temp, top_k=top_k, repetition_penalty=1.0)
+    assert forced is None
+    p = torch.zeros(V1, dtype=torch.float64)
+    p[si] = sp.double()
+    n = got.numel()
+    freq = torch.bincount(got.long(), minlength=V1).double() / n
+    assert float(freq[p == 0].sum()) == 0.0, "a token outside the reference's kept set was drawn"
+    tol = 5.0 * torch.sqrt(p * (1 - p) / n) + 0.004
+    worst = ((freq - p).abs() - tol).max()
+    assert float(worst) <= 0.0, (float(worst), int(((freq - p).abs() - tol).argmax()))
+    assert int((p > 0).sum()) >= 2
+
+
+def test_sampler_nonce_changes_the_take_and_pins_it():
+    """Same (seed, nonce) -> the same draws; another nonce -> another take (every call used to replay one sequence)."""
+    B, V1, steps = 8, 2049, 16
+    base = rnd(V1, seed=320, scale=1.5)
+    lg = dev(base[None].repeat(B, 1))
+    runs = []
+    for nonce in (5, 5, 6):
+        rig = _SamplerRig(B, Tar=steps + 1)
+        rig.set_params(0.95, 1.0, False, rep=1.0)
+        rig.nonce.fill_(nonce)
+        hip.ar_init(rig.st)
+        for _ in range(steps):
+            hip.ar_sample(rig.st, lg, V1)
+        torch.cuda.synchronize()
+        runs.append(rig.hist[:, :steps].cpu())
+    assert torch.equal(runs[0], runs[1])
+    assert not torch.equal(runs[0], runs[2])
+    assert len({tuple(r.tolist()) for r in runs[0]}) > 1  # rows differ too (the row index is part of the counter)
 
 
 def test_sampler_anti_loop_detection():

@@ -61,8 +61,24 @@ def test_reference_cache_written_by_the_reference_loads_here(tmp_path):
     assert torch.equal(again.sv_ref, ref.sv_ref) and torch.equal(again.ref_kv_caches[2]["v"], ref.ref_kv_caches[2]["v"])
 
 
-def test_reference_cache_loader_refuses_foreign_classes(tmp_path):
+class _Evil:
+    """A payload whose unpickling would call a builtin (what a crafted cache file does)."""
+
+    def __reduce__(self):
+        return (eval, ("__import__('os').getpid()",))
+
+
+def test_reference_cache_loader_refuses_foreign_classes_and_builtins(tmp_path):
+    """weights_only=True + an allow-list of exactly the PreparedReference dataclass (as demo/server.py:99,104 loads them)."""
     p = str(tmp_path / "bad.pt")
     torch.save({"x": io.BytesIO}, p)
-    with pytest.raises(pickle.UnpicklingError):
+    with pytest.raises(ValueError):
         wire.load_reference(p)
+    p2 = str(tmp_path / "evil.pt")
+    torch.save({"x": _Evil()}, p2)
+    with pytest.raises(ValueError):
+        wire.load_reference(p2)
+    p3 = str(tmp_path / "notref.pt")
+    torch.save({"sv_ref": torch.zeros(1)}, p3)
+    with pytest.raises(ValueError):
+        wire.load_reference(p3)
