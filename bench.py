@@ -12,8 +12,13 @@ synthesises its own 32 utterances, there is no data-path collective; the timed r
 barrier + device sync on both sides and the MAX over ranks is reported.
 
 One JSON line is printed by rank 0.  Extra objects on it:
-  roofline     -- the dominant kernel family of the step (by summed HIP-event time on the engine streams),
-                  its algorithmic flops (MFMA bound) or bytes (HBM bound) per launch / its average launch time
+  roofline     -- the dominant kernel family of the step BY SUMMED HIP-EVENT TIME over every instrumented family, the AR
+                  frame graph included (it is the largest: the 23-launch per-frame graph of the autoregressive loop):
+                  algorithmic bytes (HBM bound) or flops (MFMA bound) per launch / average launch time; the other
+                  families follow in roofline_more
+  parity       -- ties the timed run to correct results: every timed step ran the same seeded job, so the first and the
+                  last step must be bit-identical; and one greedy 32 x 200 batch is generated next to the timed region and
+                  row 0 is compared with the CPU oracle in the baseline child (codebook 0 exact, refined tokens audited)
   cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference, validated against the reference
                   in tests/) timed on this host on a bounded sample of the same workload
 """
@@ -68,6 +73,32 @@ def make_inputs(rank: int):
     return ids, ref_tq
 
 
+def oracle_parity(cfg, wn, path: str):
+    """Row 0 of the engine's greedy batch (token matrix saved by the parent) against the oracle: codebook 0 must be
+    equal; refined tokens equal, or every deviating decision an audited near-tie (oracle.nar_audit)."""
+    from oracle import sopro_oracle as O
+
+    got = torch.from_numpy(np.load(path)).long()
+    w = O.to_torch(wn)
+    ids, ref_tq = make_inputs(0)
+    torch.set_num_threads(min(os.cpu_count() or 1, 8))
+    with torch.inference_mode():
+        ref = O.prepare_reference(ref_tq, w, cfg)
+        kw = dict(max_frames=FRAMES - 1, top_p=0.0, temperature=1.0, anti_loop=False, style_strength=float(cfg.style_strength))
+        want = O.generate_tokens(ids[0], ref, w, cfg, **kw)
+        out = {"row": 0, "frames": int(want.shape[0]), "shape_equal": tuple(want.shape) == tuple(got.shape)}
+        if out["shape_equal"]:
+            out["codebook0_equal"] = bool(torch.equal(want[:, 0], got[:, 0]))
+            out["refined_mismatches"] = int((want != got).sum())
+            if out["refined_mismatches"] and out["codebook0_equal"]:
+                prep = O.prepare_conditioning(ids[0], ref, w, cfg, max_frames=FRAMES - 1, style_strength=kw["style_strength"])
+                n_off, gap = O.nar_audit(prep["cond_ar"][:, : got.shape[0]], got.unsqueeze(0), w, cfg)
+                out["audit_off_argmax"], out["audit_worst_logit_gap"] = n_off, gap
+        out["ok"] = bool(out["shape_equal"] and out.get("codebook0_equal") and
+                         (out["refined_mismatches"] == 0 or out.get("audit_worst_logit_gap", 1.0) < 1e-4))
+    return out
+
+
 def cpu_baseline(cfg, mc, wn, mn, n_utts: int):
     """The oracle on the host cores, one utterance at a time (the reference has no batched API)."""
     from oracle import sopro_oracle as O
@@ -92,9 +123,25 @@ def cpu_baseline(cfg, mc, wn, mn, n_utts: int):
                       f"{dt:.1f} s wall"}
 
 
-def ar_step_bytes(B: int, S: int) -> float:
-    """weights + cond/embedding rows + ring buffers + K/V, fp32 (w = a = 4 bytes)."""
-    return 10_575_492 * 4 + B * (768 + 32_256 + 2304 * S) * 4
+def ar_step_bytes(B: int, S: int, wbytes: int = 4, abytes: int = 4) -> float:
+    """weights + cond/embedding rows + ring buffers + K/V per AR frame (w = a = 4 bytes in fp32)."""
+    return 10_575_492 * wbytes + B * (768 + 32_256 + 2304 * S) * abytes
+
+
+def latest_profile(suffix: str) -> dict:
+    """profiles/rNN_<suffix> of the latest round that has one (rocprofv3 summaries of this same command, tools/pmc_summary.py,
+    tools/ar_kernel_table.py); {} when there is none."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    if not files:
+        return {}
+    try:
+        d = json.load(open(files[-1]))
+        d.setdefault("source", os.path.relpath(files[-1], ROOT))
+        return d
+    except Exception:  # noqa: BLE001
+        return {}
 
 
 _T0 = time.perf_counter()
@@ -113,15 +160,19 @@ def main() -> None:
     ap.add_argument("--profile-steps", type=int, default=4, help="instrumented repeat of the steps for the per-kernel roofline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=6)
-    ap.add_argument("--ttfa-runs", type=int, default=20)
+    ap.add_argument("--ttfa-runs", type=int, default=50, help="stream() calls timed for the p50 time-to-first-audio (after 5 warm-ups)")
     ap.add_argument("--lanes", type=int, default=4, help="engines pipelined on one GPU (1 = strictly sequential batches)")
     ap.add_argument("--ar-cus", type=int, default=64, help="CUs of each AR partition (latency-bound phase) when lanes > 1")
     ap.add_argument("--ar-shared", type=int, default=1, help="1: the AR partitions are one CU range used by --ar-parts AR phases at once")
     ap.add_argument("--bulk-slots", type=int, default=1, help="refinement / decoding phases allowed at the same time on the throughput partition")
     ap.add_argument("--ar-parts", type=int, default=2, help="independent AR partitions (concurrent AR phases) when lanes > 1")
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per step (default: BASELINE configs[1])")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="f32 (default): the parity configuration; bf16: bf16 weights/operands with fp32 accumulation (BASELINE configs[1] wording)")
     ap.add_argument("--frames", type=int, default=FRAMES, help="frames per utterance (default: BASELINE configs[1]; 400 = the long-form case)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--parity-tokens", type=str, default="", help=argparse.SUPPRESS)
+    ap.add_argument("--input-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: a 1-GPU run on the inputs of rank R
     args = ap.parse_args()
     BATCH, FRAMES = int(args.batch), int(args.frames)
 
@@ -130,8 +181,10 @@ def main() -> None:
         from sopro_amd.weights import synth_mimi_weights, synth_sopro_weights
 
         cfg, mc = SoproTTSConfig(), MimiDecoderConfig()
-        print(json.dumps(cpu_baseline(cfg, mc, synth_sopro_weights(cfg, VOCAB, 0, suppress_eos=True), synth_mimi_weights(mc, 0),
-                                      args.cpu_utts)), flush=True)
+        wn = synth_sopro_weights(cfg, VOCAB, 0, suppress_eos=True)
+        par = oracle_parity(cfg, wn, args.parity_tokens) if args.parity_tokens else None
+        base = cpu_baseline(cfg, mc, wn, synth_mimi_weights(mc, 0), args.cpu_utts)
+        print(json.dumps({"cpu_baseline": base, "parity": par}), flush=True)
         return
 
     if args.gpus > 1 and "RANK" not in os.environ:  # started by hand: re-launch as one rank per GPU, like the driver does
@@ -158,20 +211,30 @@ def main() -> None:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        # communicators are created lazily by the first collective: do that here, far away from the timed region
+        warm_t = torch.zeros(1, device="cpu" if share_gpu else device)
+        dist.all_reduce(warm_t, op=dist.ReduceOp.MAX)
+        dist.barrier()
 
     from sopro_amd import hip
 
     log("building engine")
     tts, cfg, mc, wn, mn = build_engine(device)
-    ids, ref_tq = make_inputs(rank)
+    ids, ref_tq = make_inputs(rank if args.input_rank < 0 else args.input_rank)
     ref = tts.prepare_reference(ref_tokens_tq=ref_tq)  # per-voice, outside the timed region (README "precalculate" flow)
     refs = [ref] * BATCH
-    kw = dict(max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True, text_ids=ids)
+    # one seed for every step: the steps are then the same job, and their outputs must be bit-identical (checked below)
+    kw = dict(max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True, text_ids=ids, seed=20260924)
 
     job = dict(texts=[""] * BATCH, refs=refs, **kw)
+    kept = []  # device waveforms of the first and the last timed step (references only: nothing is copied in the timed region)
 
     def check(out):
         assert all(o.shape[-1] == FRAMES * 1920 for o in out)
+        if len(kept) < 2:
+            kept.append(out)
+        else:
+            kept[1] = out
 
     pipe = None
     if args.lanes > 1:
@@ -203,6 +266,7 @@ def main() -> None:
     warm = max(args.warmup, 2 * args.lanes if pipe is not None else 2)
     run_steps(warm)
     fence()
+    kept.clear()
     log("timed steps")
     phases = {}
     t0 = time.perf_counter()
@@ -210,6 +274,22 @@ def main() -> None:
     fence()
     dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f} s for {args.steps} steps; peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    steps_identical = bool(len(kept) == 2 and all(torch.equal(a, b) for a, b in zip(kept[0], kept[1])))
+    finite = bool(kept and all(bool(torch.isfinite(o).all()) for o in kept[-1]))
+    # content hash of this rank's last step (PCM16 of every utterance): N ranks must reproduce what N single-GPU runs give
+    import hashlib
+
+    from sopro_amd.wire import float_to_pcm16le
+
+    hsh = hashlib.sha256()
+    for o in (kept[-1] if kept else []):
+        hsh.update(float_to_pcm16le(o.reshape(1, -1)))
+    rank_hashes = [hsh.hexdigest()[:16]]
+    if world > 1:
+        allh = [None] * world
+        dist.all_gather_object(allh, rank_hashes[0])
+        rank_hashes = allh
+    kept.clear()
     if world > 1:
         t = torch.tensor([dt], device="cpu" if share_gpu else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -225,121 +305,151 @@ def main() -> None:
         fence()
         hip.set_profiler(None)
 
-    # ---- roofline of the dominant kernel family (HIP events recorded on the engine streams during the timed steps)
+    # ---- rooflines of the instrumented families (HIP events recorded on the engine streams during the instrumented repeat)
     fam = prof.summary()
-    pmc = {}
-    try:  # HBM bytes per launch from the rocprofv3 PMC passes of this command (tools/pmc_summary.py -> profiles/)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["families"]
-    except Exception:  # noqa: BLE001
-        pmc = {}
-    try:  # matrix-core busy share from the SQ_VALU_MFMA_BUSY_CYCLES pass (tools/pmc_summary.py --mfma; whole chip per kernel)
-        busy = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_busy.json")))["families"]
-    except Exception:  # noqa: BLE001
-        busy = {}
-    roof, roof_ar = None, None
+    pmc, busy, ark = latest_profile("pmc_summary.json").get("families", {}), latest_profile("pmc_mfma_busy.json").get("families", {}), \
+        latest_profile("ar_kernels.json")
     share = (256 - args.ar_cus * (1 if args.ar_shared else args.ar_parts)) / 256.0 if args.lanes > 1 else 1.0  # CUs of the bulk partition
-    roof_split = None
+    ar_share = (args.ar_cus * (1 if args.ar_shared else args.ar_parts)) / 256.0 if args.lanes > 1 else 1.0
+    measured = f"HIP events on the launch stream over an instrumented repeat of {nprof} steps right after the timed region"
+
+    def mfma_entry(key, title, peak, passes, extra_note):
+        f = fam[key]
+        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        e = {"kernel": title, "bound": "mfma", "achieved": round(ach, 3), "peak": round(peak * share, 2), "unit": "TFLOP/s",
+             "frac": round(ach / (peak * share), 5), "cu_share": share, "peak_full_chip": peak, "frac_full_chip": round(ach / peak, 5),
+             "traffic": pmc.get(key, {}).get("traffic_bytes_per_launch"), "launches": f["launches"],
+             "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2), "ms_per_step": round(f["ms"] / max(1, nprof), 3),
+             "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"])), "measured": measured}
+        if passes > 1:
+            e["mfma_passes_per_product"] = passes
+            e["frac_of_pass_ceiling"] = round(ach / (peak * share / passes), 5)
+            e["note"] = f"achieved = algorithmic (fp32-equivalent) flops / launch time; each product costs {passes} bf16 MFMA passes. " + extra_note
+        if key in busy:
+            e["mfma_busy_pmc"] = busy[key].get("mfma_busy_share_at_2p4ghz")
+        return e
+
+    entries = []  # (summed ms, entry)
     if "gemm_bf16x3_kernel" in fam:
-        f = fam["gemm_bf16x3_kernel"]
-        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-        roof_split = {"kernel": "gemm_bf16x3_kernel (Mimi decoder contractions; v_mfma_f32_32x32x16_bf16, 3 passes per product)",
-                      "bound": "mfma", "achieved": round(ach, 3), "peak": round(PEAK_BF16_MFMA_TFLOPS * share, 2), "unit": "TFLOP/s",
-                      "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS * share), 5), "cu_share": share,
-                      "peak_three_pass": round(PEAK_BF16_MFMA_TFLOPS * share / 3.0, 2),
-                      "frac_three_pass": round(ach / (PEAK_BF16_MFMA_TFLOPS * share / 3.0), 5),
-                      "traffic": pmc.get("gemm_bf16x3_kernel", {}).get("traffic_bytes_per_launch"), "launches": f["launches"],
-                      "mfma_busy_pmc": busy.get("gemm_bf16x3_kernel", {}).get("mfma_busy_share_at_2p4ghz"),
-                      "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2),
-                      "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"])),
-                      "note": "achieved = algorithmic (fp32-equivalent) flops / launch time; each product costs three bf16 MFMA passes"}
-    roof_x6 = None
+        entries.append((fam["gemm_bf16x3_kernel"]["ms"], mfma_entry(
+            "gemm_bf16x3_kernel", "gemm_bf16x3_kernel (Mimi decoder contractions; v_mfma_f32_32x32x16_bf16, 3 passes per product)",
+            PEAK_BF16_MFMA_TFLOPS, 3, "16-bit operands, waveform contract 1e-4 of peak")))
     if "gemm_bf16x6_kernel" in fam:
-        f = fam["gemm_bf16x6_kernel"]
-        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-        roof_x6 = {"kernel": "gemm_bf16x6_kernel (NAR contractions; v_mfma_f32_32x32x16_bf16, 6 passes per product, 24-bit operands)",
-                   "bound": "mfma", "achieved": round(ach, 3), "peak": round(PEAK_BF16_MFMA_TFLOPS * share, 2), "unit": "TFLOP/s",
-                   "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS * share), 5), "cu_share": share,
-                   "peak_six_pass": round(PEAK_BF16_MFMA_TFLOPS * share / 6.0, 2),
-                   "frac_six_pass": round(ach / (PEAK_BF16_MFMA_TFLOPS * share / 6.0), 5),
-                   "traffic": pmc.get("gemm_bf16x6_kernel", {}).get("traffic_bytes_per_launch"), "launches": f["launches"],
-                   "mfma_busy_pmc": busy.get("gemm_bf16x6_kernel", {}).get("mfma_busy_share_at_2p4ghz"),
-                   "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2),
-                   "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"])),
-                   "note": "achieved = algorithmic (fp32-equivalent) flops / launch time; each product costs six bf16 MFMA passes"}
+        entries.append((fam["gemm_bf16x6_kernel"]["ms"], mfma_entry(
+            "gemm_bf16x6_kernel", "gemm_bf16x6_kernel (NAR contractions; v_mfma_f32_32x32x16_bf16, 6 passes per product, 24-bit operands)",
+            PEAK_BF16_MFMA_TFLOPS, 6, "fp32-class products: refined tokens must equal the fp32 reference's")))
+    if "gemm_bf16x1_kernel" in fam:
+        entries.append((fam["gemm_bf16x1_kernel"]["ms"], mfma_entry(
+            "gemm_bf16x1_kernel", "gemm_bf16x1_kernel (bf16 mode: NAR + Mimi contractions, bf16 operands, fp32 accumulate, one MFMA pass)",
+            PEAK_BF16_MFMA_TFLOPS, 1, "")))
     if "gemm_f32_kernel" in fam:
-        f = fam["gemm_f32_kernel"]
-        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-        roof = {"kernel": "gemm_f32_kernel (all tile shapes; v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": round(ach, 3),
-                "peak": round(PEAK_F32_MFMA_TFLOPS * share, 2), "unit": "TFLOP/s", "frac": round(ach / (PEAK_F32_MFMA_TFLOPS * share), 5),
-                "cu_share": share, "peak_full_chip": PEAK_F32_MFMA_TFLOPS, "frac_full_chip": round(ach / PEAK_F32_MFMA_TFLOPS, 5),
-                "traffic": pmc.get("gemm_f32_kernel", {}).get("traffic_bytes_per_launch"), "launches": f["launches"],
-                "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2),
-                "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"]))}
+        entries.append((fam["gemm_f32_kernel"]["ms"], mfma_entry(
+            "gemm_f32_kernel", "gemm_f32_kernel (all tile shapes; v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1, "")))
     if "ar_step_graph" in fam:
         f = fam["ar_step_graph"]
         per_launch_ms = f["ms"] / max(1, f["launches"])
-        bytes_step = ar_step_bytes(BATCH, TEXT_LEN)
+        bytes_step = ar_step_bytes(BATCH, TEXT_LEN, 2 if args.precision == "bf16" else 4)
         ach = bytes_step / (per_launch_ms * 1e-3) / 1e9
-        tr = None
-        if pmc:
-            per_frame = {"skinny_kernel": 19, "xattn_step_kernel": 3, "ar_sample_kernel": 1}
-            tr = round(sum(pmc.get(k, {}).get("traffic_bytes_per_launch", 0) * n for k, n in per_frame.items()))
-        roof_ar = {"kernel": "AR frame (hipGraph of 23 launches: skinny_kernel x19, xattn_step_kernel x3, ar_sample_kernel)", "bound": "hbm",
-                   "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5),
-                   "traffic": tr, "launches": f["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
-                   "algorithmic_bytes_per_launch": bytes_step}
-    # `roofline` = the compute kernel family with the largest share of a step; the others follow as roofline_more
-    cands = [(fam[k]["ms"], r) for k, r in (("gemm_f32_kernel", roof), ("gemm_bf16x3_kernel", roof_split),
-                                                 ("gemm_bf16x6_kernel", roof_x6)) if r is not None]
-    cands.sort(key=lambda t: -t[0])
-    roof = cands[0][1] if cands else None
-    roof_more = [r for _, r in cands[1:]] + ([roof_ar] if roof_ar is not None else [])
-    for r in [roof] + roof_more:
-        if r is not None:
-            r["measured"] = f"HIP events on the launch stream over an instrumented repeat of {nprof} steps right after the timed region"
+        per_frame = ark.get("launches_per_frame") or {"skinny_kernel": 19, "xattn_step_kernel": 3, "ar_sample_kernel": 1}
+        tr = round(sum(pmc.get(k, {}).get("traffic_bytes_per_launch", 0) * n for k, n in per_frame.items())) if pmc else None
+        e = {"kernel": f"AR frame (hipGraph of {sum(per_frame.values())} launches: " + ", ".join(f"{k} x{n}" for k, n in per_frame.items()) + ")",
+             "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5),
+             "traffic": tr or None, "traffic_ratio": round(tr / bytes_step, 3) if tr else None, "launches": f["launches"],
+             "avg_launch_us": round(per_launch_ms * 1e3, 2), "ms_per_step": round(f["ms"] / max(1, nprof), 3),
+             "algorithmic_bytes_per_launch": bytes_step, "rows_per_launch": BATCH, "cu_share": ar_share, "measured": measured,
+             "note": ("one launch = one frame of one 32-row batch; in the pipeline two AR phases replay concurrently on the generation "
+                      "partition, so the phase sum exceeds the wall time per step" if args.lanes > 1 else "sequential batches, whole chip")}
+        if ark.get("kernels"):
+            e["per_kernel_us_rocprof"] = ark["kernels"]
+            e["per_kernel_source"] = ark.get("source")
+        entries.append((f["ms"], e))
+    entries.sort(key=lambda t: -t[0])
+    roof = entries[0][1] if entries else None
+    roof_more = [e for _, e in entries[1:]]
     families = {k: {"ms_per_step": round(v["ms"] / max(1, nprof), 3), "launches_per_step": v["launches"] // max(1, nprof),
                     "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 3) if v["flops"] else None} for k, v in fam.items()}
 
     if pipe is not None:
         pipe.close()  # the latency leg below runs on the whole chip
 
+    # ---- the AR frame alone on the whole chip (nothing else running): what the frame costs without the pipeline's contention
+    iso = None
+    if rank == 0 and roof is not None and "ar_step_graph" in fam:
+        log("isolated AR frame")
+        prep = tts.model.phase_cond(ids, refs, max_frames=FRAMES - 1, style_strength=float(cfg.style_strength))
+        arkw = dict(max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True, style_strength=float(cfg.style_strength),
+                    min_gen_frames=None, prep=prep, seed=1)
+        tts.model.phase_ar(ids, refs, **arkw)  # records the frame graph of this stream
+        p2 = hip.Profiler()
+        hip.set_profiler(p2)
+        tts.model.phase_ar(ids, refs, **arkw)
+        torch.cuda.synchronize()
+        hip.set_profiler(None)
+        f = p2.summary().get("ar_step_graph")
+        if f:
+            us = f["ms"] / max(1, f["launches"]) * 1e3
+            bts = ar_step_bytes(BATCH, TEXT_LEN, 2 if args.precision == "bf16" else 4)
+            iso = {"avg_launch_us": round(us, 2), "achieved_GBps": round(bts / (us * 1e-6) / 1e9, 1),
+                   "frac": round(bts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 5), "launches": f["launches"],
+                   "what": "one 32-row AR phase alone on all 256 CUs, HIP events around every frame-graph replay"}
+        for e in [roof] + roof_more:
+            if e["kernel"].startswith("AR frame"):
+                e["isolated_whole_chip"] = iso
+
+    # ---- one greedy batch of the same shape for the parity leg (row 0 goes to the oracle in the CPU child below)
+    parity_path = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import tempfile
+
+        log("greedy parity batch")
+        gt = tts.model.generate_tokens_batch(ids, refs, max_frames=FRAMES - 1, top_p=0.0, temperature=1.0, anti_loop=False,
+                                             style_strength=float(cfg.style_strength))
+        parity_path = os.path.join(tempfile.mkdtemp(prefix="sopro_bench_"), "row0.npy")
+        np.save(parity_path, gt[0].cpu().numpy())
+
     # ---- p50 time-to-first-audio of stream(), batch 1 (BASELINE.json configs[2]); outside the timed steps
     ttfa = None
     if rank == 0 and args.ttfa_runs > 0:
         log("ttfa")
         lat = []
-        for i in range(args.ttfa_runs + 3):
+        TTFA_WARM = 5
+        for i in range(args.ttfa_runs + TTFA_WARM):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             it = tts.stream("", ref=ref, max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True, chunk_frames=6,
                             text_ids=ids[i % BATCH])
             first = next(it)
             torch.cuda.synchronize()
-            if i >= 3:
+            if i >= TTFA_WARM:
                 lat.append((time.perf_counter() - t1) * 1e3)
+            it.close()
             del it, first
         ttfa = float(np.percentile(lat, 50))
 
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import subprocess
 
-        log("cpu baseline (oracle, child process, <= 150 s)")
+        log("cpu baseline + oracle parity (child process, <= 180 s)")
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-utts", str(args.cpu_utts), "--frames", str(FRAMES),
-                                "--batch", str(BATCH)],
-                               capture_output=True, text=True, timeout=150, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
-            cpu = json.loads(r.stdout.strip().splitlines()[-1])
+                                "--batch", str(BATCH), "--parity-tokens", parity_path or ""],
+                               capture_output=True, text=True, timeout=180, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+            both = json.loads(r.stdout.strip().splitlines()[-1])
+            cpu, parity = both["cpu_baseline"], both["parity"]
         except Exception as e:  # noqa: BLE001  (a missing baseline must not void the GPU measurement)
             log(f"cpu baseline failed: {e!r}")
             cpu = None
+    parity = dict(parity or {}, timed_steps_identical=steps_identical, timed_outputs_finite=finite, rank_output_sha16=rank_hashes,
+                  how="all timed steps run one seeded job: first vs last step compared bit for bit; oracle leg: row 0 of a greedy batch of "
+                      "the same shape vs oracle/sopro_oracle.py (codebook 0 exact; refined tokens exact or audited near-ties < 1e-4)")
 
     if rank == 0:
         audio_sec = world * args.steps * BATCH * FRAMES * FRAME_SEC
         line = {
             "metric": "audio_seconds_per_second", "value": round(audio_sec / dt, 2), "unit": "audio-s/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "warmup_run": warm, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"Sopro-135M synthesize, {BATCH} utterances x {FRAMES} frames per GPU ({'BASELINE configs[1]' if (BATCH, FRAMES) == (32, 200) else 'non-default shape'}), "
                                    f"S={TEXT_LEN} text tokens, {REF_FRAMES}-frame reference voice prepared outside the timed region, "
                                    "top_p=0.9 T=1.05 anti_loop (reference defaults), synthetic weights with EOS suppressed",
@@ -354,7 +464,7 @@ def main() -> None:
             "phase_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phases.items()},
             "kernel_families": families,
             "ttfa_ms_p50": None if ttfa is None else round(ttfa, 3),
-            "roofline": roof, "roofline_more": roof_more, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_more": roof_more, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

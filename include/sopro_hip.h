@@ -19,7 +19,7 @@
  *     addresses are `seg_stride` elements apart (this is how per-utterance zero padding in
  *     front of causal convolutions is addressed without copies);
  *   - weights are fp32 [N, K] row-major (torch nn.Linear layout); convolution weights are
- *     repacked by the host into that layout (sopro_amd/engine/pack.py).
+ *     repacked by the host into that layout (sopro_amd/pack.py).
  */
 #ifndef SOPRO_HIP_H
 #define SOPRO_HIP_H

@@ -1,0 +1,35 @@
+"""bench.py's multi-rank path on ONE GPU (SOPRO_BENCH_SHARE_GPU=1: every rank on device 0, gloo for the barrier / MAX):
+the launch path the driver uses for N > 1 (torch.distributed.run, one rank per GPU), the per-rank input sharding and the
+rank-0 JSON line.  Each rank's output must be what a single-GPU run on that rank's inputs produces."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+SMALL = ["--steps", "2", "--warmup", "1", "--batch", "4", "--frames", "24", "--lanes", "1", "--profile-steps", "0", "--ttfa-runs", "0",
+         "--no-cpu-baseline"]
+
+
+def _bench(extra, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, *extra], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, **(env or {})), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_two_ranks_reproduce_two_single_gpu_runs():
+    two = _bench(["--gpus", "2"], env={"SOPRO_BENCH_SHARE_GPU": "1", "MASTER_PORT": "29547"})
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["steps"] == 2
+    assert two["parity"]["timed_steps_identical"] and two["parity"]["timed_outputs_finite"]
+    hashes = two["parity"]["rank_output_sha16"]
+    assert len(hashes) == 2 and hashes[0] != hashes[1]  # the ranks synthesise different utterances
+    for r in (0, 1):
+        one = _bench(["--gpus", "1", "--input-rank", str(r)])
+        assert one["n_gpus"] == 1 and one["parity"]["rank_output_sha16"] == [hashes[r]], r
+    # whole-job aggregate: two ranks' audio over the slower rank's time
+    assert two["value"] > 0 and abs(two["value"] * two["ms_per_step"] - 2 * 4 * 24 * 0.08 * 1e3) < 1e-3 * two["value"] * two["ms_per_step"]
