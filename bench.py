@@ -55,7 +55,7 @@ class Tok:
         raise RuntimeError("bench passes token ids directly")
 
 
-def build_engine(device: str):
+def build_engine(device: str, precision: str = "f32"):
     from sopro_amd import SoproTTS
     from sopro_amd.config import MimiDecoderConfig, SoproTTSConfig
     from sopro_amd.weights import synth_mimi_weights, synth_sopro_weights
@@ -63,7 +63,7 @@ def build_engine(device: str):
     cfg, mc = SoproTTSConfig(), MimiDecoderConfig()
     wn = synth_sopro_weights(cfg, VOCAB, 0, suppress_eos=True)  # EOS bias -1e9: fixed-length runs
     mn = synth_mimi_weights(mc, 0)
-    return SoproTTS.from_weights(cfg, wn, mn, Tok(), device=device), cfg, mc, wn, mn
+    return SoproTTS.from_weights(cfg, wn, mn, Tok(), device=device, precision=precision), cfg, mc, wn, mn
 
 
 def make_inputs(rank: int):
@@ -219,7 +219,7 @@ def main() -> None:
     from sopro_amd import hip
 
     log("building engine")
-    tts, cfg, mc, wn, mn = build_engine(device)
+    tts, cfg, mc, wn, mn = build_engine(device, args.precision)
     ids, ref_tq = make_inputs(rank if args.input_rank < 0 else args.input_rank)
     ref = tts.prepare_reference(ref_tokens_tq=ref_tq)  # per-voice, outside the timed region (README "precalculate" flow)
     refs = [ref] * BATCH
@@ -459,8 +459,11 @@ def main() -> None:
                                       f"{'one shared partition' if args.ar_shared else 'partitions'} of {args.ar_cus} CUs while conditioning, NAR and Mimi "
                                       f"decode of other batches run on the other {int(round(256 * share))} CUs (hipExtStreamCreateWithCUMask); NAR and Mimi "
                                       "launch sequences are recorded hipGraphs") if args.lanes > 1 else "none"},
-            "dtype_detail": "fp32 tensors and accumulation everywhere; conditioning + AR on v_mfma_f32_*_f32; NAR contractions with operands split into "
-                            "three bf16 pieces (24 mantissa bits, 6 MFMA passes); Mimi decoder contractions with two pieces (16 bits, 3 passes)",
+            "dtype_detail": ("fp32 tensors and accumulation everywhere; conditioning + AR on v_mfma_f32_*_f32; NAR contractions with operands split into "
+                             "three bf16 pieces (24 mantissa bits, 6 MFMA passes); Mimi decoder contractions with two pieces (16 bits, 3 passes)")
+                            if args.precision == "f32" else
+                            ("bf16 mode (SURVEY 8d config 2): NAR + Mimi contractions with both operands rounded to bf16 once, one MFMA pass, fp32 accumulators, "
+                             "norms, softmax and residual streams; conditioning and the AR frame stay fp32.  Not a parity line: see tests/test_gpu_bf16_mode.py"),
             "phase_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phases.items()},
             "kernel_families": families,
             "ttfa_ms_p50": None if ttfa is None else round(ttfa, 3),

@@ -123,6 +123,14 @@ int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopr
  * prologues NONE / ADDVEC, epilogues NONE / GELU / RES / GLU.  The weight must have been packed with pieces = 3; of `ext`
  * (may be NULL) only the split-K fields apply. */
 int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
+/* One-pass variant = the engine's bf16 mode (BASELINE.json configs[1] / SURVEY 8d config 2: bf16 weights and activations,
+ * fp32 accumulators, norms and softmax in fp32): both operands are rounded to bf16 once (W when it is packed with
+ * pieces = 1, A while it is staged), one v_mfma_f32_32x32x16_bf16 pass per product.  Replaces, for the contractions of
+ * src/sopro/nn/nar.py:89-116, blocks.py:113-162 and HF:modeling_mimi.py:210-447,602-726, what torch.autocast(bfloat16)
+ * would run.  Takes every (prologue, epilogue, fused-RMSNorm, activated-output c_mode 3 / 4, split-K) form of the two
+ * entry points above except the split-form operands (a_format 1, c_mode 1 / 2).  Not a parity path: judged by logit error /
+ * token agreement / waveform error against the fp32 oracle (tests/test_gpu_bf16_mode.py). */
+int sopro_gemm_bf16x1(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
 /* W [N, ldw] fp32 (device) -> `pieces` (2: bf16x3, 3: bf16x6) bf16 planes in MFMA fragment order
  * [n/32][k/16][piece][lane][8]; `packed` holds sopro_packed_w_bytes(N, K, pieces) bytes, 16-byte aligned. */
 int sopro_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t pieces, void* packed, void* stream);

@@ -42,7 +42,11 @@ class MimiDecodeState:
 
 
 class MimiCodec:
-    def __init__(self, weights: Dict[str, "np.ndarray"], mc: Optional[MimiDecoderConfig] = None, device: str = "cuda:0"):
+    def __init__(self, weights: Dict[str, "np.ndarray"], mc: Optional[MimiDecoderConfig] = None, device: str = "cuda:0",
+                 precision: str = "f32"):
+        if precision not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        self.precision = precision  # "bf16": decoder contractions with bf16 operands, one MFMA pass (fp32 accumulate / activations)
         hip.load()
         if not torch.cuda.is_available():
             raise hip.SoproHipError("no HIP device visible: the Mimi decoder has no CPU fallback")
@@ -72,7 +76,7 @@ class MimiCodec:
                 for k, v in self.w.items():
                     if v.dim() == 2 and k.endswith(".w") and (k.startswith(("tr.", "sea.conv0", "sea.up", "sea.res", "rvq_proj")))\
                             and int(v.shape[0]) >= 64 and int(v.shape[1]) % 32 == 0:
-                        self.wd[k] = hip.pack_w_bf16x3(v)
+                        self.wd[k] = hip.pack_w_bf16x1(v) if precision == "bf16" else hip.pack_w_bf16x3(v)
                 torch.cuda.synchronize(self.device)
             n_st = len(self.mc.upsampling_ratios)
             need = ["rvq_proj.w", "sea.conv0.w"] + [f"sea.up{i}.w" for i in range(n_st)] + \

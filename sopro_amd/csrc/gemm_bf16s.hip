@@ -1,6 +1,8 @@
 // fp32 contraction at bf16 matrix-core rate: every operand is split into NPL bf16 pieces (x = p0 + p1 [+ p2], each the
 // round-to-nearest bf16 of what the previous pieces left) and the product is accumulated in fp32 with
 // v_mfma_f32_32x32x16_bf16 over the piece pairs that matter:
+//   NPL = 1 ("bf16x1"): p0*p0                              the bf16 mode of the engine (BASELINE configs[1]: bf16 weights
+//                       and activations, fp32 accumulators): operands rounded to bf16 once, one MFMA pass.
 //   NPL = 2 ("bf16x3"): p1*p0 + p0*p1 + p0*p0             16 mantissa bits per operand, ~2^-17 relative per product.
 //                       For paths whose contract is a waveform tolerance (Mimi decoder).
 //   NPL = 3 ("bf16x6"): + p1*p1 + p2*p0 + p0*p2            24 mantissa bits per operand, dropped terms <= 2^-25: the
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
 
   const int frow = lane & 31, fg = lane >> 5;
   // piece pairs (A piece, B piece), smallest terms first
-  constexpr int NPAIR = NPL == 2 ? 3 : 6;
-  constexpr int PA[6] = {NPL == 2 ? 1 : 2, 0, NPL == 2 ? 0 : 1, 1, 0, 0};
+  constexpr int NPAIR = NPL == 1 ? 1 : (NPL == 2 ? 3 : 6);
+  constexpr int PA[6] = {NPL == 1 ? 0 : (NPL == 2 ? 1 : 2), 0, NPL == 2 ? 0 : 1, 1, 0, 0};
   constexpr int PB[6] = {0, NPL == 2 ? 1 : 2, NPL == 2 ? 0 : 1, 0, 1, 0};
   auto compute = [&](int buf, const uint4 (&rb)[TN][2][NPL]) {
     const unsigned char* a = As + buf * BM * AROW + (wm * TM * 32 + frow) * AROW + fg * 16;
@@ -357,11 +359,11 @@ inline int amode_of(const sopro_gemm_args& g, const sopro_gemm_split_ext& ext) {
 }
 
 // The (epilogue, A format, output mode) combinations the engine issues; anything else is refused.
-template <int WM, int WN, int TM, int TN>
+template <int NPL, int WM, int WN, int TM, int TN>
 int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
   const int key = g.epilogue * 100 + amode_of(g, ext) * 10 + ext.c_mode;
 #define SOPRO_CASE(E, A, O) \
-  case (E) * 100 + (A) * 10 + (O): return launch_one<2, WM, WN, TM, TN, E, A, O>(g, wp, ksubs, ext, s)
+  case (E) * 100 + (A) * 10 + (O): return launch_one<NPL, WM, WN, TM, TN, E, A, O>(g, wp, ksubs, ext, s)
   switch (key) {
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 0);  // transformer qkv, RVQ output projections
     SOPRO_CASE(SOPRO_EPI_GELU, 0, 0);  // transformer fc1
@@ -371,25 +373,30 @@ int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 3);  // activated-copy flow of the SEANet decoder: ELU applied once, by the producer
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 4);
     SOPRO_CASE(SOPRO_EPI_RES, 0, 3);
-    SOPRO_CASE(SOPRO_EPI_NONE, 0, 1);  // split-form activation flow (SOPRO_MIMI_SPLIT_FORM): fp32 in, ELU + split out
-    SOPRO_CASE(SOPRO_EPI_NONE, 0, 2);
-    SOPRO_CASE(SOPRO_EPI_NONE, 2, 0);
-    SOPRO_CASE(SOPRO_EPI_NONE, 2, 1);
-    SOPRO_CASE(SOPRO_EPI_NONE, 2, 2);
-    SOPRO_CASE(SOPRO_EPI_RES, 2, 1);
     default: break;
   }
+  if constexpr (NPL == 2) {
+    switch (key) {
+      SOPRO_CASE(SOPRO_EPI_NONE, 0, 1);  // split-form activation flow (SOPRO_MIMI_SPLIT_FORM): fp32 in, ELU + split out
+      SOPRO_CASE(SOPRO_EPI_NONE, 0, 2);
+      SOPRO_CASE(SOPRO_EPI_NONE, 2, 0);
+      SOPRO_CASE(SOPRO_EPI_NONE, 2, 1);
+      SOPRO_CASE(SOPRO_EPI_NONE, 2, 2);
+      SOPRO_CASE(SOPRO_EPI_RES, 2, 1);
+      default: break;
+    }
+  }
 #undef SOPRO_CASE
-  sopro_set_error("sopro_gemm_bf16x3: (epilogue %d, prologue %d, a_format %d, c_mode %d) is not an available combination",
-                  g.epilogue, g.prologue, ext.a_format, ext.c_mode);
+  sopro_set_error("sopro_gemm_bf16x%d: (epilogue %d, prologue %d, a_format %d, c_mode %d) is not an available combination",
+                  NPL == 2 ? 3 : NPL, g.epilogue, g.prologue, ext.a_format, ext.c_mode);
   return -2;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int NPL, int WM, int WN, int TM, int TN>
 int launch_cfg6(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
   const int key = g.epilogue * 10 + amode_of(g, ext);
 #define SOPRO_CASE(E, A) \
-  case (E) * 10 + (A): return launch_one<3, WM, WN, TM, TN, E, A, 0>(g, wp, ksubs, ext, s)
+  case (E) * 10 + (A): return launch_one<NPL, WM, WN, TM, TN, E, A, 0>(g, wp, ksubs, ext, s)
   switch (key) {
     SOPRO_CASE(SOPRO_EPI_NONE, 0);  // plain projections
     SOPRO_CASE(SOPRO_EPI_GELU, 0);  // FF1
@@ -401,10 +408,10 @@ int launch_cfg6(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
   }
 #undef SOPRO_CASE
   if constexpr (WN * TN * 32 >= 64) {
-    if (key == SOPRO_EPI_GLU * 10) return launch_one<3, WM, WN, TM, TN, SOPRO_EPI_GLU, 0, 0>(g, wp, ksubs, ext, s);
-    if (key == SOPRO_EPI_GLU * 10 + 4) return launch_one<3, WM, WN, TM, TN, SOPRO_EPI_GLU, 4, 0>(g, wp, ksubs, ext, s);  // RMSNorm -> GLU
+    if (key == SOPRO_EPI_GLU * 10) return launch_one<NPL, WM, WN, TM, TN, SOPRO_EPI_GLU, 0, 0>(g, wp, ksubs, ext, s);
+    if (key == SOPRO_EPI_GLU * 10 + 4) return launch_one<NPL, WM, WN, TM, TN, SOPRO_EPI_GLU, 4, 0>(g, wp, ksubs, ext, s);  // RMSNorm -> GLU
   }
-  sopro_set_error("sopro_gemm_bf16x6: (epilogue %d, prologue %d) is not an available combination", g.epilogue, g.prologue);
+  sopro_set_error("sopro_gemm_bf16x%d: (epilogue %d, prologue %d) is not an available combination", NPL == 3 ? 6 : NPL, g.epilogue, g.prologue);
   return -2;
 }
 
@@ -436,18 +443,20 @@ extern "C" int sopro_gemm_bf16_set_tile_override(int cfg) {
 }
 
 extern "C" int64_t sopro_packed_w_bytes(int32_t N, int32_t K, int32_t pieces) {
-  if (N <= 0 || K <= 0 || (pieces != 2 && pieces != 3)) return 0;
+  if (N <= 0 || K <= 0 || pieces < 1 || pieces > 3) return 0;
   return (int64_t)((N + 31) / 32) * ((K + 31) / 32 * 2) * pieces * 64 * 16;
 }
 
 extern "C" int sopro_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t pieces, void* packed, void* stream) {
   SOPRO_CHECK_ARG(W && packed && N > 0 && K > 0 && ldw >= K, "bad pointers or sizes");
-  SOPRO_CHECK_ARG(pieces == 2 || pieces == 3, "pieces must be 2 (bf16x3) or 3 (bf16x6)");
+  SOPRO_CHECK_ARG(pieces >= 1 && pieces <= 3, "pieces must be 1 (bf16x1), 2 (bf16x3) or 3 (bf16x6)");
   SOPRO_CHECK_ARG(aligned16(packed), "packed must be 16-byte aligned");
   const int ksubs = (K + 31) / 32 * 2;
   const int64_t total = (int64_t)((N + 31) / 32) * ksubs * pieces * 64;
   const dim3 grid((unsigned)((total + 255) / 256));
-  if (pieces == 2)
+  if (pieces == 1)
+    hipLaunchKernelGGL(pack_w_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, reinterpret_cast<uint4*>(packed), ksubs, total);
+  else if (pieces == 2)
     hipLaunchKernelGGL(pack_w_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, reinterpret_cast<uint4*>(packed), ksubs, total);
   else
     hipLaunchKernelGGL(pack_w_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, reinterpret_cast<uint4*>(packed), ksubs, total);
@@ -488,15 +497,50 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
   const uint4* wp = reinterpret_cast<const uint4*>(packed_w);
   const int ksubs = (g.K + 31) / 32 * 2;
   switch (g_tile_override) {
-    case 1: return launch_cfg3<2, 2, 2, 2>(g, wp, ksubs, ext, s);
-    case 2: return launch_cfg3<2, 2, 4, 2>(g, wp, ksubs, ext, s);
-    case 4: return launch_cfg3<2, 2, 2, 1>(g, wp, ksubs, ext, s);
-    case 5: return launch_cfg3<2, 2, 1, 1>(g, wp, ksubs, ext, s);
+    case 1: return launch_cfg3<2, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
+    case 2: return launch_cfg3<2, 2, 2, 4, 2>(g, wp, ksubs, ext, s);
+    case 4: return launch_cfg3<2, 2, 2, 2, 1>(g, wp, ksubs, ext, s);
+    case 5: return launch_cfg3<2, 2, 2, 1, 1>(g, wp, ksubs, ext, s);
     default: break;
   }
   // few columns, or few rows (streaming chunks, batch 1: small tiles keep the split-K partial sums small): 64x64
-  if (g.N <= 64 || g.M <= 64) return launch_cfg3<2, 2, 1, 1>(g, wp, ksubs, ext, s);
-  return launch_cfg3<2, 2, 2, 2>(g, wp, ksubs, ext, s);
+  if (g.N <= 64 || g.M <= 64) return launch_cfg3<2, 2, 2, 1, 1>(g, wp, ksubs, ext, s);
+  return launch_cfg3<2, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
+}
+
+// bf16 mode: one pass.  Takes what either split entry point takes, except split-form operands (a_format 1, c_mode 1 / 2).
+extern "C" int sopro_gemm_bf16x1(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* x, void* stream) {
+  SOPRO_CHECK_ARG(a != nullptr, "args is NULL");
+  sopro_gemm_args g = *a;
+  sopro_gemm_split_ext ext;
+  memset(&ext, 0, sizeof(ext));
+  if (x) ext = *x;
+  SOPRO_CHECK_ARG(ext.a_format == 0 && (ext.c_mode == 0 || ext.c_mode == 3 || ext.c_mode == 4), "bf16x1 reads fp32 rows and writes fp32 rows (c_mode 0, 3, 4)");
+  SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f && ext.c_mode == 0),
+                  "fused RMSNorm needs K % 32 == 0, no split-K, no prologue, eps > 0 and a plain output");
+  if (int rc = check_common(g, ext, packed_w)) return rc;
+  if (ext.c_mode != 0) {
+    const bool second = ext.c_mode == 4;
+    float* d = second ? ext.C2 : g.C;
+    const int64_t ldd = second ? ext.ldc2 : g.ldc, dseg = second ? ext.c2_seg_stride : g.c_seg_stride;
+    SOPRO_CHECK_ARG((g.N & 3) == 0 && d && aligned16(d) && (ldd & 3) == 0 && (dseg & 3) == 0 && ldd >= g.N,
+                    "activated output rows must be 16-byte aligned (N, ld, seg stride multiples of 4)");
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const uint4* wp = reinterpret_cast<const uint4*>(packed_w);
+  const int ksubs = (g.K + 31) / 32 * 2;
+  // few output tiles (NAR's few-thousand-row shapes, streaming chunks): small tiles; the decoder's big shapes: 128x128
+  const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  const bool small = g.N <= 64 || g.M <= 64 || t128 < 256;
+  const bool nar_like = ext.rms_norm || g.epilogue == SOPRO_EPI_GLU || g.prologue == SOPRO_PRO_ADDVEC;
+  if (nar_like) {
+    SOPRO_CHECK_ARG(ext.c_mode == 0 && (g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ADDVEC), "GLU / RMSNorm / ADDVEC forms write plain fp32");
+    if (g.epilogue == SOPRO_EPI_GLU) return small ? launch_cfg6<1, 2, 2, 1, 2>(g, wp, ksubs, ext, s) : launch_cfg6<1, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
+    return small ? launch_cfg6<1, 2, 2, 1, 1>(g, wp, ksubs, ext, s) : launch_cfg6<1, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
+  }
+  SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ELU, "prologue must be NONE, ELU or ADDVEC");
+  SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES, "epilogue must be NONE, GELU, RES or GLU");
+  return small ? launch_cfg3<1, 2, 2, 1, 1>(g, wp, ksubs, ext, s) : launch_cfg3<1, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
 }
 
 extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* x, void* stream) {
@@ -516,12 +560,12 @@ extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w,
   const uint4* wp = reinterpret_cast<const uint4*>(packed_w);
   const int ksubs = (g.K + 31) / 32 * 2;
   switch (g_tile_override) {
-    case 1: return launch_cfg6<2, 2, 2, 2>(g, wp, ksubs, ext, s);
-    case 4: return launch_cfg6<2, 2, 1, 2>(g, wp, ksubs, ext, s);
-    case 5: if (g.epilogue != SOPRO_EPI_GLU) return launch_cfg6<2, 2, 1, 1>(g, wp, ksubs, ext, s); break;
+    case 1: return launch_cfg6<3, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
+    case 4: return launch_cfg6<3, 2, 2, 1, 2>(g, wp, ksubs, ext, s);
+    case 5: if (g.epilogue != SOPRO_EPI_GLU) return launch_cfg6<3, 2, 2, 1, 1>(g, wp, ksubs, ext, s); break;
     default: break;
   }
   // measured on the NAR shapes (tools/gemm_x6_probe.py): a few thousand rows, K <= 1536 -> the small tiles win
-  if (g.epilogue == SOPRO_EPI_GLU) return launch_cfg6<2, 2, 1, 2>(g, wp, ksubs, ext, s);
-  return launch_cfg6<2, 2, 1, 1>(g, wp, ksubs, ext, s);
+  if (g.epilogue == SOPRO_EPI_GLU) return launch_cfg6<3, 2, 2, 1, 2>(g, wp, ksubs, ext, s);
+  return launch_cfg6<3, 2, 2, 1, 1>(g, wp, ksubs, ext, s);
 }

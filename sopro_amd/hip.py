@@ -83,6 +83,7 @@ SYMBOLS = {
     "sopro_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "sopro_gemm_bf16x3": (C.c_int, [_p, _p, _p, _p]),
     "sopro_gemm_bf16x6": (C.c_int, [_p, _p, _p, _p]),
+    "sopro_gemm_bf16x1": (C.c_int, [_p, _p, _p, _p]),
     "sopro_pack_w_bf16": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     "sopro_packed_w_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "sopro_gemm_bf16_set_tile_override": (C.c_int, [C.c_int]),
@@ -243,14 +244,21 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     if packed:
         x = SplitExt()
         if rms_eps > 0.0:  # fused RMSNorm of the A rows (W must carry the norm's weight vector)
-            if W.pieces != 3:
-                raise SoproHipError("fused RMSNorm is a six-pass (pieces = 3) feature")
+            if W.pieces == 2:
+                raise SoproHipError("fused RMSNorm is a six-pass (pieces = 3) or one-pass (pieces = 1) feature")
             x.rms_norm, x.rms_eps = 1, float(rms_eps)
         ks = _auto_ksplit(M, N, K, W.pieces, epilogue) if (dbg is None and _splitk_enabled and rms_eps <= 0.0) else 1
         if ks > 1:
             ws, tk = _splitk_buffers()
             x.ksplit, x.n_tickets, x.ws, x.ws_bytes, x.tickets = ks, int(tk.numel()), ptr(ws), int(ws.numel()) * 4, ptr(tk, torch.int32)
-    if packed and W.pieces == 3:
+    if packed and W.pieces == 1:
+        if a_split or c_mode in (1, 2):
+            raise SoproHipError("split-form operands belong to the three-pass (pieces = 2) path")
+        x.c_mode = c_mode
+        x.C2 = (ptr(C2) + 4 * c2_off) if C2 is not None else None
+        x.ldc2, x.c2_seg_stride = (n_out if ldc2 is None else ldc2), c2_seg_stride
+        _check(load().sopro_gemm_bf16x1(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_bf16x1")
+    elif packed and W.pieces == 3:
         if a_split or c_mode:
             raise SoproHipError("split-form operands belong to the three-pass (pieces = 2) path")
         _check(load().sopro_gemm_bf16x6(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_bf16x6")
@@ -264,7 +272,7 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     else:
         _check(load().sopro_gemm_f32(C.byref(g), _stream()), "sopro_gemm_f32")
     if e0 is not None:
-        _prof.end(("gemm_bf16x6_kernel" if W.pieces == 3 else "gemm_bf16x3_kernel") if packed else "gemm_f32_kernel", 2.0 * M * N * K, e0)
+        _prof.end({1: "gemm_bf16x1_kernel", 2: "gemm_bf16x3_kernel", 3: "gemm_bf16x6_kernel"}[W.pieces] if packed else "gemm_f32_kernel", 2.0 * M * N * K, e0)
 
 
 _splitk_enabled = os.environ.get("SOPRO_NO_SPLITK", "0") != "1"
@@ -278,6 +286,9 @@ def _auto_ksplit(M: int, N: int, K: int, pieces: int, epilogue: int) -> int:
     would otherwise run at one memory latency per 32-wide step on a handful of workgroups."""
     if pieces == 3:
         bm, bn = (64, 128) if epilogue == EPI_GLU else (64, 64)
+    elif pieces == 1:  # sopro_gemm_bf16x1's tile rule
+        small = N <= 64 or M <= 64 or (-(-M // 128) * -(-N // 128)) < 256
+        bm, bn = ((64, 128) if epilogue == EPI_GLU else (64, 64)) if small else (128, 128)
     else:
         bm, bn = (64, 64) if (N <= 64 or M <= 64) else (128, 128)
     tiles = -(-M // bm) * -(-N // bn)
@@ -304,7 +315,7 @@ def _splitk_buffers():
 
 
 class PackedW:
-    """A weight matrix [N, K] split into 2 or 3 bf16 pieces in MFMA fragment order (sopro_pack_w_bf16)."""
+    """A weight matrix [N, K] as 1, 2 or 3 bf16 pieces in MFMA fragment order (sopro_pack_w_bf16)."""
 
     __slots__ = ("data", "N", "K", "pieces")
 
@@ -330,6 +341,11 @@ def pack_w_bf16x3(W: torch.Tensor) -> PackedW:
 
 def pack_w_bf16x6(W: torch.Tensor) -> PackedW:
     return pack_w_bf16(W, 3)
+
+
+def pack_w_bf16x1(W: torch.Tensor) -> PackedW:
+    """bf16 mode: the weight rounded to bf16 once (one MFMA pass per product)."""
+    return pack_w_bf16(W, 1)
 
 
 class SkinnyW:

@@ -72,10 +72,15 @@ class SoproTTSModel:
     """Weights on the device + the orchestration of the hot path."""
 
     def __init__(self, cfg: SoproTTSConfig, weights: Dict[str, "np.ndarray"], device: str = "cuda:0", *, seed: int = 0,
-                 use_graph: bool = True):
+                 use_graph: bool = True, precision: str = "f32"):
         hip.load()  # fail loudly here when the kernel library is missing
         if not torch.cuda.is_available():
             raise hip.SoproHipError("no HIP device visible: the Sopro engine has no CPU fallback")
+        if precision not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' (parity with the fp32 reference) or 'bf16' (bf16 operands, fp32 accumulate)")
+        # "bf16" = SURVEY.md 8d config 2: the NAR / text / reference-encoder contractions round both operands to bf16 once (one
+        # MFMA pass instead of six); norms, softmax, accumulators, the residual stream and the AR frame stay fp32.
+        self.precision = precision
         self.cfg = cfg
         self.device = torch.device(device)
         self.seed = int(seed)
@@ -111,6 +116,7 @@ class SoproTTSModel:
         # NAR and text / reference encoder contractions on the six-pass split-bf16 matrix-core path (24 mantissa bits per
         # operand: the accuracy class of the fp32 MFMA kernel at ~1.5x its speed on these shapes); SOPRO_NAR_F32=1 keeps fp32.
         self.wx: Dict[str, hip.PackedW] = {}
+        pack_w = hip.pack_w_bf16x1 if precision == "bf16" else hip.pack_w_bf16x6
         if os.environ.get("SOPRO_NAR_F32", "0") != "1":
             unfused = os.environ.get("SOPRO_NORM_UNFUSED", "0") == "1"
             with torch.cuda.device(self.device):
@@ -125,9 +131,9 @@ class SoproTTSModel:
                         elif k.endswith(".ff1.w"):
                             nk = k[: -len("ff1.w")] + "ff.norm.weight"
                         if nk is not None and nk in self.w and not unfused:
-                            self.wx[k + "n"] = hip.pack_w_bf16x6((v * self.w[nk][None, :]).contiguous())
+                            self.wx[k + "n"] = pack_w((v * self.w[nk][None, :]).contiguous())
                             continue
-                        self.wx[k] = hip.pack_w_bf16x6(v)
+                        self.wx[k] = pack_w(v)
                 torch.cuda.synchronize(self.device)
         # AR-step weights in the fragment order of the skinny kernel (1 KiB of consecutive memory per load instruction);
         # SOPRO_AR_ROWMAJOR=1 keeps the row-major matrices.

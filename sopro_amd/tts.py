@@ -30,9 +30,10 @@ class SoproTTS:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, repo_id: str, *, revision: Optional[str] = None, cache_dir: Optional[str] = None,
-                        token: Optional[str] = None, device: Optional[str] = None) -> "SoproTTS":
+                        token: Optional[str] = None, device: Optional[str] = None, precision: str = "f32") -> "SoproTTS":
         """reference: src/sopro/model.py:419-451.  ``repo_id`` may also be a local directory holding
-        ``model.safetensors`` (+ tokenizer files) and, for the codec, ``mimi/model.safetensors``."""
+        ``model.safetensors`` (+ tokenizer files) and, for the codec, ``mimi/model.safetensors``.  ``precision`` (new):
+        "f32" reproduces the fp32 reference; "bf16" runs the NAR / Mimi contractions with bf16 operands."""
         device = device or "cuda"
         if os.path.isdir(repo_id):
             local_dir = repo_id
@@ -54,17 +55,18 @@ class SoproTTS:
 
             mdir = snapshot_download(repo_id=DEFAULT_MIMI_ID, cache_dir=cache_dir, token=token)
             mimi_weights = load_safetensors(os.path.join(mdir, "model.safetensors"))
-        return cls.from_weights(cfg, weights, mimi_weights, tokenizer, device=device)
+        return cls.from_weights(cfg, weights, mimi_weights, tokenizer, device=device, precision=precision)
 
     @classmethod
     def from_weights(cls, cfg: SoproTTSConfig, weights: Dict[str, np.ndarray], mimi_weights: Dict[str, np.ndarray],
-                     tokenizer: Any, *, device: str = "cuda", seed: int = 0, use_graph: bool = True) -> "SoproTTS":
+                     tokenizer: Any, *, device: str = "cuda", seed: int = 0, use_graph: bool = True,
+                     precision: str = "f32") -> "SoproTTS":
         """Build from in-memory checkpoints (reference ``state_dict`` names; HF Mimi names)."""
         dev = torch.device(device)
         if dev.type == "cuda" and dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
-        model = SoproTTSModel(cfg, weights, str(dev), seed=seed, use_graph=use_graph)
-        codec = MimiCodec(mimi_weights, MimiDecoderConfig(num_quantizers=int(cfg.num_codebooks)), str(dev))
+        model = SoproTTSModel(cfg, weights, str(dev), seed=seed, use_graph=use_graph, precision=precision)
+        codec = MimiCodec(mimi_weights, MimiDecoderConfig(num_quantizers=int(cfg.num_codebooks)), str(dev), precision=precision)
         return cls(model, cfg, tokenizer, codec, str(dev))
 
     # ------------------------------------------------------------------ reference API
