@@ -116,7 +116,8 @@ class SoproTTSModel:
         # NAR and text / reference encoder contractions on the six-pass split-bf16 matrix-core path (24 mantissa bits per
         # operand: the accuracy class of the fp32 MFMA kernel at ~1.5x its speed on these shapes); SOPRO_NAR_F32=1 keeps fp32.
         self.wx: Dict[str, hip.PackedW] = {}
-        pack_w = hip.pack_w_bf16x1 if precision == "bf16" else hip.pack_w_bf16x6
+        # (the text / reference encoders feed the AR loop's conditioning: they keep their six-pass form in both modes)
+        pack_for = lambda key: hip.pack_w_bf16x1 if (precision == "bf16" and key.startswith("nar.")) else hip.pack_w_bf16x6  # noqa: E731
         if os.environ.get("SOPRO_NAR_F32", "0") != "1":
             unfused = os.environ.get("SOPRO_NORM_UNFUSED", "0") == "1"
             with torch.cuda.device(self.device):
@@ -131,9 +132,9 @@ class SoproTTSModel:
                         elif k.endswith(".ff1.w"):
                             nk = k[: -len("ff1.w")] + "ff.norm.weight"
                         if nk is not None and nk in self.w and not unfused:
-                            self.wx[k + "n"] = pack_w((v * self.w[nk][None, :]).contiguous())
+                            self.wx[k + "n"] = pack_for(k)((v * self.w[nk][None, :]).contiguous())
                             continue
-                        self.wx[k] = pack_w(v)
+                        self.wx[k] = pack_for(k)(v)
                 torch.cuda.synchronize(self.device)
         # AR-step weights in the fragment order of the skinny kernel (1 KiB of consecutive memory per load instruction);
         # SOPRO_AR_ROWMAJOR=1 keeps the row-major matrices.
