@@ -35,6 +35,11 @@ extern "C" {
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
 int sopro_abi_version(void);
+/* Scheduling knob (no reference counterpart): every launch of the long-running split-bf16 contraction kernels requests at
+ * least `bytes` of LDS.  Above 80 KiB that caps them at one workgroup per CU, which leaves wave slots, registers and LDS on
+ * every CU for the short kernels of an AR frame generated at the same time on another stream - the alternative to carving
+ * the chip up with CU masks (sopro_stream_create_cu_range).  0 = off.  Recorded graphs keep the value they were recorded with. */
+int sopro_set_lds_floor(int bytes);
 /* device facts: out[0]=CU count, out[1]=LDS bytes per block, out[2]=clock kHz, out[3]=gfx arch number */
 int sopro_device_info(int device, int* out4);
 

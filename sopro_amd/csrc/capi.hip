@@ -14,11 +14,19 @@ void sopro_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int g_sopro_lds_floor = 0;
+
 extern "C" {
 
 const char* sopro_last_error(void) { return g_err; }
 
 int sopro_abi_version(void) { return SOPRO_ABI_VERSION; }
+
+int sopro_set_lds_floor(int bytes) {
+  SOPRO_CHECK_ARG(bytes >= 0 && bytes <= 96 * 1024, "LDS floor must be within 0..96 KiB");
+  g_sopro_lds_floor = bytes;
+  return 0;
+}
 
 int sopro_device_info(int device, int* out4) {
   SOPRO_CHECK_ARG(out4 != nullptr, "out4 is NULL");

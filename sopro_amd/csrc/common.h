@@ -11,6 +11,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void sopro_set_error(const char* fmt, ...);
+// Floor of the dynamic LDS request of the long-running contraction kernels (sopro_set_lds_floor): above half of a CU's
+// 160 KB it caps them at ONE workgroup per CU, which leaves registers, wave slots and LDS on every CU for the short kernels
+// of a concurrently generating AR frame (co-scheduling without CU masks).
+extern int g_sopro_lds_floor;
 
 #define SOPRO_CHECK_ARG(cond, msg)                                  \
   do {                                                              \

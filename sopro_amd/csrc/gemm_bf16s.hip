@@ -335,10 +335,12 @@ int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro
   const int ks = ext.ksplit > 1 ? ext.ksplit : 1;
   static bool attr_done[2] = {false, false};
   auto kern = ks > 1 ? gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT, true> : gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT, false>;
+  constexpr size_t lds_cap = lds > (size_t)96 * 1024 ? lds : (size_t)96 * 1024;  // room for sopro_set_lds_floor
   if (!attr_done[ks > 1]) {
-    SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
     attr_done[ks > 1] = true;
   }
+  const size_t lds_req = lds > (size_t)g_sopro_lds_floor ? lds : (size_t)g_sopro_lds_floor;
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   if (ks > 1) {
     const int64_t need = (int64_t)ks * ntm * ntn * BM * BN * (int64_t)sizeof(float);
@@ -348,7 +350,7 @@ int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro
       return -2;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(ntm * ntn, ks), dim3(WM * WN * 64), lds, s, g, wp, ksubs, ext);
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, ks), dim3(WM * WN * 64), lds_req, s, g, wp, ksubs, ext);
   SOPRO_LAUNCH_CHECK();
 }
 

@@ -72,6 +72,7 @@ class ArState(C.Structure):
 SYMBOLS = {
     "sopro_last_error": (C.c_char_p, []),
     "sopro_abi_version": (C.c_int, []),
+    "sopro_set_lds_floor": (C.c_int, [C.c_int]),
     "sopro_device_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "sopro_capture_begin": (C.c_int, [_p]),
     "sopro_capture_end": (C.c_int, [_p, C.POINTER(_p)]),
@@ -175,6 +176,9 @@ class Profiler:
 
 
 _prof: Optional[Profiler] = None
+# bench.py: when a list, ar_generate_batch appends (frames, start event, end event) of every AR phase - two HIP events per
+# phase on the AR stream, cheap enough for the timed region itself
+phase_log: Optional[list] = None
 
 
 def set_profiler(p: Optional[Profiler]) -> None:
@@ -532,6 +536,11 @@ def seanet_tail(h: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.T
                 bf: float, wav: torch.Tensor, *, B: int, T: int, h_seg_stride: int, wav_seg_stride: int) -> None:
     _check(load().sopro_seanet_tail_f32(ptr(h), h_seg_stride, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(wf), bf, ptr(wav),
                                         wav_seg_stride, B, T, _stream()), "sopro_seanet_tail_f32")
+
+
+def set_lds_floor(nbytes: int) -> None:
+    """Minimum dynamic-LDS request of the split-bf16 GEMM launches (> 80 KiB: one workgroup per CU); see sopro_set_lds_floor."""
+    _check(load().sopro_set_lds_floor(int(nbytes)), "sopro_set_lds_floor")
 
 
 def ar_init(st: ArState) -> None:

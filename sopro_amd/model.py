@@ -417,6 +417,10 @@ class SoproTTSModel:
         # a batch that turns out to be finished are discarded below).
         steps = 0
         pending = None
+        ev0 = None
+        if hip.phase_log is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(self.stream)
         while steps < Tar:
             n = min(int(poll_every), Tar - steps)
             run.advance(n)
@@ -424,6 +428,10 @@ class SoproTTSModel:
             if pending is not None and pending() >= B:
                 break
             pending = run.poll_async(stop_on_first_eos)
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(self.stream)
+            hip.phase_log.append((steps, B, ev0, ev1))
         hist, first_eos = run.history(steps)
         run.done = True
         lens = [int(f) if f >= 0 else steps for f in first_eos]

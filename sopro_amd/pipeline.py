@@ -27,6 +27,10 @@ class PipelinedSynthesizer:
         Lane i generates on partition i % ar_parts.  With ``ar_shared`` the partitions are ONE CU range of ``ar_cus`` CUs
         that ``ar_parts`` AR phases use at the same time (their short kernels interleave on the same CUs)."""
         self.device = tts.device
+        self.unpartitioned = int(ar_cus) <= 0
+        if self.unpartitioned:
+            self._init_unpartitioned(tts, int(lanes), max(1, int(ar_parts)), bulk_slots)
+            return
         if getattr(tts.model, "_driver", None) is not None:
             raise RuntimeError("this engine is already driven by a " + type(tts.model._driver).__name__ + " (close it first): "
                                "the schedulers re-point the engine's streams at CU partitions")
@@ -58,11 +62,39 @@ class PipelinedSynthesizer:
         self.ar_cus, self.ar_parts, self.bulk_cus = ar_cus, ar_parts, total - bulk0
         tts.model._driver = self
 
+    def _init_unpartitioned(self, tts, lanes: int, ar_parts: int, bulk_slots: int) -> None:
+        """``ar_cus <= 0``: no CU masks.  Every stream may use the whole chip; the long contraction kernels of the throughput
+        phases are capped at one workgroup per CU (``hip.set_lds_floor``), so every CU always has wave slots, registers and
+        LDS left for the short kernels of the AR frames, which are issued on high-priority streams."""
+        if getattr(tts.model, "_driver", None) is not None:
+            raise RuntimeError("this engine is already driven by a " + type(tts.model._driver).__name__ + " (close it first)")
+        self.lanes = []
+        self._saved = (tts.model.stream, tts.model.bulk_stream, tts.codec.stream, tts.model.prep_stream)
+        self._streams = []
+        hip.set_lds_floor(int(__import__("os").environ.get("SOPRO_LDS_FLOOR_KB", "84")) * 1024)
+        for i in range(lanes):
+            lane = tts if i == 0 else tts.clone_lane()
+            lane.model.stream = torch.cuda.Stream(device=self.device, priority=-1)
+            lane.model.bulk_stream = torch.cuda.Stream(device=self.device, priority=0)
+            lane.model.prep_stream = lane.model.bulk_stream
+            lane.codec.stream = lane.model.bulk_stream
+            lane.model._ar_cache.clear()
+            lane.model._nar_graphs.clear()
+            lane.codec._graphs.clear()
+            self.lanes.append(lane)
+        self._full = [lane.model.stream for lane in self.lanes]
+        self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
+        self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))
+        self.ar_cus, self.ar_parts, self.bulk_cus = 0, ar_parts, hip.device_info(self.device.index or 0)["cus"]
+        tts.model._driver = self
+
     def close(self) -> None:
         """Drop the extra lanes, destroy the CU-masked streams (and the graphs recorded on them) and give lane 0
         (the caller's engine) its full-chip streams back."""
         if not self.lanes:
             return
+        if self.unpartitioned:
+            hip.set_lds_floor(0)
         torch.cuda.synchronize(self.device)
         for lane in self.lanes:
             lane.model._ar_cache.clear()  # hipGraphExecDestroy now, not at interpreter shutdown
