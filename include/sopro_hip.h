@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 17
+#define SOPRO_ABI_VERSION 18
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -231,6 +231,12 @@ int sopro_text_embed_f32(const int32_t* ids, const int32_t* lens, const float* t
  * inner > 1: the `inner` heads of a NAR stage are consecutive rows of one logits matrix and fill consecutive codebooks) */
 int sopro_argmax_rows_f32(const float* x, int64_t ldx, int32_t* out, int64_t ldo, int32_t inner, int32_t rows, int32_t N,
                           void* stream);
+/* Second half of the arg-max fused into a projection (sopro_gemm_bf16x6 / x1 with ext.c_mode = 5, which writes per 64-column
+ * tile and row one (float max, int32 column) pair to ext.C2 [M][ext.ldc2] instead of the logits - replaces the
+ * `logits.argmax(dim=-1)` of src/sopro/model.py:338-345 without the [M, heads * V] logits ever reaching memory):
+ * out[r * ldo + h] = (column of the best of the `per_head` pairs of head h) - h * V, first maximum on ties. */
+int sopro_argmax_partials_i32(const float* partials, int64_t ldp, int32_t* out, int64_t ldo, int32_t heads, int32_t per_head, int32_t V,
+                              int32_t rows, void* stream);
 
 /* ---- Mimi encode side (reference audio -> tokens: src/sopro/codec/mimi.py:42-63) ---------------------- */
 /* Single-input-channel FIR bank, channels-last output:
@@ -304,6 +310,13 @@ int sopro_final_conv_f32(const float* h, int64_t h_seg_stride, const float* w, f
 int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
                           const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
                           int32_t T, void* stream);
+/* Fused MimiResnetBlock at the 128-channel level of the SEANet decoder (HF:modeling_mimi.py:408-447, dim 128: k=3 conv
+ * 128->64, k=1 conv 64->128, residual) followed by the ELU of the next layer: out = ELU(h + c2(ELU(c1(ELU(h))))).
+ * h, out: [B][2 + T][128] (two zero rows in front of each segment; out's are not written), h != out.  w1 [64][3*128]
+ * (tap-major K), w2 [128][64].  h is read once, out written once; both weight matrices stay in registers. */
+int sopro_seanet_res128_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2, const float* b2,
+                            float* out, int64_t out_seg_stride, int32_t B, int32_t T, void* stream);
+int sopro_seanet_res_set_tiles(int tiles); /* developer probe / tests: 64-row tiles per workgroup, 0 = by size */
 int sopro_seanet_tail_set_tiles(int tiles); /* developer probe / tests: 126-sample tiles per workgroup, 0 = by size */
 
 /* ---- autoregressive driver state ----------------------------------------------------------- */

@@ -61,6 +61,7 @@ class MimiCodec:
         self.use_graph = os.environ.get("SOPRO_NO_BULK_GRAPH", "0") != "1"
         self._graphs = hip.GraphCache("mimi_graph", cap=32)  # recorded decode launch sequences per (B, T)
         self.fuse_tail = os.environ.get("SOPRO_UNFUSED_TAIL", "0") != "1"
+        self.fuse_res = os.environ.get("SOPRO_UNFUSED_RES", "0") != "1"  # 128-channel residual block as one kernel
         # Decoder contractions run on the split-bf16 matrix-core path (16 mantissa bits per operand, fp32 accumulate:
         # waveform error ~1e-5 of peak, inside the 1e-4 contract); SOPRO_MIMI_F32=1 keeps them on the fp32 MFMA kernel.
         self.split_bf16 = os.environ.get("SOPRO_MIMI_F32", "0") != "1"
@@ -385,6 +386,14 @@ class MimiCodec:
                 return
             # ConvTranspose1d(ch -> co, k=2r, s=r): row t of A = [x[t-1] | x[t]] of the activated input; raw to Ho, ELU to Hn
             Hn = ws.get(f"sea.e{si + 1}", (B, 2 + orow, co), zero=True)  # 2 zero rows: left pad of the k=3 conv
+            if self.fuse_res and co == 128 and hid == 64 and int(mc.residual_kernel_size) == 3:
+                # one kernel for the whole residual block (+ the next layer's ELU): the producer writes the raw tensor only,
+                # the block reads it once and writes the activated result once (sopro_seanet_res128_f32)
+                hip.gemm(He, gw(f"sea.up{si}.w"), Ho, **up)
+                hip.seanet_res128(Ho, w[f"sea.res{si}.c1.w"], w[f"sea.res{si}.c1.b"], w[f"sea.res{si}.c2.w"], w[f"sea.res{si}.c2.b"], Hn,
+                                  B=B, T=orow, h_seg_stride=(2 + orow) * co, out_seg_stride=(2 + orow) * co)
+                He, ch, rows, pad_in = Hn, co, orow, 2
+                continue
             hip.gemm(He, gw(f"sea.up{si}.w"), Ho, c_mode=4, C2=Hn, ldc2=r * co, c2_seg_stride=(2 + orow) * co, c2_off=2 * co, **up)
             # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x)))); its output is only ever read through ELU
             Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))

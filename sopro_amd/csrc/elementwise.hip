@@ -220,6 +220,25 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   if (lane == 0) out[(int64_t)(row / inner) * ldo + row % inner] = (bi == 0x7fffffff) ? 0 : bi;
 }
 
+// second half of the arg-max fused into a projection (gemm c_mode 5): head h of row r = the best of its `per_head` partial
+// (value, global column) pairs, in column order, first maximum wins; the token is the column within the head
+__global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __restrict__ part, int64_t ldp, int* __restrict__ out,
+                                                              int64_t ldo, int heads, int per_head, int V, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t row = i / heads;
+  const int h = (int)(i % heads);
+  const float2* p = reinterpret_cast<const float2*>(part) + row * ldp + (int64_t)h * per_head;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = 0; j < per_head; ++j) {
+    const float2 v = p[j];
+    const int idx = __float_as_int(v.y);
+    if (v.x > best || (v.x == best && idx < bi)) { best = v.x; bi = idx; }
+  }
+  out[row * ldo + h] = (bi == 0x7fffffff) ? 0 : bi - h * V;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Mimi encode side: single-channel FIR bank (first SEANet conv, polyphase resampler) and the
 // residual-VQ assignment step
@@ -488,6 +507,17 @@ int sopro_fir1_f32(const float* x, int64_t x_seg_stride, int32_t n_in, const flo
   SOPRO_CHECK_ARG(B > 0 && B <= 65535 && n_in > 0 && n_out > 0 && C > 0 && K > 0 && stride > 0 && left >= 0 && ldo >= C, "bad sizes");
   hipLaunchKernelGGL(fir1_kernel, dim3(nblk((int64_t)n_out * C, 256), B), dim3(256), 0, (hipStream_t)stream, x, x_seg_stride, n_in, w,
                      bias, out, ldo, o_seg_stride, n_out, C, K, stride, left);
+  SOPRO_LAUNCH_CHECK();
+}
+
+int sopro_argmax_partials_i32(const float* partials, int64_t ldp, int32_t* out, int64_t ldo, int32_t heads, int32_t per_head, int32_t V,
+                              int32_t rows, void* stream) {
+  SOPRO_CHECK_ARG(partials && out && rows > 0 && heads > 0 && per_head > 0 && V > 0 && ldp >= (int64_t)heads * per_head && ldo >= heads,
+                  "bad pointers or sizes");
+  SOPRO_CHECK_ARG((reinterpret_cast<uintptr_t>(partials) & 7u) == 0, "partials must be 8-byte aligned");
+  const int64_t total = (int64_t)rows * heads;
+  hipLaunchKernelGGL(argmax_partials_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, partials, ldp, out, ldo, heads,
+                     per_head, V, total);
   SOPRO_LAUNCH_CHECK();
 }
 

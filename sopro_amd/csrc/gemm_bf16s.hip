@@ -417,6 +417,15 @@ int launch_cfg6(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
   return -2;
 }
 
+// c_mode 5: per-row arg-max partials instead of C (64x64 tiles: 32 partials per 2048 columns)
+template <int NPL>
+int launch_argmax(sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
+  SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE && g.prologue == SOPRO_PRO_NONE && !ext.rms_norm && ext.a_format == 0,
+                  "arg-max output takes a plain contraction (no prologue / epilogue / fused norm)");
+  SOPRO_CHECK_ARG(ext.C2 && ext.ldc2 >= (g.N + 63) / 64, "arg-max output: C2 = [M][ldc2 >= ceil(N / 64)] (value, index) pairs");
+  return launch_one<NPL, 2, 2, 1, 1, SOPRO_EPI_NONE, 0, 5>(g, wp, ksubs, ext, s);
+}
+
 int check_common(sopro_gemm_args& g, sopro_gemm_split_ext& ext, const void* packed_w) {
   if (g.a_seg_stride == 0) g.a_seg_stride = (int64_t)g.rows_per_seg * g.lda;
   if (g.c_seg_stride == 0) g.c_seg_stride = (int64_t)g.rows_per_seg * g.ldc;
@@ -425,7 +434,7 @@ int check_common(sopro_gemm_args& g, sopro_gemm_split_ext& ext, const void* pack
   SOPRO_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0, "M, N, K must be positive");
   SOPRO_CHECK_ARG((g.K & 3) == 0, "K must be a multiple of 4");
   SOPRO_CHECK_ARG(g.rows_per_seg > 0, "rows_per_seg must be positive");
-  SOPRO_CHECK_ARG(g.A && packed_w && g.C, "A, packed_w, C must be non-NULL");
+  SOPRO_CHECK_ARG(g.A && packed_w && (g.C || ext.c_mode == 5), "A, packed_w, C must be non-NULL");
   SOPRO_CHECK_ARG(aligned16(g.A) && aligned16(packed_w), "A and packed_w must be 16-byte aligned");
   SOPRO_CHECK_ARG((g.lda & 3) == 0 && (g.a_seg_stride & 3) == 0, "lda, a_seg_stride must be multiples of 4");
   SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_RES || g.R != nullptr, "EPI_RES needs R");
@@ -517,10 +526,12 @@ extern "C" int sopro_gemm_bf16x1(const sopro_gemm_args* a, const void* packed_w,
   sopro_gemm_split_ext ext;
   memset(&ext, 0, sizeof(ext));
   if (x) ext = *x;
-  SOPRO_CHECK_ARG(ext.a_format == 0 && (ext.c_mode == 0 || ext.c_mode == 3 || ext.c_mode == 4), "bf16x1 reads fp32 rows and writes fp32 rows (c_mode 0, 3, 4)");
+  SOPRO_CHECK_ARG(ext.a_format == 0 && (ext.c_mode == 0 || ext.c_mode == 3 || ext.c_mode == 4 || ext.c_mode == 5),
+                  "bf16x1 reads fp32 rows and writes fp32 rows (c_mode 0, 3, 4) or arg-max partials (5)");
   SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f && ext.c_mode == 0),
                   "fused RMSNorm needs K % 32 == 0, no split-K, no prologue, eps > 0 and a plain output");
   if (int rc = check_common(g, ext, packed_w)) return rc;
+  if (ext.c_mode == 5) return launch_argmax<1>(g, reinterpret_cast<const uint4*>(packed_w), (g.K + 31) / 32 * 2, ext, reinterpret_cast<hipStream_t>(stream));
   if (ext.c_mode != 0) {
     const bool second = ext.c_mode == 4;
     float* d = second ? ext.C2 : g.C;
@@ -551,7 +562,8 @@ extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w,
   sopro_gemm_split_ext ext;
   memset(&ext, 0, sizeof(ext));
   if (x) ext = *x;
-  SOPRO_CHECK_ARG(ext.a_format == 0 && ext.c_mode == 0, "the six-pass path reads and writes fp32 rows (only the split-K and RMSNorm fields of ext apply)");
+  SOPRO_CHECK_ARG(ext.a_format == 0 && (ext.c_mode == 0 || ext.c_mode == 5),
+                  "the six-pass path reads fp32 rows and writes fp32 rows, or arg-max partials (c_mode 5)");
   SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f),
                   "fused RMSNorm needs K % 32 == 0, no split-K, no prologue and eps > 0");
   if (int rc = check_common(g, ext, packed_w)) return rc;
@@ -561,6 +573,7 @@ extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w,
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const uint4* wp = reinterpret_cast<const uint4*>(packed_w);
   const int ksubs = (g.K + 31) / 32 * 2;
+  if (ext.c_mode == 5) return launch_argmax<3>(g, wp, ksubs, ext, s);
   switch (g_tile_override) {
     case 1: return launch_cfg6<3, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
     case 4: return launch_cfg6<3, 2, 2, 1, 2>(g, wp, ksubs, ext, s);

@@ -9,6 +9,9 @@
 // tensor stays available as a residual operand while the next contraction reads its activated form without any prologue
 // work).  Split form: every aligned group of 32 channels (128 bytes as fp32) becomes [32 hi bf16 | 32 lo bf16], so an
 // element keeps its 128-byte line and every fp32 stride / offset keeps its meaning.
+// OUT: 5 = no C at all: per tile row the maximum of the tile's columns and its column index go to ext.C2 as (float value,
+// int32 index) pairs, [M][ext.ldc2 = column tiles] - the arg-max of a wide projection (the 31 NAR heads: 2048 logits each,
+// src/sopro/model.py:338-345) without ever writing the logits; sopro_argmax_partials_i32 finishes the reduction.
 // rs (optional, LDS): one scale per tile row applied to the accumulator before the bias: the RMSNorm of the operand row
 // when its weight vector has been folded into W (out = rs * (x W'^T) + b).
 template <int WM, int WN, int TM, int TN, int EPI, int OUT = 0>
@@ -41,6 +44,31 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
         }
   }
   __syncthreads();
+  if constexpr (OUT == 5) {
+    constexpr int TPR5 = NT / BM;   // threads per tile row
+    constexpr int CPT = BN / TPR5;  // consecutive columns per thread
+    const int row = tid / TPR5, part = tid % TPR5;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll 8
+    for (int c = 0; c < CPT; ++c) {  // ascending column: a strict > keeps the first maximum (torch.argmax on exact ties)
+      const int n = n0 + part * CPT + c;
+      const float v = Cs[row * CLD + part * CPT + c];
+      if (n < g.N && v > best) { best = v; bi = n; }
+    }
+#pragma unroll
+    for (int o = 1; o < TPR5; o <<= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (part == 0 && m0 + row < g.M) {
+      float* pp = ext->C2 + ((int64_t)(m0 + row) * ext->ldc2 + n0 / BN) * 2;
+      pp[0] = best;
+      pp[1] = __int_as_float(bi);
+    }
+    return;
+  }
   constexpr bool glu = EPI == SOPRO_EPI_GLU;
   constexpr bool res = EPI == SOPRO_EPI_RES;
   constexpr int TPR = BN / 4;          // threads per tile row (one float4 each)

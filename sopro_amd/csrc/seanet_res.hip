@@ -1,0 +1,193 @@
+// Fused MimiResnetBlock of the SEANet decoder at the 128-channel / 6 kHz level (HF:modeling_mimi.py:408-447):
+//     out = ELU( h + Conv1d(64->128, k=1)( ELU( Conv1d(128->64, k=3)( ELU(h) ) ) ) )
+// (the trailing ELU belongs to the next layer, the last transposed convolution, which reads nothing else).  h is the raw
+// output of the third transposed convolution: 1.57 GB for 32 x 200 frames, the largest activation the generic GEMM flow
+// still moved several times (raw + activated copy written by the producer, the activated copy read by the k=3 conv, the
+// 64-channel intermediate written and read back, the raw copy re-read as the skip operand, the result written: ~11 GB).
+// Fused, h is read once (+ an L2-resident re-read for the skip operand) and the activated result is written once.
+//
+// WEIGHT-STATIONARY: both weight matrices (128 KB) live in registers as split-bf16 MFMA B fragments for the whole life of
+// a workgroup, spread over its four waves, and the workgroup walks `tiles` consecutive 64-row tiles of one utterance:
+//   conv k=3 (K = 384): wave w owns output columns 32*(w&1).. and the K half (w>>1) -> 12 substeps x (hi, lo) = 96 registers;
+//                       the two K halves of a 32x32 block are added through LDS in a fixed order (deterministic);
+//   conv k=1 (K = 64):  wave w owns output columns 32*w..                            ->  4 substeps x (hi, lo) = 32 registers.
+// Same arithmetic class as the decoder's other contractions (gemm_bf16s.hip, NPL = 2): operands x = hi + lo in bf16,
+// lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  ELU(h) is activated and split once per
+// element while the tile is staged (LDS row = [128 hi | 128 lo] + 16 B pad = 528 B: the k=3 window of a row is three
+// consecutive LDS rows and the 16-lane ds_read_b128 fragment reads are conflict free); the intermediate stays in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int RC = 128;           // channels
+constexpr int RH = 64;            // hidden channels of the block
+constexpr int RTO = 64;           // output rows per tile
+constexpr int RHR = RTO + 2;      // staged rows: samples s0-2 .. s0+RTO-1
+constexpr int REROW = 2 * RC * 2 + 16;   // 528
+constexpr int RYROW = 2 * RH * 2 + 16;   // 272
+
+typedef __bf16 rbf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ rbf16x8 rfrag(const uint4& v) { return *reinterpret_cast<const rbf16x8*>(&v); }
+
+__device__ __forceinline__ void rsplit8(const float* __restrict__ p, uint4& hi, uint4& lo) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  split2_bf16(a.x, a.y, hi.x, lo.x);
+  split2_bf16(a.z, a.w, hi.y, lo.y);
+  split2_bf16(b.x, b.y, hi.z, lo.z);
+  split2_bf16(b.z, b.w, hi.w, lo.w);
+}
+
+__global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __restrict__ h, int64_t h_seg_stride,
+                                                               const float* __restrict__ w1, const float* __restrict__ b1,
+                                                               const float* __restrict__ w2, const float* __restrict__ b2,
+                                                               float* __restrict__ out, int64_t out_seg_stride, int T, int tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char es[RHR * REROW];   // split ELU(h)
+  __shared__ __attribute__((aligned(16))) unsigned char ys[RTO * RYROW];   // split ELU(intermediate)
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];          // K-half exchange of the first convolution
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int frow = lane & 31, fg = lane >> 5;
+  const int nt1 = wave & 1, kh = wave >> 1;
+  const float* hb = h + (int64_t)b * h_seg_stride;   // 2 zero rows, then T rows of RC floats
+  float* ob = out + (int64_t)b * out_seg_stride;     // same layout
+
+  // ---- weights as (hi, lo) B fragments, once per workgroup: n = lane & 31, k = 16 * substep + 8 * (lane >> 5) .. + 7
+  uint4 w1h[12], w1l[12];
+#pragma unroll
+  for (int s = 0; s < 12; ++s) rsplit8(w1 + (int64_t)(nt1 * 32 + frow) * (3 * RC) + (kh * 12 + s) * 16 + fg * 8, w1h[s], w1l[s]);
+  uint4 w2h[4], w2l[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) rsplit8(w2 + (int64_t)(wave * 32 + frow) * RH + s * 16 + fg * 8, w2h[s], w2l[s]);
+  const float b1v = b1[nt1 * 32 + frow];
+  const float b2v = b2[wave * 32 + frow];
+
+  // tile request: rows s0-2 .. s0+RTO-1 (padded rows s0 .. s0+RTO+1).  All requests of a tile are issued back to back (one
+  // memory round); rows past the end are redirected to padded row 0, a zero row, so the loads are branch-free.
+  float4 v[9];
+  auto request = [&](int s0) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int idx = tid + q * 256;          // float4 index: 32 per row
+      const int r = idx >> 5, c4 = idx & 31;
+      const int p = s0 + r;                   // padded row
+      const int pc = (r < RHR && p < T + 2) ? p : 0;
+      v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)pc * RC + c4 * 4);
+    }
+  };
+
+  for (int it = 0; it < tiles; ++it) {
+    const int s0 = ((int)blockIdx.x * tiles + it) * RTO;
+    if (s0 >= T) break;              // uniform over the workgroup
+    // (no barrier here: the last readers of es finished before the second barrier of the previous tile, ys and red are
+    // rewritten only behind this tile's first barrier)
+
+    // ---- stage the rows: ELU + split once per element.  (Requesting the next tile during the second convolution instead
+    // was measured slower: the 36 extra live registers spill, 1.38 ms against 1.18 ms for 32 x 200 frames.)
+    request(s0);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int idx = tid + q * 256;
+      const int r = idx >> 5, c4 = idx & 31;
+      if (r < RHR) {
+        uint2 hi, lo;
+        split2_bf16(eluf_(v[q].x), eluf_(v[q].y), hi.x, lo.x);
+        split2_bf16(eluf_(v[q].z), eluf_(v[q].w), hi.y, lo.y);
+        *reinterpret_cast<uint2*>(es + r * REROW + c4 * 8) = hi;
+        *reinterpret_cast<uint2*>(es + r * REROW + 2 * RC + c4 * 8) = lo;
+      }
+    }
+    __syncthreads();
+
+    // ---- conv k=3, 128 -> 64: intermediate row m (sample s0+m) reads staged rows m, m+1, m+2.
+    // K index = tap * 128 + channel; substep s covers tap s / 8, channels 16 * (s % 8) .. + 15
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+      const unsigned char* a = es + (mt * 32 + frow) * REROW + fg * 16;
+#pragma unroll
+      for (int s = 0; s < 12; ++s) {
+        const int sg = kh * 12 + s;
+        const unsigned char* p = a + (sg >> 3) * REROW + (sg & 7) * 32;
+        const uint4 ah = *reinterpret_cast<const uint4*>(p), al = *reinterpret_cast<const uint4*>(p + 2 * RC);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(al), rfrag(w1h[s]), acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w1l[s]), acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w1h[s]), acc[mt], 0, 0, 0);
+      }
+    }
+    // the two K halves of a block meet through LDS: wave (nt, kh) keeps row tile kh and hands row tile 1-kh to wave (nt, 1-kh)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = kh ? acc[0][r] : acc[1][r];
+    __syncthreads();
+    {
+      const int mt = kh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float mine = kh ? acc[1][r] : acc[0][r];
+        const float other = red[((wave ^ 2) * 16 + r) * 64 + lane];
+        const float v = (kh ? other + mine : mine + other) + b1v;   // K half 0 first, whichever wave adds
+        const int mr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+        unsigned hi, lo;
+        split2_bf16(eluf_(v), 0.f, hi, lo);
+        *reinterpret_cast<unsigned short*>(ys + mr * RYROW + (nt1 * 32 + frow) * 2) = (unsigned short)(hi & 0xffffu);
+        *reinterpret_cast<unsigned short*>(ys + mr * RYROW + 2 * RH + (nt1 * 32 + frow) * 2) = (unsigned short)(lo & 0xffffu);
+      }
+    }
+    __syncthreads();
+
+    // ---- conv k=1, 64 -> 128 (wave w: output columns 32w ..) + skip, ELU, store
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      // skip operand in the accumulator layout (an L2-resident re-read of rows the tile request brought in), requested
+      // ahead of this row tile's MFMAs
+      float skip[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+        skip[r] = hb[(int64_t)((s0 + m < T) ? s0 + m + 2 : 0) * RC + wave * 32 + frow];  // past the end: zero row 0
+      }
+      f32x16 acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+      const unsigned char* a = ys + (mt * 32 + frow) * RYROW + fg * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const uint4 ah = *reinterpret_cast<const uint4*>(a + s * 32), al = *reinterpret_cast<const uint4*>(a + 2 * RH + s * 32);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(al), rfrag(w2h[s]), acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w2l[s]), acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w2h[s]), acc2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+        if (s0 + m < T) ob[(int64_t)(s0 + m + 2) * RC + wave * 32 + frow] = eluf_(skip[r] + acc2[r] + b2v);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+static int g_res_tiles = 0;  // developer probe / tests: tiles per workgroup, 0 = heuristic
+extern "C" int sopro_seanet_res_set_tiles(int tiles) {
+  g_res_tiles = tiles > 0 ? tiles : 0;
+  return 0;
+}
+
+extern "C" int sopro_seanet_res128_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
+                                        const float* b2, float* out, int64_t out_seg_stride, int32_t B, int32_t T, void* stream) {
+  SOPRO_CHECK_ARG(h && w1 && b1 && w2 && b2 && out && B > 0 && T > 0, "bad pointers or sizes");
+  SOPRO_CHECK_ARG(h != out, "the block is not computed in place (a tile reads two rows of its left neighbour)");
+  SOPRO_CHECK_ARG(aligned16(h) && aligned16(w1) && aligned16(w2) && aligned16(out) && (h_seg_stride & 3) == 0 && (out_seg_stride & 3) == 0,
+                  "alignment");
+  SOPRO_CHECK_ARG(h_seg_stride >= (int64_t)(T + 2) * RC && out_seg_stride >= (int64_t)(T + 2) * RC, "segments hold 2 + T rows of 128 floats");
+  const int ntile = (T + RTO - 1) / RTO;
+  // the weight fragments cost ~1000 VALU instructions per wave: amortised over several tiles once every CU has work anyway
+  const int64_t all = (int64_t)ntile * B;
+  const int tiles = g_res_tiles > 0 ? g_res_tiles : (all >= 16 * 2048 ? 16 : (all >= 8 * 1024 ? 8 : (all >= 2048 ? 2 : 1)));
+  dim3 grid((ntile + tiles - 1) / tiles, B);
+  hipLaunchKernelGGL(seanet_res128_kernel, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride,
+                     T, tiles);
+  SOPRO_LAUNCH_CHECK();
+}

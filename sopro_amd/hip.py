@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -89,6 +89,8 @@ SYMBOLS = {
     "sopro_packed_w_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "sopro_gemm_bf16_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_seanet_tail_set_tiles": (C.c_int, [C.c_int]),
+    "sopro_seanet_res_set_tiles": (C.c_int, [C.c_int]),
+    "sopro_seanet_res128_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "sopro_gemm_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_pack_skinny_w": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     "sopro_skinny_packed_floats": (_i64, [_i32, _i32, _i32]),
@@ -104,6 +106,7 @@ SYMBOLS = {
     "sopro_codebook_sum_f32": (C.c_int, [_p, _i32, _p, _p, _p, _i32, _p, _i64, _p, _f32, _f32, _p, _i64, _i64, _i32, _i32, _i32, _p]),
     "sopro_text_embed_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "sopro_argmax_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p]),
+    "sopro_argmax_partials_i32": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "sopro_fir1_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "sopro_rvq_assign_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _i32, _p, _i64, _i32, _p]),
     "sopro_attention_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
@@ -231,7 +234,7 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     g.W = None if packed else ptr(W)
     g.ldw = K if ldw is None else ldw
     g.bias = ptr(bias)
-    g.C = ptr(Cout) + 4 * c_off
+    g.C = (ptr(Cout) + 4 * c_off) if Cout is not None else None  # None only with c_mode 5 (arg-max partials to C2)
     g.ldc = n_out if ldc is None else ldc
     g.c_seg_stride = c_seg_stride
     g.R = (ptr(R) + 4 * r_off) if R is not None else None
@@ -263,8 +266,10 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
         x.ldc2, x.c2_seg_stride = (n_out if ldc2 is None else ldc2), c2_seg_stride
         _check(load().sopro_gemm_bf16x1(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_bf16x1")
     elif packed and W.pieces == 3:
-        if a_split or c_mode:
+        if a_split or c_mode not in (0, 5):
             raise SoproHipError("split-form operands belong to the three-pass (pieces = 2) path")
+        if c_mode == 5:
+            x.c_mode, x.C2, x.ldc2 = 5, ptr(C2) + 4 * c2_off, (-(-N // 64) if ldc2 is None else ldc2)
         _check(load().sopro_gemm_bf16x6(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_bf16x6")
     elif packed:
         x.a_format, x.c_mode = int(bool(a_split)), c_mode
@@ -465,6 +470,13 @@ def argmax_rows(x: torch.Tensor, out: torch.Tensor, *, rows: int, N: int, ldx: O
                                         _stream()), "sopro_argmax_rows_f32")
 
 
+def argmax_partials(part: torch.Tensor, out: torch.Tensor, *, rows: int, heads: int, per_head: int, V: int, ldp: int, ldo: int = 1,
+                    o_off: int = 0) -> None:
+    """Finish the arg-max that ``gemm(..., c_mode=5, C2=part)`` started: out[r * ldo + h] = token of head h of row r."""
+    _check(load().sopro_argmax_partials_i32(ptr(part), ldp, ptr(out, torch.int32) + 4 * o_off, ldo, heads, per_head, V, rows, _stream()),
+           "sopro_argmax_partials_i32")
+
+
 def fir1(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, B: int, n_in: int, n_out: int, C_: int, K: int, stride: int,
          left: int, bias: Optional[torch.Tensor] = None, ldo: Optional[int] = None, x_seg_stride: Optional[int] = None,
          o_seg_stride: Optional[int] = None, o_off: int = 0) -> None:
@@ -536,6 +548,13 @@ def seanet_tail(h: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.T
                 bf: float, wav: torch.Tensor, *, B: int, T: int, h_seg_stride: int, wav_seg_stride: int) -> None:
     _check(load().sopro_seanet_tail_f32(ptr(h), h_seg_stride, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(wf), bf, ptr(wav),
                                         wav_seg_stride, B, T, _stream()), "sopro_seanet_tail_f32")
+
+
+def seanet_res128(h: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, out: torch.Tensor, *, B: int,
+                  T: int, h_seg_stride: int, out_seg_stride: int) -> None:
+    """Fused 128-channel residual block of the SEANet decoder + the next layer's ELU (sopro_seanet_res128_f32)."""
+    _check(load().sopro_seanet_res128_f32(ptr(h), h_seg_stride, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(out), out_seg_stride, B, T,
+                                          _stream()), "sopro_seanet_res128_f32")
 
 
 def set_lds_floor(nbytes: int) -> None:

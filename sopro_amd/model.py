@@ -529,7 +529,12 @@ class SoproTTSModel:
         xa = self.ws.get("nar.xa", (M, D))
         xb = self.ws.get("nar.xb", (M, D))
         z = self.ws.get("nar.z", (M, int(cfg.nar_head_dim)))
-        logits = self.ws.get("nar.logits", (M, max(len(c) for _, c in self._stage_cbs) * V))
+        nh_max = max(len(c) for _, c in self._stage_cbs)
+        fused_argmax = bool(self.wx) and V % 64 == 0 and os.environ.get("SOPRO_NAR_LOGITS", "0") != "1"
+        if fused_argmax:  # (max, column) per row and 64-column tile instead of the logits: 1/32 of their bytes
+            part = self.ws.get("nar.part", (M, nh_max * (V // 64), 2))
+        else:
+            logits = self.ws.get("nar.logits", (M, nh_max * V))
         HD = int(cfg.nar_head_dim)
         for sid, (stage, cbs) in enumerate(self._stage_cbs):
             # prev = sum_j softmax(w[known])_j * E[cb_j*V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
@@ -547,9 +552,16 @@ class SoproTTSModel:
             hip.gemm(xb, self.wx.get("nar.pre.w") or w["nar.pre.w"], z, M=M, N=HD, K=D, bias=w["nar.pre.b"])
             # all heads of the stage in one contraction (head-id embeddings live in the bias), one arg-max launch
             nh = len(cbs)
-            hip.gemm(z, self.wx.get(f"nar.heads.{stage}.w") or w[f"nar.heads.{stage}.w"], logits, M=M, N=nh * V, K=HD,
-                     bias=w[f"nar.heads.{stage}.b"])
-            hip.argmax_rows(logits, toks, rows=M * nh, N=V, ldo=Q, o_off=cbs[0], inner=nh)
+            hw = self.wx.get(f"nar.heads.{stage}.w")
+            if fused_argmax and hw is not None:
+                # the arg-max runs in the contraction's epilogue (per 64-column tile) + one small reduction: no logits in HBM
+                hip.gemm(z, hw, None, M=M, N=nh * V, K=HD, bias=w[f"nar.heads.{stage}.b"], c_mode=5, C2=part, ldc2=nh_max * (V // 64))
+                hip.argmax_partials(part, toks, rows=M, heads=nh, per_head=V // 64, V=V, ldp=nh_max * (V // 64), ldo=Q, o_off=cbs[0])
+            else:
+                if fused_argmax:
+                    logits = self.ws.get("nar.logits", (M, nh_max * V))
+                hip.gemm(z, hw or w[f"nar.heads.{stage}.w"], logits, M=M, N=nh * V, K=HD, bias=w[f"nar.heads.{stage}.b"])
+                hip.argmax_rows(logits, toks, rows=M * nh, N=V, ldo=Q, o_off=cbs[0], inner=nh)
 
     # ------------------------------------------------------------------ text + reference -> tokens
     @torch.inference_mode()

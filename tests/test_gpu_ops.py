@@ -198,6 +198,34 @@ def test_gemm_bf16x6_epilogues_and_addvec():
         hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, prologue=hip.PRO_ELU)
 
 
+@pytest.mark.parametrize("pieces", [3, 1])
+@pytest.mark.parametrize("M,heads,V,K", [(200, 3, 2048, 256), (6, 16, 2048, 256), (77, 2, 128, 64)])
+def test_gemm_argmax_epilogue_equals_argmax_of_the_logits(pieces, M, heads, V, K):
+    """c_mode 5: the per-head arg-max is taken in the contraction's epilogue (per 64-column tile) and finished by
+    sopro_argmax_partials_i32 - the same tokens as writing the logits and running the arg-max kernel over them, exact ties
+    (duplicated weight rows) going to the lower index like torch.argmax (src/sopro/model.py:338-345)."""
+    N = heads * V
+    A, W, b = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=K ** -0.5), rnd(N, seed=63, scale=0.1)
+    twin = 900 if V > 900 else 100
+    W[twin] = W[5]
+    b[twin] = b[5]  # an exact tie inside head 0: the lower index (5) must win where it is the maximum of a row
+    A[0] = 8.0 * W[5] / W[5].norm()  # and make it the maximum of row 0
+    Wp = hip.pack_w_bf16(dev(W), pieces)
+    logits = torch.empty(M, N, device=DEV)
+    hip.gemm(dev(A), Wp, logits, M=M, N=N, K=K, bias=dev(b))
+    want = torch.full((M, heads + 2), -1, dtype=torch.int32, device=DEV)
+    hip.argmax_rows(logits, want, rows=M * heads, N=V, ldo=heads + 2, o_off=1, inner=heads)
+    part = torch.full((M, N // 64 + 3, 2), float("nan"), device=DEV)
+    got = torch.full((M, heads + 2), -1, dtype=torch.int32, device=DEV)
+    hip.gemm(dev(A), Wp, None, M=M, N=N, K=K, bias=dev(b), c_mode=5, C2=part, ldc2=N // 64 + 3)
+    hip.argmax_partials(part, got, rows=M, heads=heads, per_head=V // 64, V=V, ldp=N // 64 + 3, ldo=heads + 2, o_off=1)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert int(got[0, 1]) == 5 and bool((got[:, 0] == -1).all()) and bool((got[:, -1] == -1).all())
+    ref = logits.cpu().view(M, heads, V).argmax(-1).to(torch.int32)
+    assert torch.equal(got[:, 1:-1].cpu(), ref)
+
+
 @pytest.mark.parametrize("M,K", [(6, 384), (200, 384), (1000, 384), (70, 64), (1, 32)])
 def test_gemm_bf16x6_fused_rmsnorm(M, K):
     """RMSNorm inside the GEMM (ext.rms_norm; reference: src/sopro/nn/blocks.py:26-37 followed by the block's GLU / FF1
@@ -678,6 +706,39 @@ def test_seanet_tail_tiles_per_workgroup_is_the_same_function():
     assert bool(torch.isfinite(outs[0]).all())
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+def test_seanet_res128_fused_block_matches_the_layers():
+    """MimiResnetBlock(dim 128) + the next layer's ELU in one weight-stationary kernel (HF:modeling_mimi.py:408-447):
+    against torch's convolutions, for one and several tiles per workgroup (bit-identical), partial last tile, batch of 3."""
+    B, T = 3, 333  # 6 tiles of 64 rows, the last one partial
+    h = rnd(B, T, 128, seed=720)
+    w1, b1 = rnd(64, 128, 3, seed=721, scale=0.05), rnd(64, seed=722, scale=0.1)
+    w2, b2 = rnd(128, 64, 1, seed=723, scale=0.12), rnd(128, seed=724, scale=0.1)
+    x = h.transpose(1, 2)
+    y = O.causal_conv1d(F.elu(x), w1, b1)
+    y = O.causal_conv1d(F.elu(y), w2, b2)
+    ref = F.elu(x + y).transpose(1, 2)
+    hb = torch.zeros(B, 2 + T + 5, 128)  # segment stride larger than the rows in use
+    hb[:, 2:2 + T] = h
+    args = [dev(t) for t in (hb, pack.pack_conv1d(w1), b1, pack.pack_conv1d(w2), b2)]
+    lib, outs = hip.load(), []
+    try:
+        for tiles in (0, 1, 2, 4):
+            lib.sopro_seanet_res_set_tiles(tiles)
+            out = torch.full((B, 2 + T + 5, 128), float("nan"), device=DEV)
+            out[:, :2] = 0.0
+            hip.seanet_res128(*args, out, B=B, T=T, h_seg_stride=(2 + T + 5) * 128, out_seg_stride=(2 + T + 5) * 128)
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        lib.sopro_seanet_res_set_tiles(0)
+    close(outs[0][:, 2:2 + T], ref, 1e-4, "fused 128-channel residual block")  # split-bf16 contractions (16 mantissa bits per operand)
+    assert bool(torch.isnan(outs[0][:, 2 + T:]).all()) and float(outs[0][:, :2].abs().max()) == 0.0  # nothing outside rows 2 .. 2+T
+    for o in outs[1:]:
+        assert torch.equal(o[:, 2:2 + T], outs[0][:, 2:2 + T])
+    with pytest.raises(hip.SoproHipError):
+        hip.seanet_res128(args[0], *args[1:], args[0], B=B, T=T, h_seg_stride=(2 + T + 5) * 128, out_seg_stride=(2 + T + 5) * 128)
 
 
 @pytest.mark.parametrize("N,K,glu", [(1536, 384, False), (384, 1536, False), (2049, 384, False), (768, 384, True)])
