@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 18
+#define SOPRO_ABI_VERSION 19
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -354,6 +354,68 @@ int sopro_ar_sample(const sopro_ar_state* st, const float* logits, int64_t ld_lo
  * window reset, start[row] = *step.  The caller has already written the row's cond block, its cross-attention operands
  * and zeroed its ring-buffer columns, all on the same stream. */
 int sopro_ar_admit(const sopro_ar_state* st, int32_t row, void* stream);
+
+/* ==========================================================================================================
+ * Stage-level entry points: the launch SEQUENCES of the hot path as C functions, so that a host that is not
+ * Python drives generation with a handful of calls instead of re-implementing sopro_amd/model.py + codec.py.
+ * They are thin sequencers over the operator entry points above (same kernels, same order as the Python host)
+ * and cover the three stages of SoproTTS.synthesize after conditioning:
+ *   sopro_ar_begin / sopro_ar_run_graph / sopro_ar_tokens  - SoproTTSModel.ar_stream    (src/sopro/model.py:218-305;
+ *                                                            per frame ARRVQ1Generator.step, nn/generator.py:98-130)
+ *   sopro_nar_refine                                       - SoproTTSModel.nar_refine   (src/sopro/model.py:307-347)
+ *   sopro_mimi_decode                                      - MimiCodec.decode_full      (src/sopro/codec/mimi.py:65-72
+ *                                                            -> HF MimiModel._decode_frame, HF:modeling_mimi.py:1388-1406)
+ * Weights: the engine is handed the repacked tensors of sopro_amd/pack.py by name (device pointers, fp32 unless noted;
+ * `python -m sopro_amd.export` writes them to a flat file for hosts without Python) and builds the matrix-core operand
+ * forms (sopro_pack_w_bf16, sopro_pack_skinny_w) itself in sopro_engine_finalize.  All activations / tokens are caller-owned
+ * device buffers; scratch comes from caller-provided workspaces sized by the *_workspace_bytes functions.  Every call only
+ * enqueues on `stream`; nothing synchronises, nothing is allocated after sopro_engine_finalize (so the AR frame sequence is
+ * recorded into a hipGraph on the first sopro_ar_run_graph).  One engine per device, not thread-safe.
+ * ========================================================================================================== */
+typedef struct sopro_engine sopro_engine;
+typedef struct sopro_engine_cfg {
+  /* Sopro (src/sopro/config.py) */
+  int32_t d_model, codebook_size, num_codebooks, nar_head_dim, bos_row;
+  int32_t n_layers_ar, ar_kernel, ar_dilations[16], ar_xattn[16] /* 1: block i is followed by a text cross-attention */;
+  float ar_gate[16];                 /* tanh(gate) of that cross-attention block (src/sopro/nn/text.py:131) */
+  int32_t n_layers_nar, nar_kernel, nar_dilations[16];
+  int32_t n_stages, stage_first_cb[8], stage_n_cb[8];   /* stages B, C, D, E: codebooks [first, first + n) */
+  float nar_mix[8][2];               /* softmax(nar.mix.<stage>) (src/sopro/nn/nar.py:95-97) */
+  float nar_prev_cb_weights[64];     /* raw nar_prev_cb_weights (softmax over the known codebooks is taken per stage) */
+  /* Mimi decode side (HF:configuration_mimi.py) */
+  int32_t mimi_hidden, mimi_codebook_dim, mimi_heads, mimi_head_dim, mimi_layers, mimi_window, mimi_inter;
+  int32_t mimi_n_ratios, mimi_ratios[8], mimi_num_filters, mimi_kernel, mimi_res_kernel, mimi_last_kernel, mimi_compress;
+  int32_t mimi_n_semantic, mimi_rope_positions;
+  float mimi_norm_eps, mimi_final_bias;
+} sopro_engine_cfg;
+int sopro_engine_create(const sopro_engine_cfg* cfg, sopro_engine** out);
+/* name: a key of sopro_amd.pack.pack_sopro / pack_mimi ("ar.blocks.0.glu.w", "nar.heads.B.w", "tr.3.qkv.w", "sea.up1.w", ...)
+ * plus "rope.cos" / "rope.sin" [positions, head_dim / 2].  The engine keeps the pointer; the caller keeps the memory. */
+int sopro_engine_set_tensor(sopro_engine* e, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim);
+/* checks that every tensor the three stages need is present and builds the packed operand forms (allocates device memory) */
+int sopro_engine_finalize(sopro_engine* e, void* stream);
+int sopro_engine_destroy(sopro_engine* e);
+
+/* ---- autoregressive stage.  S_cap = S rounded up to 64.  The workspace must stay alive (and untouched) until the tokens
+ * have been read; one generation at a time per engine. */
+int64_t sopro_ar_workspace_bytes(const sopro_engine* e, int32_t B, int32_t S, int32_t Tar);
+/* cond_ar [B, Tar, D], txt_seq [B, S, D] (conditioning outputs), text_lens [B] or NULL (= S); params = {top_p, temperature,
+ * anti_loop, recovery top_p, recovery temperature, repetition penalty, top_k <= 64, min_gen_frames}; (seed, nonce) key the sampler. */
+int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* cond_ar, const float* txt_seq, const int32_t* text_lens,
+                   int32_t S, int32_t Tar, const float params[8], uint64_t seed, uint32_t nonce, void* stream);
+/* n_steps more frames (23 launches each, replayed from a hipGraph recorded on the first call) */
+int sopro_ar_run_graph(sopro_engine* e, int32_t n_steps, void* stream);
+/* device-to-device copies: hist [B, Tar] int32 (codebook-0 tokens, EOS = codebook_size), first_eos [B] (-1 = none), n_stopped [1] */
+int sopro_ar_tokens(sopro_engine* e, int32_t* hist, int32_t* first_eos, int32_t* n_stopped, void* stream);
+
+/* ---- NAR refinement: tokens [B, T, Q] int32 out; column 0 <- rvq1 [B, T], columns 1..Q-1 refined.  lens [B] or NULL (= T). */
+int64_t sopro_nar_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T);
+int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_t cond_bstride, const int32_t* rvq1, const int32_t* lens,
+                     int32_t B, int32_t T, int32_t* tokens, void* stream);
+
+/* ---- Mimi decode: tokens [B, T, Q] int32 -> wav [B, T * 1920] fp32 */
+int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T);
+int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,762 @@
+// Stage-level entry points (include/sopro_hip.h, "Stage-level entry points"): the launch sequences of the AR loop, the NAR
+// refinement and the Mimi decoder as host C++ over the operator entry points of this library.  No kernels here.  The
+// sequences are the ones sopro_amd/model.py (_ARRun / _ARPlan.issue_step / _nar_issue) and sopro_amd/codec.py
+// (_decode_issue / _transformer / _seanet_act) issue; tests/test_gpu_stages.py checks the two hosts against each other
+// and against the oracle.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct Ten {
+  const void* p = nullptr;
+  int64_t shape[4] = {0, 0, 0, 0};
+  int ndim = 0;
+  const float* f() const { return reinterpret_cast<const float*>(p); }
+};
+
+struct Wt {  // weight operand of a contraction: fp32 [N, K] row-major and / or its packed bf16 pieces
+  const float* f32 = nullptr;
+  const void* packed = nullptr;
+  int pieces = 0;
+};
+
+constexpr float RMS_EPS = 1e-6f;  // src/sopro/nn/blocks.py:27
+
+struct Carver {  // carves a caller-provided workspace into 256-byte aligned buffers
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base(reinterpret_cast<char*>(b)) {}
+  template <class T>
+  T* take(size_t n) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (n * sizeof(T) + 255) & ~size_t(255);
+    return p;
+  }
+};
+
+struct ArPlan {
+  int B = 0, S = 0, S_cap = 0, Tar = 0;
+  void* ws = nullptr;
+  float *cond, *x[4], *part, *u, *logits, *kp[16], *vp[16], *xp, *params, *rings[16], *nkv, *kvd;
+  int32_t *klens, *hist, *ctr, *first_eos, *stop_t, *recent;
+  uint32_t* nonce;
+  sopro_ar_state st;
+  void* graph = nullptr;
+  int graph_B = 0, graph_S_cap = 0, graph_Tar = 0;
+  void* graph_ws = nullptr;
+};
+
+}  // namespace
+
+struct sopro_engine {
+  sopro_engine_cfg c;
+  std::map<std::string, Ten> t;
+  std::map<std::string, Wt> w;       // contraction operands by pack name
+  std::map<std::string, const float*> sk;  // AR-step weights in skinny fragment order
+  std::vector<void*> owned;
+  bool final = false;
+  // NAR constants
+  std::vector<int32_t*> nar_cols, nar_offs;
+  std::vector<float*> nar_cw, ad_mul, ad_add;
+  std::vector<int> nar_known;
+  // Mimi constants
+  int32_t *sem_col = nullptr, *sem_off = nullptr, *ac_col = nullptr, *ac_off = nullptr;
+  float* ones = nullptr;
+  ArPlan ar;
+};
+
+namespace {
+
+#define STG(call)                       \
+  do {                                  \
+    const int rc_ = (call);             \
+    if (rc_ != 0) return rc_;           \
+  } while (0)
+
+int need(const sopro_engine* e, const std::string& name, const Ten** out, int ndim = 0) {
+  auto it = e->t.find(name);
+  if (it == e->t.end() || !it->second.p) {
+    sopro_set_error("stage API: tensor '%s' was not given to sopro_engine_set_tensor", name.c_str());
+    return -2;
+  }
+  if (ndim && it->second.ndim != ndim) {
+    sopro_set_error("stage API: tensor '%s' has %d dimensions, expected %d", name.c_str(), it->second.ndim, ndim);
+    return -2;
+  }
+  *out = &it->second;
+  return 0;
+}
+
+const float* F(const sopro_engine* e, const std::string& name) {
+  auto it = e->t.find(name);
+  return it == e->t.end() ? nullptr : it->second.f();
+}
+
+template <class T>
+int dev_alloc(sopro_engine* e, size_t n, T** out) {
+  void* p = nullptr;
+  SOPRO_HIP(hipMalloc(&p, n * sizeof(T)));
+  e->owned.push_back(p);
+  *out = reinterpret_cast<T*>(p);
+  return 0;
+}
+
+template <class T>
+int dev_upload(sopro_engine* e, const std::vector<T>& h, T** out) {
+  STG(dev_alloc(e, h.size(), out));
+  SOPRO_HIP(hipMemcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// [N, K] fp32 device matrix (optionally with its columns scaled by a device vector: an RMSNorm weight folded in) -> bf16 pieces
+int pack_pieces(sopro_engine* e, const std::string& key, const std::string& out_key, int pieces, const char* fold_vec, hipStream_t s) {
+  const Ten* t;
+  STG(need(e, key, &t, 2));
+  const int N = (int)t->shape[0], K = (int)t->shape[1];
+  const float* src = t->f();
+  if (fold_vec) {
+    const Ten* v;
+    STG(need(e, fold_vec, &v));
+    std::vector<float> hw((size_t)N * K), hv(K);
+    SOPRO_HIP(hipMemcpy(hw.data(), src, hw.size() * 4, hipMemcpyDeviceToHost));
+    SOPRO_HIP(hipMemcpy(hv.data(), v->p, (size_t)K * 4, hipMemcpyDeviceToHost));
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k) hw[(size_t)n * K + k] *= hv[k];  // (x * rstd * w_norm) W^T == rstd * x (W * w_norm)^T
+    float* d;
+    STG(dev_upload(e, hw, &d));
+    src = d;
+  }
+  const int64_t bytes = sopro_packed_w_bytes(N, K, pieces);
+  char* dst;
+  STG(dev_alloc(e, (size_t)bytes, &dst));
+  STG(sopro_pack_w_bf16(src, K, N, K, pieces, dst, s));
+  Wt w;
+  w.f32 = fold_vec ? nullptr : t->f();
+  w.packed = dst;
+  w.pieces = pieces;
+  e->w[out_key] = w;
+  return 0;
+}
+
+int plain(sopro_engine* e, const std::string& key) {
+  const Ten* t;
+  STG(need(e, key, &t));
+  Wt w;
+  w.f32 = t->f();
+  e->w[key] = w;
+  return 0;
+}
+
+struct G {  // one contraction: mirrors sopro_amd.hip.gemm's keyword arguments
+  int M = 0, N = 0, K = 0;
+  int64_t lda = -1, ldc = -1, ldr = -1, ldw = -1;
+  const float *bias = nullptr, *R = nullptr, *scale = nullptr, *pro_vec = nullptr;
+  int epi = SOPRO_EPI_NONE, pro = SOPRO_PRO_NONE, rows_per_seg = -1;
+  int64_t a_seg = 0, c_seg = 0, r_seg = 0;
+  int c_mode = 0;
+  float* C2 = nullptr;
+  int64_t ldc2 = -1, c2_seg = 0;
+  float rms_eps = 0.f;
+};
+
+int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override, float* C, const G& o) {
+  const int n_out = o.epi == SOPRO_EPI_GLU ? o.N / 2 : o.N;
+  sopro_gemm_args g;
+  memset(&g, 0, sizeof(g));
+  g.A = A;
+  g.lda = o.lda < 0 ? o.K : o.lda;
+  g.a_seg_stride = o.a_seg;
+  g.W = w_f32_override ? w_f32_override : w.f32;
+  g.ldw = o.ldw < 0 ? o.K : o.ldw;
+  g.bias = o.bias;
+  g.C = C;
+  g.ldc = o.ldc < 0 ? n_out : o.ldc;
+  g.c_seg_stride = o.c_seg;
+  g.R = o.R;
+  g.ldr = o.ldr < 0 ? n_out : o.ldr;
+  g.r_seg_stride = o.r_seg;
+  g.scale = o.scale;
+  g.pro_vec = o.pro_vec;
+  g.M = o.M; g.N = o.N; g.K = o.K;
+  g.rows_per_seg = o.rows_per_seg < 0 ? o.M : o.rows_per_seg;
+  g.prologue = o.pro; g.epilogue = o.epi;
+  if (!w_f32_override && w.packed) {
+    sopro_gemm_split_ext x;
+    memset(&x, 0, sizeof(x));
+    x.c_mode = o.c_mode;
+    x.C2 = o.C2;
+    x.ldc2 = o.ldc2 < 0 ? n_out : o.ldc2;
+    x.c2_seg_stride = o.c2_seg;
+    if (o.rms_eps > 0.f) { x.rms_norm = 1; x.rms_eps = o.rms_eps; }
+    if (w.pieces == 3) return sopro_gemm_bf16x6(&g, w.packed, &x, s);
+    if (w.pieces == 1) return sopro_gemm_bf16x1(&g, w.packed, &x, s);
+    return sopro_gemm_bf16x3(&g, w.packed, &x, s);
+  }
+  if (!g.W) {
+    sopro_set_error("stage API: a contraction has neither an fp32 nor a packed weight");
+    return -2;
+  }
+  return sopro_gemm_f32(&g, s);
+}
+
+int norm(hipStream_t s, const float* x, float* out, const float* w, int rows, int C, float eps, int kind = SOPRO_NORM_RMS,
+         const float* b = nullptr, const float* mul = nullptr, const float* add = nullptr, int rows_per_seg = -1, int64_t x_seg = 0) {
+  return sopro_norm_f32(x, C, x_seg, out, C, w, b, mul, add, rows, rows_per_seg < 0 ? rows : rows_per_seg, C, eps, kind, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sopro_engine_create(const sopro_engine_cfg* cfg, sopro_engine** out) {
+  SOPRO_CHECK_ARG(cfg && out, "NULL argument");
+  SOPRO_CHECK_ARG(cfg->d_model == 384 && cfg->n_layers_ar >= 1 && cfg->n_layers_ar <= 16 && cfg->n_layers_nar >= 1 && cfg->n_layers_nar <= 16,
+                  "d_model must be 384 (kernel family), 1..16 layers");
+  SOPRO_CHECK_ARG(cfg->n_stages >= 1 && cfg->n_stages <= 8 && cfg->num_codebooks <= 64 && cfg->mimi_n_ratios >= 1 && cfg->mimi_n_ratios <= 8,
+                  "1..8 NAR stages, <= 64 codebooks, 1..8 decoder ratios");
+  sopro_engine* e = new sopro_engine();
+  e->c = *cfg;
+  *out = e;
+  return 0;
+}
+
+int sopro_engine_set_tensor(sopro_engine* e, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim) {
+  SOPRO_CHECK_ARG(e && name && dev_ptr && shape && ndim >= 1 && ndim <= 4, "bad arguments");
+  SOPRO_CHECK_ARG(!e->final, "the engine is finalized");
+  Ten t;
+  t.p = dev_ptr;
+  t.ndim = ndim;
+  for (int i = 0; i < ndim; ++i) t.shape[i] = shape[i];
+  e->t[name] = t;
+  return 0;
+}
+
+int sopro_engine_destroy(sopro_engine* e) {
+  if (!e) return 0;
+  if (e->ar.graph) (void)sopro_graph_destroy(e->ar.graph);
+  for (void* p : e->owned) (void)hipFree(p);
+  delete e;
+  return 0;
+}
+
+int sopro_engine_finalize(sopro_engine* e, void* stream) {
+  SOPRO_CHECK_ARG(e && !e->final, "NULL or already finalized engine");
+  hipStream_t s = (hipStream_t)stream;
+  const sopro_engine_cfg& c = e->c;
+  const Ten* t;
+  // ---- AR step: skinny fragment order for the four big projections of every block and the head
+  for (int i = 0; i < c.n_layers_ar; ++i) {
+    const std::string p = "ar.blocks." + std::to_string(i);
+    for (const char* nm : {".glu.w", ".ff1.w", ".ff2.w"}) {
+      STG(need(e, p + nm, &t, 2));
+      const int N = (int)t->shape[0], K = (int)t->shape[1], glu = std::string(nm) == ".glu.w";
+      float* d;
+      STG(dev_alloc(e, (size_t)sopro_skinny_packed_floats(N, K, glu), &d));
+      STG(sopro_pack_skinny_w(t->f(), K, N, K, glu, d, s));
+      e->sk[p + nm] = d;
+    }
+    for (const char* nm : {".glu.b", ".dw.w", ".dw.b", ".ff1.b", ".ff2.b"}) STG(need(e, p + nm, &t));
+    if (c.ar_xattn[i]) {
+      const std::string pa = "ar.x_attns." + std::to_string(i);
+      for (const char* nm : {".nkv.weight", ".kv.w", ".q.wT", ".o.w"}) STG(need(e, pa + nm, &t));
+    }
+  }
+  {
+    STG(need(e, "ar.head.w", &t, 2));
+    float* d;
+    STG(dev_alloc(e, (size_t)sopro_skinny_packed_floats((int)t->shape[0], (int)t->shape[1], 0), &d));
+    STG(sopro_pack_skinny_w(t->f(), t->shape[1], (int)t->shape[0], (int)t->shape[1], 0, d, s));
+    e->sk["ar.head.w"] = d;
+    STG(need(e, "ar.head.b", &t));
+    STG(need(e, "cb_embed", &t, 2));
+  }
+  // ---- NAR: six-pass operands, the two RMSNorm weights of a block folded into the projections they feed
+  for (int i = 0; i < c.n_layers_nar; ++i) {
+    const std::string p = "nar.blocks." + std::to_string(i);
+    STG(pack_pieces(e, p + ".glu.w", p + ".glu.wn", 3, (p + ".norm.weight").c_str(), s));
+    STG(pack_pieces(e, p + ".ff1.w", p + ".ff1.wn", 3, (p + ".ff.norm.weight").c_str(), s));
+    STG(pack_pieces(e, p + ".ff2.w", p + ".ff2.w", 3, nullptr, s));
+    for (const char* nm : {".glu.b", ".dw.w", ".dw.b", ".ff1.b", ".ff2.b"}) STG(need(e, p + nm, &t));
+  }
+  STG(pack_pieces(e, "nar.pre.w", "nar.pre.w", 3, nullptr, s));
+  const char* stage_names[8] = {"B", "C", "D", "E", "F", "G", "H", "I"};
+  std::vector<int> known = {0};
+  for (int sgi = 0; sgi < c.n_stages; ++sgi) {
+    const std::string hk = std::string("nar.heads.") + stage_names[sgi];
+    STG(pack_pieces(e, hk + ".w", hk + ".w", 3, nullptr, s));
+    STG(need(e, hk + ".b", &t));
+    // prev = sum_j softmax(w[known])_j * E[cb_j * V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
+    std::vector<int32_t> cols(known.begin(), known.end()), offs;
+    std::vector<float> cw;
+    float mx = -1e30f, sum = 0.f;
+    for (int k : known) mx = fmaxf(mx, c.nar_prev_cb_weights[k]);
+    for (int k : known) { cw.push_back(expf(c.nar_prev_cb_weights[k] - mx)); sum += cw.back(); }
+    for (float& v : cw) v /= sum;
+    for (int k : known) offs.push_back(k * c.codebook_size);
+    int32_t *dc, *dofs;
+    float* dw;
+    STG(dev_upload(e, cols, &dc));
+    STG(dev_upload(e, offs, &dofs));
+    STG(dev_upload(e, cw, &dw));
+    e->nar_cols.push_back(dc); e->nar_offs.push_back(dofs); e->nar_cw.push_back(dw);
+    e->nar_known.push_back((int)known.size());
+    for (int j = 0; j < c.stage_n_cb[sgi]; ++j) known.push_back(c.stage_first_cb[sgi] + j);
+  }
+  for (const char* nm : {"nar.norm.weight", "nar.pre.b", "nar.stage_emb", "nar.adapter.norm.weight", "nar.adapter.mlp.0.w", "nar.adapter.mlp.0.b",
+                         "nar.adapter.mlp.2.w", "nar.adapter.mlp.2.b"})
+    STG(need(e, nm, &t));
+  {  // per-stage adapter coefficients (1 + tanh g, tanh b): input independent (src/sopro/nn/nar.py:25-32)
+    const int ns = c.n_stages, D = c.d_model;
+    float *h, *gb;
+    STG(dev_alloc(e, (size_t)ns * 256, &h));
+    STG(dev_alloc(e, (size_t)ns * 2 * D, &gb));
+    G o; o.M = ns; o.N = 256; o.K = D; o.bias = F(e, "nar.adapter.mlp.0.b"); o.epi = SOPRO_EPI_GELU;
+    Wt w0; w0.f32 = F(e, "nar.adapter.mlp.0.w");
+    STG(gemm(s, F(e, "nar.stage_emb"), w0, nullptr, h, o));
+    G o2; o2.M = ns; o2.N = 2 * D; o2.K = 256; o2.bias = F(e, "nar.adapter.mlp.2.b");
+    Wt w2; w2.f32 = F(e, "nar.adapter.mlp.2.w");
+    STG(gemm(s, h, w2, nullptr, gb, o2));
+    for (int sg = 0; sg < ns; ++sg) {
+      float *mul, *add;
+      STG(dev_alloc(e, (size_t)D, &mul));
+      STG(dev_alloc(e, (size_t)D, &add));
+      STG(sopro_tanh_affine_f32(gb + (size_t)sg * 2 * D, mul, 1.0f, 1.0f, D, s));
+      STG(sopro_tanh_affine_f32(gb + (size_t)sg * 2 * D + D, add, 0.0f, 1.0f, D, s));
+      e->ad_mul.push_back(mul); e->ad_add.push_back(add);
+    }
+  }
+  // ---- Mimi decoder: three-pass operands (16 mantissa bits: waveform contract), raw fp32 for the two fused SEANet kernels
+  STG(pack_pieces(e, "rvq_proj.w", "rvq_proj.w", 2, nullptr, s));
+  for (int l = 0; l < c.mimi_layers; ++l) {
+    const std::string p = "tr." + std::to_string(l);
+    for (const char* nm : {".qkv.w", ".o.w", ".fc1.w", ".fc2.w"}) STG(pack_pieces(e, p + nm, p + nm, 2, nullptr, s));
+    for (const char* nm : {".ln1.w", ".ln1.b", ".ln2.w", ".ln2.b", ".ls1", ".ls2"}) STG(need(e, p + nm, &t));
+  }
+  STG(pack_pieces(e, "sea.conv0.w", "sea.conv0.w", 2, nullptr, s));
+  STG(need(e, "sea.conv0.b", &t));
+  for (int si = 0; si < c.mimi_n_ratios; ++si) {
+    const std::string u = "sea.up" + std::to_string(si), r = "sea.res" + std::to_string(si);
+    STG(pack_pieces(e, u + ".w", u + ".w", 2, nullptr, s));
+    STG(need(e, u + ".b", &t));
+    for (const char* nm : {".c1.w", ".c1.b", ".c2.w", ".c2.b"}) STG(need(e, r + nm, &t));
+    STG(need(e, r + ".c1.w", &t, 2));
+    if ((int)t->shape[0] >= 64 && (int)t->shape[0] != 64) {  // hidden > 64: generic contractions (64 = the fused 128-channel block)
+      STG(pack_pieces(e, r + ".c1.w", r + ".c1.w", 2, nullptr, s));
+      STG(pack_pieces(e, r + ".c2.w", r + ".c2.w", 2, nullptr, s));
+    }
+  }
+  for (const char* nm : {"codebooks", "upsample.w", "sea.final.w", "rope.cos", "rope.sin"}) STG(need(e, nm, &t));
+  {
+    const int Q = c.num_codebooks, V = c.codebook_size, ns = c.mimi_n_semantic;
+    std::vector<int32_t> sc, so, ac, ao;
+    for (int q = 0; q < ns; ++q) { sc.push_back(q); so.push_back(q * V); }
+    for (int q = ns; q < Q; ++q) { ac.push_back(q); ao.push_back(q * V); }
+    STG(dev_upload(e, sc, &e->sem_col)); STG(dev_upload(e, so, &e->sem_off));
+    STG(dev_upload(e, ac, &e->ac_col)); STG(dev_upload(e, ao, &e->ac_off));
+    std::vector<float> one((size_t)Q, 1.0f);
+    STG(dev_upload(e, one, &e->ones));
+  }
+  e->final = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ autoregressive stage
+static size_t ar_carve(const sopro_engine* e, ArPlan& p, void* ws, int B, int S, int Tar) {
+  const sopro_engine_cfg& c = e->c;
+  const int D = c.d_model, V1 = c.codebook_size + 1, S_cap = (S + 63) / 64 * 64, H = 4;
+  Carver cv(ws);
+  p.cond = cv.take<float>((size_t)B * Tar * D);
+  for (int i = 0; i < 4; ++i) p.x[i] = cv.take<float>((size_t)B * D);
+  p.part = cv.take<float>((size_t)4 * B * D);
+  p.u = cv.take<float>((size_t)B * 4 * D);
+  p.logits = cv.take<float>((size_t)B * V1);
+  for (int i = 0; i < c.n_layers_ar; ++i) {
+    p.kp[i] = p.vp[i] = nullptr;
+    if (c.ar_xattn[i]) {
+      p.kp[i] = cv.take<float>((size_t)B * H * S_cap * D);
+      p.vp[i] = cv.take<float>((size_t)B * H * S_cap * D);
+    }
+  }
+  p.xp = cv.take<float>((size_t)H * B * D);
+  p.params = cv.take<float>(8);
+  for (int i = 0; i < c.n_layers_ar; ++i) p.rings[i] = cv.take<float>((size_t)((c.ar_kernel - 1) * c.ar_dilations[i] + 1) * B * D);
+  p.nkv = cv.take<float>((size_t)B * S * D);
+  p.kvd = cv.take<float>((size_t)B * S * 2 * D);
+  p.klens = cv.take<int32_t>(B);
+  p.hist = cv.take<int32_t>((size_t)B * Tar);
+  p.ctr = cv.take<int32_t>(8);
+  p.first_eos = cv.take<int32_t>(B);
+  p.stop_t = cv.take<int32_t>(B);
+  p.recent = cv.take<int32_t>((size_t)B * 64);
+  p.nonce = cv.take<uint32_t>(B);
+  return cv.off;
+}
+
+int64_t sopro_ar_workspace_bytes(const sopro_engine* e, int32_t B, int32_t S, int32_t Tar) {
+  if (!e || B <= 0 || S <= 0 || Tar <= 0) return 0;
+  ArPlan tmp;
+  return (int64_t)ar_carve(e, tmp, nullptr, B, S, Tar);
+}
+
+// one frame: the launch sequence of sopro_amd.model._ARPlan.issue_step (reference step: src/sopro/nn/generator.py:98-130)
+static int ar_issue_step(sopro_engine* e, hipStream_t s) {
+  const sopro_engine_cfg& c = e->c;
+  ArPlan& p = e->ar;
+  const int B = p.B, D = c.d_model, k = c.ar_kernel, H = 4;
+  const int64_t BD = (int64_t)B * D;
+  float *X0 = p.x[0], *XA = p.x[1], *XB = p.x[2];
+  const float* base = X0;
+  const float* pend = nullptr;  // three partial buffers the next kernel adds while staging
+  for (int i = 0; i < c.n_layers_ar; ++i) {
+    const std::string pr = "ar.blocks." + std::to_string(i);
+    float* out = (i % 2 == 0) ? XA : XB;
+    const int dil = c.ar_dilations[i];
+    sopro_skinny_args a;
+    // RMSNorm -> GLU -> ring write -> dilated taps -> +x   (src/sopro/nn/blocks.py:150-157, 76-110)
+    memset(&a, 0, sizeof(a));
+    a.X = base; a.ldx = D; a.W = e->sk[pr + ".glu.w"]; a.ldw = D; a.w_layout = 1; a.bias = F(e, pr + ".glu.b");
+    a.Y = out; a.ldy = D; a.ldr = D;
+    a.ring = p.rings[i]; a.dw_w = F(e, pr + ".dw.w"); a.dw_b = F(e, pr + ".dw.b"); a.step = p.ctr;
+    a.Xp = pend; a.xp_stride = BD; a.np = pend ? 3 : 0;
+    a.eps = RMS_EPS; a.B = B; a.N = 2 * D; a.K = D; a.epilogue = SOPRO_EPI_GLU_DW;
+    a.ring_len = (k - 1) * dil + 1; a.ring_bcap = B; a.dil = dil; a.ksize = k; a.rms_norm = 1;
+    STG(sopro_skinny_f32(&a, s));
+    // RMSNorm -> Linear -> GELU (blocks.py:158-160)
+    memset(&a, 0, sizeof(a));
+    a.X = out; a.ldx = D; a.W = e->sk[pr + ".ff1.w"]; a.ldw = D; a.w_layout = 1; a.bias = F(e, pr + ".ff1.b");
+    a.Y = p.u; a.ldy = 4 * D; a.ldr = 4 * D; a.eps = RMS_EPS; a.B = B; a.N = 4 * D; a.K = D; a.epilogue = SOPRO_EPI_GELU; a.rms_norm = 1;
+    STG(sopro_skinny_f32(&a, s));
+    // Linear 4D -> D + residual as 4 K-slices (blocks.py:161-162)
+    memset(&a, 0, sizeof(a));
+    a.X = p.u; a.ldx = 4 * D; a.W = e->sk[pr + ".ff2.w"]; a.ldw = 4 * D; a.w_layout = 1; a.bias = F(e, pr + ".ff2.b");
+    a.Y = p.part; a.ldy = D; a.R = out; a.ldr = D; a.eps = RMS_EPS; a.B = B; a.N = D; a.K = 4 * D; a.epilogue = SOPRO_EPI_RES;
+    a.ksplit = 1; a.y_part_stride = BD;
+    STG(sopro_skinny_f32(&a, s));
+    base = p.part; pend = p.part + BD;
+    if (c.ar_xattn[i]) {
+      // cached text cross-attention, projections folded into the cached operands (src/sopro/nn/text.py:85-132)
+      sopro_xattn_args x;
+      memset(&x, 0, sizeof(x));
+      x.X = base; x.ldx = D; x.Xp = pend; x.xp_stride = BD; x.np = 3;
+      x.Kp = p.kp[i]; x.Vp = p.vp[i]; x.klens = p.klens; x.Y = p.xp; x.y_part_stride = BD;
+      x.eps = RMS_EPS; x.gate = c.ar_gate[i]; x.scale = 1.0f / sqrtf((float)(D / H));
+      x.B = B; x.H = H; x.D = D; x.S_cap = p.S_cap;
+      STG(sopro_xattn_step_f32(&x, s));
+      base = p.xp; pend = p.xp + BD;
+    }
+  }
+  sopro_skinny_args a;
+  memset(&a, 0, sizeof(a));
+  a.X = base; a.ldx = D; a.W = e->sk["ar.head.w"]; a.ldw = D; a.w_layout = 1; a.bias = F(e, "ar.head.b");
+  a.Y = p.logits; a.ldy = c.codebook_size + 1; a.ldr = c.codebook_size + 1; a.Xp = pend; a.xp_stride = BD; a.np = pend ? 3 : 0;
+  a.eps = RMS_EPS; a.B = B; a.N = c.codebook_size + 1; a.K = D; a.rms_norm = 1;
+  STG(sopro_skinny_f32(&a, s));
+  // the sampler writes the next frame's input into state.x_cur == x[0], where block 0 reads
+  return sopro_ar_sample(&p.st, p.logits, c.codebook_size + 1, s);
+}
+
+int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* cond_ar, const float* txt_seq, const int32_t* text_lens,
+                   int32_t S, int32_t Tar, const float params[8], uint64_t seed, uint32_t nonce, void* stream) {
+  SOPRO_CHECK_ARG(e && e->final && workspace && cond_ar && txt_seq && params && B > 0 && S > 0 && Tar > 0, "bad arguments (finalize the engine first)");
+  SOPRO_CHECK_ARG(params[6] >= 1.f && params[6] <= 64.f, "top_k must be in [1, 64] (the reference uses 50)");
+  hipStream_t s = (hipStream_t)stream;
+  const sopro_engine_cfg& c = e->c;
+  ArPlan& p = e->ar;
+  const int D = c.d_model, H = 4, dh = D / H;
+  ar_carve(e, p, workspace, B, S, Tar);
+  p.B = B; p.S = S; p.S_cap = (S + 63) / 64 * 64; p.Tar = Tar; p.ws = workspace;
+  SOPRO_HIP(hipMemcpyAsync(p.cond, cond_ar, (size_t)B * Tar * D * 4, hipMemcpyDeviceToDevice, s));
+  if (text_lens) {
+    SOPRO_HIP(hipMemcpyAsync(p.klens, text_lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    SOPRO_HIP(hipMemsetD32Async((hipDeviceptr_t)p.klens, S, B, s));
+  }
+  // K/V of the text for the cross-attention layers (src/sopro/nn/text.py:75-83), query / output projections folded in
+  for (int i = 0; i < c.n_layers_ar; ++i) {
+    if (!c.ar_xattn[i]) continue;
+    const std::string pa = "ar.x_attns." + std::to_string(i);
+    STG(norm(s, txt_seq, p.nkv, F(e, pa + ".nkv.weight"), B * S, D, RMS_EPS));
+    G o; o.M = B * S; o.N = 2 * D; o.K = D;
+    Wt kv; kv.f32 = F(e, pa + ".kv.w");
+    STG(gemm(s, p.nkv, kv, nullptr, p.kvd, o));
+    for (int h = 0; h < H; ++h) {
+      G f; f.M = B * S; f.N = D; f.K = dh; f.lda = 2 * D; f.rows_per_seg = S; f.ldc = D; f.c_seg = (int64_t)H * p.S_cap * D;
+      Wt none;
+      STG(gemm(s, p.kvd + h * dh, none, F(e, pa + ".q.wT") + (size_t)h * D * dh, p.kp[i] + (size_t)h * p.S_cap * D, f));
+      f.ldw = D;
+      STG(gemm(s, p.kvd + D + h * dh, none, F(e, pa + ".o.w") + h * dh, p.vp[i] + (size_t)h * p.S_cap * D, f));
+    }
+  }
+  for (int i = 0; i < c.n_layers_ar; ++i)
+    SOPRO_HIP(hipMemsetAsync(p.rings[i], 0, (size_t)((c.ar_kernel - 1) * c.ar_dilations[i] + 1) * B * D * 4, s));
+  SOPRO_HIP(hipMemsetAsync(p.hist, 0, (size_t)B * Tar * 4, s));
+  SOPRO_HIP(hipMemcpyAsync(p.params, params, 8 * sizeof(float), hipMemcpyHostToDevice, s));
+  SOPRO_HIP(hipMemsetD32Async((hipDeviceptr_t)p.nonce, (int)nonce, B, s));
+  sopro_ar_state& st = p.st;
+  memset(&st, 0, sizeof(st));
+  st.x_cur = p.x[0]; st.cond = p.cond; st.emb = F(e, "cb_embed"); st.hist = p.hist;
+  st.step = p.ctr; st.arrive = p.ctr + 1; st.n_stopped = p.ctr + 2;
+  st.first_eos = p.first_eos; st.stop_t = p.stop_t; st.recent = p.recent; st.params = p.params; st.nonce = p.nonce;
+  st.seed = seed; st.B = B; st.D = D; st.Tar = Tar; st.max_steps = Tar; st.V = c.codebook_size; st.bos_row = c.bos_row;
+  STG(sopro_ar_init(&st, s));
+  // a recorded frame graph holds raw pointers into the workspace it was recorded on
+  if (p.graph && (p.graph_B != B || p.graph_S_cap != p.S_cap || p.graph_Tar != Tar || p.graph_ws != workspace)) {
+    STG(sopro_graph_destroy(p.graph));
+    p.graph = nullptr;
+  }
+  return 0;
+}
+
+int sopro_ar_run_graph(sopro_engine* e, int32_t n_steps, void* stream) {
+  SOPRO_CHECK_ARG(e && e->ar.ws && n_steps >= 0 && stream, "sopro_ar_begin first; a non-default stream is needed for graph capture");
+  ArPlan& p = e->ar;
+  if (!p.graph) {
+    STG(sopro_capture_begin(stream));
+    const int rc = ar_issue_step(e, (hipStream_t)stream);
+    void* g = nullptr;
+    const int rc2 = sopro_capture_end(stream, &g);
+    if (rc != 0) return rc;
+    if (rc2 != 0) return rc2;
+    p.graph = g; p.graph_B = p.B; p.graph_S_cap = p.S_cap; p.graph_Tar = p.Tar; p.graph_ws = p.ws;
+  }
+  for (int i = 0; i < n_steps; ++i) STG(sopro_graph_launch(p.graph, stream));
+  return 0;
+}
+
+int sopro_ar_tokens(sopro_engine* e, int32_t* hist, int32_t* first_eos, int32_t* n_stopped, void* stream) {
+  SOPRO_CHECK_ARG(e && e->ar.ws, "sopro_ar_begin first");
+  hipStream_t s = (hipStream_t)stream;
+  const ArPlan& p = e->ar;
+  if (hist) SOPRO_HIP(hipMemcpyAsync(hist, p.hist, (size_t)p.B * p.Tar * 4, hipMemcpyDeviceToDevice, s));
+  if (first_eos) SOPRO_HIP(hipMemcpyAsync(first_eos, p.first_eos, (size_t)p.B * 4, hipMemcpyDeviceToDevice, s));
+  if (n_stopped) SOPRO_HIP(hipMemcpyAsync(n_stopped, p.ctr + 2, 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ NAR refinement
+struct NarWs { float *xa, *xb, *h, *x1, *u, *z, *part, *cond; int32_t* lens; };
+static size_t nar_carve(const sopro_engine* e, NarWs& w, void* ws, int B, int T) {
+  const sopro_engine_cfg& c = e->c;
+  const size_t M = (size_t)B * T, D = c.d_model;
+  int nh_max = 0;
+  for (int i = 0; i < c.n_stages; ++i) nh_max = c.stage_n_cb[i] > nh_max ? c.stage_n_cb[i] : nh_max;
+  Carver cv(ws);
+  w.xa = cv.take<float>(M * D); w.xb = cv.take<float>(M * D); w.h = cv.take<float>(M * D); w.x1 = cv.take<float>(M * D);
+  w.u = cv.take<float>(M * 4 * D); w.z = cv.take<float>(M * c.nar_head_dim);
+  w.part = cv.take<float>(M * nh_max * (c.codebook_size / 64) * 2);
+  w.cond = cv.take<float>(M * D);
+  w.lens = cv.take<int32_t>(B);
+  return cv.off;
+}
+
+int64_t sopro_nar_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T) {
+  if (!e || B <= 0 || T <= 0) return 0;
+  NarWs w;
+  return (int64_t)nar_carve(e, w, nullptr, B, T);
+}
+
+// full-sequence SSMLiteBlock over dense [B*T, D] rows (reference: src/sopro/nn/blocks.py:143-148), norms fused into the contractions
+static int ssm_block_seq(sopro_engine* e, hipStream_t s, const NarWs& w, const float* x, float* out, const std::string& p, int B, int T,
+                         int ksize, int dil, const int32_t* lens) {
+  const int D = e->c.d_model, M = B * T;
+  const int total = (ksize - 1) * dil, left = total / 2;  // non-causal: symmetric zero padding (blocks.py:68-72)
+  G g; g.M = M; g.N = 2 * D; g.K = D; g.bias = F(e, p + ".glu.b"); g.epi = SOPRO_EPI_GLU; g.rms_eps = RMS_EPS;
+  STG(gemm(s, x, e->w[p + ".glu.wn"], nullptr, w.h, g));
+  STG(sopro_dwconv_f32(w.h, F(e, p + ".dw.w"), F(e, p + ".dw.b"), x, w.x1, lens, B, T, D, ksize, dil, left, 1, s));
+  G f1; f1.M = M; f1.N = 4 * D; f1.K = D; f1.bias = F(e, p + ".ff1.b"); f1.epi = SOPRO_EPI_GELU; f1.rms_eps = RMS_EPS;
+  STG(gemm(s, w.x1, e->w[p + ".ff1.wn"], nullptr, w.u, f1));
+  G f2; f2.M = M; f2.N = D; f2.K = 4 * D; f2.bias = F(e, p + ".ff2.b"); f2.epi = SOPRO_EPI_RES; f2.R = w.x1;
+  return gemm(s, w.u, e->w[p + ".ff2.w"], nullptr, out, f2);
+}
+
+int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_t cond_bstride, const int32_t* rvq1, const int32_t* lens,
+                     int32_t B, int32_t T, int32_t* tokens, void* stream) {
+  SOPRO_CHECK_ARG(e && e->final && workspace && cond && rvq1 && tokens && B > 0 && T > 0, "bad arguments (finalize the engine first)");
+  hipStream_t s = (hipStream_t)stream;
+  const sopro_engine_cfg& c = e->c;
+  const int D = c.d_model, V = c.codebook_size, Q = c.num_codebooks, HD = c.nar_head_dim, M = B * T;
+  SOPRO_CHECK_ARG(V % 64 == 0, "codebook_size must be a multiple of 64 (arg-max partials per 64 columns)");
+  NarWs w;
+  nar_carve(e, w, workspace, B, T);
+  int nh_max = 0;
+  for (int i = 0; i < c.n_stages; ++i) nh_max = c.stage_n_cb[i] > nh_max ? c.stage_n_cb[i] : nh_max;
+  const float* cnd = cond;
+  if (cond_bstride != (int64_t)T * D) {  // the first T rows of longer conditioning blocks (cond_ar has max_frames + 1 rows): densify once
+    SOPRO_HIP(hipMemcpy2DAsync(w.cond, (size_t)T * D * 4, cond, (size_t)cond_bstride * 4, (size_t)T * D * 4, B, hipMemcpyDeviceToDevice, s));
+    cnd = w.cond;
+  }
+  SOPRO_HIP(hipMemcpy2DAsync(tokens, (size_t)Q * 4, rvq1, 4, 4, (size_t)M, hipMemcpyDeviceToDevice, s));  // column 0 <- codebook 0
+  const int32_t* lens_d = nullptr;
+  if (lens) {
+    SOPRO_HIP(hipMemcpyAsync(w.lens, lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    lens_d = w.lens;
+  }
+  const char* stage_names[8] = {"B", "C", "D", "E", "F", "G", "H", "I"};
+  for (int sid = 0; sid < c.n_stages; ++sid) {
+    float *xa = w.xa, *xb = w.xb;
+    // prev = sum_j cw_j * E[cb_j * V + tok_j]; x = mix0 * cond + mix1 * prev   (embeddings.py:77-112, nar.py:95-97)
+    STG(sopro_codebook_sum_f32(tokens, Q, e->nar_cols[sid], e->nar_offs[sid], e->nar_cw[sid], e->nar_known[sid], F(e, "cb_embed"),
+                               e->t["cb_embed"].shape[0], cnd, c.nar_mix[sid][0], c.nar_mix[sid][1], xa, D, 0, M, M, D, s));
+    STG(norm(s, xa, xb, F(e, "nar.adapter.norm.weight"), M, D, RMS_EPS, SOPRO_NORM_RMS, nullptr, e->ad_mul[sid], e->ad_add[sid], M));
+    std::swap(xa, xb);
+    for (int i = 0; i < c.n_layers_nar; ++i) {
+      STG(ssm_block_seq(e, s, w, xa, xb, "nar.blocks." + std::to_string(i), B, T, c.nar_kernel, c.nar_dilations[i], lens_d));
+      std::swap(xa, xb);
+    }
+    STG(norm(s, xa, xb, F(e, "nar.norm.weight"), M, D, RMS_EPS));
+    G pz; pz.M = M; pz.N = HD; pz.K = D; pz.bias = F(e, "nar.pre.b");
+    STG(gemm(s, xb, e->w["nar.pre.w"], nullptr, w.z, pz));
+    // all heads of the stage in one contraction, arg-max in its epilogue (head-id embeddings live in the bias)
+    const int nh = c.stage_n_cb[sid];
+    const std::string hk = std::string("nar.heads.") + stage_names[sid];
+    G hg; hg.M = M; hg.N = nh * V; hg.K = HD; hg.bias = F(e, hk + ".b"); hg.c_mode = 5; hg.C2 = w.part; hg.ldc2 = (int64_t)nh_max * (V / 64);
+    STG(gemm(s, w.z, e->w[hk + ".w"], nullptr, nullptr, hg));
+    STG(sopro_argmax_partials_i32(w.part, (int64_t)nh_max * (V / 64), tokens + c.stage_first_cb[sid], Q, nh, V / 64, V, M, s));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ Mimi decode
+struct MimiWs {
+  int32_t* tok;
+  float *emb, *q, *X, *y, *qkv, *ao, *hd, *e0, *hraw[8], *hact[8], *y1[8];
+};
+static size_t mimi_carve(const sopro_engine* e, MimiWs& w, void* ws, int B, int T) {
+  const sopro_engine_cfg& c = e->c;
+  const size_t HS = c.mimi_hidden, CD = c.mimi_codebook_dim, N2 = 2 * (size_t)T, PADX = c.mimi_kernel - 1;
+  Carver cv(ws);
+  w.tok = cv.take<int32_t>((size_t)B * T * c.num_codebooks);
+  w.emb = cv.take<float>((size_t)B * T * 2 * CD);
+  w.q = cv.take<float>((size_t)B * T * HS);
+  w.X = cv.take<float>((size_t)B * (PADX + N2) * HS);
+  w.y = cv.take<float>((size_t)B * N2 * HS);
+  w.qkv = cv.take<float>((size_t)B * N2 * 3 * HS);
+  w.ao = cv.take<float>((size_t)B * N2 * HS);
+  w.hd = cv.take<float>((size_t)B * N2 * c.mimi_inter);
+  size_t ch = (size_t)c.mimi_num_filters << c.mimi_n_ratios, rows = N2;
+  w.e0 = cv.take<float>((size_t)B * (1 + rows) * ch);
+  for (int si = 0; si < c.mimi_n_ratios; ++si) {
+    const size_t co = ch / 2, orow = rows * c.mimi_ratios[si];
+    w.hraw[si] = cv.take<float>((size_t)B * (2 + orow) * co);
+    w.hact[si] = si + 1 < c.mimi_n_ratios ? cv.take<float>((size_t)B * (2 + orow) * co) : nullptr;
+    w.y1[si] = si + 1 < c.mimi_n_ratios ? cv.take<float>((size_t)B * orow * (co / c.mimi_compress)) : nullptr;
+    ch = co; rows = orow;
+  }
+  return cv.off;
+}
+
+int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T) {
+  if (!e || B <= 0 || T <= 0) return 0;
+  MimiWs w;
+  return (int64_t)mimi_carve(e, w, nullptr, B, T);
+}
+
+int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream) {
+  SOPRO_CHECK_ARG(e && e->final && workspace && tokens && wav && B > 0 && T > 0, "bad arguments (finalize the engine first)");
+  hipStream_t s = (hipStream_t)stream;
+  const sopro_engine_cfg& c = e->c;
+  const int Q = c.num_codebooks, HS = c.mimi_hidden, CD = c.mimi_codebook_dim, N2 = 2 * T, PADX = c.mimi_kernel - 1;
+  const int H = c.mimi_heads, dh = c.mimi_head_dim, ns = c.mimi_n_semantic;
+  SOPRO_CHECK_ARG(N2 <= c.mimi_rope_positions, "more positions than the RoPE tables hold");
+  SOPRO_CHECK_ARG(c.mimi_res_kernel == 3 && c.mimi_last_kernel == 3 && c.mimi_compress == 2, "the SEANet sequence is written for k = 3 residual / last convs, compress 2");
+  MimiWs w;
+  mimi_carve(e, w, workspace, B, T);
+  // the zero rows in front of every segment of a convolution input are never written by the kernels: clear just those
+  {
+    SOPRO_HIP(hipMemset2DAsync(w.X, (size_t)(PADX + N2) * HS * 4, 0, (size_t)PADX * HS * 4, B, s));
+    size_t chz = (size_t)c.mimi_num_filters << c.mimi_n_ratios, rowz = (size_t)N2;
+    SOPRO_HIP(hipMemset2DAsync(w.e0, (1 + rowz) * chz * 4, 0, chz * 4, B, s));
+    for (int si = 0; si < c.mimi_n_ratios; ++si) {
+      const size_t co = chz / 2, orow = rowz * c.mimi_ratios[si];
+      SOPRO_HIP(hipMemset2DAsync(w.hraw[si], (2 + orow) * co * 4, 0, 2 * co * 4, B, s));
+      if (w.hact[si]) SOPRO_HIP(hipMemset2DAsync(w.hact[si], (2 + orow) * co * 4, 0, 2 * co * 4, B, s));
+      chz = co; rowz = orow;
+    }
+  }
+  // ---- RVQ decode + output projections (HF:modeling_mimi.py:1128-1137)
+  const int64_t cb_rows = e->t["codebooks"].shape[0];
+  STG(sopro_codebook_sum_f32(tokens, Q, e->sem_col, e->sem_off, e->ones, ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb, 2 * CD, 0,
+                             B * T, B * T, CD, s));
+  STG(sopro_codebook_sum_f32(tokens, Q, e->ac_col, e->ac_off, e->ones, Q - ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb + CD, 2 * CD,
+                             0, B * T, B * T, CD, s));
+  G pj; pj.M = B * T; pj.N = HS; pj.K = 2 * CD;
+  STG(gemm(s, w.emb, e->w["rvq_proj.w"], nullptr, w.q, pj));
+  // ---- upsample into the zero-padded transformer stream (HF:1208-1216)
+  const int64_t xs = (int64_t)(PADX + N2) * HS;
+  STG(sopro_upsample2_f32(w.q, F(e, "upsample.w"), w.X + (size_t)PADX * HS, xs, B, T, HS, s));
+  // ---- transformer: 8 pre-LN layers, RoPE, causal window (HF:729-928)
+  const int n = N2;
+  for (int l = 0; l < c.mimi_layers; ++l) {
+    const std::string p = "tr." + std::to_string(l);
+    STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln1.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln1.b"), nullptr, nullptr, n, xs));
+    G qg; qg.M = B * n; qg.N = 3 * HS; qg.K = HS;
+    STG(gemm(s, w.y, e->w[p + ".qkv.w"], nullptr, w.qkv, qg));
+    STG(sopro_rope_f32(w.qkv, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, 0, H, dh, s));
+    STG(sopro_rope_f32(w.qkv + HS, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, 0, H, dh, s));
+    sopro_attn_args a;
+    memset(&a, 0, sizeof(a));
+    a.Q = w.qkv; a.ldq = 3 * HS; a.q_bstride = (int64_t)n * 3 * HS;
+    a.K = w.qkv + HS; a.ldk = 3 * HS; a.k_bstride = (int64_t)n * 3 * HS;
+    a.V = w.qkv + 2 * HS; a.ldv = 3 * HS; a.v_bstride = (int64_t)n * 3 * HS;
+    a.O = w.ao; a.ldo = HS; a.o_bstride = (int64_t)n * HS;
+    a.B = B; a.H = H; a.dh = dh; a.Tq = n; a.Tk = n; a.causal = 1; a.window = c.mimi_window; a.scale = 1.0f / sqrtf((float)dh);
+    STG(sopro_attention_f32(&a, s));
+    G og; og.M = B * n; og.N = HS; og.K = HS; og.epi = SOPRO_EPI_RES; og.R = w.X + (size_t)PADX * HS; og.scale = F(e, p + ".ls1");
+    og.c_seg = xs; og.r_seg = xs; og.rows_per_seg = n;
+    STG(gemm(s, w.ao, e->w[p + ".o.w"], nullptr, w.X + (size_t)PADX * HS, og));
+    STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln2.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln2.b"), nullptr, nullptr, n, xs));
+    G f1; f1.M = B * n; f1.N = c.mimi_inter; f1.K = HS; f1.epi = SOPRO_EPI_GELU;
+    STG(gemm(s, w.y, e->w[p + ".fc1.w"], nullptr, w.hd, f1));
+    G f2; f2.M = B * n; f2.N = HS; f2.K = c.mimi_inter; f2.epi = SOPRO_EPI_RES; f2.R = w.X + (size_t)PADX * HS; f2.scale = F(e, p + ".ls2");
+    f2.c_seg = xs; f2.r_seg = xs; f2.rows_per_seg = n;
+    STG(gemm(s, w.hd, e->w[p + ".fc2.w"], nullptr, w.X + (size_t)PADX * HS, f2));
+  }
+  // ---- SEANet decoder (HF:931-961), activated-copy flow of sopro_amd.codec.MimiCodec._seanet_act
+  int ch = c.mimi_num_filters << c.mimi_n_ratios, rows = N2, pad_in = 1;
+  {  // first conv k = 7 -> ELU; one zero row in front = x[t-1] of the transposed conv
+    G g; g.M = B * rows; g.N = ch; g.K = c.mimi_kernel * HS; g.lda = HS; g.bias = F(e, "sea.conv0.b"); g.rows_per_seg = rows; g.a_seg = xs;
+    g.c_seg = (int64_t)(1 + rows) * ch; g.ldc = ch; g.c_mode = 3;
+    STG(gemm(s, w.X, e->w["sea.conv0.w"], nullptr, w.e0 + ch, g));
+  }
+  const float* He = w.e0;
+  for (int si = 0; si < c.mimi_n_ratios; ++si) {
+    const int r = c.mimi_ratios[si], co = ch / 2, orow = rows * r, hid = co / c.mimi_compress;
+    const bool last = si == c.mimi_n_ratios - 1;
+    const std::string u = "sea.up" + std::to_string(si), rs = "sea.res" + std::to_string(si);
+    float* Ho = w.hraw[si];
+    G up; up.M = B * rows; up.N = r * co; up.K = 2 * ch; up.lda = ch; up.bias = F(e, u + ".b"); up.rows_per_seg = rows;
+    up.a_seg = (int64_t)(pad_in + rows) * ch; up.c_seg = (int64_t)(2 + orow) * co; up.ldc = (int64_t)r * co;
+    const float* A = He + (size_t)(pad_in - 1) * ch;
+    if (last) {
+      SOPRO_CHECK_ARG(co == 64 && hid == 32, "the fused tail is written for a 64-channel last stage");
+      STG(gemm(s, A, e->w[u + ".w"], nullptr, Ho + 2 * co, up));
+      return sopro_seanet_tail_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"),
+                                   F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, orow, s);
+    }
+    float* Hn = w.hact[si];
+    if (co == 128 && hid == 64) {
+      STG(gemm(s, A, e->w[u + ".w"], nullptr, Ho + 2 * co, up));
+      STG(sopro_seanet_res128_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
+                                  (int64_t)(2 + orow) * co, B, orow, s));
+    } else {
+      up.c_mode = 4; up.C2 = Hn + 2 * co; up.ldc2 = (int64_t)r * co; up.c2_seg = (int64_t)(2 + orow) * co;
+      STG(gemm(s, A, e->w[u + ".w"], nullptr, Ho + 2 * co, up));
+      // residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x)))); its output is only ever read through ELU
+      G c1; c1.M = B * orow; c1.N = hid; c1.K = 3 * co; c1.lda = co; c1.bias = F(e, rs + ".c1.b"); c1.rows_per_seg = orow;
+      c1.a_seg = (int64_t)(2 + orow) * co; c1.c_mode = 3;
+      STG(gemm(s, Hn, e->w[rs + ".c1.w"], nullptr, w.y1[si], c1));
+      G c2; c2.M = B * orow; c2.N = co; c2.K = hid; c2.bias = F(e, rs + ".c2.b"); c2.epi = SOPRO_EPI_RES; c2.R = Ho + 2 * co; c2.rows_per_seg = orow;
+      c2.c_seg = (int64_t)(2 + orow) * co; c2.r_seg = (int64_t)(2 + orow) * co; c2.ldc = co; c2.ldr = co; c2.c_mode = 3;
+      STG(gemm(s, w.y1[si], e->w[rs + ".c2.w"], nullptr, Hn + 2 * co, c2));
+    }
+    He = Hn; ch = co; rows = orow; pad_in = 2;
+  }
+  sopro_set_error("sopro_mimi_decode: the decoder has no last stage");
+  return -2;
+}
+
+}  // extern "C"

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -68,6 +68,19 @@ class ArState(C.Structure):
                 ("start", _p), ("row_max", _p), ("row_params", _p), ("nonce", _p)]
 
 
+class EngineCfg(C.Structure):
+    """sopro_engine_cfg (stage-level entry points)."""
+    _fields_ = [("d_model", _i32), ("codebook_size", _i32), ("num_codebooks", _i32), ("nar_head_dim", _i32), ("bos_row", _i32),
+                ("n_layers_ar", _i32), ("ar_kernel", _i32), ("ar_dilations", _i32 * 16), ("ar_xattn", _i32 * 16), ("ar_gate", _f32 * 16),
+                ("n_layers_nar", _i32), ("nar_kernel", _i32), ("nar_dilations", _i32 * 16),
+                ("n_stages", _i32), ("stage_first_cb", _i32 * 8), ("stage_n_cb", _i32 * 8), ("nar_mix", (_f32 * 2) * 8),
+                ("nar_prev_cb_weights", _f32 * 64),
+                ("mimi_hidden", _i32), ("mimi_codebook_dim", _i32), ("mimi_heads", _i32), ("mimi_head_dim", _i32), ("mimi_layers", _i32),
+                ("mimi_window", _i32), ("mimi_inter", _i32), ("mimi_n_ratios", _i32), ("mimi_ratios", _i32 * 8), ("mimi_num_filters", _i32),
+                ("mimi_kernel", _i32), ("mimi_res_kernel", _i32), ("mimi_last_kernel", _i32), ("mimi_compress", _i32),
+                ("mimi_n_semantic", _i32), ("mimi_rope_positions", _i32), ("mimi_norm_eps", _f32), ("mimi_final_bias", _f32)]
+
+
 # every symbol declared in include/sopro_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "sopro_last_error": (C.c_char_p, []),
@@ -116,6 +129,18 @@ SYMBOLS = {
     "sopro_upsample2_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_final_conv_f32": (C.c_int, [_p, _i64, _p, _f32, _p, _i64, _i32, _i32, _p]),
     "sopro_seanet_tail_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _f32, _p, _i64, _i32, _i32, _p]),
+    "sopro_engine_create": (C.c_int, [C.POINTER(EngineCfg), C.POINTER(_p)]),
+    "sopro_engine_set_tensor": (C.c_int, [_p, C.c_char_p, _p, C.POINTER(_i64), _i32]),
+    "sopro_engine_finalize": (C.c_int, [_p, _p]),
+    "sopro_engine_destroy": (C.c_int, [_p]),
+    "sopro_ar_workspace_bytes": (_i64, [_p, _i32, _i32, _i32]),
+    "sopro_ar_begin": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i32, _i32, C.POINTER(_f32), C.c_uint64, C.c_uint32, _p]),
+    "sopro_ar_run_graph": (C.c_int, [_p, _i32, _p]),
+    "sopro_ar_tokens": (C.c_int, [_p, _p, _p, _p, _p]),
+    "sopro_nar_workspace_bytes": (_i64, [_p, _i32, _i32]),
+    "sopro_nar_refine": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _p, _p]),
+    "sopro_mimi_workspace_bytes": (_i64, [_p, _i32, _i32]),
+    "sopro_mimi_decode": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p]),
     "sopro_ar_init": (C.c_int, [C.POINTER(ArState), _p]),
     "sopro_ar_sample": (C.c_int, [C.POINTER(ArState), _p, _i64, _p]),
     "sopro_ar_admit": (C.c_int, [C.POINTER(ArState), _i32, _p]),

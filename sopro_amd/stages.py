@@ -1,0 +1,150 @@
+"""ctypes driver of the stage-level C entry points (include/sopro_hip.h: sopro_engine_*, sopro_ar_*, sopro_nar_refine,
+sopro_mimi_decode) - what a host that is NOT this Python package would write, in ~100 lines: hand the repacked weights
+to the engine by name, then three calls per stage.  The Python host (model.py / codec.py) issues the same launch sequences
+itself; ``tests/test_gpu_stages.py`` checks the two against each other and against the oracle.  INTEGRATION.md shows the
+same calls from C."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import hip
+
+_POS = "BCDEFGHI"
+
+
+def engine_cfg(cfg, mc, gates: Dict[int, float], nar_mix, prev_w, final_bias: float, rope_positions: int) -> hip.EngineCfg:
+    c = hip.EngineCfg()
+    c.d_model, c.codebook_size, c.num_codebooks, c.nar_head_dim, c.bos_row = int(cfg.d_model), int(cfg.codebook_size), int(cfg.num_codebooks), \
+        int(cfg.nar_head_dim), int(cfg.bos_row)
+    c.n_layers_ar, c.ar_kernel = int(cfg.n_layers_ar), int(cfg.ar_kernel)
+    for i, d in enumerate(cfg.ar_dilations):
+        c.ar_dilations[i] = int(d)
+    for i in cfg.ar_xattn_layers:
+        c.ar_xattn[i], c.ar_gate[i] = 1, float(gates[i])
+    c.n_layers_nar, c.nar_kernel = int(cfg.n_layers_nar), int(cfg.nar_kernel_size)
+    for i, d in enumerate(cfg.nar_dilations):
+        c.nar_dilations[i] = int(d)
+    sc = cfg.stage_codebooks()
+    order = cfg.stage_order()
+    c.n_stages = len(order)
+    for i, s in enumerate(order):
+        c.stage_first_cb[i], c.stage_n_cb[i] = int(sc[s][0]), len(sc[s])
+        c.nar_mix[i][0], c.nar_mix[i][1] = float(nar_mix[i][0]), float(nar_mix[i][1])
+    for i, v in enumerate(prev_w):
+        c.nar_prev_cb_weights[i] = float(v)
+    c.mimi_hidden, c.mimi_codebook_dim, c.mimi_heads, c.mimi_head_dim = int(mc.hidden_size), int(mc.codebook_dim), int(mc.num_attention_heads), int(mc.head_dim)
+    c.mimi_layers, c.mimi_window, c.mimi_inter = int(mc.num_hidden_layers), int(mc.sliding_window), int(mc.intermediate_size)
+    c.mimi_n_ratios = len(mc.upsampling_ratios)
+    for i, r in enumerate(mc.upsampling_ratios):
+        c.mimi_ratios[i] = int(r)
+    c.mimi_num_filters, c.mimi_kernel, c.mimi_res_kernel, c.mimi_last_kernel = int(mc.num_filters), int(mc.kernel_size), int(mc.residual_kernel_size), int(mc.last_kernel_size)
+    c.mimi_compress, c.mimi_n_semantic, c.mimi_rope_positions = int(mc.compress), int(mc.num_semantic_quantizers), int(rope_positions)
+    c.mimi_norm_eps, c.mimi_final_bias = float(mc.norm_eps), float(final_bias)
+    return c
+
+
+class StageEngine:
+    """The C engine over the device weights of an existing ``SoproTTS`` (no copies: the engine keeps pointers)."""
+
+    def __init__(self, tts):
+        m, codec = tts.model, tts.codec
+        self.tts, self.device = tts, m.device
+        self.lib = lib = hip.load()
+        cos, sin = codec._rope_tables(1)
+        order = m.cfg.stage_order()
+        mix = [(c["mix0"], c["mix1"]) for c in m._nar_const]
+        cfg = engine_cfg(m.cfg, codec.mc, m.gates, mix, m.w["nar_prev_cb_weights"].float().cpu().tolist(), codec.final_bias, int(cos.shape[0]))
+        h = C.c_void_p()
+        hip._check(lib.sopro_engine_create(C.byref(cfg), C.byref(h)), "sopro_engine_create")
+        self.h = h
+        self._keep = [cos, sin]
+        tensors = dict(m.w)
+        for i, s in enumerate(order):  # the C side names the stages by position
+            tensors[f"nar.heads.{_POS[i]}.w"], tensors[f"nar.heads.{_POS[i]}.b"] = m.w[f"nar.heads.{s}.w"], m.w[f"nar.heads.{s}.b"]
+        tensors.update({k: v for k, v in codec.w.items()})
+        tensors["rope.cos"], tensors["rope.sin"] = cos, sin
+        for name, t in tensors.items():
+            if not (t.is_cuda and t.dtype in (torch.float32, torch.int32) and t.dim() >= 1 and t.dim() <= 4):
+                continue
+            t = t.contiguous()
+            self._keep.append(t)
+            shape = (C.c_int64 * t.dim())(*[int(x) for x in t.shape])
+            hip._check(lib.sopro_engine_set_tensor(h, name.encode(), t.data_ptr(), shape, t.dim()), "sopro_engine_set_tensor")
+        self.stream = torch.cuda.Stream(device=self.device)
+        hip._check(lib.sopro_engine_finalize(h, self.stream.cuda_stream), "sopro_engine_finalize")
+        self.stream.synchronize()
+        self._ws: Dict[str, torch.Tensor] = {}
+
+    def close(self) -> None:
+        if self.h:
+            torch.cuda.synchronize(self.device)
+            self.lib.sopro_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    @torch.inference_mode()
+    def ar_generate(self, cond_ar: torch.Tensor, txt_seq: torch.Tensor, text_lens: Optional[torch.Tensor], *, top_p: float, temperature: float,
+                    anti_loop: bool, min_gen_frames: int = 12, seed: int = 0, nonce: int = 0, steps: Optional[int] = None
+                    ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (hist [B, Tar] int32, first_eos [B] int32) on the device."""
+        B, Tar, D = cond_ar.shape
+        S = int(txt_seq.shape[1])
+        lib, st = self.lib, self.stream
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        ws = self._workspace("ar", int(lib.sopro_ar_workspace_bytes(self.h, B, S, Tar)))
+        cond_ar, txt_seq = cond_ar.float().contiguous(), txt_seq.float().contiguous()
+        lens = text_lens.to(torch.int32).contiguous() if text_lens is not None else None
+        prm = (C.c_float * 8)(float(top_p), float(temperature), 1.0 if anti_loop else 0.0, 0.85, 1.2, 1.1, 50.0, float(min_gen_frames))
+        hist = torch.empty(B, Tar, dtype=torch.int32, device=self.device)
+        feos = torch.empty(B, dtype=torch.int32, device=self.device)
+        hip._check(lib.sopro_ar_begin(self.h, ws.data_ptr(), B, cond_ar.data_ptr(), txt_seq.data_ptr(), lens.data_ptr() if lens is not None else None,
+                                      S, Tar, prm, int(seed), int(nonce), st.cuda_stream), "sopro_ar_begin")
+        hip._check(lib.sopro_ar_run_graph(self.h, Tar if steps is None else int(steps), st.cuda_stream), "sopro_ar_run_graph")
+        hip._check(lib.sopro_ar_tokens(self.h, hist.data_ptr(), feos.data_ptr(), None, st.cuda_stream), "sopro_ar_tokens")
+        st.synchronize()
+        return hist, feos
+
+    @torch.inference_mode()
+    def nar_refine(self, cond: torch.Tensor, rvq1: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """cond [B, T', D] (T' >= T rows per utterance), rvq1 [B, T] -> tokens [B, T, Q] int32."""
+        B, T = rvq1.shape
+        lib, st = self.lib, self.stream
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        ws = self._workspace("nar", int(lib.sopro_nar_workspace_bytes(self.h, B, T)))
+        cond = cond.float()
+        assert cond.stride(2) == 1 and cond.stride(1) == cond.shape[2]
+        rvq1 = rvq1.to(torch.int32).contiguous()
+        lens_d = lens.to(torch.int32).contiguous() if lens is not None else None
+        out = torch.empty(B, T, int(self.tts.cfg.num_codebooks), dtype=torch.int32, device=self.device)
+        hip._check(lib.sopro_nar_refine(self.h, ws.data_ptr(), cond.data_ptr(), int(cond.stride(0)), rvq1.data_ptr(),
+                                        lens_d.data_ptr() if lens_d is not None else None, B, T, out.data_ptr(), st.cuda_stream), "sopro_nar_refine")
+        st.synchronize()
+        return out
+
+    @torch.inference_mode()
+    def mimi_decode(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens [B, T, Q] -> wav [B, T * 1920]."""
+        B, T, _ = tokens.shape
+        lib, st = self.lib, self.stream
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        ws = self._workspace("mimi", int(lib.sopro_mimi_workspace_bytes(self.h, B, T)))
+        tok = tokens.to(torch.int32).contiguous()
+        wav = torch.empty(B, T * int(self.tts.codec.mc.frame_samples), device=self.device)
+        hip._check(lib.sopro_mimi_decode(self.h, ws.data_ptr(), tok.data_ptr(), B, T, wav.data_ptr(), st.cuda_stream), "sopro_mimi_decode")
+        st.synchronize()
+        return wav

@@ -1,0 +1,94 @@
+"""The stage-level C entry points (sopro_engine_*, sopro_ar_begin / _run_graph / _tokens, sopro_nar_refine,
+sopro_mimi_decode: include/sopro_hip.h), driven through ctypes WITHOUT the launch sequencing of sopro_amd/model.py and
+codec.py: a whole utterance from conditioning outputs to samples, against the reference's full-size fixture, the oracle and
+the Python host (which issues the same kernels in the same order: results must be bit-identical)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import sopro_oracle as O
+from sopro_amd.stages import StageEngine
+
+pytestmark = pytest.mark.gpu
+GREEDY = dict(top_p=0.0, temperature=1.0, anti_loop=False)
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def eng(tts_noeos):
+    e = StageEngine(tts_noeos)
+    yield e
+    e.close()
+
+
+def test_whole_utterance_through_the_c_stages_matches_the_reference(eng, tts_noeos, cfg, w_noeos):
+    g = golden("full200")
+    tts = tts_noeos
+    maxf = int(g["max_frames"])
+    want = _t(g["tokens"].astype(np.int64))
+    ref = tts.prepare_reference(ref_tokens_tq=_t(g["ref_tq"]))
+    prep = tts.model.prepare_conditioning(_t(g["ids"]), ref, max_frames=maxf, style_strength=1.0)  # conditioning stays with the host
+    hist, feos = eng.ar_generate(prep["cond_ar"], prep["txt_seq"], None, **GREEDY)
+    assert int(feos[0]) == -1 and hist.shape == (1, maxf + 1)
+    assert torch.equal(hist[0].cpu().long(), want[:, 0]), "codebook-0 tokens differ from the reference"
+    toks = eng.nar_refine(prep["cond_ar"], hist)
+    assert toks.shape == (1, maxf + 1, 32) and torch.equal(toks[0, :, 0].cpu().long(), want[:, 0])
+    if not torch.equal(toks[0].cpu().long(), want):  # only audited near-ties may differ
+        oref = O.prepare_reference(_t(g["ref_tq"]), w_noeos, cfg)
+        oprep = O.prepare_conditioning(_t(g["ids"]), oref, w_noeos, cfg, max_frames=maxf, style_strength=1.0)
+        n_off, gap = O.nar_audit(oprep["cond_ar"][:, : maxf + 1], toks.cpu().long(), w_noeos, cfg)
+        assert gap < 1e-4, (n_off, gap)
+    wav = eng.mimi_decode(_t(g["tokens"].astype(np.int64)).unsqueeze(0).to(eng.device))
+    assert tuple(wav.shape) == (1, (maxf + 1) * 1920)
+    assert float((wav[0].cpu() - _t(g["wav"])).abs().max()) < 1e-4 * float(np.abs(g["wav"]).max())
+    # the Python host issues the same launches: identical bits
+    ptoks = tts.model.generate_tokens(_t(g["ids"]), ref, max_frames=maxf, style_strength=1.0, **GREEDY)
+    assert torch.equal(ptoks.cpu(), toks[0].cpu().long())
+    # (the Python host runs few-row contractions split-K - another summation order -, so samples agree to round-off, not bit for bit)
+    pwav = tts.codec.decode_full(want)
+    assert float((pwav.reshape(-1) - wav.reshape(-1)).abs().max()) < 2e-5 * float(np.abs(g["wav"]).max())
+
+
+def test_c_stages_on_a_ragged_sampled_batch(eng, tts_noeos):
+    """B = 5 rows, ragged text lengths, stochastic decoding with a pinned (seed, nonce), a second generation on the same
+    engine (recorded frame graph replayed on a fresh state), NAR with per-row lengths: equal to the Python host."""
+    tts = tts_noeos
+    rng = np.random.default_rng(91)
+    ids = [torch.from_numpy(rng.integers(0, 512, size=n)) for n in (33, 64, 17, 50, 41)]
+    ref = tts.prepare_reference(ref_tokens_tq=torch.from_numpy(rng.integers(0, 2048, size=(60, 32))))
+    prep = tts.model.prepare_conditioning_batch(ids, [ref] * 5, max_frames=39, style_strength=1.0)
+    kw = dict(top_p=0.9, temperature=1.05, anti_loop=True)
+    for seed in (3, 4):
+        hist, _ = eng.ar_generate(prep["cond_ar"], prep["txt_seq"], prep["text_lens"], seed=tts.model.seed, nonce=seed, **kw)
+        ph, _ = tts.model.ar_generate_batch(prep["cond_ar"], prep["txt_seq"], prep["text_lens"], max_frames=39, seed=seed, **kw)
+        assert torch.equal(hist[:, : ph.shape[1]].cpu(), ph.cpu()), seed
+    lens = torch.tensor([40, 25, 33, 40, 8], dtype=torch.int32, device=eng.device)
+    toks = eng.nar_refine(prep["cond_ar"], hist.clamp(max=2047), lens)
+    ptoks = tts.model.nar_refine(prep["cond_ar"][:, :40], hist[:, :40].clamp(max=2047), lens=lens.tolist())
+    for b, n in enumerate(lens.tolist()):
+        assert torch.equal(toks[b, :n].cpu().long(), ptoks[b, :n].cpu()), b
+    wav = eng.mimi_decode(ptoks)
+    pw = tts.codec.decode_batch(ptoks)
+    assert float((wav - pw).abs().max()) < 2e-5 * float(pw.abs().max())
+
+
+def test_missing_tensor_is_reported_by_name(tts_noeos):
+    import ctypes as C
+    from sopro_amd import hip
+    from sopro_amd.stages import engine_cfg
+
+    lib = hip.load()
+    m, codec = tts_noeos.model, tts_noeos.codec
+    cfg = engine_cfg(m.cfg, codec.mc, m.gates, [(1.0, 0.0)] * 4, [0.0] * 32, 0.0, 1024)
+    h = C.c_void_p()
+    assert lib.sopro_engine_create(C.byref(cfg), C.byref(h)) == 0
+    try:
+        assert lib.sopro_engine_finalize(h, None) == -2
+        assert b"ar.blocks.0.glu.w" in lib.sopro_last_error()
+        assert lib.sopro_ar_run_graph(h, 1, None) == -2
+    finally:
+        lib.sopro_engine_destroy(h)

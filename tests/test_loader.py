@@ -126,3 +126,29 @@ def test_from_pretrained_local_dir_matches_from_weights(tmp_path):
     kw = dict(ref_tokens_tq=ref_tq, max_frames=8, top_p=0.0, temperature=1.0, anti_loop=False)
     wa, wb = a.synthesize("hello world this is sopro", **kw), b.synthesize("hello world this is sopro", **kw)
     assert wa.shape == wb.shape and wa.shape[-1] > 0 and torch.equal(wa, wb)
+
+
+def test_export_for_non_python_hosts(tmp_path):
+    """python -m sopro_amd.export: every tensor the stage-level C entry points ask for (sopro_engine_finalize's list) is in the
+    flat file, 256-byte aligned, and reads back as the packed array."""
+    from sopro_amd.export import export_packed
+    from sopro_amd.pack import pack_mimi, pack_sopro
+
+    cfg, mc = SoproTTSConfig(), MimiDecoderConfig()
+    w, mw = synth_sopro_weights(cfg, VOCAB, 6), synth_mimi_weights(mc, 6)
+    meta = export_packed(w, mw, cfg, str(tmp_path / "packed"), rope_positions=64)
+    names = {t["name"]: t for t in meta["tensors"]}
+    for need in ("ar.blocks.0.glu.w", "ar.x_attns.1.q.wT", "ar.head.w", "cb_embed", "nar.blocks.5.ff2.w", "nar.heads.B.w", "nar.heads.E.b",
+                 "nar.adapter.mlp.2.w", "codebooks", "rvq_proj.w", "tr.7.fc2.w", "sea.conv0.w", "sea.up3.w", "sea.res2.c1.w", "sea.final.w",
+                 "rope.cos", "upsample.w"):
+        assert need in names, need
+    blob = np.fromfile(str(tmp_path / "packed.bin"), dtype=np.uint8)
+    assert blob.size == meta["bytes"] and all(t["offset"] % 256 == 0 for t in meta["tensors"])
+    ps, pm = pack_sopro(w, cfg), pack_mimi(mw, mc)
+    for name, src in (("ar.head.w", ps), ("sea.up1.w", pm), ("nar.heads.C.w", None)):
+        t = names[name]
+        a = np.frombuffer(blob, dtype=np.float32, count=int(np.prod(t["shape"])), offset=t["offset"]).reshape(t["shape"])
+        want = (src[name] if src is not None else ps["nar.heads.C.w"]).numpy()
+        assert np.array_equal(a, want), name
+    c = meta["cfg"]
+    assert c["stage_first_cb"] == [1, 4, 8, 16] and c["stage_n_cb"] == [3, 4, 8, 16] and c["ar_xattn"] == [0, 1, 0, 1, 0, 1] and c["mimi_ratios"] == [8, 6, 5, 4]
