@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 19
+#define SOPRO_ABI_VERSION 20
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -344,6 +344,7 @@ typedef struct sopro_ar_state {
    * admission so that two calls with the same text do not reuse one uniform sequence (the reference draws from torch's
    * global generator, which advances between calls).  NULL = 0.  Device memory, so a recorded frame graph sees updates. */
   const uint32_t* nonce;   /* [bcap] */
+  long long* dbg;          /* optional [bcap][12] shader-clock stamps of the sampler's phases (profiling aid), NULL in production */
 } sopro_ar_state;
 /* zero-step initialisation: step=0, flags reset, x_cur[b] = cond[b,0] + emb[bos_row]  (model.py:266-272) */
 int sopro_ar_init(const sopro_ar_state* st, void* stream);

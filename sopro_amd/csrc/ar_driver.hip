@@ -103,7 +103,7 @@ constexpr int PAIRED = 128;  // candidates handled two threads apiece by the all
 // Wave reductions run on the DPP path; five workgroup barriers in all (two of them only when a penalty applies).
 __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_state st, const float* __restrict__ logits,
                                                                  int64_t ld) {
-  __shared__ float xs[2049 + 7];
+  __shared__ unsigned pen_bits[68];
   __shared__ u64 cand_k[MAXCAND];
   __shared__ float cand_e[MAXCAND];
   __shared__ u64 selk[64];
@@ -113,6 +113,9 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const int V1 = st.V + 1;
+  long long* dbg = st.dbg ? st.dbg + (int64_t)b * 12 : nullptr;
+#define SAMP_STAMP(i) do { if (dbg && tid == 0) dbg[i] = clock64(); } while (0)
+  SAMP_STAMP(0);
 
   // ---- the only up-front memory round: frame index, policy parameters, this row's logits, its recent tokens
   // Classic mode: every row started at global frame 0.  Slot mode (st.start != NULL, continuous batching): row b was
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   }
   const float top_p = recover ? p_rec_p : p_top_p;
   const float temp = recover ? p_rec_t : p_temp;
+  SAMP_STAMP(1);
   // ---- nan_to_num, temperature (sampling.py:33-38)
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
@@ -186,31 +190,25 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
     if (temp != 0.f && temp != 1.0f) v = v / temp;
     xv[q] = v;
   }
-  // ---- repetition penalty on the unique ids among the last 50 tokens (sampling.py:40-50): patched through LDS by id
+  // ---- repetition penalty on the unique ids among the last 50 tokens (sampling.py:40-50).  Wave 0 marks the ids in a 2049-bit
+  // LDS bitmap (duplicates collapse by themselves; LDS executes one wave's operations in issue order, so its clears precede
+  // its ORs), every thread then tests the bits of its own nine logits: one barrier, no value round trip.
   const bool in_win = lane < 50 && r_mine >= 0 && r_mine < V1;
   if (rep != 1.0f && __ballot(in_win) != 0ull) {  // workgroup-uniform: every wave sees the same window
-#pragma unroll
-    for (int q = 0; q < PER; ++q)
-      if (q * SAMP_THREADS + tid < V1) xs[q * SAMP_THREADS + tid] = xv[q];
-    bool first = in_win;
     if (wave == 0) {
-#pragma unroll 7
-      for (int j = 0; j < 49; ++j) {
-        const int other = __builtin_amdgcn_readlane(r_mine, j);
-        if (j < lane && other == r_mine) first = false;
-      }
-    }
-    __syncthreads();
-    if (wave == 0 && first) {
-      const float v = xs[r_mine];
-      xs[r_mine] = v < 0.f ? v * rep : v / rep;
+      pen_bits[lane] = 0u;
+      if (lane < 4) pen_bits[64 + lane] = 0u;
+      if (in_win) atomicOr(&pen_bits[r_mine >> 5], 1u << (r_mine & 31));
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < PER; ++q)
-      if (q * SAMP_THREADS + tid < V1) xv[q] = xs[q * SAMP_THREADS + tid];
+    for (int q = 0; q < PER; ++q) {
+      const int i = q * SAMP_THREADS + tid;
+      if (i < V1 && ((pen_bits[i >> 5] >> (i & 31)) & 1u)) xv[q] = xv[q] < 0.f ? xv[q] * rep : xv[q] / rep;
+    }
   }
 
+  SAMP_STAMP(2);
   // ---- per-thread maximum as (order-preserving value bits, 4095 - index): larger == better, ties -> lower index
   unsigned ov[PER];
   unsigned tm_v = 0u, tm_i = 0u;
@@ -236,6 +234,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
     if (lane == 0) { w_best_v[wave] = wv; w_best_i[wave] = wi; w_thr[wave] = thr; }
   }
   __syncthreads();
+  SAMP_STAMP(3);
   unsigned best_v = w_best_v[0], best_i = w_best_i[0], thr = w_thr[0];
 #pragma unroll
   for (int w2 = 1; w2 < 4; ++w2) {
@@ -247,6 +246,15 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   }
   const int top_i = 4095 - (int)best_i;
   int tok = top_i;
+  // the arg-max is the token under greedy decoding and the likeliest one otherwise: its embedding row (a dependent, far
+  // load at the very end of the frame otherwise) is requested now
+  float espec[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (wave == 0 && t + 1 < tmax) {
+    const float* e = st.emb + (int64_t)top_i * st.D;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q * 64 + lane < st.D) espec[q] = e[q * 64 + lane];
+  }
   if (sampling) {
     // ---- candidates: every logit >= thr (at least kk of them), with exp(x - max) next to the key
     const float xmax = unord_f32(best_v);
@@ -271,18 +279,23 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
       base += (unsigned)__popcll(masks[q]);
     }
     __syncthreads();
+    SAMP_STAMP(4);
     const int C = (int)sh_cnt;
     // ---- all pairs: rank (entries ahead) and unnormalised mass ahead of every candidate
     if (C <= PAIRED) {
       const int c = tid >> 1, half = tid & 1;
-      const int j0 = half ? (C >> 1) : 0, j1 = half ? C : (C >> 1);
+      const int j0 = half ? (C >> 1) : 0, nj = half ? C - (C >> 1) : (C >> 1);  // nj <= 64
       const u64 kc = c < C ? cand_k[c] : ~0ull;
       int rank = 0;
       float ahead = 0.f;
-      for (int j = j0; j < j1; ++j) {
-        const bool gt = cand_k[j] > kc;
+#pragma unroll
+      for (int j = 0; j < PAIRED / 2; ++j) {  // fixed trip count: fully unrolled, every LDS broadcast issued ahead of its use
+        const int jj = min(j0 + j, C - 1);
+        const u64 kj = cand_k[jj];
+        const float ej = cand_e[jj];
+        const bool gt = j < nj && kj > kc;
         rank += gt ? 1 : 0;
-        ahead += gt ? cand_e[j] : 0.f;
+        ahead += gt ? ej : 0.f;
       }
       rank += __shfl_xor(rank, 1, 64);
       ahead += __shfl_xor(ahead, 1, 64);
@@ -301,6 +314,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
       }
     }
     __syncthreads();
+    SAMP_STAMP(5);
     if (wave == 0) {
       // top-k renormalisation, top-p cut and the draw (sampling.py:56-93): lane j owns sorted entry j.  The softmax
       // denominator cancels in the renormalisation: p_j / sum_topk p = e_j / sum_topk e  (and sum_topk p >= 1/2049, so
@@ -321,17 +335,24 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
       }
     }
   }
+  SAMP_STAMP(6);
   if (wave != 0) return;  // wave 0 holds the token (every wave does when it is the arg-max) and does the bookkeeping
 
   // ---- bookkeeping: history, EOS rule (model.py:293-305), next input (model.py:266-272)
   if (t + 1 < tmax) {
-    const float* e = st.emb + (int64_t)tok * st.D;
+    if (tok != top_i) {  // wave-uniform
+      const float* e = st.emb + (int64_t)tok * st.D;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (q * 64 + lane < st.D) espec[q] = e[q * 64 + lane];
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int d = q * 64 + lane;
-      if (d < st.D) st.x_cur[(int64_t)b * st.D + d] = cnext[q] + e[d];
+      if (d < st.D) st.x_cur[(int64_t)b * st.D + d] = cnext[q] + espec[q];
     }
   }
+  SAMP_STAMP(7);
   const int older = __shfl_up(r_mine, 1, 64);
   recent[lane] = (lane == 0) ? tok : older;
   if (lane == 0) {
@@ -344,15 +365,19 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
       }
     }
   }
+  SAMP_STAMP(8);
   // every lane's stores of this row are released before the row's ticket
   __threadfence();
+  SAMP_STAMP(9);
   if (lane == 0) {
     const int old = atomicAdd(st.arrive, 1);
     if (old == st.B - 1) {
       *st.arrive = 0;
       *st.step = tg + 1;
     }
+    if (dbg) dbg[10] = clock64();
   }
+#undef SAMP_STAMP
 }
 
 // Slot mode: (re)start row `row` at the current global frame.  Stream-ordered between two frames, so *step is stable.
