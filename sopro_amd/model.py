@@ -110,6 +110,7 @@ class SoproTTSModel:
         self.prep_stream = self.stream
         self._driver = None  # the scheduler (PipelinedSynthesizer / ContinuousSynthesizer) that currently owns the streams
         self._ar_cache: Dict[Tuple[int, int, int], "_ARPlan"] = {}
+        self._voice: Dict[int, Dict[str, Any]] = {}  # per-voice conditioning cache (see _voice_entry)
         self._runs = [0]  # generation runs started so far (shared by the lanes of clone_lane): the sampler's default nonce
         self._nar_graphs = hip.GraphCache("nar_graph", cap=64)  # recorded NAR launch sequences per (B, T)
         self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "16")) << 30  # scratch kept per batch shape, per engine
@@ -172,6 +173,7 @@ class SoproTTSModel:
         other.prep_stream = other.stream
         other._driver = None
         other._ar_cache = {}
+        other._voice = {}  # per-voice tensors are made on this lane's own preparation stream
         other._nar_graphs = hip.GraphCache("nar_graph", cap=64)
         return other
 
@@ -184,6 +186,26 @@ class SoproTTSModel:
             return int(seed) & 0xFFFFFFFF
         self._runs[0] += 1
         return (0x9E3779B9 * self._runs[0]) & 0xFFFFFFFF
+
+    def _voice_entry(self, ref: PreparedReference) -> Dict[str, Any]:
+        """Everything conditioning needs from a voice that does not depend on the text, made once per PreparedReference
+        object: dense [Tr, D] copies of the cached cross-attention K / V (the public type stores them
+        [1, H, Tr, dh] like the reference, src/sopro/nn/ref.py:120-128) and, per style strength, the SpeakerFiLM
+        coefficients.  Entries die with their PreparedReference (weakref)."""
+        import weakref
+
+        key = id(ref)
+        ent = self._voice.get(key)
+        if ent is not None and ent["ref"]() is ref:
+            return ent
+        dev, D = self.device, self.D
+        kv = []
+        for c in ref.ref_kv_caches:
+            tu = int(c["k"].shape[2])
+            kv.append((c["k"].to(dev).permute(0, 2, 1, 3).reshape(tu, D).contiguous(), c["v"].to(dev).permute(0, 2, 1, 3).reshape(tu, D).contiguous()))
+        ent = {"ref": weakref.ref(ref, lambda _r, k=key, d=self._voice: d.pop(k, None)), "kv": kv, "film": {}}
+        self._voice[key] = ent
+        return ent
 
     def rf_ar(self) -> int:
         return self.cfg.rf_ar()
@@ -324,18 +346,30 @@ class SoproTTSModel:
             base = torch.empty(B * Tar, D, device=dev)
             hip.add_pos(txt_pool, self.pe, base, B, Tar, D, 0)
             sv = torch.cat([r.sv_ref.to(dev).reshape(1, -1) for r in refs], dim=0).contiguous()
-            svd = int(sv.shape[1])
-            f1 = torch.empty(B, D, device=dev)
-            hip.gemm(sv, w["spk_film.mlp.0.w"], f1, M=B, N=D, K=svd, bias=w["spk_film.mlp.0.b"], epilogue=hip.EPI_GELU)
-            film = torch.empty(B, 2 * D, device=dev)
-            hip.gemm(f1, w["spk_film.mlp.2.w"], film, M=B, N=2 * D, K=D, bias=w["spk_film.mlp.2.b"])
-            gam = film[:, :D].contiguous()
-            bet = film[:, D:].contiguous()
-            mul = torch.empty(B, D, device=dev)
-            add = torch.empty(B, D, device=dev)
             s = float(style_strength)
-            hip.tanh_affine(gam, mul, 1.0, s, B * D)
-            hip.tanh_affine(bet, add, 0.0, s, B * D)
+            # SpeakerFiLM coefficients depend on the voice (and the style strength) only: computed once per voice and kept
+            # with its dense K / V (self._voice), so a call with known voices launches nothing for them  (speaker.py:76-85)
+            vcs = [self._voice_entry(r) for r in refs]
+            todo = [i for i, vc in enumerate(vcs) if s not in vc["film"]]
+            if todo:
+                uniq = list({id(vcs[i]): i for i in todo}.values())
+                svu = sv[uniq].contiguous()
+                n, svd = len(uniq), int(sv.shape[1])
+                f1 = torch.empty(n, D, device=dev)
+                hip.gemm(svu, w["spk_film.mlp.0.w"], f1, M=n, N=D, K=svd, bias=w["spk_film.mlp.0.b"], epilogue=hip.EPI_GELU)
+                film = torch.empty(n, 2 * D, device=dev)
+                hip.gemm(f1, w["spk_film.mlp.2.w"], film, M=n, N=2 * D, K=D, bias=w["spk_film.mlp.2.b"])
+                gam, bet = film[:, :D].contiguous(), film[:, D:].contiguous()
+                mul_u, add_u = torch.empty(n, D, device=dev), torch.empty(n, D, device=dev)
+                hip.tanh_affine(gam, mul_u, 1.0, s, n * D)
+                hip.tanh_affine(bet, add_u, 0.0, s, n * D)
+                for j, i in enumerate(uniq):
+                    vcs[i]["film"][s] = (mul_u[j], add_u[j])
+            if all(vc is vcs[0] for vc in vcs):
+                mul, add = (t.unsqueeze(0).expand(B, D).contiguous() for t in vcs[0]["film"][s])
+            else:
+                mul = torch.stack([vc["film"][s][0] for vc in vcs]).contiguous()
+                add = torch.stack([vc["film"][s][1] for vc in vcs]).contiguous()
             cond = torch.empty(B * Tar, D, device=dev)
             hip.norm(base, cond, w["spk_film.norm.weight"], rows=B * Tar, C_=D, eps=1e-5, kind=hip.NORM_LN,
                      b=w["spk_film.norm.bias"], mul=mul, add=add, rows_per_seg=Tar)
@@ -359,17 +393,20 @@ class SoproTTSModel:
                     order.append(r)
             row_u = [seen[id(r)] for r in refs]
             U = len(order)
-            Ku = torch.zeros(U, Tr, D, device=dev)
-            Vu = torch.zeros(U, Tr, D, device=dev)
+            Ku = torch.zeros(U, Tr, D, device=dev) if U > 1 else None
+            Vu = torch.zeros(U, Tr, D, device=dev) if U > 1 else None
             sel = None if U in (1, B) else torch.tensor(row_u, dtype=torch.long, device=dev)
             kv_bstride = 0 if (U == 1 and B > 1) else Tr * D
             for i in range(int(cfg.ref_xattn_layers)):
                 p = f"ref_xattn.blocks.{i}"
-                for u, r in enumerate(order):
-                    c = r.ref_kv_caches[i]
-                    tu = int(c["k"].shape[2])
-                    Ku[u, :tu] = c["k"].to(dev).permute(0, 2, 1, 3).reshape(tu, D)
-                    Vu[u, :tu] = c["v"].to(dev).permute(0, 2, 1, 3).reshape(tu, D)
+                if U == 1:  # the voice's own dense [Tr, D] copies, made once (self._voice)
+                    Ku, Vu = self._voice_entry(order[0])["kv"][i]
+                    Ku, Vu = Ku.unsqueeze(0), Vu.unsqueeze(0)
+                else:
+                    for u, r in enumerate(order):
+                        ku, vu = self._voice_entry(r)["kv"][i]
+                        tu = int(ku.shape[0])
+                        Ku[u, :tu], Vu[u, :tu] = ku, vu
                 Kb = Ku if sel is None else Ku.index_select(0, sel)
                 Vb = Vu if sel is None else Vu.index_select(0, sel)
                 hip.norm(cond, nq, w[p + ".nq.weight"], rows=B * Tar, C_=D, eps=RMS_EPS)

@@ -187,3 +187,38 @@ def test_load_audio_file_formats(tmp_path):
         f.write(b"data" + struct.pack("<I", len(body)) + body)
     wf, sr = audio.load_audio_file(pf)
     assert sr == 24000 and np.array_equal(wf, x[:, 0])
+
+
+def test_sinc_resample_derivation_pins_alignment_gain_and_length():
+    """torchaudio is not installable here, so ``sinc_resample`` (the restatement of ``torchaudio.functional.resample``'s
+    published algorithm: Hann-windowed sinc, lowpass_filter_width 6, rolloff 0.99, zero padding, output length
+    ceil(n * new / orig)) is pinned by what that algorithm must do, independently of how it is coded:
+      * a sinusoid well inside both pass bands comes out as the SAME sinusoid sampled at the new rate (this fixes the
+        polyphase alignment - an off-by-one phase or tap shift shows up as an O(1) error -, the filter gain and the kernel);
+      * DC gain 1, output length ceil(n * new / orig), identity at equal rates;
+      * down-by-2 then up-by-2 returns a band-limited signal.
+    Interior samples only (the zero padding at the edges is part of the algorithm)."""
+    for sr_in, sr_out in ((16000, 24000), (44100, 24000), (48000, 24000), (22050, 24000), (8000, 24000)):
+        n = 4000
+        t_in = np.arange(n) / sr_in
+        f0 = 0.11 * min(sr_in, sr_out)  # well below 0.99 * Nyquist of both rates
+        x = np.sin(2 * np.pi * f0 * t_in + 0.3).astype(np.float32)
+        y = O.sinc_resample(_t(x), sr_in, sr_out).numpy()
+        g = np.gcd(sr_in, sr_out)
+        orig, new = sr_in // g, sr_out // g
+        assert y.shape[0] == -(-n * new // orig)
+        t_out = np.arange(y.shape[0]) / sr_out
+        want = np.sin(2 * np.pi * f0 * t_out + 0.3)
+        edge = int(0.02 * sr_out)  # 20 ms: many filter widths
+        err = np.abs(y[edge:-edge] - want[edge:-edge]).max()
+        assert err < 2e-3, (sr_in, sr_out, err)
+        # a one-sample misalignment at the input rate would be this large: the bound above is far below it
+        assert 2 * np.pi * f0 / sr_in > 0.2
+        dc = O.sinc_resample(torch.ones(n), sr_in, sr_out).numpy()
+        assert np.abs(dc[edge:-edge] - 1.0).max() < 2e-3
+    x = np.random.default_rng(3).standard_normal(1000).astype(np.float32)
+    assert np.array_equal(O.sinc_resample(_t(x), 24000, 24000).numpy(), x)
+    t48 = np.arange(9600) / 48000.0
+    sig = (np.sin(2 * np.pi * 440 * t48) + 0.5 * np.sin(2 * np.pi * 3100 * t48 + 1.0)).astype(np.float32)
+    back = O.sinc_resample(O.sinc_resample(_t(sig), 48000, 24000), 24000, 48000).numpy()
+    assert back.shape == sig.shape and np.abs(back[2000:-2000] - sig[2000:-2000]).max() < 5e-3
