@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 20
+#define SOPRO_ABI_VERSION 21
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -417,6 +417,26 @@ int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_
 /* ---- Mimi decode: tokens [B, T, Q] int32 -> wav [B, T * 1920] fp32 */
 int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T);
 int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream);
+
+/* ---- streaming decode (MimiStreamDecoder.decode_step's MimiModel.decode(..., decoder_past_key_values=...) call,
+ * src/sopro/codec/mimi.py:152-156): one utterance, T frames at a time, the decoder transformer attending over the cached
+ * keys / values of earlier calls.  The chunking policy around it (2-frame token overlap, cropping: mimi.py:131-181) is
+ * pointer arithmetic and stays with the host (sopro_amd/codec.py MimiStreamDecoder shows it).  `kv` is a caller-owned
+ * device buffer of sopro_mimi_stream_kv_bytes(e, cap_rows) bytes; the host-side fields are updated by the calls.
+ * evict = 1: the cache keeps the last window-1 positions after each call (transformers 5.x sliding-window layers);
+ * sopro_mimi_stream_trim drops the last `n` cached positions and switches to evict = 0, positions continuing from the
+ * trimmed length: drop_cache_tail's legacy branch (mimi.py:92-103, transformers 4.57.6; quirk Q6). */
+typedef struct sopro_mimi_stream_state {
+  float* kv;          /* [layers][2 halves][cap_rows][2 * hidden] post-RoPE (k | v) rows */
+  int32_t cap_rows;   /* >= window - 1 + 2 * (frames per call) while evict = 1; everything generated while evict = 0 */
+  int32_t kv_len, pos, evict, half;
+} sopro_mimi_stream_state;
+int64_t sopro_mimi_stream_kv_bytes(const sopro_engine* e, int32_t cap_rows);
+int sopro_mimi_stream_init(const sopro_engine* e, sopro_mimi_stream_state* st, void* kv, int32_t cap_rows);
+int sopro_mimi_stream_trim(sopro_mimi_stream_state* st, int32_t n);
+/* workspace: sopro_mimi_workspace_bytes(e, 1, T) */
+int sopro_mimi_decode_stream(sopro_engine* e, void* workspace, sopro_mimi_stream_state* st, const int32_t* tokens, int32_t T, float* wav,
+                             void* stream);
 
 #ifdef __cplusplus
 }

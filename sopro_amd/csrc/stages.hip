@@ -655,13 +655,16 @@ int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T) 
   return (int64_t)mimi_carve(e, w, nullptr, B, T);
 }
 
-int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream) {
+static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream,
+                            sopro_mimi_stream_state* sst) {
   SOPRO_CHECK_ARG(e && e->final && workspace && tokens && wav && B > 0 && T > 0, "bad arguments (finalize the engine first)");
   hipStream_t s = (hipStream_t)stream;
   const sopro_engine_cfg& c = e->c;
   const int Q = c.num_codebooks, HS = c.mimi_hidden, CD = c.mimi_codebook_dim, N2 = 2 * T, PADX = c.mimi_kernel - 1;
   const int H = c.mimi_heads, dh = c.mimi_head_dim, ns = c.mimi_n_semantic;
-  SOPRO_CHECK_ARG(N2 <= c.mimi_rope_positions, "more positions than the RoPE tables hold");
+  const int past = sst ? sst->pos : 0;
+  SOPRO_CHECK_ARG(past + N2 <= c.mimi_rope_positions, "more positions than the RoPE tables hold");
+  SOPRO_CHECK_ARG(!sst || (B == 1 && sst->kv && sst->kv_len + N2 <= sst->cap_rows), "streaming state: one utterance, kv_len + 2T <= cap_rows");
   SOPRO_CHECK_ARG(c.mimi_res_kernel == 3 && c.mimi_last_kernel == 3 && c.mimi_compress == 2, "the SEANet sequence is written for k = 3 residual / last convs, compress 2");
   MimiWs w;
   mimi_carve(e, w, workspace, B, T);
@@ -695,16 +698,38 @@ int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, i
     STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln1.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln1.b"), nullptr, nullptr, n, xs));
     G qg; qg.M = B * n; qg.N = 3 * HS; qg.K = HS;
     STG(gemm(s, w.y, e->w[p + ".qkv.w"], nullptr, w.qkv, qg));
-    STG(sopro_rope_f32(w.qkv, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, 0, H, dh, s));
-    STG(sopro_rope_f32(w.qkv + HS, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, 0, H, dh, s));
+    STG(sopro_rope_f32(w.qkv, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, past, H, dh, s));
+    STG(sopro_rope_f32(w.qkv + HS, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, past, H, dh, s));
     sopro_attn_args a;
     memset(&a, 0, sizeof(a));
     a.Q = w.qkv; a.ldq = 3 * HS; a.q_bstride = (int64_t)n * 3 * HS;
-    a.K = w.qkv + HS; a.ldk = 3 * HS; a.k_bstride = (int64_t)n * 3 * HS;
-    a.V = w.qkv + 2 * HS; a.ldv = 3 * HS; a.v_bstride = (int64_t)n * 3 * HS;
     a.O = w.ao; a.ldo = HS; a.o_bstride = (int64_t)n * HS;
-    a.B = B; a.H = H; a.dh = dh; a.Tq = n; a.Tk = n; a.causal = 1; a.window = c.mimi_window; a.scale = 1.0f / sqrtf((float)dh);
+    a.B = B; a.H = H; a.dh = dh; a.Tq = n; a.causal = 1; a.window = c.mimi_window; a.scale = 1.0f / sqrtf((float)dh);
+    if (!sst) {
+      a.K = w.qkv + HS; a.ldk = 3 * HS; a.k_bstride = (int64_t)n * 3 * HS;
+      a.V = w.qkv + 2 * HS; a.ldv = 3 * HS; a.v_bstride = (int64_t)n * 3 * HS;
+      a.Tk = n;
+    } else {
+      // keys / values of earlier calls (post-RoPE) followed by this call's: append the (k | v) rows to the layer's cache
+      float* cache = sst->kv + ((size_t)(l * 2 + sst->half) * sst->cap_rows) * 2 * HS;
+      SOPRO_HIP(hipMemcpy2DAsync(cache + (size_t)sst->kv_len * 2 * HS, (size_t)2 * HS * 4, w.qkv + HS, (size_t)3 * HS * 4, (size_t)2 * HS * 4, n,
+                                 hipMemcpyDeviceToDevice, s));
+      const int Tk = sst->kv_len + n;
+      a.K = cache; a.ldk = 2 * HS; a.V = cache + HS; a.ldv = 2 * HS; a.Tk = Tk;
+      a.q_pos0 = past; a.k_pos0 = past + n - Tk;
+      a.q_bstride = a.o_bstride = 0;
+      // what the next call sees: sliding-window layers keep the last window-1 positions (moved to the other half of the
+      // layer's buffer), plain layers everything
+      if (sst->evict && Tk > c.mimi_window - 1) {
+        const int keep = c.mimi_window - 1;
+        float* other = sst->kv + ((size_t)(l * 2 + (sst->half ^ 1)) * sst->cap_rows) * 2 * HS;
+        STG(sopro_attention_f32(&a, s));
+        SOPRO_HIP(hipMemcpyAsync(other, cache + (size_t)(Tk - keep) * 2 * HS, (size_t)keep * 2 * HS * 4, hipMemcpyDeviceToDevice, s));
+        goto attended;
+      }
+    }
     STG(sopro_attention_f32(&a, s));
+  attended:;
     G og; og.M = B * n; og.N = HS; og.K = HS; og.epi = SOPRO_EPI_RES; og.R = w.X + (size_t)PADX * HS; og.scale = F(e, p + ".ls1");
     og.c_seg = xs; og.r_seg = xs; og.rows_per_seg = n;
     STG(gemm(s, w.ao, e->w[p + ".o.w"], nullptr, w.X + (size_t)PADX * HS, og));
@@ -757,6 +782,48 @@ int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, i
   }
   sopro_set_error("sopro_mimi_decode: the decoder has no last stage");
   return -2;
+}
+
+int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream) {
+  return mimi_decode_core(e, workspace, tokens, B, T, wav, stream, nullptr);
+}
+
+int64_t sopro_mimi_stream_kv_bytes(const sopro_engine* e, int32_t cap_rows) {
+  if (!e || cap_rows <= 0) return 0;
+  return (int64_t)e->c.mimi_layers * 2 * cap_rows * 2 * e->c.mimi_hidden * 4;
+}
+
+int sopro_mimi_stream_init(const sopro_engine* e, sopro_mimi_stream_state* st, void* kv, int32_t cap_rows) {
+  SOPRO_CHECK_ARG(e && st && kv && cap_rows >= e->c.mimi_window, "NULL argument or cap_rows below the attention window");
+  st->kv = reinterpret_cast<float*>(kv);
+  st->cap_rows = cap_rows;
+  st->kv_len = 0; st->pos = 0; st->evict = 1; st->half = 0;
+  return 0;
+}
+
+int sopro_mimi_stream_trim(sopro_mimi_stream_state* st, int32_t n) {
+  SOPRO_CHECK_ARG(st && n >= 0, "bad arguments");
+  if (st->kv_len == 0 || n == 0) return 0;
+  st->kv_len = st->kv_len > n ? st->kv_len - n : 0;
+  st->pos = st->kv_len;  // positions continue from the trimmed length: the rebuilt cache reports its own length
+  st->evict = 0;
+  return 0;
+}
+
+int sopro_mimi_decode_stream(sopro_engine* e, void* workspace, sopro_mimi_stream_state* st, const int32_t* tokens, int32_t T, float* wav,
+                             void* stream) {
+  SOPRO_CHECK_ARG(st != nullptr, "state is NULL");
+  const int n = 2 * T, Tk = st->kv_len + n;
+  const int rc = mimi_decode_core(e, workspace, tokens, 1, T, wav, stream, st);
+  if (rc != 0) return rc;
+  if (st->evict && Tk > e->c.mimi_window - 1) {
+    st->kv_len = e->c.mimi_window - 1;
+    st->half ^= 1;
+  } else {
+    st->kv_len = Tk;
+  }
+  st->pos += n;
+  return 0;
 }
 
 }  // extern "C"

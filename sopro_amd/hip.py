@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
@@ -81,6 +81,11 @@ class EngineCfg(C.Structure):
                 ("mimi_n_semantic", _i32), ("mimi_rope_positions", _i32), ("mimi_norm_eps", _f32), ("mimi_final_bias", _f32)]
 
 
+class MimiStreamState(C.Structure):
+    """sopro_mimi_stream_state"""
+    _fields_ = [("kv", _p), ("cap_rows", _i32), ("kv_len", _i32), ("pos", _i32), ("evict", _i32), ("half", _i32)]
+
+
 # every symbol declared in include/sopro_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "sopro_last_error": (C.c_char_p, []),
@@ -141,6 +146,10 @@ SYMBOLS = {
     "sopro_nar_refine": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _p, _p]),
     "sopro_mimi_workspace_bytes": (_i64, [_p, _i32, _i32]),
     "sopro_mimi_decode": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p]),
+    "sopro_mimi_stream_kv_bytes": (_i64, [_p, _i32]),
+    "sopro_mimi_stream_init": (C.c_int, [_p, C.POINTER(MimiStreamState), _p, _i32]),
+    "sopro_mimi_stream_trim": (C.c_int, [C.POINTER(MimiStreamState), _i32]),
+    "sopro_mimi_decode_stream": (C.c_int, [_p, _p, C.POINTER(MimiStreamState), _p, _i32, _p, _p]),
     "sopro_ar_init": (C.c_int, [C.POINTER(ArState), _p]),
     "sopro_ar_sample": (C.c_int, [C.POINTER(ArState), _p, _i64, _p]),
     "sopro_ar_admit": (C.c_int, [C.POINTER(ArState), _i32, _p]),

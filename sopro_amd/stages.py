@@ -148,3 +148,41 @@ class StageEngine:
         hip._check(lib.sopro_mimi_decode(self.h, ws.data_ptr(), tok.data_ptr(), B, T, wav.data_ptr(), st.cuda_stream), "sopro_mimi_decode")
         st.synchronize()
         return wav
+
+
+class StageStreamDecoder:
+    """MimiStreamDecoder.decode_step (src/sopro/codec/mimi.py:115-181) over ``sopro_mimi_decode_stream``: the 2-frame token
+    overlap and the cropping are the host's few lines, the decode with the cached keys / values is the C call."""
+
+    def __init__(self, eng: StageEngine, overlap_frames: int = 2, trim: str = "none", cap_rows: int = 4096):
+        self.eng, self.ov, self.trim = eng, int(overlap_frames), trim
+        lib = eng.lib
+        self.kv = torch.empty(int(lib.sopro_mimi_stream_kv_bytes(eng.h, cap_rows)), dtype=torch.uint8, device=eng.device)
+        self.st = hip.MimiStreamState()
+        hip._check(lib.sopro_mimi_stream_init(eng.h, C.byref(self.st), self.kv.data_ptr(), cap_rows), "sopro_mimi_stream_init")
+        self.tail: Optional[torch.Tensor] = None
+
+    @torch.inference_mode()
+    def decode_step(self, codes_chunk_tq: torch.Tensor) -> torch.Tensor:
+        eng, lib = self.eng, self.eng.lib
+        hop = int(eng.tts.codec.mc.frame_samples)
+        chunk = codes_chunk_tq.to(eng.device).to(torch.int32)
+        n_new = int(chunk.shape[0])
+        ov = 0
+        codes_in = chunk
+        if self.ov > 0 and self.tail is not None and self.tail.numel() > 0:
+            ov = min(self.ov, int(self.tail.shape[0]))
+            codes_in = torch.cat([self.tail[-ov:], chunk], dim=0)
+        if self.trim == "legacy" and ov > 0:
+            hip._check(lib.sopro_mimi_stream_trim(C.byref(self.st), ov), "sopro_mimi_stream_trim")
+        T = int(codes_in.shape[0])
+        st = eng.stream
+        st.wait_stream(torch.cuda.current_stream(eng.device))
+        ws = eng._workspace("mimi", int(lib.sopro_mimi_workspace_bytes(eng.h, 1, T)))
+        codes_in = codes_in.contiguous()
+        wav = torch.empty(1, T * hop, device=eng.device)
+        hip._check(lib.sopro_mimi_decode_stream(eng.h, ws.data_ptr(), C.byref(self.st), codes_in.data_ptr(), T, wav.data_ptr(), st.cuda_stream),
+                   "sopro_mimi_decode_stream")
+        st.synchronize()
+        self.tail = codes_in[-min(self.ov, T):].clone() if self.ov > 0 else None
+        return wav[:, : (ov + n_new) * hop][:, ov * hop:]

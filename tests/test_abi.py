@@ -39,6 +39,7 @@ def test_struct_layouts_match_the_header(tmp_path):
         "sopro_xattn_args": (hip.XattnArgs, ["X", "Xp", "norm_w", "Kp", "klens", "Y", "eps", "scale", "np", "S_cap"]),
         "sopro_engine_cfg": (hip.EngineCfg, ["d_model", "bos_row", "ar_dilations", "ar_gate", "nar_dilations", "stage_n_cb", "nar_mix", "nar_prev_cb_weights",
                                              "mimi_hidden", "mimi_ratios", "mimi_compress", "mimi_rope_positions", "mimi_norm_eps", "mimi_final_bias"]),
+        "sopro_mimi_stream_state": (hip.MimiStreamState, ["kv", "cap_rows", "kv_len", "pos", "evict", "half"]),
         "sopro_ar_state": (hip.ArState, ["x_cur", "emb", "hist", "recent", "params", "seed", "B", "bos_row", "start", "row_max", "row_params", "nonce", "dbg"]),
     }
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "sopro_hip.h"', "int main(void){"]

@@ -76,6 +76,27 @@ def test_c_stages_on_a_ragged_sampled_batch(eng, tts_noeos):
     assert float((wav - pw).abs().max()) < 2e-5 * float(pw.abs().max())
 
 
+@pytest.mark.parametrize("trim", ["none", "legacy"])
+def test_streaming_decode_through_the_c_stage(eng, tts_noeos, trim):
+    """sopro_mimi_decode_stream (+ _trim for the legacy policy) against the Python host's MimiStreamDecoder over 40 chunks of
+    6 frames: the cache passes the 250-position window ("none": eviction to the last 249) or keeps growing ("legacy")."""
+    from sopro_amd.codec import MimiStreamDecoder
+    from sopro_amd.stages import StageStreamDecoder
+
+    g = golden("full400")
+    codes = _t(g["tokens"].astype(np.int64))[:240]
+    cdec = StageStreamDecoder(eng, trim=trim)
+    pdec, pst = MimiStreamDecoder(tts_noeos.codec, trim=trim), None
+    worst, scale = 0.0, float(np.abs(g["wav"]).max())
+    for i in range(0, 240, 6):
+        cw = cdec.decode_step(codes[i:i + 6])
+        pw, pst = pdec.decode_step(codes[i:i + 6], pst)
+        assert cw.shape == pw.shape == (1, 6 * 1920)
+        worst = max(worst, float((cw - pw).abs().max()))
+    assert worst < 2e-5 * scale, worst  # few-row contractions: the Python host splits K, the C sequence does not (round-off only)
+    assert cdec.st.pos == pst.pos and cdec.st.kv_len == pst.kv_len and cdec.st.evict == int(pst.evict)
+
+
 def test_missing_tensor_is_reported_by_name(tts_noeos):
     import ctypes as C
     from sopro_amd import hip
