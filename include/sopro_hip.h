@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 21
+#define SOPRO_ABI_VERSION 22
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -120,6 +120,11 @@ typedef struct sopro_gemm_split_ext {
   int32_t n_tickets;
   float* ws; int64_t ws_bytes;
   int32_t* tickets;
+  /* Tile walk: 0 / 1 = row-major (a workgroup index walks the column tiles of one row tile, then the next row tile);
+   * g > 1 = grouped: g row tiles at a time are walked row-tile-fastest, so the workgroups that run at the same time on an XCD
+   * (each XCD gets one contiguous range of the walk) share g row blocks of A and a few column blocks of W in its 4 MB L2
+   * instead of streaming the whole W once per row tile.  Filled from sopro_gemm_set_group_m when 0. */
+  int32_t group_m;
 } sopro_gemm_split_ext;
 int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
 /* Six-pass variant for token paths (NAR refinement, conditioning: src/sopro/nn/nar.py, blocks.py): operands split into
@@ -141,6 +146,7 @@ int sopro_gemm_bf16x1(const sopro_gemm_args* a, const void* packed_w, const sopr
 int sopro_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t pieces, void* packed, void* stream);
 int64_t sopro_packed_w_bytes(int32_t N, int32_t K, int32_t pieces);
 int sopro_gemm_bf16_set_tile_override(int cfg); /* developer probe */
+int sopro_gemm_set_group_m(int g);              /* default tile-walk group of the split-bf16 contractions (see group_m) */
 
 /* Batch-of-at-most-a-few-dozen-rows contraction for the autoregressive step
  * (src/sopro/nn/generator.py:98-130): Y[b, n] = epi( rs[b] * sum_k Xin[b, k] * W[n, k] + bias[n] ),

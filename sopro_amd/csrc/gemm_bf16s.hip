@@ -66,7 +66,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   const int wm = wave / WN, wn = wave % WN;
   const int ntn = (g.N + BN - 1) / BN;
   const int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-  const int mt = bid / ntn, nt = bid % ntn;
+  int mt = bid / ntn, nt = bid % ntn;
+  if (ext.group_m > 1) {  // grouped walk: group_m row tiles at a time, row tile fastest (see sopro_gemm_split_ext.group_m)
+    const int ntm_all = (g.M + BM - 1) / BM;
+    const int per = ext.group_m * ntn;
+    const int grp = bid / per, rem = bid - grp * per;
+    const int first = grp * ext.group_m;
+    const int gsz = min(ntm_all - first, ext.group_m);
+    mt = first + rem % gsz;
+    nt = rem / gsz;
+  }
   const int m0 = mt * BM, n0 = nt * BN;
   const int lrow = tid >> 3, lc4 = tid & 7;
   const int rps = g.rows_per_seg;
@@ -447,6 +456,12 @@ int check_common(sopro_gemm_args& g, sopro_gemm_split_ext& ext, const void* pack
 
 }  // namespace
 
+static int g_group_m = 0;
+extern "C" int sopro_gemm_set_group_m(int g) {
+  g_group_m = g > 1 ? g : 0;
+  return 0;
+}
+
 static int g_tile_override = 0;  // developer probe: 1: 128x128, 2: 256x128, 4: 128x64 (x6: 64x128), 5: 64x64
 extern "C" int sopro_gemm_bf16_set_tile_override(int cfg) {
   g_tile_override = cfg;
@@ -480,6 +495,7 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
   sopro_gemm_split_ext ext;
   memset(&ext, 0, sizeof(ext));
   if (x) ext = *x;
+  if (ext.group_m == 0) ext.group_m = g_group_m;
   if (int rc = check_common(g, ext, packed_w)) return rc;
   SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ELU, "prologue must be NONE or ELU");
   SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES,
@@ -526,6 +542,7 @@ extern "C" int sopro_gemm_bf16x1(const sopro_gemm_args* a, const void* packed_w,
   sopro_gemm_split_ext ext;
   memset(&ext, 0, sizeof(ext));
   if (x) ext = *x;
+  if (ext.group_m == 0) ext.group_m = g_group_m;
   SOPRO_CHECK_ARG(ext.a_format == 0 && (ext.c_mode == 0 || ext.c_mode == 3 || ext.c_mode == 4 || ext.c_mode == 5),
                   "bf16x1 reads fp32 rows and writes fp32 rows (c_mode 0, 3, 4) or arg-max partials (5)");
   SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f && ext.c_mode == 0),
@@ -562,6 +579,7 @@ extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w,
   sopro_gemm_split_ext ext;
   memset(&ext, 0, sizeof(ext));
   if (x) ext = *x;
+  if (ext.group_m == 0) ext.group_m = g_group_m;
   SOPRO_CHECK_ARG(ext.a_format == 0 && (ext.c_mode == 0 || ext.c_mode == 5),
                   "the six-pass path reads fp32 rows and writes fp32 rows, or arg-max partials (c_mode 5)");
   SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f),

@@ -16,8 +16,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
+DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
 NORM_RMS, NORM_LN = 0, 1
@@ -36,7 +37,7 @@ class GemmArgs(C.Structure):
 class SplitExt(C.Structure):
     _fields_ = [("a_format", _i32), ("c_mode", _i32), ("C2", _p), ("ldc2", _i64), ("c2_seg_stride", _i64),
                 ("rms_norm", _i32), ("rms_eps", _f32), ("ksplit", _i32), ("n_tickets", _i32), ("ws", _p), ("ws_bytes", _i64),
-                ("tickets", _p)]
+                ("tickets", _p), ("group_m", _i32)]
 
 
 class SkinnyArgs(C.Structure):
@@ -106,6 +107,7 @@ SYMBOLS = {
     "sopro_pack_w_bf16": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     "sopro_packed_w_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "sopro_gemm_bf16_set_tile_override": (C.c_int, [C.c_int]),
+    "sopro_gemm_set_group_m": (C.c_int, [C.c_int]),
     "sopro_seanet_tail_set_tiles": (C.c_int, [C.c_int]),
     "sopro_seanet_res_set_tiles": (C.c_int, [C.c_int]),
     "sopro_seanet_res128_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
@@ -180,6 +182,7 @@ def load() -> C.CDLL:
     v = lib.sopro_abi_version()
     if v != ABI_VERSION:
         raise SoproHipError(f"{LIB_PATH} has ABI version {v}, the Python host expects {ABI_VERSION}: rebuild it")
+    lib.sopro_gemm_set_group_m(int(os.environ.get("SOPRO_GEMM_GROUP_M", str(DEFAULT_GROUP_M))))
     _lib = lib
     return lib
 

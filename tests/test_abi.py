@@ -32,7 +32,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     import subprocess
 
     checks = {
-        "sopro_gemm_split_ext": (hip.SplitExt, ["a_format", "c_mode", "C2", "ldc2", "c2_seg_stride", "rms_norm", "rms_eps", "ksplit", "n_tickets", "ws", "ws_bytes", "tickets"]),
+        "sopro_gemm_split_ext": (hip.SplitExt, ["a_format", "c_mode", "C2", "ldc2", "c2_seg_stride", "rms_norm", "rms_eps", "ksplit", "n_tickets", "ws", "ws_bytes", "tickets", "group_m"]),
         "sopro_gemm_args": (hip.GemmArgs, ["A", "W", "C", "R", "scale", "pro_vec", "dbg", "M", "rows_per_seg", "epilogue"]),
         "sopro_skinny_args": (hip.SkinnyArgs, ["X", "W", "Y", "scale", "ring", "step", "Xp", "y_part_stride", "dbg", "eps", "B", "epilogue", "ring_len", "ksize", "np", "ksplit", "rms_norm", "w_layout"]),
         "sopro_attn_args": (hip.AttnArgs, ["Q", "K", "V", "O", "klens", "B", "Tk", "causal", "window", "scale"]),

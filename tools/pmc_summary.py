@@ -16,13 +16,16 @@ import sys
 
 
 def fam(name: str) -> str:
+    if "gemm_bf16s_kernel<1" in name:
+        return "gemm_bf16x1_kernel"
     if "gemm_bf16s_kernel<2" in name:
         return "gemm_bf16x3_kernel"
     if "gemm_bf16s_kernel<3" in name:
         return "gemm_bf16x6_kernel"
     if "attn_window_mfma_kernel" in name:
         return "attention_kernel"
-    for k in ("gemm_f32_kernel", "skinny_kernel", "xattn_step_kernel", "ar_sample_kernel", "seanet_tail_kernel", "attention_kernel"):
+    for k in ("gemm_f32_kernel", "skinny_kernel", "xattn_step_kernel", "ar_sample_kernel", "seanet_tail_kernel", "seanet_res128_kernel",
+              "attention_kernel", "argmax_partials_kernel"):
         if k in name:
             return k
     return "other"
