@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 22
+#define SOPRO_ABI_VERSION 23
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -179,7 +179,9 @@ typedef struct sopro_skinny_args {
   int32_t B, N, K, epilogue;
   int32_t ring_len, ring_bcap, dil, ksize;
   int32_t np, ksplit, rms_norm;
-  int32_t w_layout;       /* 0: W is [N, ldw] row-major; 1: W was laid out by sopro_pack_skinny_w (ldw unused) */
+  int32_t w_layout;       /* 0: W is [N, ldw] row-major; 1: W was laid out by sopro_pack_skinny_w (ldw unused);
+                           * 2: bf16 weights from sopro_pack_skinny_w_bf16 (the engine's bf16 mode: activations are rounded to
+                           *    bf16 as MFMA operands, v_mfma_f32_16x16x32_bf16 with fp32 accumulation) */
 } sopro_skinny_args;
 int sopro_skinny_f32(const sopro_skinny_args* args, void* stream);
 /* Fragment order for the AR-step weights: [column tile][K/32][2][64 lanes][4 floats] - lane (i = lane & 15, g = lane >> 4) of
@@ -188,6 +190,9 @@ int sopro_skinny_f32(const sopro_skinny_args* args, void* stream);
  * kernel reads 1 KiB of consecutive memory.  Rows past N are zero.  `out` holds sopro_skinny_packed_floats(N, K, glu) floats. */
 int sopro_pack_skinny_w(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t glu, float* out, void* stream);
 int64_t sopro_skinny_packed_floats(int32_t N, int32_t K, int32_t glu);
+/* The same fragment order with bf16 elements ([column tile][K/32][64 lanes][8 bf16]): `out` holds
+ * sopro_skinny_packed_floats(N, K, glu) * 2 bytes.  For w_layout = 2. */
+int sopro_pack_skinny_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t glu, void* out, void* stream);
 
 /* ---- normalisation / elementwise ------------------------------------------------------- */
 enum { SOPRO_NORM_RMS = 0, SOPRO_NORM_LN = 1 };

@@ -28,7 +28,20 @@ constexpr int XLD = KS + 4;    // padded LDS row
 constexpr int MAXTAPS = 13;
 constexpr int SQ = 6;          // float4 per staging thread and source (24 floats)
 
-template <bool GLU, int NP, bool NORM>
+typedef __bf16 sk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sk_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float sk_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt2_bf16(float x, float y) {
+  const sk_f32x2 v = {x, y};
+  const sk_bf16x2 h = __builtin_convertvector(v, sk_bf16x2);
+  return *reinterpret_cast<const unsigned*>(&h);
+}
+
+// WB (bf16 mode of the engine): the weights are bf16 in the fragment order of sopro_pack_skinny_w_bf16 (half the bytes of the
+// frame's dominant stream), the staged activations are rounded to bf16 as they leave LDS, and a 32-wide K chunk is ONE
+// v_mfma_f32_16x16x32_bf16 (fp32 accumulate) instead of eight exact-fp32 MFMAs.  Norm statistics, biases, the ring buffer,
+// the taps and the residual stay fp32.
+template <bool GLU, int NP, bool NORM, bool WB>
 __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) {
   __shared__ float xs[16 * XLD];          // raw (combined) input slice
   __shared__ float red[4 * 4 * 64];
@@ -80,6 +93,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
   const int kchunks = a.K >> 5;
   const float* wbase = packed ? a.W + ((int64_t)ntile * kchunks * 2) * 256 + lane * 4 : a.W + (int64_t)w_row * a.ldw + g * 8;
   const int64_t w_chunk = packed ? 512 : 32, w_half = packed ? 256 : 4;
+  const uint4* wbase16 = reinterpret_cast<const uint4*>(a.W) + (int64_t)ntile * kchunks * 64 + lane;  // WB: [tile][chunk][lane] x 16 B
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int srow = tid >> 4, spart = tid & 15;  // staging: row, float4 column within each 64-float group
@@ -91,11 +105,16 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
     const int k0 = ks * KS;
     // ---- all weight fragments of this slice for this wave (3 chunks x 2 float4)
     float4 wf[3][2];
+    uint4 wh[3];
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc) {
-      const float* wp = wbase + (int64_t)((k0 >> 5) + wave * 3 + cc) * w_chunk;
-      wf[cc][0] = *reinterpret_cast<const float4*>(wp);
-      wf[cc][1] = *reinterpret_cast<const float4*>(wp + w_half);
+      if constexpr (WB) {
+        wh[cc] = wbase16[(int64_t)((k0 >> 5) + wave * 3 + cc) * 64];
+      } else {
+        const float* wp = wbase + (int64_t)((k0 >> 5) + wave * 3 + cc) * w_chunk;
+        wf[cc][0] = *reinterpret_cast<const float4*>(wp);
+        wf[cc][1] = *reinterpret_cast<const float4*>(wp + w_half);
+      }
     }
     // ---- input slice (+ producer's partial sums, fixed order) -> LDS
     {
@@ -152,6 +171,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
       const int kl = (wave * 3 + cc) * 32 + g * 8;
       const float4 x0 = *reinterpret_cast<const float4*>(xs + i * XLD + kl);
       const float4 x1 = *reinterpret_cast<const float4*>(xs + i * XLD + kl + 4);
+      if constexpr (WB) {
+        const uint4 xa = make_uint4(cvt2_bf16(x0.x, x0.y), cvt2_bf16(x0.z, x0.w), cvt2_bf16(x1.x, x1.y), cvt2_bf16(x1.z, x1.w));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const sk_bf16x8*>(&xa), *reinterpret_cast<const sk_bf16x8*>(&wh[cc]), acc, 0, 0, 0);
+        continue;
+      }
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, wf[cc][0].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, wf[cc][0].y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, wf[cc][0].z, acc, 0, 0, 0);
@@ -230,9 +254,42 @@ __global__ __launch_bounds__(256) void pack_skinny_kernel(const float* __restric
   out[idx] = v;
 }
 
+// bf16 form: one thread per 16-byte fragment piece (8 consecutive k of one weight row)
+__global__ __launch_bounds__(256) void pack_skinny_bf16_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, int glu,
+                                                               uint4* __restrict__ out, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const int64_t tc = idx >> 6;
+  const int kchunks = K >> 5;
+  const int chunk = (int)(tc % kchunks), t = (int)(tc / kchunks);
+  const int i = lane & 15, g = lane >> 4;
+  const int D = N / 2;
+  int row;
+  bool ok;
+  if (glu) {
+    const int n = t * 8 + (i & 7);
+    ok = n < D;
+    row = (i < 8) ? n : D + n;
+  } else {
+    row = t * 16 + i;
+    ok = row < N;
+  }
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (ok) {
+    const float* p = W + (int64_t)row * ldw + chunk * 32 + g * 8;
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v = make_uint4(cvt2_bf16(a.x, a.y), cvt2_bf16(a.z, a.w), cvt2_bf16(b.x, b.y), cvt2_bf16(b.z, b.w));
+  }
+  out[idx] = v;
+}
+
 template <bool GLU, int NP, bool NORM>
 int launch(const sopro_skinny_args& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM>), grid, dim3(256), 0, s, a);
+  if (a.w_layout == 2)
+    hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM, true>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM, false>), grid, dim3(256), 0, s, a);
   SOPRO_LAUNCH_CHECK();
 }
 
@@ -254,6 +311,16 @@ extern "C" int sopro_pack_skinny_w(const float* W, int64_t ldw, int32_t N, int32
   SOPRO_LAUNCH_CHECK();
 }
 
+extern "C" int sopro_pack_skinny_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t glu, void* out, void* stream) {
+  SOPRO_CHECK_ARG(W && out && N > 0 && K > 0 && ldw >= K, "bad pointers or sizes");
+  SOPRO_CHECK_ARG((K & 31) == 0 && (ldw & 3) == 0 && aligned16(W) && aligned16(out), "K % 32 == 0, ldw % 4 == 0, 16-byte aligned W / out");
+  SOPRO_CHECK_ARG(!glu || (N & 1) == 0, "glu: N must be even");
+  const int64_t total = sopro_skinny_packed_floats(N, K, glu) / 8;  // 16-byte pieces: half the bytes of the fp32 form
+  hipLaunchKernelGGL(pack_skinny_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, glu,
+                     reinterpret_cast<uint4*>(out), total);
+  SOPRO_LAUNCH_CHECK();
+}
+
 extern "C" int sopro_skinny_f32(const sopro_skinny_args* p, void* stream) {
   SOPRO_CHECK_ARG(p != nullptr, "args is NULL");
   const sopro_skinny_args& a = *p;
@@ -261,7 +328,7 @@ extern "C" int sopro_skinny_f32(const sopro_skinny_args* p, void* stream) {
   SOPRO_CHECK_ARG((a.K % KS) == 0, "K must be a multiple of 384");
   SOPRO_CHECK_ARG(a.X && a.W && a.Y, "X, W, Y must be non-NULL");
   SOPRO_CHECK_ARG(aligned16(a.X) && aligned16(a.W) && (a.ldx & 3) == 0 && (a.ldw & 3) == 0, "X/W must be 16-byte aligned with ld % 4 == 0");
-  SOPRO_CHECK_ARG(a.w_layout == 0 || a.w_layout == 1, "w_layout must be 0 (row-major) or 1 (sopro_pack_skinny_w)");
+  SOPRO_CHECK_ARG(a.w_layout >= 0 && a.w_layout <= 2, "w_layout must be 0 (row-major), 1 (sopro_pack_skinny_w) or 2 (sopro_pack_skinny_w_bf16)");
   SOPRO_CHECK_ARG(!a.rms_norm || a.K == KS, "rms_norm needs K == 384");
   SOPRO_CHECK_ARG(a.epilogue != SOPRO_EPI_RES || a.R, "EPI_RES needs R");
   SOPRO_CHECK_ARG(a.epilogue != SOPRO_EPI_GLU, "EPI_GLU is not a skinny epilogue (use EPI_GLU_DW)");

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -113,6 +113,7 @@ SYMBOLS = {
     "sopro_seanet_res128_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "sopro_gemm_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_pack_skinny_w": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
+    "sopro_pack_skinny_w_bf16": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     "sopro_skinny_packed_floats": (_i64, [_i32, _i32, _i32]),
     "sopro_skinny_f32": (C.c_int, [C.POINTER(SkinnyArgs), _p]),
     "sopro_norm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32, _p]),
@@ -397,22 +398,27 @@ def pack_w_bf16x1(W: torch.Tensor) -> PackedW:
 class SkinnyW:
     """AR-step weights in the fragment order of ``sopro_pack_skinny_w`` (every load instruction reads 1 KiB of consecutive memory)."""
 
-    __slots__ = ("data", "N", "K", "glu")
+    __slots__ = ("data", "N", "K", "glu", "bf16")
 
-    def __init__(self, data: torch.Tensor, N: int, K: int, glu: bool):
-        self.data, self.N, self.K, self.glu = data, N, K, glu
+    def __init__(self, data: torch.Tensor, N: int, K: int, glu: bool, bf16: bool = False):
+        self.data, self.N, self.K, self.glu, self.bf16 = data, N, K, glu, bf16
 
 
-def pack_skinny_w(W: torch.Tensor, glu: bool = False) -> SkinnyW:
+def pack_skinny_w(W: torch.Tensor, glu: bool = False, bf16: bool = False) -> SkinnyW:
+    """``bf16``: the engine's bf16 mode - weights rounded to bf16 (half the bytes), one bf16 MFMA per 32-wide K chunk."""
     N, K = int(W.shape[0]), int(W.shape[1])
     n = int(load().sopro_skinny_packed_floats(N, K, int(glu)))
     if n <= 0:
         raise SoproHipError(f"pack_skinny_w: unsupported shape {N}x{K} (K % 32 == 0; glu: N even)")
     Wc = W.contiguous()
-    out = torch.empty(n, dtype=torch.float32, device=W.device)
     with torch.cuda.device(W.device):
-        _check(load().sopro_pack_skinny_w(ptr(Wc), K, N, K, int(glu), ptr(out), _stream()), "sopro_pack_skinny_w")
-    return SkinnyW(out, N, K, bool(glu))
+        if bf16:
+            out = torch.empty(n // 2, dtype=torch.int32, device=W.device)
+            _check(load().sopro_pack_skinny_w_bf16(ptr(Wc), K, N, K, int(glu), ptr(out, torch.int32), _stream()), "sopro_pack_skinny_w_bf16")
+        else:
+            out = torch.empty(n, dtype=torch.float32, device=W.device)
+            _check(load().sopro_pack_skinny_w(ptr(Wc), K, N, K, int(glu), ptr(out), _stream()), "sopro_pack_skinny_w")
+    return SkinnyW(out, N, K, bool(glu), bool(bf16))
 
 
 def skinny(X: torch.Tensor, W, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: Optional[int] = None,
@@ -428,7 +434,7 @@ def skinny(X: torch.Tensor, W, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: 
     if isinstance(W, SkinnyW):
         if (W.N, W.K, W.glu) != (N, K, epilogue == EPI_GLU_DW):
             raise SoproHipError(f"packed weight is {W.N}x{W.K} glu={W.glu}, the call says {N}x{K} glu={epilogue == EPI_GLU_DW}")
-        a.W, a.ldw, a.w_layout = ptr(W.data), K, 1
+        a.W, a.ldw, a.w_layout = (ptr(W.data, torch.int32), K, 2) if W.bf16 else (ptr(W.data), K, 1)
     else:
         a.W, a.ldw = ptr(W), K
     a.bias = ptr(bias)

@@ -78,8 +78,9 @@ class SoproTTSModel:
             raise hip.SoproHipError("no HIP device visible: the Sopro engine has no CPU fallback")
         if precision not in ("f32", "bf16"):
             raise ValueError("precision must be 'f32' (parity with the fp32 reference) or 'bf16' (bf16 operands, fp32 accumulate)")
-        # "bf16" = SURVEY.md 8d config 2: the NAR / text / reference-encoder contractions round both operands to bf16 once (one
-        # MFMA pass instead of six); norms, softmax, accumulators, the residual stream and the AR frame stay fp32.
+        # "bf16" = SURVEY.md 8d config 2: the NAR contractions round both operands to bf16 once (one MFMA pass instead of six)
+        # and the AR frame streams bf16 weights (activations rounded to bf16 as MFMA operands); accumulators, norms, softmax,
+        # the residual stream, ring buffers and the conditioning (text / reference encoders, cross-attention) stay fp32.
         self.precision = precision
         self.cfg = cfg
         self.device = torch.device(device)
@@ -145,7 +146,8 @@ class SoproTTSModel:
                 for k, v in self.w.items():
                     if (k.startswith("ar.blocks.") and k.endswith((".glu.w", ".ff1.w", ".ff2.w"))) or k == "ar.head.w":
                         if v.dim() == 2 and int(v.shape[1]) % 32 == 0:
-                            self.wk[k] = hip.pack_skinny_w(v, glu=k.endswith(".glu.w"))
+                            # bf16 mode: the frame's weight stream in bf16 (fp32 accumulate, fp32 norms / ring / residual)
+                            self.wk[k] = hip.pack_skinny_w(v, glu=k.endswith(".glu.w"), bf16=(precision == "bf16"))
                 torch.cuda.synchronize(self.device)
         self._ones: Dict[int, torch.Tensor] = {}
         sc = cfg.stage_codebooks()

@@ -94,6 +94,47 @@ def test_gemm_bf16x1_epilogues_prologues_norm_and_row_windows():
         hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, a_split=True)
 
 
+@pytest.mark.parametrize("B", [1, 16, 32, 37])
+def test_skinny_bf16_weights_match_the_rounded_product(B, w):
+    """AR-step contractions in bf16 mode (w_layout 2): bf16 weights in fragment order, activations rounded to bf16 as MFMA
+    operands, fp32 accumulate - against torch on the rounded operands; RMSNorm statistics, bias, GELU, the K-split residual
+    form and the GLU / ring-buffer tail stay fp32."""
+    D = 384
+    # RMSNorm -> projection (+ bias, GELU): the row scale comes from the raw fp32 row, the product from the rounded one
+    X, nw, W, b = rnd(B, D, seed=20), 1 + 0.1 * rnd(D, seed=21), rnd(4 * D, D, seed=22, scale=D ** -0.5), rnd(4 * D, seed=23)
+    Wf = (W * nw[None, :]).contiguous()
+    rs = torch.rsqrt((X.double() ** 2).mean(-1, keepdim=True) + 1e-6)
+    ref = ((bf(X).double() @ bf(Wf).double().t()) * rs + b.double()).float()
+    Y = torch.full((B, 4 * D), float("nan"), device=DEV)
+    hip.skinny(dev(X), hip.pack_skinny_w(dev(Wf), bf16=True), Y, B=B, N=4 * D, K=D, rms_norm=True, eps=1e-6, bias=dev(b), epilogue=hip.EPI_GELU)
+    close(Y, F.gelu(ref), 5e-5, "bf16 ff1")
+    # head (N = 2049: a ragged last tile)
+    Wh, bh = rnd(2049, D, seed=24, scale=D ** -0.5), rnd(2049, seed=25)
+    Yh = torch.full((B, 2049), float("nan"), device=DEV)
+    hip.skinny(dev(X), hip.pack_skinny_w(dev(Wh), bf16=True), Yh, B=B, N=2049, K=D, rms_norm=True, eps=1e-6, bias=dev(bh))
+    close(Yh, ((bf(X).double() @ bf(Wh).double().t()) * rs + bh.double()).float(), 5e-5, "bf16 head")
+    # K = 1536 as four K-slices, slice 0 carrying bias + residual
+    U, W2, b2, R = rnd(B, 4 * D, seed=26), rnd(D, 4 * D, seed=27, scale=(4 * D) ** -0.5), rnd(D, seed=28), rnd(B, D, seed=29)
+    P = torch.full((4, B, D), float("nan"), device=DEV)
+    hip.skinny(dev(U), hip.pack_skinny_w(dev(W2), bf16=True), P, B=B, N=D, K=4 * D, bias=dev(b2), epilogue=hip.EPI_RES, R=dev(R), ksplit=True,
+               y_part_stride=B * D)
+    close(P.sum(0), R + b2 + bf(U) @ bf(W2).t(), 1e-4, "bf16 ff2 slices")
+    # GLU -> ring buffer -> taps -> + x, on an empty ring: only the newest tap contributes
+    p, k, dil = "ar.blocks.1", 13, 2
+    L = (k - 1) * dil + 1
+    ring = torch.zeros(L, B, D, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    gw = (w[p + ".glu.pro.weight"] * w[p + ".norm.weight"][None, :]).contiguous()
+    Yg = torch.empty(B, D, device=DEV)
+    hip.skinny(dev(X), hip.pack_skinny_w(dev(gw), glu=True, bf16=True), Yg, B=B, N=2 * D, K=D, rms_norm=True, eps=1e-6, bias=dev(w[p + ".glu.pro.bias"]),
+               epilogue=hip.EPI_GLU_DW, ring=ring, dw_w=dev(pack.pack_dw(w[p + ".dw.dw.weight"])), dw_b=dev(w[p + ".dw.dw.bias"]), step=step,
+               ring_len=L, ring_bcap=B, dil=dil, ksize=k)
+    pre = ((bf(X).double() @ bf(gw).double().t()) * rs).float() + w[p + ".glu.pro.bias"]
+    h = pre[:, :D] * torch.sigmoid(pre[:, D:])
+    close(Yg, X + h * w[p + ".dw.dw.weight"][:, 0, -1] + w[p + ".dw.dw.bias"], 1e-4, "bf16 glu tail")
+    close(ring[0], h, 5e-5, "ring row of this frame")
+
+
 @pytest.fixture(scope="module")
 def tts_bf16(cfg, sopro_np_noeos, mimi_np):
     from sopro_amd import SoproTTS
@@ -101,6 +142,7 @@ def tts_bf16(cfg, sopro_np_noeos, mimi_np):
 
 
 def test_bf16_mode_quality_against_the_fp32_reference(tts_bf16, cfg, mc, w_noeos):
+    # (prep below runs on the bf16 engine: conditioning is fp32-class in both modes)
     """On the reference's 200-frame fixture (S = 64, Tr = 150): refined-token agreement with the fp32 reference given its
     codebook-0 tokens, the oracle's own logit gap where the bf16 arg-max differs, and the waveform error of the bf16
     decoder on the reference's tokens.  Numbers go to the test log (DESIGN.md quotes them); the floors only catch a broken path."""
@@ -120,11 +162,30 @@ def test_bf16_mode_quality_against_the_fp32_reference(tts_bf16, cfg, mc, w_noeos
     ref_wav = torch.from_numpy(g["wav"])
     werr = float((wav - ref_wav).abs().max()) / float(ref_wav.abs().max())
     snr = 10.0 * float(torch.log10((ref_wav ** 2).mean() / ((wav - ref_wav) ** 2).mean()))
-    # codebook 0 (the AR loop) is fp32 in this mode: generation from text must reproduce the reference's codebook-0 tokens
-    toks = tts.model.generate_tokens(torch.from_numpy(g["ids"]), ref, max_frames=int(g["max_frames"]), style_strength=1.0,
-                                     top_p=0.0, temperature=1.0, anti_loop=False)
-    cb0_equal = bool(torch.equal(toks[:, 0].cpu(), want[:, 0]))
-    print(f"\\nbf16 mode vs fp32 reference (full200): cond_ar max err {cond_err:.2e}; refined-token agreement {agree:.4f} "
-          f"({n_off} of {T * 31} off the fp32 arg-max, worst fp32 logit gap {gap:.3f}); waveform max err {werr:.3e} of peak, SNR {snr:.1f} dB; "
-          f"codebook 0 equal: {cb0_equal}")
-    assert agree > 0.80 and werr < 0.05 and snr > 30.0
+    # the AR frame streams bf16 weights in this mode: teacher-forced on the reference's own codebook-0 tokens, how often is the
+    # bf16 frame's arg-max the reference's next token, and how far are its logits from the fp32 oracle's?
+    from sopro_amd.model import _ARRun
+
+    m = tts.model
+    run = _ARRun(m, prep["cond_ar"], prep["txt_seq"], None, top_p=0.0, temperature=1.0, anti_loop=False, min_gen_frames=10 ** 6)
+    ost = O.ar_init_state(1, oprep["txt_seq"], oprep["text_mask"], w_noeos, cfg)
+    E = w_noeos["cb_embed.emb.weight"]
+    hits, worst_lg, hist = 0, 0.0, []
+    for t in range(T):
+        prev = E[int(cfg.num_codebooks) * int(cfg.codebook_size)] if t == 0 else E[int(want[t - 1, 0])]
+        x = oprep["cond_ar"][:, t, :] + prev.unsqueeze(0)
+        olog = O.ar_step(x, ost, w_noeos, cfg)[0]
+        with torch.cuda.stream(m.stream):
+            run.plan.x[0].copy_(x.to(m.device))
+        run.advance(1)
+        m.stream.synchronize()
+        glog = run.plan.logits[0].cpu()
+        worst_lg = max(worst_lg, float((glog - olog).abs().max()))
+        hits += int(int(O.penalised_logits(glog, hist, 1.0, 1.1).argmax()) == int(want[t, 0]))
+        hist.append(int(want[t, 0]))
+    run.done = True
+    ar_agree = hits / T
+    print(f"\nbf16 mode vs fp32 reference (full200): cond_ar max err {cond_err:.2e}; AR teacher-forced: next-token agreement {ar_agree:.4f}, "
+          f"max |dlogit| {worst_lg:.3f}; refined-token agreement {agree:.4f} ({n_off} of {T * 31} off the fp32 arg-max, worst fp32 logit "
+          f"gap {gap:.3f}); waveform max err {werr:.3e} of peak, SNR {snr:.1f} dB")
+    assert agree > 0.80 and werr < 0.05 and snr > 30.0 and ar_agree > 0.85 and worst_lg < 0.5
