@@ -454,18 +454,28 @@ class SoproTTSModel:
         # The stop poll trails the launches by one chunk: chunk k+1 is enqueued before the host looks at chunk k's counter, so
         # the GPU never waits for the host round trip (rows that have stopped are masked on the device; the extra frames of
         # a batch that turns out to be finished are discarded below).
+        poll_every = int(os.environ.get("SOPRO_AR_POLL", poll_every))
         steps = 0
         pending = None
         ev0 = None
         if hip.phase_log is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record(self.stream)
+        # While no row of a batch has stopped yet, frames are enqueued four polls' worth at a time: the launch thread then
+        # has ~15 ms of queued work ahead of the GPU instead of ~4, which is what it takes to ride out a descheduled host
+        # thread on a busy machine (measured: 14.5 k vs 17.6 k audio-s/s on the same build, load average 16).  Once the first
+        # row has stopped - the batch may be over any frame now - and for small batches (latency matters, all rows tend to stop
+        # together) the poll is back to every `poll_every` frames.
+        seen_stop = B < 8
         while steps < Tar:
-            n = min(int(poll_every), Tar - steps)
+            n = min(int(poll_every) * (1 if seen_stop else 4), Tar - steps)
             run.advance(n)
             steps += n
-            if pending is not None and pending() >= B:
-                break
+            if pending is not None:
+                got = pending()
+                seen_stop = seen_stop or got > 0
+                if got >= B:
+                    break
             pending = run.poll_async(stop_on_first_eos)
         if ev0 is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
