@@ -275,6 +275,16 @@ def main() -> None:
     fence()
     dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f} s for {args.steps} steps; peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    if os.environ.get("SOPRO_BENCH_TRACE") and pipe is not None:  # developer aid: which lane ran which step when, and its phase times
+        for rep in range(int(os.environ["SOPRO_BENCH_TRACE"])):
+            if rep:
+                ph2 = {}
+                t1 = time.perf_counter()
+                pipe.run([job] * args.steps, timings=ph2)
+                fence()
+                log(f"trace repeat {rep}: {time.perf_counter() - t1:.3f} s")
+            for i, lane, a, b, tj in sorted(pipe.trace):
+                log(f"  step {i:3d} lane {lane} {a * 1e3:8.1f} -> {b * 1e3:8.1f} ms  " + " ".join(f"{k}={v * 1e3:.1f}" for k, v in tj.items()))
     ar_log, hip.phase_log = hip.phase_log, None
     ar_frames = sum(n for n, _b, _e0, _e1 in ar_log)
     ar_ms = sum(e0.elapsed_time(e1) for _n, _b, e0, e1 in ar_log)

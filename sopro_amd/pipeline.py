@@ -54,9 +54,14 @@ class PipelinedSynthesizer:
             lane.model._nar_graphs.clear()
             lane.codec._graphs.clear()
             self.lanes.append(lane)
-        # An empty pipeline has nothing on the throughput partition yet: the first AR phases of a run use the whole chip
-        # (the recorded frame graph replays on any stream), which shortens the fill of the pipeline.
-        self._full = [torch.cuda.Stream(device=self.device) for _ in range(int(lanes))]
+        # An empty pipeline has nothing on the throughput partition yet: the first AR phase of each partition lock gets an equal
+        # share of the WHOLE chip (the recorded frame graph replays on any stream), which shortens the fill of the pipeline.
+        # These are CU-masked streams too (disjoint ranges): an ordinary stream generating beside a CU-masked one was
+        # measured at 390-830 us per frame for both (tools/ar_concurrency_probe.py, "64-CU partition + whole chip"), while
+        # two disjoint halves give the same 136 us per frame as two ordinary streams.
+        share = total // ar_parts
+        self._full = [hip.cu_range_stream((i % ar_parts) * share, share, self.device) for i in range(int(lanes))]
+        self._streams += self._full
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
         self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))
         self.ar_cus, self.ar_parts, self.bulk_cus = ar_cus, ar_parts, total - bulk0
@@ -118,6 +123,34 @@ class PipelinedSynthesizer:
         nxt = [0]
         pick = threading.Lock()
 
+        # An empty pipeline has nothing on the throughput partition yet, so the FIRST AR phase of each partition lock may use
+        # the whole chip (the recorded frame graph replays on any stream): 141 instead of 270 us per frame, which shortens
+        # the fill of the pipeline.  Which phase that is gets decided when the lock is TAKEN, not by job index: a whole-chip
+        # phase that lost the race for its lock and then ran beside a partition-bound one was measured at 400-750 us per
+        # frame for both (profiles/r02_experiments.md, "start-up race") - the slow mode of one bench run in three.
+        ar_started = [0] * self.ar_parts
+        ar_finished = [0]
+
+        class _ArSlot:
+            def __init__(slot, lane, part, lane_idx):
+                slot.lane, slot.part, slot.lane_idx = lane, part, lane_idx
+
+            def __enter__(slot):
+                self.ar_locks[slot.part].acquire()
+                slot.masked = slot.lane.model.stream
+                with pick:
+                    first = ar_started[slot.part] == 0 and ar_finished[0] == 0
+                    ar_started[slot.part] += 1
+                if first and not self.unpartitioned:
+                    slot.lane.model.stream = self._full[slot.lane_idx]
+
+            def __exit__(slot, *exc):
+                slot.lane.model.stream = slot.masked
+                with pick:
+                    ar_finished[0] += 1
+                self.ar_locks[slot.part].release()
+                return False
+
         def worker(lane, ar_lock, lane_idx):
             # the worker's current stream is the lane's own (never the NULL stream, which would serialise the lanes)
             with torch.cuda.stream(lane.model.stream):
@@ -127,23 +160,29 @@ class PipelinedSynthesizer:
                         nxt[0] += 1
                     if i >= len(jobs) or errors:
                         return
-                    masked = lane.model.stream
-                    if i < self.ar_parts:
-                        lane.model.stream = self._full[lane_idx]
+                    tj = {} if timings is not None else None
+                    t_job = time.perf_counter()
                     try:
-                        results[i] = lane.synthesize_batch(phase_locks=(ar_lock, self.bulk_lock), timings=timings, **jobs[i])
+                        results[i] = lane.synthesize_batch(phase_locks=(ar_lock, self.bulk_lock), timings=tj, **jobs[i])
                     except BaseException as e:  # noqa: BLE001
                         errors.append(e)
                         return
-                    finally:
-                        lane.model.stream = masked
+                    if tj is not None:
+                        with pick:
+                            for k, v in tj.items():
+                                timings[k] = timings.get(k, 0.0) + v
+                            self.trace.append((i, lane_idx, t_job - t_run, time.perf_counter() - t_run, tj))
 
         n_run = max(1, min(len(self.lanes), len(jobs)))
         import sys
+        import time
+
+        self.trace = []  # (job, lane, start s, end s, per-phase seconds) of the last timed run: who was slow, and when
+        t_run = time.perf_counter()
 
         swi = sys.getswitchinterval()
         sys.setswitchinterval(2e-4)  # lanes hand the interpreter over between launches; 5 ms hand-over stalls a whole AR poll
-        threads = [threading.Thread(target=worker, args=(lane, self.ar_locks[i % self.ar_parts], i)) for i, lane in enumerate(self.lanes[:n_run])]
+        threads = [threading.Thread(target=worker, args=(lane, _ArSlot(lane, i % self.ar_parts, i), i)) for i, lane in enumerate(self.lanes[:n_run])]
         for t in threads:
             t.start()
         for t in threads:

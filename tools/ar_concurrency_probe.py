@@ -34,12 +34,13 @@ def phase(lane, prep, out, i):
         bar.wait()
         t0 = time.perf_counter()
         run.advance(steps)
+        host[i] = (time.perf_counter() - t0) / steps * 1e6  # the enqueue alone (the launch thread's cost per frame)
         lane.model.stream.synchronize()
         out[i] = (time.perf_counter() - t0) / steps * 1e6
 
 
 def case(name, streams):
-    global bar
+    global bar, host
     n = len(streams)
     for l, s in zip(lanes, streams):
         l.model.stream = l.model.prep_stream = l.model.bulk_stream = s
@@ -47,13 +48,14 @@ def case(name, streams):
     res = []
     for rep in range(3):
         out = [0.0] * n
+        host = [0.0] * n
         bar = threading.Barrier(n)
         th = [threading.Thread(target=phase, args=(lanes[i], preps[i], out, i)) for i in range(n)]
         for t in th:
             t.start()
         for t in th:
             t.join()
-        res.append("/".join(f"{o:6.1f}" for o in out))
+        res.append("/".join(f"{o:6.1f}" for o in out) + " (host " + "/".join(f"{h:.0f}" for h in host) + ")")
     print(f"{name:44s} us/frame per phase: " + "   ".join(res), flush=True)
 
 
@@ -78,4 +80,7 @@ for n in (64, 96, 128):
     case(f"1 phase, {n}-CU partition", [M(0, n)])
     case(f"2 phases, one shared {n}-CU partition", [M(0, n), M(0, n)])
 case("2 phases, disjoint 64 + 64 CUs", [M(0, 64), M(64, 64)])
+case("2 phases: whole chip + 64-CU partition", [S(), M(0, 64)])
+case("2 phases: 64-CU partition + whole chip", [M(0, 64), S()])
+case("2 phases: whole chip + CUs 64..255", [S(), M(64, 192)])
 case("2 phases, disjoint 128 + 128 CUs", [M(0, 128), M(128, 128)])
