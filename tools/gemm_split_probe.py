@@ -21,6 +21,9 @@ if os.environ.get("PROBE_NOELU", "0") == "1":  # the activated-copy flow: the pr
     shapes = [(n, M, N, K, e, 0) for (n, M, N, K, e, p) in shapes]
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 3, 4, 5]
 lib = hip.load()
+if os.environ.get("PROBE_CUS"):  # time on a CU-masked stream (the throughput partition of the pipeline: PROBE_CUS=192)
+    n_cus = int(os.environ["PROBE_CUS"])
+    torch.cuda.set_stream(hip.cu_range_stream(256 - n_cus, n_cus, torch.device(DEV)))
 for name, M, N, K, epi, pro in shapes:
     g = torch.Generator(device=DEV).manual_seed(1)
     A = torch.randn(M, K, device=DEV, generator=g)
