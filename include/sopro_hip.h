@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 23
+#define SOPRO_ABI_VERSION 24
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -328,6 +328,15 @@ int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const float* w1,
 int sopro_seanet_res128_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2, const float* b2,
                             float* out, int64_t out_seg_stride, int32_t B, int32_t T, void* stream);
 int sopro_seanet_res_set_tiles(int tiles); /* developer probe / tests: 64-row tiles per workgroup, 0 = by size */
+/* Last transposed convolution of the SEANet decoder, ConvTranspose1d(128 -> 64, k = 8, s = 4) (HF:modeling_mimi.py:931-961),
+ * weight-stationary: out[b][t][0..255] = bias + W . [x[b][t] | x[b][t+1]], t < T, with x [B][>= 1 + T][128] the ACTIVATED input
+ * whose row 0 of every segment is the zero row in front of the first sample, W [256][256] = pack_convtr1d's matrix (row =
+ * output phase * 64 + channel, column = tap half * 128 + input channel), bias [256], out rows of 256 floats (= 4 output
+ * samples x 64 channels).  Same results as sopro_gemm_bf16x3 (passes = 3) / sopro_gemm_bf16x1 (passes = 1) on that shape, bit
+ * for bit; the weights are split once per workgroup and stay in registers. */
+int sopro_seanet_up128_f32(const float* x, int64_t x_seg_stride, const float* w, const float* bias, float* out,
+                           int64_t out_seg_stride, int32_t B, int32_t T, int32_t passes, void* stream);
+int sopro_seanet_up_set_tiles(int tiles); /* developer probe / tests: 64-row tiles per workgroup, 0 = by size */
 int sopro_seanet_tail_set_tiles(int tiles); /* developer probe / tests: 126-sample tiles per workgroup, 0 = by size */
 
 /* ---- autoregressive driver state ----------------------------------------------------------- */

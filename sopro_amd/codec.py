@@ -62,6 +62,8 @@ class MimiCodec:
         self._graphs = hip.GraphCache("mimi_graph", cap=32)  # recorded decode launch sequences per (B, T)
         self.fuse_tail = os.environ.get("SOPRO_UNFUSED_TAIL", "0") != "1"
         self.fuse_res = os.environ.get("SOPRO_UNFUSED_RES", "0") != "1"  # 128-channel residual block as one kernel
+        self.ws_up = os.environ.get("SOPRO_GEMM_UP", "0") != "1"  # last transposed convolution weight-stationary (seanet_up.hip)
+        self.passes = 1 if precision == "bf16" else 3
         # Decoder contractions run on the split-bf16 matrix-core path (16 mantissa bits per operand, fp32 accumulate:
         # waveform error ~1e-5 of peak, inside the 1e-4 contract); SOPRO_MIMI_F32=1 keeps them on the fp32 MFMA kernel.
         self.split_bf16 = os.environ.get("SOPRO_MIMI_F32", "0") != "1"
@@ -371,7 +373,11 @@ class MimiCodec:
                       a_off=(pad_in - 1) * ch, c_off=2 * co, c_seg_stride=(2 + orow) * co, ldc=r * co)
             if last:
                 # ConvTranspose1d -> raw fp32 only: the last stage runs in the fused tail (or on the fp32 kernels)
-                hip.gemm(He, gw(f"sea.up{si}.w"), Ho, **up)
+                if self.ws_up and ch == 128 and co == 64 and r == 4:  # weight-stationary form of this K = 256, N = 256 contraction
+                    hip.seanet_up128(He, w[f"sea.up{si}.w"], w[f"sea.up{si}.b"], Ho, B=B, T=rows, x_seg_stride=(pad_in + rows) * ch,
+                                     x_off=(pad_in - 1) * ch, out_seg_stride=(2 + orow) * co, out_off=2 * co, passes=self.passes)
+                else:
+                    hip.gemm(He, gw(f"sea.up{si}.w"), Ho, **up)
                 if self.fuse_tail and co == 64 and hid == 32 and int(mc.residual_kernel_size) == 3 and int(mc.last_kernel_size) == 3:
                     hip.seanet_tail(Ho, w[f"sea.res{si}.c1.w"], w[f"sea.res{si}.c1.b"], w[f"sea.res{si}.c2.w"], w[f"sea.res{si}.c2.b"],
                                     w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)

@@ -758,7 +758,10 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     const float* A = He + (size_t)(pad_in - 1) * ch;
     if (last) {
       SOPRO_CHECK_ARG(co == 64 && hid == 32, "the fused tail is written for a 64-channel last stage");
-      STG(gemm(s, A, e->w[u + ".w"], nullptr, Ho + 2 * co, up));
+      if (ch == 128 && r == 4)  // weight-stationary form of the K = 256, N = 256 contraction (same results)
+        STG(sopro_seanet_up128_f32(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), Ho + 2 * co, up.c_seg, B, rows, 3, s));
+      else
+        STG(gemm(s, A, e->w[u + ".w"], nullptr, Ho + 2 * co, up));
       return sopro_seanet_tail_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"),
                                    F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, orow, s);
     }

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -110,6 +110,8 @@ SYMBOLS = {
     "sopro_gemm_set_group_m": (C.c_int, [C.c_int]),
     "sopro_seanet_tail_set_tiles": (C.c_int, [C.c_int]),
     "sopro_seanet_res_set_tiles": (C.c_int, [C.c_int]),
+    "sopro_seanet_up_set_tiles": (C.c_int, [C.c_int]),
+    "sopro_seanet_up128_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_seanet_res128_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "sopro_gemm_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_pack_skinny_w": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
@@ -598,6 +600,13 @@ def seanet_res128(h: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch
     """Fused 128-channel residual block of the SEANet decoder + the next layer's ELU (sopro_seanet_res128_f32)."""
     _check(load().sopro_seanet_res128_f32(ptr(h), h_seg_stride, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(out), out_seg_stride, B, T,
                                           _stream()), "sopro_seanet_res128_f32")
+
+
+def seanet_up128(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, *, B: int, T: int, x_seg_stride: int,
+                 out_seg_stride: int, x_off: int = 0, out_off: int = 0, passes: int = 3) -> None:
+    """Weight-stationary last transposed convolution of the SEANet decoder (sopro_seanet_up128_f32); offsets in floats."""
+    _check(load().sopro_seanet_up128_f32(ptr(x) + 4 * x_off, x_seg_stride, ptr(w), ptr(bias), ptr(out) + 4 * out_off, out_seg_stride, B, T,
+                                         passes, _stream()), "sopro_seanet_up128_f32")
 
 
 def set_lds_floor(nbytes: int) -> None:

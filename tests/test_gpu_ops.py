@@ -741,6 +741,47 @@ def test_seanet_res128_fused_block_matches_the_layers():
         hip.seanet_res128(args[0], *args[1:], args[0], B=B, T=T, h_seg_stride=(2 + T + 5) * 128, out_seg_stride=(2 + T + 5) * 128)
 
 
+@pytest.mark.parametrize("passes", [3, 1])
+def test_seanet_up128_weight_stationary_equals_the_tile_kernel(passes):
+    """Last transposed convolution of SEANet (ConvTranspose1d 128 -> 64, k = 8, s = 4; HF:modeling_mimi.py:931-961) in its
+    weight-stationary form: against torch's conv_transpose1d, bit for bit against the generic split-bf16 tile kernel on the
+    same operands (three-pass and bf16-mode one-pass), for any number of tiles per workgroup, partial last tile, batch of 3,
+    segment strides larger than the rows in use."""
+    B, T, ci, co, r = 3, 333, 128, 64, 4
+    x = rnd(B, T, ci, seed=760)
+    wt, bt = rnd(ci, co, 2 * r, seed=761, scale=0.06), rnd(co, seed=762, scale=0.1)
+    ref = F.conv_transpose1d(x.transpose(1, 2), wt, bt, stride=r)[..., :T * r].transpose(1, 2)  # causal: trim the right tail
+    W, bias = pack.pack_convtr1d(wt, bt, r)  # [r*co, 2*ci], [r*co]
+    xs, os_ = (1 + T + 3) * ci, (2 + T * r + 7) * co
+    xb = torch.zeros(B, 1 + T + 3, ci)
+    xb[:, 1:1 + T] = x
+    xd, Wd, bd = dev(xb), dev(W), dev(bias)
+    lib, outs = hip.load(), []
+    try:
+        for tiles in (0, 1, 2, 5):
+            lib.sopro_seanet_up_set_tiles(tiles)
+            out = torch.full((B, 2 + T * r + 7, co), float("nan"), device=DEV)
+            hip.seanet_up128(xd, Wd, bd, out, B=B, T=T, x_seg_stride=xs, out_seg_stride=os_, out_off=2 * co, passes=passes)
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        lib.sopro_seanet_up_set_tiles(0)
+    got = outs[0][:, 2:2 + T * r]
+    close(got, ref, 1e-4 if passes == 3 else 2e-2, "weight-stationary transposed convolution")
+    assert bool(torch.isnan(outs[0][:, :2]).all()) and bool(torch.isnan(outs[0][:, 2 + T * r:]).all())  # nothing outside its rows
+    for o in outs[1:]:
+        assert torch.equal(o[:, 2:2 + T * r], got)
+    # the generic kernel on the same shape: row t of A = [x[t-1] | x[t]] (overlapping rows, lda = ci)
+    Wp = hip.pack_w_bf16x3(Wd) if passes == 3 else hip.pack_w_bf16x1(Wd)
+    out2 = torch.full((B, 2 + T * r + 7, co), float("nan"), device=DEV)
+    hip.gemm(xd, Wp, out2, M=B * T, N=r * co, K=2 * ci, lda=ci, bias=bd, rows_per_seg=T, a_seg_stride=xs, c_off=2 * co, c_seg_stride=os_,
+             ldc=r * co)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.cpu()[:, 2:2 + T * r], got)
+    with pytest.raises(hip.SoproHipError):
+        hip.seanet_up128(xd, Wd, bd, out2, B=B, T=T, x_seg_stride=xs, out_seg_stride=os_, passes=2)
+
+
 @pytest.mark.parametrize("N,K,glu", [(1536, 384, False), (384, 1536, False), (2049, 384, False), (768, 384, True)])
 def test_skinny_packed_weights_are_the_same_function(N, K, glu):
     """sopro_pack_skinny_w only changes where the kernel finds a weight: bit-identical outputs (ragged last tile, K slices, GLU tail)."""
