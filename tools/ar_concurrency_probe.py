@@ -21,7 +21,8 @@ tts, cfg, mc, wn, mn = build_engine("cuda:0")
 dev = tts.device
 ids, ref_tq = make_inputs(0)
 ref = tts.prepare_reference(ref_tokens_tq=ref_tq)
-lanes = [tts, tts.clone_lane()]
+NL = int(os.environ.get("PROBE_LANES", "2"))
+lanes = [tts] + [tts.clone_lane() for _ in range(NL - 1)]
 kw = dict(top_p=0.9, temperature=1.05, anti_loop=True)
 preps = [l.model.prepare_conditioning_batch(ids[:B], [ref] * B, max_frames=steps - 1) for l in lanes]
 torch.cuda.synchronize()
@@ -73,6 +74,10 @@ if len(sys.argv) > 3 and sys.argv[3] == "masks":
     for name, (mk, n) in layouts.items():
         case(f"1 phase, {n} CUs, {name}", [mk()])
         case(f"2 phases shared, {n} CUs, {name}", [mk(), mk()])
+    sys.exit(0)
+if NL > 2:  # PROBE_LANES=4 python tools/ar_concurrency_probe.py 16 200: more, smaller chains on the shared partition
+    for n in range(1, NL + 1):
+        case(f"{n} phases of {B} rows, one shared 64-CU partition", [M(0, 64) for _ in range(n)])
     sys.exit(0)
 case("1 phase, whole chip", [S()])
 case("2 phases, whole chip, ordinary streams", [S(), S()])
