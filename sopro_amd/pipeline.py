@@ -43,10 +43,14 @@ class PipelinedSynthesizer:
         self._saved = (tts.model.stream, tts.model.bulk_stream, tts.codec.stream, tts.model.prep_stream)
         self._streams = []
         bulk0 = n_ar
+        mk = lambda lo, n: hip.cu_range_stream(lo, n, self.device)  # noqa: E731
         for i in range(int(lanes)):
             lane = tts if i == 0 else tts.clone_lane()
-            lane.model.stream = hip.cu_range_stream(0 if ar_shared else (i % ar_parts) * ar_cus, ar_cus, self.device)
-            lane.model.bulk_stream = hip.cu_range_stream(bulk0, total - bulk0, self.device)
+            # (one stream set per lane, not per partition: sharing the AR stream of a lock, one refinement / decode stream and
+            # one conditioning stream between the lanes - 6 hardware queues instead of 12 - measured 31.3 against 29.5 ms per
+            # step: the conditioning of one lane then queues behind another lane's decode)
+            lane.model.stream = mk(0 if ar_shared else (i % ar_parts) * ar_cus, ar_cus)
+            lane.model.bulk_stream = mk(bulk0, total - bulk0)
             lane.model.prep_stream = lane.model.bulk_stream  # idle while this lane generates; GEMM-shaped preparation belongs there
             self._streams += [lane.model.stream, lane.model.bulk_stream]
             lane.codec.stream = lane.model.bulk_stream
@@ -59,8 +63,8 @@ class PipelinedSynthesizer:
         # These are CU-masked streams too (disjoint ranges): an ordinary stream generating beside a CU-masked one was
         # measured at 390-830 us per frame for both (tools/ar_concurrency_probe.py, "64-CU partition + whole chip"), while
         # two disjoint halves give the same 136 us per frame as two ordinary streams.
-        share = total // ar_parts
-        self._full = [hip.cu_range_stream((i % ar_parts) * share, share, self.device) for i in range(int(lanes))]
+        share = max(32, (total // ar_parts) // 32 * 32)  # whole multiples of 32 CUs (see the partition-size note in DESIGN.md)
+        self._full = [mk((i % ar_parts) * share, share) for i in range(int(lanes))]
         self._streams += self._full
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
         self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))

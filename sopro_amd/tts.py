@@ -136,13 +136,18 @@ class SoproTTS:
         ss = float(style_strength if style_strength is not None else self.cfg.style_strength)
         from .model import _PhaseTimer
 
+        # Every phase runs with ITS stream as the current one: stray torch ops (slices, clamps, allocations) are then queued where
+        # the phase's kernels are, and no phase ever waits on a stream another engine of a pipeline may be generating on.
+        self.model.prep_stream.wait_stream(torch.cuda.current_stream(self.device))  # the caller's inputs
         # conditioning needs no generation slot: it overlaps with whatever the other engines are doing
-        prep = self.model.phase_cond(ids, refs, max_frames=max_frames, style_strength=ss, ev=_PhaseTimer(self.model.prep_stream, timings))
-        with ar_lock:  # latency-bound phase: AR graph replay
+        with torch.cuda.stream(self.model.prep_stream):
+            prep = self.model.phase_cond(ids, refs, max_frames=max_frames, style_strength=ss, ev=_PhaseTimer(self.model.prep_stream, timings))
+        with ar_lock, torch.cuda.stream(self.model.stream):  # latency-bound phase: AR graph replay (a pipeline picks the stream with the lock)
             ev = _PhaseTimer(self.model.stream, timings)
             state = self.model.phase_ar(ids, refs, max_frames=max_frames, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
                                         style_strength=ss, min_gen_frames=min_gen_frames, ev=ev, prep=prep, seed=seed)
-        with bulk_lock:  # throughput-bound phase: NAR refinement + Mimi decode
+        # (the AR phase ends with its token history on the host side of a stream sync: the next phase needs no stream wait)
+        with bulk_lock, torch.cuda.stream(self.model.bulk_stream):  # throughput-bound phase: NAR refinement + Mimi decode
             t0 = time.perf_counter()
             full = self.model.phase_nar(state, full=True)  # [B, Tn, Q]
             t1 = time.perf_counter()
