@@ -28,6 +28,11 @@ ref = tts.prepare_reference(ref_tokens_tq=ref_tq)
 lanes = [tts, tts.clone_lane()]
 kw = dict(top_p=0.9, temperature=1.05, anti_loop=True)
 preps = [l.model.prepare_conditioning_batch(ids[:B], [ref] * B, max_frames=steps - 1) for l in lanes]
+if os.environ.get("PROBE_ALIAS") == "1":  # what would L2-hot weights buy? every block reads block 0's matrices (0.7 MB per XCD)
+    for l in lanes:
+        for i in range(1, 6):
+            for suf in (".glu.w", ".ff1.w", ".ff2.w"):
+                l.model.wk[f"ar.blocks.{i}{suf}"] = l.model.wk[f"ar.blocks.0{suf}"]
 for l in lanes:
     s = hip.cu_range_stream(0, 64, dev)
     l.model.stream = l.model.prep_stream = l.model.bulk_stream = s
