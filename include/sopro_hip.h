@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 24
+#define SOPRO_ABI_VERSION 25
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -56,6 +56,14 @@ int sopro_stream_create_cu_range(int first_cu, int n_cus, void** stream_out);
  * XCD), and whole-XCD partitions cannot be expressed. */
 int sopro_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream_out);
 int sopro_stream_destroy(void* stream);
+/* Page-locked host memory for the small device -> host mirrors a host loop polls (stop counters, slot snapshots), and the
+ * copy behind the launches queued so far on `stream` (the caller records an event after it and waits for that event).  The
+ * engine keeps these outside torch's pinned-memory cache: that cache remembers an event per stream a block was used on and
+ * queries it at the next pinned allocation - after the CU-masked stream was destroyed, or while another thread records a
+ * launch sequence (both seen as hipErrorCapturedEvent / hipErrorStreamCaptureUnsupported on ROCm 7.2). */
+int sopro_host_alloc(int64_t bytes, void** out);   /* zero-filled */
+int sopro_host_free(void* p);
+int sopro_copy_to_host_async(void* dst_host, const void* src_dev, int64_t bytes, void* stream);
 
 /* ---- dense contraction ------------------------------------------------------------------ */
 enum { SOPRO_PRO_NONE = 0, SOPRO_PRO_ELU = 1, SOPRO_PRO_ADDVEC = 2 };

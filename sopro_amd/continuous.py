@@ -206,7 +206,7 @@ class ContinuousSynthesizer:
         ss = float(rq["style_strength"] if rq.get("style_strength") is not None else cfg.style_strength)
         min_gen = int(rq["min_gen_frames"] if rq.get("min_gen_frames") is not None else cfg.min_gen_frames)
         prm = torch.tensor([float(rq.get("top_p", 0.9)), float(rq.get("temperature", 1.05)), 1.0 if rq.get("anti_loop", True) else 0.0,
-                            0.85, 1.2, 1.1, 50.0, float(min_gen)], dtype=torch.float32).pin_memory()
+                            0.85, 1.2, 1.1, 50.0, float(min_gen)], dtype=torch.float32)
         return {"ids": ids, "ref": rq["ref"], "mf": mf, "ss": ss, "prm": prm, "seed": rq.get("seed"), "future": Future()}
 
     def submit(self, **rq) -> "Future[torch.Tensor]":
@@ -293,10 +293,10 @@ class ContinuousSynthesizer:
                         plan.step()
                     slot_i = gen["snap_i"] = (gen.get("snap_i", 0) + 1) & 1
                     if "snap" not in gen:
-                        gen["snap"] = [torch.zeros(4, self.slots, dtype=torch.int32).pin_memory() for _ in range(2)]
+                        gen["snap"] = [hip.HostMirror(4 * self.slots) for _ in range(2)]
                         gen["snap_ev"] = [torch.cuda.Event() for _ in range(2)]
-                    snap = torch.stack([plan.start, plan.stop_t, plan.first_eos, plan.ctr[0:1].expand(self.slots)])
-                    gen["snap"][slot_i].copy_(snap, non_blocking=True)
+                    snap = torch.stack([plan.start, plan.stop_t, plan.first_eos, plan.ctr[0:1].expand(self.slots)]).contiguous()
+                    gen["snap"][slot_i].copy_from(snap.view(-1))
                     gen["snap_ev"][slot_i].record(st)
                     self.stats["frames"] += self.poll_every
                     self.stats["slot_frames_used"] += self.poll_every * len(active)
@@ -312,7 +312,8 @@ class ContinuousSynthesizer:
                     gen["have_prev"] = True
                     chunk += 1
                     gen["snap_ev"][look].synchronize()
-                    start, stop_t, first_eos, stepv = gen["snap"][look].tolist()
+                    flat = gen["snap"][look].values()
+                    start, stop_t, first_eos, stepv = (flat[i * self.slots:(i + 1) * self.slots] for i in range(4))
                     step = stepv[0]
                     # ---- harvest: EOS rule satisfied (model.py:301-305) or frame budget used up
                     done: List[Dict[str, Any]] = []

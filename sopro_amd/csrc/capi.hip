@@ -107,6 +107,24 @@ int sopro_stream_destroy(void* stream) {
   return 0;
 }
 
+int sopro_host_alloc(int64_t bytes, void** out) {
+  SOPRO_CHECK_ARG(bytes > 0 && out != nullptr, "bytes must be positive, out non-NULL");
+  SOPRO_HIP(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+  memset(*out, 0, (size_t)bytes);
+  return 0;
+}
+
+int sopro_host_free(void* p) {
+  if (p) SOPRO_HIP(hipHostFree(p));
+  return 0;
+}
+
+int sopro_copy_to_host_async(void* dst_host, const void* src_dev, int64_t bytes, void* stream) {
+  SOPRO_CHECK_ARG(dst_host && src_dev && bytes > 0, "NULL pointer or empty copy");
+  SOPRO_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+
 int sopro_graph_destroy(void* graph_exec) {
   if (graph_exec) SOPRO_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
   return 0;

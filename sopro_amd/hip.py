@@ -10,13 +10,14 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -91,6 +92,9 @@ class MimiStreamState(C.Structure):
 SYMBOLS = {
     "sopro_last_error": (C.c_char_p, []),
     "sopro_abi_version": (C.c_int, []),
+    "sopro_host_alloc": (C.c_int, [_i64, C.POINTER(_p)]),
+    "sopro_host_free": (C.c_int, [_p]),
+    "sopro_copy_to_host_async": (C.c_int, [_p, _p, _i64, _p]),
     "sopro_set_lds_floor": (C.c_int, [C.c_int]),
     "sopro_device_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "sopro_capture_begin": (C.c_int, [_p]),
@@ -691,14 +695,61 @@ class GraphCache:
         self.seen.clear()
 
 
+# A recording is thread-local (hipStreamCaptureModeThreadLocal), but the runtime still refused a pinned-host allocation made
+# by ANOTHER thread while one was open ("operation not permitted when stream is capturing", once in a few hundred pipelined
+# runs, when one lane recorded its launch sequence while another made its first poll buffer).  Recordings and pinned
+# allocations are rare and short: they take turns.
+_capture_lock = threading.RLock()
+
+
 def capture_begin() -> None:
-    _check(load().sopro_capture_begin(_stream()), "sopro_capture_begin")
+    _capture_lock.acquire()
+    try:
+        _check(load().sopro_capture_begin(_stream()), "sopro_capture_begin")
+    except BaseException:
+        _capture_lock.release()
+        raise
 
 
 def capture_end() -> Graph:
     out = _p()
-    _check(load().sopro_capture_end(_stream(), C.byref(out)), "sopro_capture_end")
+    try:
+        _check(load().sopro_capture_end(_stream(), C.byref(out)), "sopro_capture_end")
+    finally:
+        _capture_lock.release()
     return Graph(out.value)
+
+
+class HostMirror:
+    """``n`` int32 of page-locked host memory that a host loop polls: ``copy_from(t)`` queues the device -> host copy behind
+    the launches issued so far on the current stream (record an event after it and wait for that event before reading
+    ``values()``).  Outside torch's pinned-memory cache on purpose (see sopro_host_alloc)."""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+        out = _p()
+        with _capture_lock:  # no page-locked allocation while another thread records a launch sequence
+            _check(load().sopro_host_alloc(4 * self.n, C.byref(out)), "sopro_host_alloc")
+        self.ptr = out.value
+        self._view = (C.c_int32 * self.n).from_address(self.ptr)
+        self._keep = None
+
+    def copy_from(self, t: torch.Tensor) -> None:
+        if t.dtype != torch.int32 or not t.is_contiguous() or t.numel() != self.n or not t.is_cuda:
+            raise SoproHipError(f"HostMirror.copy_from: expected a contiguous device int32 tensor of {self.n} elements")
+        self._keep = t  # the source of a queued copy stays alive
+        _check(load().sopro_copy_to_host_async(self.ptr, t.data_ptr(), 4 * self.n, _stream()), "sopro_copy_to_host_async")
+
+    def values(self) -> list:
+        return list(self._view)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None) and _lib is not None:
+                _lib.sopro_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
 
 
 def cu_range_stream(first_cu: int, n_cus: int, device: Optional[torch.device] = None) -> "torch.cuda.Stream":

@@ -916,15 +916,15 @@ class _ARRun:
         with torch.cuda.stream(self.m.stream):
             slot = plan.poll_slot = (getattr(plan, "poll_slot", 0) + 1) & 1
             if not hasattr(plan, "poll_host"):
-                plan.poll_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+                plan.poll_host = [hip.HostMirror(1) for _ in range(2)]
                 plan.poll_ev = [torch.cuda.Event() for _ in range(2)]
             src = (plan.first_eos >= 0).sum().to(torch.int32).view(1) if first_eos else plan.ctr[2:3]
-            plan.poll_host[slot].copy_(src, non_blocking=True)
+            plan.poll_host[slot].copy_from(src)
             plan.poll_ev[slot].record(self.m.stream)
 
         def wait() -> int:
             plan.poll_ev[slot].synchronize()
-            return int(plan.poll_host[slot][0])
+            return int(plan.poll_host[slot].values()[0])
 
         return wait
 

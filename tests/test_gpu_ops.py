@@ -741,6 +741,25 @@ def test_seanet_res128_fused_block_matches_the_layers():
         hip.seanet_res128(args[0], *args[1:], args[0], B=B, T=T, h_seg_stride=(2 + T + 5) * 128, out_seg_stride=(2 + T + 5) * 128)
 
 
+def test_host_mirror_copies_behind_the_queued_launches():
+    """hip.HostMirror: page-locked int32 words outside torch's pinned-memory cache; the copy is ordered on the current stream."""
+    m = hip.HostMirror(6)
+    assert m.values() == [0] * 6
+    t = torch.arange(6, dtype=torch.int32, device=DEV)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        t2 = t * 7  # a launch the copy has to wait for
+        m.copy_from(t2)
+        ev = torch.cuda.Event()
+        ev.record(s)
+    ev.synchronize()
+    assert m.values() == [0, 7, 14, 21, 28, 35]
+    with pytest.raises(hip.SoproHipError):
+        m.copy_from(t[:5])
+    with pytest.raises(hip.SoproHipError):
+        m.copy_from(t.float())
+
+
 @pytest.mark.parametrize("passes", [3, 1])
 def test_seanet_up128_weight_stationary_equals_the_tile_kernel(passes):
     """Last transposed convolution of SEANet (ConvTranspose1d 128 -> 64, k = 8, s = 4; HF:modeling_mimi.py:931-961) in its

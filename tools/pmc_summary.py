@@ -24,7 +24,7 @@ def fam(name: str) -> str:
         return "gemm_bf16x6_kernel"
     if "attn_window_mfma_kernel" in name:
         return "attention_kernel"
-    for k in ("gemm_f32_kernel", "skinny_kernel", "xattn_step_kernel", "ar_sample_kernel", "seanet_tail_kernel", "seanet_res128_kernel",
+    for k in ("gemm_f32_kernel", "skinny_kernel", "xattn_step_kernel", "ar_sample_kernel", "seanet_tail_kernel", "seanet_res128_kernel", "seanet_up128_kernel",
               "attention_kernel", "argmax_partials_kernel"):
         if k in name:
             return k
