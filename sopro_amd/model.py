@@ -106,6 +106,7 @@ class SoproTTSModel:
         npos = int(cfg.pos_emb_max) + 8  # reference: src/sopro/model.py:62-64
         self.pe = sinusoid_table(npos, self.D).to(self.device)
         self.ws = Workspace(self.device)
+        self._ref_ws = Workspace(self.device)  # prepare_reference's scratch (see there)
         self.stream = torch.cuda.Stream(device=self.device)
         self.bulk_stream = self.stream  # throughput-bound phase (NAR); a pipeline may point it at another CU partition
         self.prep_stream = self.stream
@@ -170,6 +171,7 @@ class SoproTTSModel:
 
         other = copy.copy(self)
         other.ws = Workspace(self.device)
+        other._ref_ws = Workspace(self.device)
         other.stream = torch.cuda.Stream(device=self.device)
         other.bulk_stream = other.stream
         other.prep_stream = other.stream
@@ -216,9 +218,10 @@ class SoproTTSModel:
         return self.cfg.rf_nar()
 
     def _ssm_block_seq(self, x: torch.Tensor, out: torch.Tensor, p: str, *, B: int, T: int, ksize: int, dil: int,
-                       causal: bool, lens: Optional[torch.Tensor]) -> None:
+                       causal: bool, lens: Optional[torch.Tensor], ws: Optional[Workspace] = None) -> None:
         """Full-sequence SSMLiteBlock over dense [B*T, D] rows (reference: src/sopro/nn/blocks.py:143-148)."""
-        D, M, w, ws = self.D, B * T, self.w, self.ws
+        D, M, w = self.D, B * T, self.w
+        ws = ws if ws is not None else self.ws
         h = ws.get("ssm.h", (M, D))
         x1 = ws.get("ssm.x1", (M, D))
         u = ws.get("ssm.u", (M, 4 * D))
@@ -279,7 +282,8 @@ class SoproTTSModel:
             xb = torch.empty(T, D, device=dev)
             hip.codebook_sum(tok, self.Q, col, off, w["ref_cw"], w["cb_embed"], xa, rows=T, D=D)
             for i in range(int(cfg.ref_enc_layers)):
-                self._ssm_block_seq(xa, xb, f"ref_enc_blocks.{i}", B=1, T=T, ksize=7, dil=1, causal=False, lens=None)
+                # own scratch: a client thread may prepare a voice while a scheduler drives this engine's other streams
+                self._ssm_block_seq(xa, xb, f"ref_enc_blocks.{i}", B=1, T=T, ksize=7, dil=1, causal=False, lens=None, ws=self._ref_ws)
                 xa, xb = xb, xa
             ref_seq = torch.empty(1, T, D, device=dev)
             hip.norm(xa, ref_seq, w["ref_enc_norm.weight"], rows=T, C_=D, eps=RMS_EPS)
