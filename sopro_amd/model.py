@@ -446,15 +446,16 @@ class SoproTTSModel:
     def ar_generate_batch(self, cond_ar: torch.Tensor, txt_seq: torch.Tensor, text_lens: Optional[torch.Tensor], *,
                           max_frames: int, top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True,
                           min_gen_frames: Optional[int] = None, stop_on_first_eos: bool = False,
-                          poll_every: int = 16, seed: Optional[int] = None) -> Tuple[torch.Tensor, List[int]]:
+                          poll_every: int = 16, seed: Optional[int] = None, run: Optional["_ARRun"] = None) -> Tuple[torch.Tensor, List[int]]:
         """Run the AR loop for B rows until every row has stopped or max_frames+1 steps were taken
         (reference loop: src/sopro/model.py:218-305, one row).  Returns (hist [B, steps] int32 on the
         device, per-row frame counts T_b following generate_tokens' cut at the FIRST EOS, model.py:385-390)."""
         B, Tar, _ = cond_ar.shape
         if Tar != int(max_frames) + 1:
             raise ValueError("cond_ar must have max_frames+1 rows")
-        run = _ARRun(self, cond_ar, txt_seq, text_lens, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-                     min_gen_frames=min_gen_frames, seed=seed)
+        if run is None:
+            run = _ARRun(self, cond_ar, txt_seq, text_lens, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
+                         min_gen_frames=min_gen_frames, seed=seed)
         # The stop poll trails the launches by one chunk: chunk k+1 is enqueued before the host looks at chunk k's counter, so
         # the GPU never waits for the host round trip (rows that have stopped are masked on the device; the extra frames of
         # a batch that turns out to be finished are discarded below).
@@ -649,14 +650,22 @@ class SoproTTSModel:
             ev.mark("cond")
         return prep
 
+    @torch.inference_mode()
+    def ar_prepare(self, prep, *, top_p, temperature, anti_loop, min_gen_frames, seed=None) -> "_ARRun":
+        """The per-batch preparation of the AR phase (plan buffers, folded text operands of the cross-attention layers: ~30
+        GEMM-shaped launches on the preparation stream).  Needs no generation slot: a scheduler calls it while the batch waits
+        for one and hands the run to phase_ar, so the slot only ever replays frames."""
+        return _ARRun(self, prep["cond_ar"], prep["txt_seq"], prep["text_lens"], top_p=top_p, temperature=temperature,
+                      anti_loop=anti_loop, min_gen_frames=min_gen_frames, seed=seed)
+
     def phase_ar(self, ids_list, refs, *, max_frames, top_p, temperature, anti_loop, style_strength, min_gen_frames, ev=None,
-                 prep=None, seed=None):
+                 prep=None, seed=None, run=None):
         """Latency-bound half of generate_tokens_batch: (conditioning +) the AR graph replay."""
         if prep is None:
             prep = self.phase_cond(ids_list, refs, max_frames=max_frames, style_strength=style_strength, ev=ev)
         hist, lens = self.ar_generate_batch(prep["cond_ar"], prep["txt_seq"], prep["text_lens"], max_frames=max_frames,
                                             top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-                                            min_gen_frames=min_gen_frames, seed=seed)
+                                            min_gen_frames=min_gen_frames, seed=seed, run=run)
         if ev is not None:
             ev.mark("ar")
         return {"cond_ar": prep["cond_ar"], "hist": hist, "lens": lens, "B": len(ids_list)}
@@ -898,10 +907,18 @@ class _ARRun:
             nonce = m.next_nonce(seed)
             plan.nonce.fill_(nonce - (1 << 32) if nonce >= (1 << 31) else nonce)  # the uint32 bit pattern in an int32 tensor
             hip.ar_init(plan.state)
-        m.stream.wait_stream(m.prep_stream)
         plan.ensure_graph()
+        self._started = False  # the first advance() orders the generation stream behind this preparation
+
+    def _start(self) -> None:
+        # here, not in __init__: a scheduler prepares the run OUTSIDE its generation slot and picks the generation stream with
+        # the slot (the engine's own stream or a pipeline-fill stream)
+        self.m.stream.wait_stream(self.m.prep_stream)
+        self._started = True
 
     def advance(self, n: int) -> None:
+        if not self._started:
+            self._start()
         with torch.cuda.stream(self.m.stream):
             for _ in range(int(n)):
                 self.plan.step()

@@ -141,11 +141,17 @@ class SoproTTS:
         self.model.prep_stream.wait_stream(torch.cuda.current_stream(self.device))  # the caller's inputs
         # conditioning needs no generation slot: it overlaps with whatever the other engines are doing
         with torch.cuda.stream(self.model.prep_stream):
-            prep = self.model.phase_cond(ids, refs, max_frames=max_frames, style_strength=ss, ev=_PhaseTimer(self.model.prep_stream, timings))
+            ev = _PhaseTimer(self.model.prep_stream, timings)
+            prep = self.model.phase_cond(ids, refs, max_frames=max_frames, style_strength=ss)
+            # the AR phase's own preparation (plan buffers, folded text operands) belongs here too: the generation slot then
+            # only replays frames (it sat idle for 2-3.5 ms per phase while this ran inside it)
+            run = self.model.ar_prepare(prep, top_p=top_p, temperature=temperature, anti_loop=anti_loop, min_gen_frames=min_gen_frames,
+                                        seed=seed)
+            ev.mark("cond")
         with ar_lock, torch.cuda.stream(self.model.stream):  # latency-bound phase: AR graph replay (a pipeline picks the stream with the lock)
             ev = _PhaseTimer(self.model.stream, timings)
             state = self.model.phase_ar(ids, refs, max_frames=max_frames, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-                                        style_strength=ss, min_gen_frames=min_gen_frames, ev=ev, prep=prep, seed=seed)
+                                        style_strength=ss, min_gen_frames=min_gen_frames, ev=ev, prep=prep, seed=seed, run=run)
         # (the AR phase ends with its token history on the host side of a stream sync: the next phase needs no stream wait)
         with bulk_lock, torch.cuda.stream(self.model.bulk_stream):  # throughput-bound phase: NAR refinement + Mimi decode
             t0 = time.perf_counter()
