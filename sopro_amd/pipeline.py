@@ -127,11 +127,11 @@ class PipelinedSynthesizer:
         nxt = [0]
         pick = threading.Lock()
 
-        # An empty pipeline has nothing on the throughput partition yet, so the FIRST AR phase of each partition lock may use
-        # the whole chip (the recorded frame graph replays on any stream): 141 instead of 270 us per frame, which shortens
-        # the fill of the pipeline.  Which phase that is gets decided when the lock is TAKEN, not by job index: a whole-chip
-        # phase that lost the race for its lock and then ran beside a partition-bound one was measured at 400-750 us per
-        # frame for both (profiles/r02_experiments.md, "start-up race") - the slow mode of one bench run in three.
+        # An empty pipeline has nothing on the throughput partition yet, so the FIRST AR phase of each partition lock runs on its
+        # share of the whole chip (`self._full`: 136 instead of 255-270 us per frame), which shortens the fill of the pipeline.
+        # Which phase that is gets decided when the lock is TAKEN, not by job index: a fill phase that lost the race for its
+        # lock and then ran beside a partition-bound one was measured at 400-750 us per frame for both
+        # (profiles/r02_experiments.md, "start-up race") - the slow mode of one bench run in three.
         ar_started = [0] * self.ar_parts
         ar_finished = [0]
 
