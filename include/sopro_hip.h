@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 25
+#define SOPRO_ABI_VERSION 26
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -47,6 +47,9 @@ int sopro_device_info(int device, int* out4);
 int sopro_capture_begin(void* stream);
 int sopro_capture_end(void* stream, void** graph_exec_out);
 int sopro_graph_launch(void* graph_exec, void* stream);
+/* n replays back to back in one call: a host whose launch thread shares an interpreter lock with other threads (the Python
+ * host: ctypes drops the lock for the duration of a call) queues a whole chunk of AR frames without taking it n times. */
+int sopro_graph_launch_n(void* graph_exec, void* stream, int32_t n);
 int sopro_graph_destroy(void* graph_exec);
 /* stream restricted to CUs [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask); destroy with sopro_stream_destroy */
 int sopro_stream_create_cu_range(int first_cu, int n_cus, void** stream_out);

@@ -69,6 +69,12 @@ int sopro_graph_launch(void* graph_exec, void* stream) {
   return 0;
 }
 
+int sopro_graph_launch_n(void* graph_exec, void* stream, int32_t n) {
+  SOPRO_CHECK_ARG(graph_exec != nullptr && n >= 0, "graph is NULL or n < 0");
+  for (int32_t i = 0; i < n; ++i) SOPRO_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return 0;
+}
+
 /* A HIP stream whose kernels may only use CUs [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask): lets a
  * latency-bound launch sequence keep a slice of the chip while a throughput-bound phase runs on the rest. */
 int sopro_stream_create_cu_range(int first_cu, int n_cus, void** stream_out) {

@@ -65,7 +65,7 @@ def export_packed(weights: Dict[str, np.ndarray], mimi_weights: Dict[str, np.nda
             table.append({"name": name, "dtype": "f32" if a.dtype == np.float32 else "i32", "shape": list(a.shape), "offset": off})
             f.write(a.tobytes(order="C"))
             off += a.nbytes
-    meta = {"cfg": ecfg, "tensors": table, "bytes": off, "abi_version": 25}
+    meta = {"cfg": ecfg, "tensors": table, "bytes": off, "abi_version": 26}
     with open(out_prefix + ".json", "w") as f:
         json.dump(meta, f)
     return meta

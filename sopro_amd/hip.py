@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -92,6 +92,7 @@ class MimiStreamState(C.Structure):
 SYMBOLS = {
     "sopro_last_error": (C.c_char_p, []),
     "sopro_abi_version": (C.c_int, []),
+    "sopro_graph_launch_n": (C.c_int, [_p, _p, _i32]),
     "sopro_host_alloc": (C.c_int, [_i64, C.POINTER(_p)]),
     "sopro_host_free": (C.c_int, [_p]),
     "sopro_copy_to_host_async": (C.c_int, [_p, _p, _i64, _p]),
@@ -642,6 +643,14 @@ class Graph:
         _check(load().sopro_graph_launch(self.handle, _stream()), "sopro_graph_launch")
         if e0 is not None:
             _prof.end(self.family, 0.0, e0)
+
+    def launch_n(self, n: int) -> None:
+        """n replays back to back (one call: the interpreter lock is dropped once for all of them)."""
+        if _prof is not None:
+            for _ in range(int(n)):
+                self.launch()
+            return
+        _check(load().sopro_graph_launch_n(self.handle, _stream(), int(n)), "sopro_graph_launch_n")
 
     def __del__(self):
         try:

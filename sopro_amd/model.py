@@ -920,8 +920,11 @@ class _ARRun:
         if not self._started:
             self._start()
         with torch.cuda.stream(self.m.stream):
-            for _ in range(int(n)):
-                self.plan.step()
+            if self.m.use_graph:
+                self.plan.graph.launch_n(int(n))  # one call for the whole chunk of frames
+            else:
+                for _ in range(int(n)):
+                    self.plan.step()
 
     def n_stopped(self, first_eos: bool = False) -> int:
         with torch.cuda.stream(self.m.stream):
