@@ -289,8 +289,7 @@ class ContinuousSynthesizer:
                     # ---- a chunk of frames for every slot, then a snapshot of the slot states behind it.  The host looks at
                     # the snapshot of the PREVIOUS chunk (the GPU never waits for the round trip) and prepares the next
                     # utterances while the frames run; a finished row idles one chunk more before it is harvested.
-                    for _ in range(self.poll_every):
-                        plan.step()
+                    plan.steps(self.poll_every)
                     slot_i = gen["snap_i"] = (gen.get("snap_i", 0) + 1) & 1
                     if "snap" not in gen:
                         gen["snap"] = [hip.HostMirror(4 * self.slots) for _ in range(2)]

@@ -854,6 +854,14 @@ class _ARPlan:
         else:
             self.issue_step()
 
+    def steps(self, n: int) -> None:
+        """n frames on the current stream; with the recorded frame graph that is ONE call into the library."""
+        if self.m.use_graph:
+            self.graph.launch_n(int(n))
+        else:
+            for _ in range(int(n)):
+                self.issue_step()
+
 
 class _ARRun:
     """One batch of utterances being generated on a plan."""
@@ -920,11 +928,7 @@ class _ARRun:
         if not self._started:
             self._start()
         with torch.cuda.stream(self.m.stream):
-            if self.m.use_graph:
-                self.plan.graph.launch_n(int(n))  # one call for the whole chunk of frames
-            else:
-                for _ in range(int(n)):
-                    self.plan.step()
+            self.plan.steps(n)  # one call for the whole chunk of frames
 
     def n_stopped(self, first_eos: bool = False) -> int:
         with torch.cuda.stream(self.m.stream):

@@ -145,7 +145,8 @@ class PipelinedSynthesizer:
                 with pick:
                     first = ar_started[slot.part] == 0 and ar_finished[0] == 0
                     ar_started[slot.part] += 1
-                if first and not self.unpartitioned:
+                slot.fill = first and not self.unpartitioned
+                if slot.fill:
                     slot.lane.model.stream = self._full[slot.lane_idx]
 
             def __exit__(slot, *exc):
@@ -176,12 +177,15 @@ class PipelinedSynthesizer:
                             for k, v in tj.items():
                                 timings[k] = timings.get(k, 0.0) + v
                             self.trace.append((i, lane_idx, t_job - t_run, time.perf_counter() - t_run, tj))
+                    with pick:
+                        self.fill_jobs += [i] if getattr(ar_lock, "fill", False) else []
 
         n_run = max(1, min(len(self.lanes), len(jobs)))
         import sys
         import time
 
         self.trace = []  # (job, lane, start s, end s, per-phase seconds) of the last timed run: who was slow, and when
+        self.fill_jobs = []  # jobs whose AR phase ran on a pipeline-fill stream (at most one per partition lock and run)
         t_run = time.perf_counter()
 
         swi = sys.getswitchinterval()

@@ -279,6 +279,36 @@ def test_two_lane_pipeline_equals_sequential(tts, ref_prep):
             assert torch.equal(x, y), "pipelined result differs from the sequential path"
 
 
+def test_four_lanes_two_generation_slots_fill_streams_and_order(tts, ref_prep):
+    """The bench configuration in small (4 lanes, two AR phases at a time on one shared partition): results equal the sequential
+    path in job order, run after run, and the pipeline-fill streams (a share of the whole chip for the FIRST phase of each
+    generation slot) go to at most one phase per slot and run - whichever lane takes the slot first, not job 0 / 1."""
+    from sopro_amd.pipeline import PipelinedSynthesizer
+
+    _, ref, _ = ref_prep
+    rng = np.random.default_rng(52)
+    jobs = []
+    for j in range(7):
+        ids = [torch.from_numpy(rng.integers(0, 512, size=n)) for n in (7 + j, 12, 5, 9)]
+        jobs.append(dict(texts=[""] * 4, refs=[ref] * 4, text_ids=ids, max_frames=10 + (j % 3), top_p=0.0, temperature=1.0, anti_loop=False,
+                         style_strength=1.0))
+    seq = [tts.synthesize_batch(**j) for j in jobs]
+    pipe = PipelinedSynthesizer(tts, lanes=4, ar_cus=64, ar_parts=2, ar_shared=True)
+    try:
+        for _ in range(3):
+            par = pipe.run(jobs)
+            assert 1 <= len(pipe.fill_jobs) <= 2, pipe.fill_jobs
+            for a, b in zip(seq, par):
+                for x, y in zip(a, b):
+                    assert torch.equal(x, y), "pipelined result differs from the sequential path"
+    finally:
+        pipe.close()
+    again = [tts.synthesize_batch(**j) for j in jobs[:2]]  # the caller's engine got its own streams back
+    for a, b in zip(seq, again):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_full_size_properties_32x200(tts, cfg, sopro_np, mimi_np):
     """BASELINE config 2 size: determinism, batch invariance, causal-prefix property of the decoder."""
     from sopro_amd import SoproTTS
