@@ -284,7 +284,11 @@ def main() -> None:
                 fence()
                 log(f"trace repeat {rep}: {time.perf_counter() - t1:.3f} s")
             for i, lane, a, b, tj in sorted(pipe.trace):
-                log(f"  step {i:3d} lane {lane} {a * 1e3:8.1f} -> {b * 1e3:8.1f} ms  " + " ".join(f"{k}={v * 1e3:.1f}" for k, v in tj.items()))
+                log(f"  step {i:3d} lane {lane} {a * 1e3:8.1f} -> {b * 1e3:8.1f} ms  " + " ".join(f"{k}={v * 1e3:.1f}" for k, v in tj.items() if not k.startswith("_")))
+            bl = sorted((tj["_bulk_t0"], tj["_bulk_t1"]) for *_x, tj in pipe.trace if "_bulk_t0" in tj)
+            gaps = [(b0 - a1) * 1e3 for (_a0, a1), (b0, _b1) in zip(bl, bl[1:])]
+            if gaps:
+                log("  refinement + decode slot idle between batches (host clock, ms): " + " ".join(f"{g:.2f}" for g in gaps))
     ar_log, hip.phase_log = hip.phase_log, None
     ar_frames = sum(n for n, _b, _e0, _e1 in ar_log)
     ar_ms = sum(e0.elapsed_time(e1) for _n, _b, e0, e1 in ar_log)

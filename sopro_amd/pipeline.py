@@ -175,7 +175,8 @@ class PipelinedSynthesizer:
                     if tj is not None:
                         with pick:
                             for k, v in tj.items():
-                                timings[k] = timings.get(k, 0.0) + v
+                                if not k.startswith("_"):  # "_..." = absolute time stamps for the trace, not phase sums
+                                    timings[k] = timings.get(k, 0.0) + v
                             self.trace.append((i, lane_idx, t_job - t_run, time.perf_counter() - t_run, tj))
                     with pick:
                         self.fill_jobs += [i] if getattr(ar_lock, "fill", False) else []

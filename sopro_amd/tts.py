@@ -155,6 +155,8 @@ class SoproTTS:
         # (the AR phase ends with its token history on the host side of a stream sync: the next phase needs no stream wait)
         with bulk_lock, torch.cuda.stream(self.model.bulk_stream):  # throughput-bound phase: NAR refinement + Mimi decode
             t0 = time.perf_counter()
+            if timings is not None:
+                timings["_bulk_t0"] = t0
             full = self.model.phase_nar(state, full=True)  # [B, Tn, Q]
             t1 = time.perf_counter()
             lens = [int(n) for n in state["lens"]]
@@ -168,6 +170,7 @@ class SoproTTS:
             if timings is not None:
                 timings["nar"] = timings.get("nar", 0.0) + (t1 - t0)
                 timings["mimi"] = timings.get("mimi", 0.0) + (time.perf_counter() - t1)
+                timings["_bulk_t1"] = time.perf_counter()
         hop = int(self.codec.mc.frame_samples)
         return [wav[b, : lens[b] * hop].reshape(1, 1, -1) for b in range(B)]
 
