@@ -289,6 +289,10 @@ def main() -> None:
             gaps = [(b0 - a1) * 1e3 for (_a0, a1), (b0, _b1) in zip(bl, bl[1:])]
             if gaps:
                 log("  refinement + decode slot idle between batches (host clock, ms): " + " ".join(f"{g:.2f}" for g in gaps))
+            for part in range(args.ar_parts):  # lane i generates in slot i % ar_parts
+                al = sorted((tj["_ar_t0"], tj["_ar_t1"]) for _i, lane, _a, _b, tj in pipe.trace if "_ar_t0" in tj and lane % args.ar_parts == part)
+                g2 = [(b0 - a1) * 1e3 for (_a0, a1), (b0, _b1) in zip(al, al[1:])]
+                log(f"  generation slot {part} idle between phases (host clock, ms): " + " ".join(f"{g:.2f}" for g in g2))
     ar_log, hip.phase_log = hip.phase_log, None
     ar_frames = sum(n for n, _b, _e0, _e1 in ar_log)
     ar_ms = sum(e0.elapsed_time(e1) for _n, _b, e0, e1 in ar_log)

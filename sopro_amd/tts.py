@@ -150,8 +150,12 @@ class SoproTTS:
             ev.mark("cond")
         with ar_lock, torch.cuda.stream(self.model.stream):  # latency-bound phase: AR graph replay (a pipeline picks the stream with the lock)
             ev = _PhaseTimer(self.model.stream, timings)
+            if timings is not None:
+                timings["_ar_t0"] = time.perf_counter()
             state = self.model.phase_ar(ids, refs, max_frames=max_frames, top_p=top_p, temperature=temperature, anti_loop=anti_loop,
                                         style_strength=ss, min_gen_frames=min_gen_frames, ev=ev, prep=prep, seed=seed, run=run)
+            if timings is not None:
+                timings["_ar_t1"] = time.perf_counter()
         # (the AR phase ends with its token history on the host side of a stream sync: the next phase needs no stream wait)
         with bulk_lock, torch.cuda.stream(self.model.bulk_stream):  # throughput-bound phase: NAR refinement + Mimi decode
             t0 = time.perf_counter()
