@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 26
+#define SOPRO_ABI_VERSION 27
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -193,6 +193,9 @@ typedef struct sopro_skinny_args {
   int32_t w_layout;       /* 0: W is [N, ldw] row-major; 1: W was laid out by sopro_pack_skinny_w (ldw unused);
                            * 2: bf16 weights from sopro_pack_skinny_w_bf16 (the engine's bf16 mode: activations are rounded to
                            *    bf16 as MFMA operands, v_mfma_f32_16x16x32_bf16 with fp32 accumulation) */
+  int32_t mt, nt;         /* workgroup shape: mt 16-row groups of the batch x nt column tiles (0 or 1 = one; 2 = two).  1 x 1 has
+                           * the most workgroups and the shortest latency; 2 x 2 reads the weights once per 32 rows and halves the
+                           * activation re-reads (throughput form for a small CU partition).  Results are bit-identical. */
 } sopro_skinny_args;
 int sopro_skinny_f32(const sopro_skinny_args* args, void* stream);
 /* Fragment order for the AR-step weights: [column tile][K/32][2][64 lanes][4 floats] - lane (i = lane & 15, g = lane >> 4) of
@@ -359,13 +362,14 @@ typedef struct sopro_ar_state {
   const float* emb;        /* cb_embed.emb.weight [Q*V+1, D] */
   int32_t* hist;           /* [bcap, max_steps] sampled tokens */
   int32_t* step;           /* scalar: current frame index t */
-  int32_t* arrive;         /* scalar ticket */
+  int32_t* row_step;       /* [bcap] per-row copy of the frame index (each sampler workgroup reads and advances its own: no
+                            * ticket, no fence; *step follows row 0 and is read by the NEXT frame's kernels only) */
   int32_t* first_eos;      /* [bcap] first t with tok == EOS, -1 if none */
   int32_t* stop_t;         /* [bcap] first t with tok == EOS and t+1 >= min_gen, -1 if none */
   int32_t* n_stopped;      /* scalar: rows with stop_t >= 0 */
   int32_t* recent;         /* [bcap, 64] rolling window: slot j = token sampled j+1 frames ago, -1 = none */
   const float* params;     /* [8] top_p, temperature, anti_loop, rec_top_p, rec_temperature, rep_penalty, top_k, min_gen */
-  uint64_t seed;
+  uint64_t seed;           /* Philox key when `key` is NULL (frozen into a recorded frame graph: prefer `key`) */
   int32_t B, D, Tar, max_steps, V /* 2048, EOS id == V */, bos_row;
   /* Slot mode (continuous batching; all three NULL = every row starts at frame 0 with the shared params): */
   int32_t* start;          /* [bcap] global frame at which the row was admitted, -1 = free slot; row time = step - start */
@@ -375,6 +379,8 @@ typedef struct sopro_ar_state {
    * admission so that two calls with the same text do not reuse one uniform sequence (the reference draws from torch's
    * global generator, which advances between calls).  NULL = 0.  Device memory, so a recorded frame graph sees updates. */
   const uint32_t* nonce;   /* [bcap] */
+  const uint32_t* key;     /* [2] Philox key (seed low, high word) in device memory, so that ONE recorded frame graph serves every
+                            * seed; NULL = the by-value `seed` above */
   long long* dbg;          /* optional [bcap][12] shader-clock stamps of the sampler's phases (profiling aid), NULL in production */
 } sopro_ar_state;
 /* zero-step initialisation: step=0, flags reset, x_cur[b] = cond[b,0] + emb[bos_row]  (model.py:266-272) */
@@ -386,6 +392,42 @@ int sopro_ar_sample(const sopro_ar_state* st, const float* logits, int64_t ld_lo
  * window reset, start[row] = *step.  The caller has already written the row's cond block, its cross-attention operands
  * and zeroed its ring-buffer columns, all on the same stream. */
 int sopro_ar_admit(const sopro_ar_state* st, int32_t row, void* stream);
+
+/* ---- one autoregressive frame as ONE call --------------------------------------------------------------
+ * The launch sequence of a frame (6 x [GLU tail, FF1, FF2 (+ text cross-attention)] + head + sampler == ARRVQ1Generator.step,
+ * src/sopro/nn/generator.py:98-130, followed by sample_token, src/sopro/sampling.py:24-93) over caller-owned buffers.  Both
+ * hosts of this library use it (sopro_amd/model.py inside its stream capture; sopro_ar_run_graph below), so the sequence
+ * exists once.  Weights are the fragment-ordered images of sopro_pack_skinny_w (w_layout 1) or _bf16 (w_layout 2), RMSNorm
+ * weights folded in.  tile_*: workgroup shape of the stage kind, (mt << 4) | nt as in sopro_skinny_args (0 = 1 x 1). */
+#define SOPRO_AR_MAX_LAYERS 16
+typedef struct sopro_ar_block {
+  const void* glu_w; const float* glu_b; const float* dw_w; const float* dw_b;
+  const void* ff1_w; const float* ff1_b;
+  const void* ff2_w; const float* ff2_b;
+  float* ring;             /* [(ksize-1)*dil + 1, B, D] */
+  const float* kp;         /* xattn != 0: folded text operands [B, H, S_cap, D] (src/sopro/nn/text.py:75-83 x q_proj / out_proj) */
+  const float* vp;
+  int32_t dil, xattn;
+  float gate;              /* tanh(gate) of the cross-attention block (text.py:131) */
+  int32_t pad_;
+} sopro_ar_block;
+typedef struct sopro_ar_frame {
+  sopro_ar_block blk[SOPRO_AR_MAX_LAYERS];
+  const void* head_w; const float* head_b;
+  float* x0;               /* [B, D] input of the frame == st.x_cur */
+  float* xa; float* xb;    /* [B, D] residual stream (alternating) */
+  float* part;             /* [4, B, D] K-slice partial sums of FF2 */
+  float* u;                /* [B, 4D] */
+  float* xp;               /* [H, B, D] per-head outputs of a cross-attention block */
+  float* logits;           /* [B, V1] */
+  const int32_t* klens;    /* [B] text lengths */
+  int32_t n_layers, B, D, S_cap, V1, H, ksize, w_layout;
+  int32_t tile_glu, tile_ff1, tile_ff2, tile_head;
+  float eps;
+  int32_t pad_;
+  sopro_ar_state st;
+} sopro_ar_frame;
+int sopro_ar_issue_frame(const sopro_ar_frame* frame, void* stream);
 
 /* ==========================================================================================================
  * Stage-level entry points: the launch SEQUENCES of the hot path as C functions, so that a host that is not
@@ -427,6 +469,8 @@ int sopro_engine_set_tensor(sopro_engine* e, const char* name, const void* dev_p
 /* checks that every tensor the three stages need is present and builds the packed operand forms (allocates device memory) */
 int sopro_engine_finalize(sopro_engine* e, void* stream);
 int sopro_engine_destroy(sopro_engine* e);
+/* workgroup shapes of the AR-step stage kinds, (mt << 4) | nt each (see sopro_skinny_args; 0 = 1 x 1).  Drops a recorded frame graph. */
+int sopro_engine_set_ar_tiles(sopro_engine* e, int32_t glu, int32_t ff1, int32_t ff2, int32_t head);
 
 /* ---- autoregressive stage.  S_cap = S rounded up to 64.  The workspace must stay alive (and untouched) until the tokens
  * have been read; one generation at a time per engine. */

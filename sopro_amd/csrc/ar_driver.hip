@@ -3,6 +3,8 @@
 // frame is a fixed launch sequence with no host round trip (the reference synchronises the host
 // several times per frame in sample_token, src/sopro/sampling.py:64-93) and can be replayed
 // from a hipGraph.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -42,7 +44,8 @@ __global__ void ar_init_kernel(const sopro_ar_state st) {
     st.stop_t[b] = -1;
     for (int j = 0; j < 64; ++j) st.recent[(int64_t)b * 64 + j] = -1;
     if (st.start) st.start[b] = -1;  // slot mode: every slot starts free
-    if (b == 0) { *st.step = 0; *st.arrive = 0; *st.n_stopped = 0; }
+    st.row_step[b] = 0;
+    if (b == 0) { *st.step = 0; *st.n_stopped = 0; }
   }
 }
 
@@ -89,27 +92,35 @@ __device__ __forceinline__ unsigned wave_nth_largest_u32(unsigned v, int n) {
 
 constexpr int RECENT = 64;   // rolling token window per row: slot j = token sampled j+1 frames ago (-1 = none)
 constexpr int PER = 9;       // logits per thread: ceil(2049 / 256), element q*256 + tid
-constexpr int MAXCAND = PER * SAMP_THREADS;
-constexpr int PAIRED = 128;  // candidates handled two threads apiece by the all-pairs stage
+constexpr int WREG = PER * 64;             // candidate slots of one wave's region (every logit of the wave may qualify)
+constexpr int MAXCAND = 4 * WREG;
+constexpr int FAST = 128;    // candidates the register all-pairs stage ranks (two per lane)
 
 // sample_token (src/sopro/sampling.py:24-93) + the loop policy of src/sopro/model.py:274-305 for one row per workgroup.
 // Nothing is sorted.  What the reference does with sort / top-k / cumsum is done with counting:
 //   * top-k: every wave takes the ceil(kk/4)-th largest of its 64 per-thread maxima (32 ballot steps); the smallest of the
 //     four is a lower bound of the kk-th largest logit, so "logit >= bound" keeps a superset of the top kk (~1.4 kk
-//     entries), compacted with ballots;
-//   * an all-pairs pass gives every candidate its exact rank and the probability mass ahead of it (two threads per
-//     candidate) - i.e. its place in the sorted order and the cumulative sum the top-p rule needs - and the top kk land
-//     in rank order in one wave, which renormalises, cuts and draws with two wave reductions and two ballots.
-// Wave reductions run on the DPP path; five workgroup barriers in all (two of them only when a penalty applies).
+//     entries).  Every wave compacts its own into its own LDS region in (q, lane) order: positions do not depend on
+//     which wave gets there first (same seed -> same draw, bit for bit);
+//   * an all-pairs pass gives every candidate its exact rank and the probability mass ahead of it - i.e. its place in the
+//     sorted order and the cumulative sum the top-p rule needs.  Round 3: the candidates sit two per lane in registers of
+//     EVERY wave and wave w broadcasts candidates 32w .. 32w+31 with v_readlane (no LDS traffic, no dependent LDS
+//     latencies); the four partial (rank, mass) pairs meet through LDS in wave order.  The top kk then land in rank order
+//     in wave 0, which renormalises, cuts and draws with two wave reductions and two ballots.
+// The repetition penalty needs no workgroup-wide bitmap: every wave holds the token window in its lanes and marks the
+// entries that name its own threads' logits in 64 words of LDS.  Three workgroup barriers (one when decoding greedily).
+// Frame bookkeeping without a ticket: row b keeps its own frame counter (row_step[b]); *step - read by the ring-buffer
+// kernels of the NEXT frame only, i.e. behind a kernel boundary - is advanced by row 0's workgroup.
 __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_state st, const float* __restrict__ logits,
                                                                  int64_t ld) {
-  __shared__ unsigned pen_bits[68];
   __shared__ u64 cand_k[MAXCAND];
   __shared__ float cand_e[MAXCAND];
+  __shared__ int p_rank[4 * FAST];
+  __shared__ float p_ahead[4 * FAST];
   __shared__ u64 selk[64];
   __shared__ float sele[64], selb[64];
-  __shared__ unsigned w_thr[4], w_best_v[4], w_best_i[4];
-  __shared__ unsigned sh_cnt;
+  __shared__ unsigned w_thr[4], w_best_v[4], w_best_i[4], w_cnt[4];
+  __shared__ unsigned pen_bits[4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const int V1 = st.V + 1;
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   // ---- the only up-front memory round: frame index, policy parameters, this row's logits, its recent tokens
   // Classic mode: every row started at global frame 0.  Slot mode (st.start != NULL, continuous batching): row b was
   // admitted at global frame start[b] (-1 = free slot) with its own frame budget and parameters; its time is local.
-  const int tg = *st.step;
+  const int tg = st.row_step[b];
   const int s0 = st.start ? st.start[b] : 0;
   const int t = tg - s0;
   const int tmax = (st.start && st.row_max) ? st.row_max[b] : st.Tar;
@@ -129,6 +140,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   const float p_rec_t = prm[4], rep = prm[5];
   const int top_k = (int)prm[6], min_gen = (int)prm[7];
   const unsigned nonce = st.nonce ? st.nonce[b] : 0u;
+  const unsigned long long seed = st.key ? ((unsigned long long)st.key[0] | ((unsigned long long)st.key[1] << 32)) : st.seed;
   const float* lg = logits + (int64_t)b * ld;
   float xv[PER];
 #pragma unroll
@@ -140,14 +152,10 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   const int r_mine = recent[lane];  // every wave holds the window: lane j = token sampled j+1 frames ago
   if (!st.start && tg >= st.max_steps) return;  // classic mode, uniform over the grid: the loop is over
   if (st.start && (s0 < 0 || t >= min(tmax, st.max_steps))) {
-    // free slot, or a row past its budget waiting to be harvested: nothing to sample, but the frame still needs its ticket
+    // free slot, or a row past its budget waiting to be harvested: nothing to sample, the frame still ticks
     if (tid == 0) {
-      __threadfence();
-      const int old = atomicAdd(st.arrive, 1);
-      if (old == st.B - 1) {
-        *st.arrive = 0;
-        *st.step = tg + 1;
-      }
+      st.row_step[b] = tg + 1;
+      if (b == 0) *st.step = tg + 1;
     }
     return;
   }
@@ -159,7 +167,6 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
     for (int q = 0; q < 8; ++q)
       if (q * 64 + lane < st.D) cnext[q] = c[q * 64 + lane];
   }
-  if (tid == 0) sh_cnt = 0u;
 
   // ---- anti-loop policy (src/sopro/model.py:274-279, sampling.py:16-21): repeated tail of length 3..16, or 9 equal
   // tokens; evaluated by every wave on its own copy of the window (wave-uniform result, no exchange)
@@ -190,22 +197,18 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
     if (temp != 0.f && temp != 1.0f) v = v / temp;
     xv[q] = v;
   }
-  // ---- repetition penalty on the unique ids among the last 50 tokens (sampling.py:40-50).  Wave 0 marks the ids in a 2049-bit
-  // LDS bitmap (duplicates collapse by themselves; LDS executes one wave's operations in issue order, so its clears precede
-  // its ORs), every thread then tests the bits of its own nine logits: one barrier, no value round trip.
-  const bool in_win = lane < 50 && r_mine >= 0 && r_mine < V1;
-  if (rep != 1.0f && __ballot(in_win) != 0ull) {  // workgroup-uniform: every wave sees the same window
-    if (wave == 0) {
-      pen_bits[lane] = 0u;
-      if (lane < 4) pen_bits[64 + lane] = 0u;
-      if (in_win) atomicOr(&pen_bits[r_mine >> 5], 1u << (r_mine & 31));
-    }
-    __syncthreads();
+  // ---- repetition penalty on the unique ids among the last 50 tokens (sampling.py:40-50).  Token tok is logit (tok >> 8) of
+  // thread (tok & 255): lanes holding a window entry of THIS wave's threads mark it in the wave's own 64 words of LDS
+  // (duplicates OR the same bit; one wave's LDS operations execute in issue order: clear, mark, read - no barrier)
+  if (rep != 1.0f) {
+    const bool in_win = lane < 50 && r_mine >= 0 && r_mine < V1;
+    unsigned* mine = pen_bits + wave * 64;
+    mine[lane] = 0u;
+    if (in_win && ((r_mine >> 6) & 3) == wave) atomicOr(&mine[r_mine & 63], 1u << (r_mine >> 8));
+    const unsigned pm = mine[lane];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int i = q * SAMP_THREADS + tid;
-      if (i < V1 && ((pen_bits[i >> 5] >> (i & 31)) & 1u)) xv[q] = xv[q] < 0.f ? xv[q] * rep : xv[q] / rep;
-    }
+    for (int q = 0; q < PER; ++q)
+      if ((pm >> q) & 1u) xv[q] = xv[q] < 0.f ? xv[q] * rep : xv[q] / rep;
   }
 
   SAMP_STAMP(2);
@@ -256,66 +259,87 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
       if (q * 64 + lane < st.D) espec[q] = e[q * 64 + lane];
   }
   if (sampling) {
-    // ---- candidates: every logit >= thr (at least kk of them), with exp(x - max) next to the key
+    // ---- candidates: every logit >= thr (at least kk of them), with exp(x - max) next to the key; wave w fills its own
+    // region [w * WREG, ...) in (q, lane) order
     const float xmax = unord_f32(best_v);
-    int nc = 0;
-    u64 masks[PER];
+    {
+      const u64 lt = (1ull << lane) - 1ull;
+      unsigned pos = (unsigned)(wave * WREG);
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      masks[q] = __ballot((q * SAMP_THREADS + tid < V1) && ov[q] >= thr);
-      nc += __popcll(masks[q]);
-    }
-    unsigned base = 0u;
-    if (lane == 0 && nc > 0) base = atomicAdd(&sh_cnt, (unsigned)nc);
-    base = __builtin_amdgcn_readfirstlane(base);
-    const u64 lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      if ((masks[q] >> lane) & 1ull) {
-        const unsigned pos = base + (unsigned)__popcll(masks[q] & lt);
-        cand_k[pos] = ((u64)ov[q] << 12) | (u64)(4095 - (q * SAMP_THREADS + tid));
-        cand_e[pos] = expf(xv[q] - xmax);
+      for (int q = 0; q < PER; ++q) {
+        const u64 m = __ballot((q * SAMP_THREADS + tid < V1) && ov[q] >= thr);
+        if ((m >> lane) & 1ull) {
+          const unsigned at = pos + (unsigned)__popcll(m & lt);
+          cand_k[at] = ((u64)ov[q] << 12) | (u64)(4095 - (q * SAMP_THREADS + tid));
+          cand_e[at] = expf(xv[q] - xmax);
+        }
+        pos += (unsigned)__popcll(m);
       }
-      base += (unsigned)__popcll(masks[q]);
+      if (lane == 0) w_cnt[wave] = pos - (unsigned)(wave * WREG);
     }
     __syncthreads();
     SAMP_STAMP(4);
-    const int C = (int)sh_cnt;
-    // ---- all pairs: rank (entries ahead) and unnormalised mass ahead of every candidate
-    if (C <= PAIRED) {
-      const int c = tid >> 1, half = tid & 1;
-      const int j0 = half ? (C >> 1) : 0, nj = half ? C - (C >> 1) : (C >> 1);  // nj <= 64
-      const u64 kc = c < C ? cand_k[c] : ~0ull;
-      int rank = 0;
-      float ahead = 0.f;
+    const int c0 = (int)w_cnt[0], c1 = c0 + (int)w_cnt[1], c2 = c1 + (int)w_cnt[2], C = c2 + (int)w_cnt[3];
+    // candidate c of the concatenated order lives at region slot:
+    auto slot_of = [&](int c) { return c < c0 ? c : (c < c1 ? WREG + (c - c0) : (c < c2 ? 2 * WREG + (c - c1) : 3 * WREG + (c - c2))); };
+    if (C <= FAST) {
+      // ---- all pairs in registers: lane l of every wave holds candidates l and l + 64; wave w broadcasts 32w .. 32w + 31
+      const int ca = lane, cb = lane + 64;
+      const u64 ka = ca < C ? cand_k[slot_of(ca)] : 0ull, kb = cb < C ? cand_k[slot_of(cb)] : 0ull;   // 0 sorts below every real key
+      const float ea = ca < C ? cand_e[slot_of(ca)] : 0.f, eb = cb < C ? cand_e[slot_of(cb)] : 0.f;
+      const unsigned src_lo = (wave & 2) ? (unsigned)kb : (unsigned)ka, src_hi = (wave & 2) ? (unsigned)(kb >> 32) : (unsigned)(ka >> 32);
+      const float src_e = (wave & 2) ? eb : ea;
+      int ra = 0, rb = 0;
+      float aa = 0.f, ab = 0.f;
+      // (the broadcast lane of v_readlane is an immediate: one unrolled copy of the loop per 32-lane half)
+      auto pairs = [&](auto half) {
+        constexpr int H0 = decltype(half)::value * 32;
 #pragma unroll
-      for (int j = 0; j < PAIRED / 2; ++j) {  // fixed trip count: fully unrolled, every LDS broadcast issued ahead of its use
-        const int jj = min(j0 + j, C - 1);
-        const u64 kj = cand_k[jj];
-        const float ej = cand_e[jj];
-        const bool gt = j < nj && kj > kc;
-        rank += gt ? 1 : 0;
-        ahead += gt ? ej : 0.f;
+        for (int j = 0; j < 32; ++j) {
+          const unsigned lo = __builtin_amdgcn_readlane(src_lo, H0 + j), hi = __builtin_amdgcn_readlane(src_hi, H0 + j);
+          const float ej = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(src_e), H0 + j));
+          const u64 kj = ((u64)hi << 32) | lo;
+          const bool ga = kj > ka, gb = kj > kb;
+          ra += ga ? 1 : 0; aa += ga ? ej : 0.f;
+          rb += gb ? 1 : 0; ab += gb ? ej : 0.f;
+        }
+      };
+      if (__builtin_amdgcn_readfirstlane(wave) & 1) pairs(std::integral_constant<int, 1>{});
+      else pairs(std::integral_constant<int, 0>{});
+      p_rank[wave * FAST + ca] = ra; p_rank[wave * FAST + cb] = rb;
+      p_ahead[wave * FAST + ca] = aa; p_ahead[wave * FAST + cb] = ab;
+      __syncthreads();
+      SAMP_STAMP(5);
+      if (wave != 0) return;
+      {
+        const int rka = ((p_rank[ca] + p_rank[FAST + ca]) + p_rank[2 * FAST + ca]) + p_rank[3 * FAST + ca];
+        const int rkb = ((p_rank[cb] + p_rank[FAST + cb]) + p_rank[2 * FAST + cb]) + p_rank[3 * FAST + cb];
+        const float aha = ((p_ahead[ca] + p_ahead[FAST + ca]) + p_ahead[2 * FAST + ca]) + p_ahead[3 * FAST + ca];
+        const float ahb = ((p_ahead[cb] + p_ahead[FAST + cb]) + p_ahead[2 * FAST + cb]) + p_ahead[3 * FAST + cb];
+        if (ca < C && rka < kk) { selk[rka] = ka; sele[rka] = ea; selb[rka] = aha; }
+        if (cb < C && rkb < kk) { selk[rkb] = kb; sele[rkb] = eb; selb[rkb] = ahb; }
       }
-      rank += __shfl_xor(rank, 1, 64);
-      ahead += __shfl_xor(ahead, 1, 64);
-      if (half == 0 && c < C && rank < kk) { selk[rank] = kc; sele[rank] = cand_e[c]; selb[rank] = ahead; }
+      // one wave wrote, the same wave reads: LDS executes a wave's operations in issue order (no barrier - the other waves are gone)
+      __builtin_amdgcn_wave_barrier();
     } else {
+      // ---- many ties at the bound (degenerate logits): the same ranks from LDS, any number of candidates
       for (int c = tid; c < C; c += SAMP_THREADS) {
-        const u64 kc = cand_k[c];
+        const u64 kc = cand_k[slot_of(c)];
         int rank = 0;
         float ahead = 0.f;
         for (int j = 0; j < C; ++j) {
-          const bool gt = cand_k[j] > kc;
+          const int sj = slot_of(j);
+          const bool gt = cand_k[sj] > kc;
           rank += gt ? 1 : 0;
-          ahead += gt ? cand_e[j] : 0.f;
+          ahead += gt ? cand_e[sj] : 0.f;
         }
-        if (rank < kk) { selk[rank] = kc; sele[rank] = cand_e[c]; selb[rank] = ahead; }
+        if (rank < kk) { selk[rank] = kc; sele[rank] = cand_e[slot_of(c)]; selb[rank] = ahead; }
       }
+      __syncthreads();
+      SAMP_STAMP(5);
+      if (wave != 0) return;
     }
-    __syncthreads();
-    SAMP_STAMP(5);
-    if (wave == 0) {
+    {
       // top-k renormalisation, top-p cut and the draw (sampling.py:56-93): lane j owns sorted entry j.  The softmax
       // denominator cancels in the renormalisation: p_j / sum_topk p = e_j / sum_topk e  (and sum_topk p >= 1/2049, so
       // the reference's "mass <= 1e-12 -> arg-max" fallback cannot trigger on finite logits).
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
       const bool keep = lane < kk && (lane == 0 || !(top_p < 1.0f && before > top_p));
       const float kept = wave_sum_dpp(keep ? pj : 0.f);
       if (kept > 1e-12f) {
-        const float u = philox_uniform(st.seed, (unsigned)t, (unsigned)b, nonce) * kept;
+        const float u = philox_uniform(seed, (unsigned)t, (unsigned)b, nonce) * kept;
         const u64 hit = __ballot(keep && u < before + pj);
         const u64 kmask = __ballot(keep);
         const int pick = hit ? (int)__ffsll((long long)hit) - 1 : 63 - __clzll((long long)kmask);
@@ -364,19 +388,13 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
         atomicAdd(st.n_stopped, 1);
       }
     }
-  }
-  SAMP_STAMP(8);
-  // every lane's stores of this row are released before the row's ticket
-  __threadfence();
-  SAMP_STAMP(9);
-  if (lane == 0) {
-    const int old = atomicAdd(st.arrive, 1);
-    if (old == st.B - 1) {
-      *st.arrive = 0;
-      *st.step = tg + 1;
-    }
+    // this row's frame counter; the global one (ring-buffer slots of the next frame's kernels) follows row 0.  Plain
+    // stores: the next reader is behind a kernel boundary.
+    st.row_step[b] = tg + 1;
+    if (b == 0) *st.step = tg + 1;
     if (dbg) dbg[10] = clock64();
   }
+  SAMP_STAMP(8);
 #undef SAMP_STAMP
 }
 
@@ -399,7 +417,7 @@ extern "C" {
 
 static int check_state(const sopro_ar_state* st) {
   SOPRO_CHECK_ARG(st != nullptr, "state is NULL");
-  SOPRO_CHECK_ARG(st->x_cur && st->cond && st->emb && st->hist && st->step && st->arrive && st->first_eos && st->stop_t &&
+  SOPRO_CHECK_ARG(st->x_cur && st->cond && st->emb && st->hist && st->step && st->row_step && st->first_eos && st->stop_t &&
                       st->n_stopped && st->params && st->recent,
                   "state has NULL pointers");
   SOPRO_CHECK_ARG(st->B > 0 && st->D > 0 && st->Tar > 0 && st->max_steps > 0 && st->V > 0 && st->V + 1 <= 2049 && st->D <= 512,

@@ -41,15 +41,23 @@ __device__ __forceinline__ unsigned cvt2_bf16(float x, float y) {
 // frame's dominant stream), the staged activations are rounded to bf16 as they leave LDS, and a 32-wide K chunk is ONE
 // v_mfma_f32_16x16x32_bf16 (fp32 accumulate) instead of eight exact-fp32 MFMAs.  Norm statistics, biases, the ring buffer,
 // the taps and the residual stay fp32.
-template <bool GLU, int NP, bool NORM, bool WB>
+//
+// MT x NT (round 3): one workgroup owns MT 16-row groups of the batch and NT 16-column tiles (NT 8-channel tiles in the GLU
+// form).  A wave's weight fragments (registers) serve all MT row groups and its activation fragments (LDS) all NT column
+// tiles, so a workgroup ingests 16*NT weight rows + 16*MT activation rows for MT*NT output tiles.  1 x 1 is the latency form
+// (most workgroups, least bytes per workgroup: one frame alone on the whole chip); 2 x 2 halves both the weight bytes and
+// the activation re-reads of a 32-row batch, which is what bounds two frames sharing a 64-CU partition (a CU ingests
+// ~17-23 B/clk however many workgroups ask: profiles/r03_experiments.md).  Same arithmetic per output element in every form
+// (same K order inside a wave, same cross-wave order), so the forms are bit-identical to each other.
+template <bool GLU, int NP, bool NORM, bool WB, int MT, int NT>
 __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) {
-  __shared__ float xs[16 * XLD];          // raw (combined) input slice
-  __shared__ float red[4 * 4 * 64];
-  __shared__ float rstd_s[16];
+  __shared__ float xs[16 * MT * XLD];          // raw (combined) input slice
+  __shared__ float red[MT * NT * 4 * 4 * 64];
+  __shared__ float rstd_s[16 * MT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int ntile = blockIdx.x;
-  const int bbase = blockIdx.z * 16;
+  const int tile0 = blockIdx.x * NT;
+  const int bbase = blockIdx.z * 16 * MT;
   const int nslices = a.K / KS;
   const bool partial_out = gridDim.y > 1;
   const int D = a.N / 2;  // GLU tail only
@@ -60,94 +68,130 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
   int t_now = 0;
   if (GLU) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t_now) : "s"(a.step) : "memory");
 
-  // Column owned by this lane.  Plain: 16 output columns per workgroup.  GLU tail: 8 channels per workgroup, lanes
-  // 0-7 carry the value rows and lanes 8-15 the gate rows of the same channels (one B operand, paired by a shuffle).
+  // Columns owned by this lane.  Plain: 16 output columns per tile.  GLU tail: 8 channels per tile, lanes 0-7 carry the
+  // value rows and lanes 8-15 the gate rows of the same channels (one B operand, paired by a shuffle).
   const int ncols = GLU ? D : a.N;
-  const int n_col = GLU ? ntile * 8 + (i & 7) : ntile * 16 + i;
-  const bool col_ok = n_col < ncols && (!GLU || i < 8);
-  const int n_ld = min(n_col, ncols - 1);  // clamped: loads stay in bounds, results are discarded
-  const int w_row = GLU ? ((i < 8) ? n_ld : D + n_ld) : n_ld;
+  const int ntiles = GLU ? (D + 7) / 8 : (a.N + 15) / 16;
+  int n_col[NT], n_ld[NT], w_row[NT];
+  bool col_ok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int tile = tile0 + nt;
+    n_col[nt] = GLU ? tile * 8 + (i & 7) : tile * 16 + i;
+    col_ok[nt] = n_col[nt] < ncols && (!GLU || i < 8);
+    n_ld[nt] = min(n_col[nt], ncols - 1);  // clamped: loads stay in bounds, results are discarded
+    w_row[nt] = GLU ? ((i < 8) ? n_ld[nt] : D + n_ld[nt]) : n_ld[nt];
+  }
   const bool res_here = a.epilogue == SOPRO_EPI_RES && (!partial_out || blockIdx.y == 0);
   const bool bias_here = !partial_out || (blockIdx.y == 0 && a.epilogue == SOPRO_EPI_RES);
 
-  // ---- epilogue operands: wave w finishes accumulator row r == w, i.e. batch row bbase + (lane>>4)*4 + w, column lane&15
-  const int b_row = bbase + g * 4 + wave;
-  const int b_cl = min(b_row, a.B - 1);
-  float e_bias = 0.f, e_scale = 1.f, e_dwb = 0.f, e_res = 0.f;
-  float tapw[MAXTAPS];
-  if (a.bias && bias_here) e_bias = a.bias[w_row];
-  if (a.scale) e_scale = a.scale[n_ld];
-  if (res_here) e_res = a.R[(int64_t)b_cl * a.ldr + n_ld];
-  if (GLU) {
-    e_dwb = a.dw_b[n_ld];
+  // ---- epilogue operands: wave w finishes accumulator row r == w, i.e. batch row bbase + mt*16 + (lane>>4)*4 + w, column lane&15
+  int b_row[MT], b_cl[MT];
 #pragma unroll
-    for (int j = 0; j < MAXTAPS; ++j) {
-      // slots 0..11: weights of the older taps (0 beyond ksize-1), slot 12: weight of the newest tap
-      const float wv = a.dw_w[(int64_t)min(j, a.ksize - 1) * D + n_ld];
-      tapw[j] = (j == MAXTAPS - 1 || j < a.ksize - 1) ? wv : 0.f;
+  for (int mt = 0; mt < MT; ++mt) {
+    b_row[mt] = bbase + mt * 16 + g * 4 + wave;
+    b_cl[mt] = min(b_row[mt], a.B - 1);
+  }
+  float e_bias[NT], e_scale[NT], e_dwb[NT], e_res[MT][NT];
+  float tapw[NT][MAXTAPS];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    e_bias[nt] = (a.bias && bias_here) ? a.bias[w_row[nt]] : 0.f;
+    e_scale[nt] = a.scale ? a.scale[n_ld[nt]] : 1.f;
+    e_dwb[nt] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) e_res[mt][nt] = res_here ? a.R[(int64_t)b_cl[mt] * a.ldr + n_ld[nt]] : 0.f;
+    if (GLU) {
+      e_dwb[nt] = a.dw_b[n_ld[nt]];
+#pragma unroll
+      for (int j = 0; j < MAXTAPS; ++j) {
+        // slots 0..11: weights of the older taps (0 beyond ksize-1), slot 12: weight of the newest tap
+        const float wv = a.dw_w[(int64_t)min(j, a.ksize - 1) * D + n_ld[nt]];
+        tapw[nt][j] = (j == MAXTAPS - 1 || j < a.ksize - 1) ? wv : 0.f;
+      }
     }
   }
 
   // weight fragment addresses: row-major rows of W, or the fragment order of sopro_pack_skinny_w (1 KiB per load instruction)
   const bool packed = a.w_layout == 1;
   const int kchunks = a.K >> 5;
-  const float* wbase = packed ? a.W + ((int64_t)ntile * kchunks * 2) * 256 + lane * 4 : a.W + (int64_t)w_row * a.ldw + g * 8;
+  const float* wbase[NT];
+  const uint4* wbase16[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int tile_ld = min(tile0 + nt, ntiles - 1);
+    wbase[nt] = packed ? a.W + ((int64_t)tile_ld * kchunks * 2) * 256 + lane * 4 : a.W + (int64_t)w_row[nt] * a.ldw + g * 8;
+    wbase16[nt] = reinterpret_cast<const uint4*>(a.W) + (int64_t)tile_ld * kchunks * 64 + lane;  // WB: [tile][chunk][lane] x 16 B
+  }
   const int64_t w_chunk = packed ? 512 : 32, w_half = packed ? 256 : 4;
-  const uint4* wbase16 = reinterpret_cast<const uint4*>(a.W) + (int64_t)ntile * kchunks * 64 + lane;  // WB: [tile][chunk][lane] x 16 B
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int srow = tid >> 4, spart = tid & 15;  // staging: row, float4 column within each 64-float group
-  const int b_ld = min(bbase + srow, a.B - 1);
+  const int srow = tid >> 4, spart = tid & 15;  // staging: row within a 16-row group, float4 column within each 64-float group
   unsigned slot0 = 0;  // ring slot of the oldest tap, (t + 1) mod L: one division, then increments
-  float tapv[MAXTAPS - 1];
+  float tapv[MT][NT][MAXTAPS - 1];
 
   for (int ks = blockIdx.y; ks < nslices; ks += gridDim.y) {
     const int k0 = ks * KS;
-    // ---- all weight fragments of this slice for this wave (3 chunks x 2 float4)
-    float4 wf[3][2];
-    uint4 wh[3];
+    // ---- all weight fragments of this slice for this wave (3 chunks x 2 float4 per column tile)
+    float4 wf[NT][3][2];
+    uint4 wh[NT][3];
 #pragma unroll
-    for (int cc = 0; cc < 3; ++cc) {
-      if constexpr (WB) {
-        wh[cc] = wbase16[(int64_t)((k0 >> 5) + wave * 3 + cc) * 64];
-      } else {
-        const float* wp = wbase + (int64_t)((k0 >> 5) + wave * 3 + cc) * w_chunk;
-        wf[cc][0] = *reinterpret_cast<const float4*>(wp);
-        wf[cc][1] = *reinterpret_cast<const float4*>(wp + w_half);
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        if constexpr (WB) {
+          wh[nt][cc] = wbase16[nt][(int64_t)((k0 >> 5) + wave * 3 + cc) * 64];
+        } else {
+          const float* wp = wbase[nt] + (int64_t)((k0 >> 5) + wave * 3 + cc) * w_chunk;
+          wf[nt][cc][0] = *reinterpret_cast<const float4*>(wp);
+          wf[nt][cc][1] = *reinterpret_cast<const float4*>(wp + w_half);
+        }
       }
-    }
     // ---- input slice (+ producer's partial sums, fixed order) -> LDS
     {
-      float4 xv[SQ], pv[NP > 0 ? NP : 1][SQ];
-      // lane-contiguous: float4 q*16 + spart of the row, so that the 16 lanes of a row cover whole 128-byte lines per instruction
-      const float* xp = a.X + (int64_t)b_ld * a.ldx + k0 + spart * 4;
+      float4 xv[MT][SQ], pv[MT][NP > 0 ? NP : 1][SQ];
 #pragma unroll
-      for (int q = 0; q < SQ; ++q) xv[q] = *reinterpret_cast<const float4*>(xp + q * 64);
+      for (int mt = 0; mt < MT; ++mt) {
+        const int b_ld = min(bbase + mt * 16 + srow, a.B - 1);
+        // lane-contiguous: float4 q*16 + spart of the row, so that the 16 lanes of a row cover whole 128-byte lines per instruction
+        const float* xp = a.X + (int64_t)b_ld * a.ldx + k0 + spart * 4;
 #pragma unroll
-      for (int sidx = 0; sidx < NP; ++sidx) {
-        const float* pp = a.Xp + (int64_t)sidx * a.xp_stride + (int64_t)b_ld * a.ldx + k0 + spart * 4;
+        for (int q = 0; q < SQ; ++q) xv[mt][q] = *reinterpret_cast<const float4*>(xp + q * 64);
 #pragma unroll
-        for (int q = 0; q < SQ; ++q) pv[sidx][q] = *reinterpret_cast<const float4*>(pp + q * 64);
-      }
+        for (int sidx = 0; sidx < NP; ++sidx) {
+          const float* pp = a.Xp + (int64_t)sidx * a.xp_stride + (int64_t)b_ld * a.ldx + k0 + spart * 4;
 #pragma unroll
-      for (int sidx = 0; sidx < NP; ++sidx)
-#pragma unroll
-        for (int q = 0; q < SQ; ++q) {
-          xv[q].x += pv[sidx][q].x; xv[q].y += pv[sidx][q].y; xv[q].z += pv[sidx][q].z; xv[q].w += pv[sidx][q].w;
+          for (int q = 0; q < SQ; ++q) pv[mt][sidx][q] = *reinterpret_cast<const float4*>(pp + q * 64);
         }
-      if (NORM) {
-        float ss = 0.f;
-#pragma unroll
-        for (int q = 0; q < SQ; ++q) ss += xv[q].x * xv[q].x + xv[q].y * xv[q].y + xv[q].z * xv[q].z + xv[q].w * xv[q].w;
-        ss += __shfl_xor(ss, 1, 64);
-        ss += __shfl_xor(ss, 2, 64);
-        ss += __shfl_xor(ss, 4, 64);
-        ss += __shfl_xor(ss, 8, 64);
-        if (spart == 0) rstd_s[srow] = rsqrtf(ss / (float)KS + a.eps);
       }
-      float* dst = xs + srow * XLD + spart * 4;
 #pragma unroll
-      for (int q = 0; q < SQ; ++q) *reinterpret_cast<float4*>(dst + q * 64) = xv[q];
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int sidx = 0; sidx < NP; ++sidx)
+#pragma unroll
+          for (int q = 0; q < SQ; ++q) {
+            xv[mt][q].x += pv[mt][sidx][q].x; xv[mt][q].y += pv[mt][sidx][q].y;
+            xv[mt][q].z += pv[mt][sidx][q].z; xv[mt][q].w += pv[mt][sidx][q].w;
+          }
+        if (NORM) {
+          float ss = 0.f;
+#pragma unroll
+          for (int q = 0; q < SQ; ++q)
+            ss += xv[mt][q].x * xv[mt][q].x + xv[mt][q].y * xv[mt][q].y + xv[mt][q].z * xv[mt][q].z + xv[mt][q].w * xv[mt][q].w;
+          ss += __shfl_xor(ss, 1, 64);
+          ss += __shfl_xor(ss, 2, 64);
+          ss += __shfl_xor(ss, 4, 64);
+          ss += __shfl_xor(ss, 8, 64);
+          if (spart == 0) rstd_s[mt * 16 + srow] = rsqrtf(ss / (float)KS + a.eps);
+        }
+        float* dst = xs + (mt * 16 + srow) * XLD + spart * 4;
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) *reinterpret_cast<float4*>(dst + q * 64) = xv[mt][q];
+      }
     }
     // ---- ring-buffer taps of earlier frames: addresses need the frame index; values are used in the epilogue
     if (GLU) {
@@ -157,7 +201,10 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
       unsigned slot = slot0;
 #pragma unroll
       for (int j = 0; j < MAXTAPS - 1; ++j) {
-        tapv[j] = a.ring[((int64_t)slot * a.ring_bcap + b_cl) * D + n_ld];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) tapv[mt][nt][j] = a.ring[((int64_t)slot * a.ring_bcap + b_cl[mt]) * D + n_ld[nt]];
         slot += (unsigned)a.dil;
         if (slot >= L) slot -= L;
       }
@@ -165,25 +212,36 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
     if (dbg && tid == 0) dbg[1] = clock64();
     __syncthreads();
     if (dbg && tid == 0) dbg[2] = clock64();
-    // ---- MFMA over this wave's 3 chunks
+    // ---- MFMA over this wave's 3 chunks: A fragments (LDS) serve NT column tiles, B fragments (registers) MT row groups
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc) {
       const int kl = (wave * 3 + cc) * 32 + g * 8;
-      const float4 x0 = *reinterpret_cast<const float4*>(xs + i * XLD + kl);
-      const float4 x1 = *reinterpret_cast<const float4*>(xs + i * XLD + kl + 4);
-      if constexpr (WB) {
-        const uint4 xa = make_uint4(cvt2_bf16(x0.x, x0.y), cvt2_bf16(x0.z, x0.w), cvt2_bf16(x1.x, x1.y), cvt2_bf16(x1.z, x1.w));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const sk_bf16x8*>(&xa), *reinterpret_cast<const sk_bf16x8*>(&wh[cc]), acc, 0, 0, 0);
-        continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float4 x0 = *reinterpret_cast<const float4*>(xs + (mt * 16 + i) * XLD + kl);
+        const float4 x1 = *reinterpret_cast<const float4*>(xs + (mt * 16 + i) * XLD + kl + 4);
+        if constexpr (WB) {
+          const uint4 xa = make_uint4(cvt2_bf16(x0.x, x0.y), cvt2_bf16(x0.z, x0.w), cvt2_bf16(x1.x, x1.y), cvt2_bf16(x1.z, x1.w));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const sk_bf16x8*>(&xa),
+                                                                  *reinterpret_cast<const sk_bf16x8*>(&wh[nt][cc]), acc[mt][nt], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            f32x4 c = acc[mt][nt];
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, wf[nt][cc][0].x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, wf[nt][cc][0].y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, wf[nt][cc][0].z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, wf[nt][cc][0].w, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, wf[nt][cc][1].x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, wf[nt][cc][1].y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, wf[nt][cc][1].z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, wf[nt][cc][1].w, c, 0, 0, 0);
+            acc[mt][nt] = c;
+          }
+        }
       }
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, wf[cc][0].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, wf[cc][0].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, wf[cc][0].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, wf[cc][0].w, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, wf[cc][1].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, wf[cc][1].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, wf[cc][1].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, wf[cc][1].w, acc, 0, 0, 0);
     }
     if (ks + (int)gridDim.y < nslices) __syncthreads();  // xs is restaged by the next slice
   }
@@ -191,39 +249,48 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
   if (dbg && tid == 0) dbg[3] = clock64();
   // ---- fixed-order cross-wave reduction; afterwards wave w owns accumulator row r == w of every 4-row group
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((mt * NT + nt) * 4 + wave) * 4 + r) * 64 + lane] = acc[mt][nt][r];
   __syncthreads();
   if (dbg && tid == 0) dbg[4] = clock64();
-  float v = ((red[(0 * 4 + wave) * 64 + lane] + red[(1 * 4 + wave) * 64 + lane]) + red[(2 * 4 + wave) * 64 + lane]) +
-            red[(3 * 4 + wave) * 64 + lane];
-  if (NORM) v *= rstd_s[g * 4 + wave];  // RMSNorm row scale (its weight is folded into W)
-
   const int epi = a.epilogue;
-  if (!GLU) {
-    float* yp = partial_out ? a.Y + (int64_t)blockIdx.y * a.y_part_stride : a.Y;
-    float y = v + e_bias;
-    if (!partial_out) {
-      if (epi == SOPRO_EPI_GELU) y = gelu_erf(y);
-      else if (epi == SOPRO_EPI_TANH) y = tanhf(y);
-    }
-    if (res_here) y = e_res + e_scale * y;
-    if (col_ok && b_row < a.B) yp[(int64_t)b_row * a.ldy + n_col] = y;
-  } else {
-    const unsigned L = (unsigned)a.ring_len;
-    const unsigned slot_now = slot0 == 0 ? L - 1 : slot0 - 1;  // t mod L
-    const float pre = v + e_bias;                    // lanes 0-7: value, lanes 8-15: gate pre-activation
-    const float gate = __shfl_xor(pre, 8, 64);
-    const float h = pre * sigmoidf_(gate);
-    float y = 0.f;
+  const unsigned L = (unsigned)a.ring_len;
+  const unsigned slot_now = slot0 == 0 ? L - 1 : slot0 - 1;  // t mod L (GLU only)
 #pragma unroll
-    for (int j = 0; j < MAXTAPS - 1; ++j) y += tapw[j] * tapv[j];
-    y += tapw[MAXTAPS - 1] * h;
-    y += e_dwb;
-    if (col_ok && b_row < a.B) {
-      a.ring[((int64_t)slot_now * a.ring_bcap + b_row) * D + n_col] = h;
-      a.Y[(int64_t)b_row * a.ldy + n_col] = xs[(g * 4 + wave) * XLD + n_col] + y;
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float* rp = red + ((mt * NT + nt) * 16 + wave) * 64 + lane;
+      float v = ((rp[0 * 256] + rp[1 * 256]) + rp[2 * 256]) + rp[3 * 256];
+      if (NORM) v *= rstd_s[mt * 16 + g * 4 + wave];  // RMSNorm row scale (its weight is folded into W)
+      const bool ok = col_ok[nt] && b_row[mt] < a.B;
+      if (!GLU) {
+        float* yp = partial_out ? a.Y + (int64_t)blockIdx.y * a.y_part_stride : a.Y;
+        float y = v + e_bias[nt];
+        if (!partial_out) {
+          if (epi == SOPRO_EPI_GELU) y = gelu_erf(y);
+          else if (epi == SOPRO_EPI_TANH) y = tanhf(y);
+        }
+        if (res_here) y = e_res[mt][nt] + e_scale[nt] * y;
+        if (ok) yp[(int64_t)b_row[mt] * a.ldy + n_col[nt]] = y;
+      } else {
+        const float pre = v + e_bias[nt];                // lanes 0-7: value, lanes 8-15: gate pre-activation
+        const float gate = __shfl_xor(pre, 8, 64);
+        const float h = pre * sigmoidf_(gate);
+        float y = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXTAPS - 1; ++j) y += tapw[nt][j] * tapv[mt][nt][j];
+        y += tapw[nt][MAXTAPS - 1] * h;
+        y += e_dwb[nt];
+        if (ok) {
+          a.ring[((int64_t)slot_now * a.ring_bcap + b_row[mt]) * D + n_col[nt]] = h;
+          a.Y[(int64_t)b_row[mt] * a.ldy + n_col[nt]] = xs[(mt * 16 + g * 4 + wave) * XLD + n_col[nt]] + y;
+        }
+      }
     }
-  }
   if (dbg && tid == 0) dbg[5] = clock64();
 }
 
@@ -284,13 +351,23 @@ __global__ __launch_bounds__(256) void pack_skinny_bf16_kernel(const float* __re
   out[idx] = v;
 }
 
-template <bool GLU, int NP, bool NORM>
-int launch(const sopro_skinny_args& a, dim3 grid, hipStream_t s) {
+template <bool GLU, int NP, bool NORM, int MT, int NT>
+int launch_t(const sopro_skinny_args& a, dim3 grid, hipStream_t s) {
   if (a.w_layout == 2)
-    hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM, true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM, true, MT, NT>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM, false, MT, NT>), grid, dim3(256), 0, s, a);
   SOPRO_LAUNCH_CHECK();
+}
+
+template <bool GLU, int NP, bool NORM>
+int launch(const sopro_skinny_args& a, int ntiles, int gy, hipStream_t s) {
+  const int mt = a.mt == 2 ? 2 : 1, nt = a.nt == 2 ? 2 : 1;
+  dim3 grid((ntiles + nt - 1) / nt, gy, (a.B + 16 * mt - 1) / (16 * mt));
+  if (mt == 2 && nt == 2) return launch_t<GLU, NP, NORM, 2, 2>(a, grid, s);
+  if (mt == 2) return launch_t<GLU, NP, NORM, 2, 1>(a, grid, s);
+  if (nt == 2) return launch_t<GLU, NP, NORM, 1, 2>(a, grid, s);
+  return launch_t<GLU, NP, NORM, 1, 1>(a, grid, s);
 }
 
 }  // namespace
@@ -346,10 +423,10 @@ extern "C" int sopro_skinny_f32(const sopro_skinny_args* p, void* stream) {
   const int gy = (a.ksplit && nslices > 1) ? nslices : 1;
   SOPRO_CHECK_ARG(gy == 1 || a.epilogue == SOPRO_EPI_NONE || a.epilogue == SOPRO_EPI_RES,
                   "K-split output takes EPI_NONE or EPI_RES (slice 0 then carries bias + residual; the consumer sums the slices)");
+  SOPRO_CHECK_ARG(a.mt >= 0 && a.mt <= 2 && a.nt >= 0 && a.nt <= 2, "mt / nt must be 0 (= 1), 1 or 2");
   const int ntiles = dw ? (a.N / 2 + 7) / 8 : (a.N + 15) / 16;
-  dim3 grid(ntiles, gy, (a.B + 15) / 16);
   const bool np3 = a.np == 3, nrm = a.rms_norm != 0;
-  if (dw) return np3 ? launch<true, 3, true>(a, grid, s) : launch<true, 0, true>(a, grid, s);
-  if (nrm) return np3 ? launch<false, 3, true>(a, grid, s) : launch<false, 0, true>(a, grid, s);
-  return np3 ? launch<false, 3, false>(a, grid, s) : launch<false, 0, false>(a, grid, s);
+  if (dw) return np3 ? launch<true, 3, true>(a, ntiles, gy, s) : launch<true, 0, true>(a, ntiles, gy, s);
+  if (nrm) return np3 ? launch<false, 3, true>(a, ntiles, gy, s) : launch<false, 0, true>(a, ntiles, gy, s);
+  return np3 ? launch<false, 3, false>(a, ntiles, gy, s) : launch<false, 0, false>(a, ntiles, gy, s);
 }

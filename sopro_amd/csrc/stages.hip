@@ -44,6 +44,8 @@ struct ArPlan {
   float *cond, *x[4], *part, *u, *logits, *kp[16], *vp[16], *xp, *params, *rings[16], *nkv, *kvd;
   int32_t *klens, *hist, *ctr, *first_eos, *stop_t, *recent;
   uint32_t* nonce;
+  uint32_t* key;
+  int32_t* row_step;
   sopro_ar_state st;
   void* graph = nullptr;
   int graph_B = 0, graph_S_cap = 0, graph_Tar = 0;
@@ -67,6 +69,7 @@ struct sopro_engine {
   int32_t *sem_col = nullptr, *sem_off = nullptr, *ac_col = nullptr, *ac_off = nullptr;
   float* ones = nullptr;
   ArPlan ar;
+  int ar_tiles[4] = {0, 0, 0, 0};  // workgroup shapes of the AR-step stages (sopro_engine_set_ar_tiles)
 };
 
 namespace {
@@ -235,6 +238,16 @@ int sopro_engine_set_tensor(sopro_engine* e, const char* name, const void* dev_p
   return 0;
 }
 
+int sopro_engine_set_ar_tiles(sopro_engine* e, int32_t glu, int32_t ff1, int32_t ff2, int32_t head) {
+  SOPRO_CHECK_ARG(e != nullptr, "engine is NULL");
+  e->ar_tiles[0] = glu; e->ar_tiles[1] = ff1; e->ar_tiles[2] = ff2; e->ar_tiles[3] = head;
+  if (e->ar.graph) {  // the recorded frame holds the old shapes
+    (void)sopro_graph_destroy(e->ar.graph);
+    e->ar.graph = nullptr;
+  }
+  return 0;
+}
+
 int sopro_engine_destroy(sopro_engine* e) {
   if (!e) return 0;
   if (e->ar.graph) (void)sopro_graph_destroy(e->ar.graph);
@@ -393,6 +406,8 @@ static size_t ar_carve(const sopro_engine* e, ArPlan& p, void* ws, int B, int S,
   p.stop_t = cv.take<int32_t>(B);
   p.recent = cv.take<int32_t>((size_t)B * 64);
   p.nonce = cv.take<uint32_t>(B);
+  p.key = cv.take<uint32_t>(2);
+  p.row_step = cv.take<int32_t>(B);
   return cv.off;
 }
 
@@ -402,61 +417,28 @@ int64_t sopro_ar_workspace_bytes(const sopro_engine* e, int32_t B, int32_t S, in
   return (int64_t)ar_carve(e, tmp, nullptr, B, S, Tar);
 }
 
-// one frame: the launch sequence of sopro_amd.model._ARPlan.issue_step (reference step: src/sopro/nn/generator.py:98-130)
+// one frame: the buffers of this plan described to sopro_ar_issue_frame (ar_frame.hip), where the launch sequence lives
 static int ar_issue_step(sopro_engine* e, hipStream_t s) {
   const sopro_engine_cfg& c = e->c;
   ArPlan& p = e->ar;
-  const int B = p.B, D = c.d_model, k = c.ar_kernel, H = 4;
-  const int64_t BD = (int64_t)B * D;
-  float *X0 = p.x[0], *XA = p.x[1], *XB = p.x[2];
-  const float* base = X0;
-  const float* pend = nullptr;  // three partial buffers the next kernel adds while staging
+  sopro_ar_frame f;
+  memset(&f, 0, sizeof(f));
   for (int i = 0; i < c.n_layers_ar; ++i) {
     const std::string pr = "ar.blocks." + std::to_string(i);
-    float* out = (i % 2 == 0) ? XA : XB;
-    const int dil = c.ar_dilations[i];
-    sopro_skinny_args a;
-    // RMSNorm -> GLU -> ring write -> dilated taps -> +x   (src/sopro/nn/blocks.py:150-157, 76-110)
-    memset(&a, 0, sizeof(a));
-    a.X = base; a.ldx = D; a.W = e->sk[pr + ".glu.w"]; a.ldw = D; a.w_layout = 1; a.bias = F(e, pr + ".glu.b");
-    a.Y = out; a.ldy = D; a.ldr = D;
-    a.ring = p.rings[i]; a.dw_w = F(e, pr + ".dw.w"); a.dw_b = F(e, pr + ".dw.b"); a.step = p.ctr;
-    a.Xp = pend; a.xp_stride = BD; a.np = pend ? 3 : 0;
-    a.eps = RMS_EPS; a.B = B; a.N = 2 * D; a.K = D; a.epilogue = SOPRO_EPI_GLU_DW;
-    a.ring_len = (k - 1) * dil + 1; a.ring_bcap = B; a.dil = dil; a.ksize = k; a.rms_norm = 1;
-    STG(sopro_skinny_f32(&a, s));
-    // RMSNorm -> Linear -> GELU (blocks.py:158-160)
-    memset(&a, 0, sizeof(a));
-    a.X = out; a.ldx = D; a.W = e->sk[pr + ".ff1.w"]; a.ldw = D; a.w_layout = 1; a.bias = F(e, pr + ".ff1.b");
-    a.Y = p.u; a.ldy = 4 * D; a.ldr = 4 * D; a.eps = RMS_EPS; a.B = B; a.N = 4 * D; a.K = D; a.epilogue = SOPRO_EPI_GELU; a.rms_norm = 1;
-    STG(sopro_skinny_f32(&a, s));
-    // Linear 4D -> D + residual as 4 K-slices (blocks.py:161-162)
-    memset(&a, 0, sizeof(a));
-    a.X = p.u; a.ldx = 4 * D; a.W = e->sk[pr + ".ff2.w"]; a.ldw = 4 * D; a.w_layout = 1; a.bias = F(e, pr + ".ff2.b");
-    a.Y = p.part; a.ldy = D; a.R = out; a.ldr = D; a.eps = RMS_EPS; a.B = B; a.N = D; a.K = 4 * D; a.epilogue = SOPRO_EPI_RES;
-    a.ksplit = 1; a.y_part_stride = BD;
-    STG(sopro_skinny_f32(&a, s));
-    base = p.part; pend = p.part + BD;
-    if (c.ar_xattn[i]) {
-      // cached text cross-attention, projections folded into the cached operands (src/sopro/nn/text.py:85-132)
-      sopro_xattn_args x;
-      memset(&x, 0, sizeof(x));
-      x.X = base; x.ldx = D; x.Xp = pend; x.xp_stride = BD; x.np = 3;
-      x.Kp = p.kp[i]; x.Vp = p.vp[i]; x.klens = p.klens; x.Y = p.xp; x.y_part_stride = BD;
-      x.eps = RMS_EPS; x.gate = c.ar_gate[i]; x.scale = 1.0f / sqrtf((float)(D / H));
-      x.B = B; x.H = H; x.D = D; x.S_cap = p.S_cap;
-      STG(sopro_xattn_step_f32(&x, s));
-      base = p.xp; pend = p.xp + BD;
-    }
+    sopro_ar_block& b = f.blk[i];
+    b.glu_w = e->sk[pr + ".glu.w"]; b.glu_b = F(e, pr + ".glu.b"); b.dw_w = F(e, pr + ".dw.w"); b.dw_b = F(e, pr + ".dw.b");
+    b.ff1_w = e->sk[pr + ".ff1.w"]; b.ff1_b = F(e, pr + ".ff1.b"); b.ff2_w = e->sk[pr + ".ff2.w"]; b.ff2_b = F(e, pr + ".ff2.b");
+    b.ring = p.rings[i]; b.dil = c.ar_dilations[i]; b.xattn = c.ar_xattn[i] ? 1 : 0; b.gate = c.ar_gate[i];
+    b.kp = p.kp[i]; b.vp = p.vp[i];
   }
-  sopro_skinny_args a;
-  memset(&a, 0, sizeof(a));
-  a.X = base; a.ldx = D; a.W = e->sk["ar.head.w"]; a.ldw = D; a.w_layout = 1; a.bias = F(e, "ar.head.b");
-  a.Y = p.logits; a.ldy = c.codebook_size + 1; a.ldr = c.codebook_size + 1; a.Xp = pend; a.xp_stride = BD; a.np = pend ? 3 : 0;
-  a.eps = RMS_EPS; a.B = B; a.N = c.codebook_size + 1; a.K = D; a.rms_norm = 1;
-  STG(sopro_skinny_f32(&a, s));
-  // the sampler writes the next frame's input into state.x_cur == x[0], where block 0 reads
-  return sopro_ar_sample(&p.st, p.logits, c.codebook_size + 1, s);
+  f.head_w = e->sk["ar.head.w"]; f.head_b = F(e, "ar.head.b");
+  f.x0 = p.x[0]; f.xa = p.x[1]; f.xb = p.x[2]; f.part = p.part; f.u = p.u; f.xp = p.xp; f.logits = p.logits; f.klens = p.klens;
+  f.n_layers = c.n_layers_ar; f.B = p.B; f.D = c.d_model; f.S_cap = p.S_cap; f.V1 = c.codebook_size + 1; f.H = 4; f.ksize = c.ar_kernel;
+  f.w_layout = 1;
+  f.tile_glu = e->ar_tiles[0]; f.tile_ff1 = e->ar_tiles[1]; f.tile_ff2 = e->ar_tiles[2]; f.tile_head = e->ar_tiles[3];
+  f.eps = RMS_EPS;
+  f.st = p.st;
+  return sopro_ar_issue_frame(&f, s);
 }
 
 int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* cond_ar, const float* txt_seq, const int32_t* text_lens,
@@ -496,12 +478,15 @@ int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* con
   SOPRO_HIP(hipMemsetAsync(p.hist, 0, (size_t)B * Tar * 4, s));
   SOPRO_HIP(hipMemcpyAsync(p.params, params, 8 * sizeof(float), hipMemcpyHostToDevice, s));
   SOPRO_HIP(hipMemsetD32Async((hipDeviceptr_t)p.nonce, (int)nonce, B, s));
+  // the Philox key lives in device memory: the recorded frame graph serves every seed
+  SOPRO_HIP(hipMemsetD32Async((hipDeviceptr_t)p.key, (int)(uint32_t)seed, 1, s));
+  SOPRO_HIP(hipMemsetD32Async((hipDeviceptr_t)(p.key + 1), (int)(uint32_t)(seed >> 32), 1, s));
   sopro_ar_state& st = p.st;
   memset(&st, 0, sizeof(st));
   st.x_cur = p.x[0]; st.cond = p.cond; st.emb = F(e, "cb_embed"); st.hist = p.hist;
-  st.step = p.ctr; st.arrive = p.ctr + 1; st.n_stopped = p.ctr + 2;
+  st.step = p.ctr; st.row_step = p.row_step; st.n_stopped = p.ctr + 2;
   st.first_eos = p.first_eos; st.stop_t = p.stop_t; st.recent = p.recent; st.params = p.params; st.nonce = p.nonce;
-  st.seed = seed; st.B = B; st.D = D; st.Tar = Tar; st.max_steps = Tar; st.V = c.codebook_size; st.bos_row = c.bos_row;
+  st.key = p.key; st.seed = 0; st.B = B; st.D = D; st.Tar = Tar; st.max_steps = Tar; st.V = c.codebook_size; st.bos_row = c.bos_row;
   STG(sopro_ar_init(&st, s));
   // a recorded frame graph holds raw pointers into the workspace it was recorded on
   if (p.graph && (p.graph_B != B || p.graph_S_cap != p.S_cap || p.graph_Tar != Tar || p.graph_ws != workspace)) {

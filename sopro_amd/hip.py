@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -47,7 +47,7 @@ class SkinnyArgs(C.Structure):
                 ("Xp", _p), ("xp_stride", _i64), ("y_part_stride", _i64), ("dbg", _p), ("eps", _f32),
                 ("B", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32),
                 ("ring_len", _i32), ("ring_bcap", _i32), ("dil", _i32), ("ksize", _i32),
-                ("np", _i32), ("ksplit", _i32), ("rms_norm", _i32), ("w_layout", _i32)]
+                ("np", _i32), ("ksplit", _i32), ("rms_norm", _i32), ("w_layout", _i32), ("mt", _i32), ("nt", _i32)]
 
 
 class AttnArgs(C.Structure):
@@ -64,10 +64,28 @@ class XattnArgs(C.Structure):
 
 
 class ArState(C.Structure):
-    _fields_ = [("x_cur", _p), ("cond", _p), ("emb", _p), ("hist", _p), ("step", _p), ("arrive", _p),
+    _fields_ = [("x_cur", _p), ("cond", _p), ("emb", _p), ("hist", _p), ("step", _p), ("row_step", _p),
                 ("first_eos", _p), ("stop_t", _p), ("n_stopped", _p), ("recent", _p), ("params", _p), ("seed", C.c_uint64),
                 ("B", _i32), ("D", _i32), ("Tar", _i32), ("max_steps", _i32), ("V", _i32), ("bos_row", _i32),
-                ("start", _p), ("row_max", _p), ("row_params", _p), ("nonce", _p), ("dbg", _p)]
+                ("start", _p), ("row_max", _p), ("row_params", _p), ("nonce", _p), ("key", _p), ("dbg", _p)]
+
+
+AR_MAX_LAYERS = 16
+
+
+class ArBlock(C.Structure):
+    """sopro_ar_block"""
+    _fields_ = [("glu_w", _p), ("glu_b", _p), ("dw_w", _p), ("dw_b", _p), ("ff1_w", _p), ("ff1_b", _p), ("ff2_w", _p), ("ff2_b", _p),
+                ("ring", _p), ("kp", _p), ("vp", _p), ("dil", _i32), ("xattn", _i32), ("gate", _f32), ("pad_", _i32)]
+
+
+class ArFrame(C.Structure):
+    """sopro_ar_frame: the buffers of one autoregressive frame (the launch sequence itself is sopro_ar_issue_frame)."""
+    _fields_ = [("blk", ArBlock * AR_MAX_LAYERS), ("head_w", _p), ("head_b", _p), ("x0", _p), ("xa", _p), ("xb", _p), ("part", _p),
+                ("u", _p), ("xp", _p), ("logits", _p), ("klens", _p),
+                ("n_layers", _i32), ("B", _i32), ("D", _i32), ("S_cap", _i32), ("V1", _i32), ("H", _i32), ("ksize", _i32), ("w_layout", _i32),
+                ("tile_glu", _i32), ("tile_ff1", _i32), ("tile_ff2", _i32), ("tile_head", _i32), ("eps", _f32), ("pad_", _i32),
+                ("st", ArState)]
 
 
 class EngineCfg(C.Structure):
@@ -163,6 +181,8 @@ SYMBOLS = {
     "sopro_ar_init": (C.c_int, [C.POINTER(ArState), _p]),
     "sopro_ar_sample": (C.c_int, [C.POINTER(ArState), _p, _i64, _p]),
     "sopro_ar_admit": (C.c_int, [C.POINTER(ArState), _i32, _p]),
+    "sopro_ar_issue_frame": (C.c_int, [C.POINTER(ArFrame), _p]),
+    "sopro_engine_set_ar_tiles": (C.c_int, [_p, _i32, _i32, _i32, _i32]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -434,8 +454,9 @@ def skinny(X: torch.Tensor, W, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: 
            scale: Optional[torch.Tensor] = None, ring: Optional[torch.Tensor] = None, dw_w: Optional[torch.Tensor] = None,
            dw_b: Optional[torch.Tensor] = None, step: Optional[torch.Tensor] = None, ring_len: int = 0, ring_bcap: int = 0,
            dil: int = 1, ksize: int = 1, Xp: Optional[torch.Tensor] = None, np_: int = 0, xp_stride: int = 0,
-           ksplit: bool = False, y_part_stride: int = 0, dbg: Optional[torch.Tensor] = None) -> None:
-    """AR-step contraction.  With rms_norm the RMSNorm weight must already be folded into W (W * w_norm[None, :])."""
+           ksplit: bool = False, y_part_stride: int = 0, dbg: Optional[torch.Tensor] = None, mt: int = 1, nt: int = 1) -> None:
+    """AR-step contraction.  With rms_norm the RMSNorm weight must already be folded into W (W * w_norm[None, :]).
+    ``mt`` x ``nt``: 16-row groups x column tiles per workgroup (1 or 2 each; results are bit-identical)."""
     a = SkinnyArgs()
     a.X, a.ldx = ptr(X), (K if ldx is None else ldx)
     if isinstance(W, SkinnyW):
@@ -454,6 +475,7 @@ def skinny(X: torch.Tensor, W, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: 
     a.B, a.N, a.K, a.epilogue = B, N, K, epilogue
     a.ring_len, a.ring_bcap, a.dil, a.ksize = ring_len, ring_bcap, dil, ksize
     a.np, a.ksplit, a.rms_norm = np_, int(ksplit), int(rms_norm)
+    a.mt, a.nt = int(mt), int(nt)
     _check(load().sopro_skinny_f32(C.byref(a), _stream()), "sopro_skinny_f32")
 
 
@@ -629,6 +651,19 @@ def ar_admit(st: ArState, row: int) -> None:
 
 def ar_sample(st: ArState, logits: torch.Tensor, ld: int) -> None:
     _check(load().sopro_ar_sample(C.byref(st), ptr(logits), ld, _stream()), "sopro_ar_sample")
+
+
+def ar_issue_frame(frame: ArFrame) -> None:
+    """One autoregressive frame (23 launches) on the current stream: the sequence lives in csrc/ar_frame.hip."""
+    _check(load().sopro_ar_issue_frame(C.byref(frame), _stream()), "sopro_ar_issue_frame")
+
+
+def ar_tile_code(spec: str) -> int:
+    """'2x1' -> (mt << 4) | nt of sopro_ar_frame.tile_*"""
+    mt, nt = (int(v) for v in spec.lower().split("x"))
+    if mt not in (1, 2) or nt not in (1, 2):
+        raise ValueError(f"AR tile shape must be 1x1, 1x2, 2x1 or 2x2, got {spec!r}")
+    return (mt << 4) | nt
 
 
 class Graph:

@@ -139,17 +139,18 @@ class SoproTTSModel:
                             continue
                         self.wx[k] = pack_for(k)(v)
                 torch.cuda.synchronize(self.device)
-        # AR-step weights in the fragment order of the skinny kernel (1 KiB of consecutive memory per load instruction);
-        # SOPRO_AR_ROWMAJOR=1 keeps the row-major matrices.
+        # AR-step weights in the fragment order of the skinny kernel (1 KiB of consecutive memory per load instruction)
         self.wk: Dict[str, hip.SkinnyW] = {}
-        if os.environ.get("SOPRO_AR_ROWMAJOR", "0") != "1":
-            with torch.cuda.device(self.device):
-                for k, v in self.w.items():
-                    if (k.startswith("ar.blocks.") and k.endswith((".glu.w", ".ff1.w", ".ff2.w"))) or k == "ar.head.w":
-                        if v.dim() == 2 and int(v.shape[1]) % 32 == 0:
-                            # bf16 mode: the frame's weight stream in bf16 (fp32 accumulate, fp32 norms / ring / residual)
-                            self.wk[k] = hip.pack_skinny_w(v, glu=k.endswith(".glu.w"), bf16=(precision == "bf16"))
-                torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            for k, v in self.w.items():
+                if (k.startswith("ar.blocks.") and k.endswith((".glu.w", ".ff1.w", ".ff2.w"))) or k == "ar.head.w":
+                    # bf16 mode: the frame's weight stream in bf16 (fp32 accumulate, fp32 norms / ring / residual)
+                    self.wk[k] = hip.pack_skinny_w(v, glu=k.endswith(".glu.w"), bf16=(precision == "bf16"))
+            torch.cuda.synchronize(self.device)
+        # workgroup shapes of the AR-step stages, "<16-row groups>x<column tiles>" (sopro_skinny_args.mt / .nt; results do
+        # not depend on them).  SOPRO_AR_TILES="glu:2x1,ff1:2x2,..." or "2x2" for all.
+        self.ar_tiles = {"glu": "1x1", "ff1": "1x1", "ff2": "1x1", "head": "1x1"}
+        self.set_ar_tiles(os.environ.get("SOPRO_AR_TILES", ""))
         self._ones: Dict[int, torch.Tensor] = {}
         sc = cfg.stage_codebooks()
         self._stage_cbs = [(s, sc[s]) for s in cfg.stage_order()]
@@ -157,6 +158,21 @@ class SoproTTSModel:
         self._adapter: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None
 
     # ------------------------------------------------------------------ helpers
+    def set_ar_tiles(self, spec: str) -> None:
+        """'2x2' (every stage kind) or 'glu:2x1,ff1:2x2,ff2:2x2,head:1x2'.  Recorded frame graphs are dropped."""
+        spec = (spec or "").strip()
+        if not spec:
+            return
+        for part in spec.split(","):
+            kind, _, shape = part.strip().rpartition(":")
+            hip.ar_tile_code(shape)  # validates
+            for k in ([kind] if kind else list(self.ar_tiles)):
+                if k not in self.ar_tiles:
+                    raise ValueError(f"unknown AR stage kind {k!r} (glu, ff1, ff2, head)")
+                self.ar_tiles[k] = shape
+        for plan in getattr(self, "_ar_cache", {}).values():
+            plan.graph = None
+
     def on_stream(self, bulk: bool = False, prep: bool = False):
         """Context: run on the engine's stream, ordered after whatever the caller queued so far.  ``prep`` = the stream of the
         per-batch preparation (conditioning, text K/V folding): the AR stream itself unless a pipeline moved it to the
@@ -735,7 +751,9 @@ class _ARPlan:
         k = int(cfg.ar_kernel)
         self.rings = [z((k - 1) * int(d) + 1, B, D) for d in cfg.ar_dilations]
         self.hist = z(B, self.max_steps, dt=torch.int32)
-        self.ctr = z(8, dt=torch.int32)  # step, arrive, n_stopped
+        self.ctr = z(8, dt=torch.int32)  # step, -, n_stopped
+        self.row_step = z(B, dt=torch.int32)  # per-row copy of the frame index (the sampler's own time base: no ticket)
+        self.key = z(2, dt=torch.int32)  # Philox key (seed) in device memory: one recorded frame serves every seed
         self.first_eos = z(B, dt=torch.int32)
         self.stop_t = z(B, dt=torch.int32)
         self.params = z(8)
@@ -748,7 +766,8 @@ class _ARPlan:
         st.emb = m.w["cb_embed"].data_ptr()
         st.hist = self.hist.data_ptr()
         st.step = self.ctr.data_ptr()
-        st.arrive = self.ctr.data_ptr() + 4
+        st.row_step = self.row_step.data_ptr()
+        st.key = self.key.data_ptr()
         st.n_stopped = self.ctr.data_ptr() + 8
         st.first_eos = self.first_eos.data_ptr()
         st.stop_t = self.stop_t.data_ptr()
@@ -767,50 +786,36 @@ class _ARPlan:
         self.graph: Optional[hip.Graph] = None
         self.nlaunch = 0
 
+    def frame(self) -> "hip.ArFrame":
+        """This plan's buffers as the descriptor of sopro_ar_issue_frame (csrc/ar_frame.hip), where the launch sequence of a
+        frame lives (reference step: src/sopro/nn/generator.py:98-130)."""
+        m, cfg, w, D = self.m, self.m.cfg, self.m.w, self.m.D
+        f = hip.ArFrame()
+        bf16 = m.precision == "bf16"
+        wp = lambda key: hip.ptr(m.wk[key].data, torch.int32 if bf16 else torch.float32)  # noqa: E731
+        for i, dil in enumerate(cfg.ar_dilations):
+            p, b = f"ar.blocks.{i}", f.blk[i]
+            b.glu_w, b.glu_b, b.dw_w, b.dw_b = wp(p + ".glu.w"), hip.ptr(w[p + ".glu.b"]), hip.ptr(w[p + ".dw.w"]), hip.ptr(w[p + ".dw.b"])
+            b.ff1_w, b.ff1_b, b.ff2_w, b.ff2_b = wp(p + ".ff1.w"), hip.ptr(w[p + ".ff1.b"]), wp(p + ".ff2.w"), hip.ptr(w[p + ".ff2.b"])
+            b.ring, b.dil = hip.ptr(self.rings[i]), int(dil)
+            if i in self.kp:
+                b.xattn, b.gate, b.kp, b.vp = 1, float(m.gates[i]), hip.ptr(self.kp[i]), hip.ptr(self.vp[i])
+        f.head_w, f.head_b = wp("ar.head.w"), hip.ptr(w["ar.head.b"])
+        X0, XA, XB, _XC = self.x
+        f.x0, f.xa, f.xb = hip.ptr(X0), hip.ptr(XA), hip.ptr(XB)
+        f.part, f.u, f.xp, f.logits = hip.ptr(self.part), hip.ptr(self.u), hip.ptr(self.xp), hip.ptr(self.logits)
+        f.klens = hip.ptr(self.klens, torch.int32)
+        f.n_layers, f.B, f.D, f.S_cap, f.V1, f.H, f.ksize = len(cfg.ar_dilations), self.B, D, self.S_cap, m.V + 1, 4, int(cfg.ar_kernel)
+        f.w_layout = 2 if bf16 else 1
+        f.tile_glu, f.tile_ff1, f.tile_ff2, f.tile_head = (hip.ar_tile_code(m.ar_tiles[k]) for k in ("glu", "ff1", "ff2", "head"))
+        f.eps = RMS_EPS
+        f.st = self.state
+        return f
+
     def issue_step(self) -> None:
         """Enqueue one frame on the current stream (this is what the graph records)."""
-        m, cfg, w, B, D = self.m, self.m.cfg, self.m.w, self.B, self.m.D
-        k = int(cfg.ar_kernel)
-        H = 4  # reference: src/sopro/nn/generator.py:36
-        # Residual stream = a base buffer plus (optionally) three pending partial buffers that the next kernel adds
-        # while staging: the K-slices of a feed-forward output (slice 0 carries bias + residual) or the per-head
-        # outputs of a cross-attention block (head 0 carries the residual).
-        X0, XA, XB, _XC = self.x
-        wk = lambda key: m.wk.get(key) or w[key]  # noqa: E731  (fragment-ordered weights when packed)
-        KS = 4 * D // 384  # FF2 K slices
-        pk_ff = dict(Xp=self.part[1:], np_=KS - 1, xp_stride=B * D)
-        pk_xa = dict(Xp=self.xp[1:], np_=H - 1, xp_stride=B * D)
-        base, pend = X0, {}
-        nl = 0
-        for i, dil in enumerate(cfg.ar_dilations):
-            p = f"ar.blocks.{i}"
-            out = XA if i % 2 == 0 else XB
-            # RMSNorm -> GLU -> ring write -> dilated taps -> +x   (src/sopro/nn/blocks.py:150-157, 76-110)
-            hip.skinny(base, wk(p + ".glu.w"), out, B=B, N=2 * D, K=D, rms_norm=True, eps=RMS_EPS, bias=w[p + ".glu.b"],
-                       epilogue=hip.EPI_GLU_DW, ring=self.rings[i], dw_w=w[p + ".dw.w"], dw_b=w[p + ".dw.b"], step=self.step_t,
-                       ring_len=(k - 1) * int(dil) + 1, dil=int(dil), ksize=k,
-                       ring_bcap=B, **pend)
-            # RMSNorm -> Linear -> GELU (blocks.py:158-160)
-            hip.skinny(out, wk(p + ".ff1.w"), self.u, B=B, N=4 * D, K=D, rms_norm=True, eps=RMS_EPS,
-                       bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
-            # Linear 4D -> D + residual as 4 K-slices on 4x the workgroups (blocks.py:161-162)
-            hip.skinny(self.u, wk(p + ".ff2.w"), self.part, B=B, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=out,
-                       ksplit=True, y_part_stride=B * D)
-            base, pend = self.part[0], pk_ff
-            nl += 3
-            if i in self.kp:
-                pa = f"ar.x_attns.{i}"
-                # cached text cross-attention, projections folded into the cached operands (src/sopro/nn/text.py:85-132)
-                hip.xattn_step(base, self.xp, None, self.kp[i], self.vp[i], self.klens, B=B, H=H, D=D, S_cap=self.S_cap,
-                               gate=m.gates[i], scale=float(D // H) ** -0.5, eps=RMS_EPS, y_part_stride=B * D, **pend)
-                base, pend = self.xp[0], pk_xa
-                nl += 1
-        cur = base
-        hk = pend
-        hip.skinny(cur, wk("ar.head.w"), self.logits, B=B, N=m.V + 1, K=D, rms_norm=True, eps=RMS_EPS, bias=w["ar.head.b"], **hk)
-        # the sampler writes the next frame's input into state.x_cur, which must be where block 0 reads
-        hip.ar_sample(self.state, self.logits, m.V + 1)
-        self.nlaunch = nl + 2
+        hip.ar_issue_frame(self.frame())
+        self.nlaunch = 3 * len(self.m.cfg.ar_dilations) + len(self.kp) + 2
 
     def load_row(self, row: int, cond_row: torch.Tensor, txt_row: torch.Tensor) -> None:
         """Slot mode: install one utterance in row ``row`` (launches only, on the current stream): its conditioning rows
@@ -912,6 +917,7 @@ class _ARRun:
             plan.hist.zero_()
             plan.params.copy_(torch.tensor([float(top_p), float(temperature), 1.0 if anti_loop else 0.0, 0.85, 1.2, 1.1, float(top_k),
                                             float(min_gen)], dtype=torch.float32), non_blocking=False)
+            plan.key.copy_(torch.tensor([m.seed & 0xFFFFFFFF, (m.seed >> 32) & 0xFFFFFFFF], dtype=torch.int64).to(torch.int32), non_blocking=False)
             nonce = m.next_nonce(seed)
             plan.nonce.fill_(nonce - (1 << 32) if nonce >= (1 << 31) else nonce)  # the uint32 bit pattern in an int32 tensor
             hip.ar_init(plan.state)

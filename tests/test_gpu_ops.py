@@ -386,6 +386,55 @@ def test_skinny_norm_head(B):
     close(Y, O.rmsnorm(X, nw) @ W.t() + b, 5e-5, f"skinny head B={B}")
 
 
+@pytest.mark.parametrize("B", [1, 16, 17, 32, 40])
+@pytest.mark.parametrize("mt,nt", [(2, 1), (1, 2), (2, 2)])
+def test_skinny_workgroup_shapes_are_bit_identical(B, mt, nt, w):
+    """mt x nt (16-row groups x column tiles per workgroup) only changes who reads what: every output element sees the same
+    arithmetic in the same order, so all shapes must reproduce the 1 x 1 results bit for bit - head (odd tile count, partial-sum
+    input), FF1 (norm + GELU), FF2 (K-slices out) and the GLU / ring-buffer tail (partial-sum input, ring writes)."""
+    D, K4, V1 = 384, 1536, 2049
+    parts = dev(rnd(4, B, D, seed=910))
+    pk = dict(Xp=parts[1:], np_=3, xp_stride=B * D)
+    Wh, bh = dev(rnd(V1, D, seed=911, scale=D ** -0.5)), dev(rnd(V1, seed=912))
+    W1, b1 = dev(rnd(K4, D, seed=913, scale=D ** -0.5)), dev(rnd(K4, seed=914))
+    W2, b2, R = dev(rnd(D, K4, seed=915, scale=K4 ** -0.5)), dev(rnd(D, seed=916)), dev(rnd(B, D, seed=917))
+    U = dev(rnd(B, K4, seed=918))
+    p = "ar.blocks.1"
+    k, dil = 13, 2
+    L = (k - 1) * dil + 1
+    gw, gb = dev(w[p + ".glu.pro.weight"] * w[p + ".norm.weight"][None, :]), dev(w[p + ".glu.pro.bias"])
+    dww, dwb = dev(pack.pack_dw(w[p + ".dw.dw.weight"])), dev(w[p + ".dw.dw.bias"])
+    ring0 = dev(rnd(L, B, D, seed=919))
+    step = torch.full((1,), 5, dtype=torch.int32, device=DEV)
+
+    def run(mt_, nt_, packed):
+        t = dict(mt=mt_, nt=nt_)
+        P = (lambda W_, glu=False: hip.pack_skinny_w(W_, glu=glu)) if packed else (lambda W_, glu=False: W_)
+        out = {}
+        Y = torch.full((B, V1), float("nan"), device=DEV)
+        hip.skinny(parts[0], P(Wh), Y, B=B, N=V1, K=D, rms_norm=True, eps=1e-6, bias=bh, **pk, **t)
+        out["head"] = Y
+        Y = torch.full((B, K4), float("nan"), device=DEV)
+        hip.skinny(parts[0], P(W1), Y, B=B, N=K4, K=D, rms_norm=True, eps=1e-6, bias=b1, epilogue=hip.EPI_GELU, **t)
+        out["ff1"] = Y
+        Y = torch.full((4, B, D), float("nan"), device=DEV)
+        hip.skinny(U, P(W2), Y, B=B, N=D, K=K4, bias=b2, epilogue=hip.EPI_RES, R=R, ksplit=True, y_part_stride=B * D, **t)
+        out["ff2"] = Y
+        ring = ring0.clone()
+        Y = torch.full((B, D), float("nan"), device=DEV)
+        hip.skinny(parts[0], P(gw, True), Y, B=B, N=2 * D, K=D, rms_norm=True, eps=1e-6, bias=gb, epilogue=hip.EPI_GLU_DW, ring=ring,
+                   dw_w=dww, dw_b=dwb, step=step, ring_len=L, ring_bcap=B, dil=dil, ksize=k, **pk, **t)
+        out["glu"], out["ring"] = Y, ring
+        torch.cuda.synchronize()
+        return out
+
+    for packed in (True, False):
+        ref, got = run(1, 1, packed), run(mt, nt, packed)
+        for name in ref:
+            assert bool(torch.isfinite(ref[name]).all()), name
+            assert torch.equal(ref[name], got[name]), (name, packed, mt, nt, float((ref[name] - got[name]).abs().max()))
+
+
 def test_skinny_epilogues():
     B, K, N = 32, 1536, 384
     X, W, b, R, sc = rnd(B, K, seed=24), rnd(N, K, seed=25, scale=K ** -0.5), rnd(N, seed=26), rnd(B, N, seed=27), rnd(N, seed=28)
@@ -843,10 +892,13 @@ class _SamplerRig:
         self.first_eos, self.stop_t, self.params = z(B, dt=torch.int32), z(B, dt=torch.int32), z(8)
         self.recent = z(B, 64, dt=torch.int32)
         self.nonce = z(B, dt=torch.int32)
+        self.row_step = z(B, dt=torch.int32)
+        self.key = torch.tensor([7, 0], dtype=torch.int32, device=DEV)  # Philox key (seed) in device memory
         st = hip.ArState()
         st.nonce = self.nonce.data_ptr()
+        st.row_step, st.key = self.row_step.data_ptr(), self.key.data_ptr()
         st.x_cur, st.cond, st.emb, st.hist = self.x.data_ptr(), self.cond.data_ptr(), self.emb.data_ptr(), self.hist.data_ptr()
-        st.step, st.arrive, st.n_stopped = self.ctr.data_ptr(), self.ctr.data_ptr() + 4, self.ctr.data_ptr() + 8
+        st.step, st.n_stopped = self.ctr.data_ptr(), self.ctr.data_ptr() + 8
         st.first_eos, st.stop_t, st.params = self.first_eos.data_ptr(), self.stop_t.data_ptr(), self.params.data_ptr()
         st.recent = self.recent.data_ptr()
         st.seed, st.B, st.D, st.Tar, st.max_steps, st.V, st.bos_row = 7, B, D, Tar, Tar, V, 2 * V
@@ -966,6 +1018,35 @@ def test_sampler_nonce_changes_the_take_and_pins_it():
     assert len({tuple(r.tolist()) for r in runs[0]}) > 1  # rows differ too (the row index is part of the counter)
 
 
+def test_sampler_key_in_device_memory_and_run_to_run_determinism():
+    """(1) the Philox key is read from device memory, so a recorded frame graph follows a new seed; (2) candidate
+    positions no longer depend on which wave arrives first: the same (key, nonce) gives the same tokens run after run, also on
+    the many-candidates path and with logits that put the top-p cut / the draw on close calls."""
+    B, V1, steps = 32, 2049, 24
+    for scale in (1.5, 0.02, -1.0):
+        base = rnd(V1, seed=330, scale=abs(scale))
+        if scale < 0:
+            base[:200] = 10.0 - 1e-3 * torch.arange(200)  # > 128 candidates: the general ranking path
+        lg = dev(base[None].repeat(B, 1))
+        runs = []
+        rig = _SamplerRig(B, Tar=steps + 1)
+        rig.set_params(0.9, 1.05, False)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            hip.capture_begin()
+            hip.ar_sample(rig.st, lg, V1)
+            g = hip.capture_end()  # ONE recorded launch serves every key
+            for key in (7, 7, 7, 8):
+                rig.key.copy_(torch.tensor([key, 0], dtype=torch.int32), non_blocking=False)
+                hip.ar_init(rig.st)
+                for _ in range(steps):
+                    g.launch()
+                s.synchronize()
+                runs.append(rig.hist[:, :steps].cpu())
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), scale
+        assert not torch.equal(runs[0], runs[3]), scale
+
+
 def test_sampler_anti_loop_detection():
     """repeated_tail / streak >= 8 switch that frame to the recovery parameters (model.py:274-279).
     Recovery top_p is set to 0 here so that a detected loop shows up as an exact arg-max."""
@@ -988,6 +1069,7 @@ def test_sampler_anti_loop_detection():
         rig.recent.copy_(rec)
         rig.ctr.zero_()
         rig.ctr[0] = L
+        rig.row_step.fill_(L)  # the sampler's own (per-row) frame counter
         lg = flat[None].repeat(B, 1)
         hip.ar_sample(rig.st, dev(lg), V1)
         torch.cuda.synchronize()
