@@ -73,6 +73,16 @@ def make_inputs(rank: int):
     return ids, ref_tq
 
 
+def make_voices(rank: int, n: int):
+    """One reference voice per utterance (ref_tokens of utterance i from seed 1000 + index).  Voice 0 is the
+    voice of make_inputs(rank), so row 0 of a batch is the utterance the oracle leg checks."""
+    out = [make_inputs(rank)[1]]
+    for i in range(1, n):
+        rng = np.random.default_rng(1000 + 4096 * (rank + 1) + i)
+        out.append(torch.from_numpy(rng.integers(0, 2048, size=(REF_FRAMES, 32))))
+    return out
+
+
 def oracle_parity(cfg, wn, path: str):
     """Row 0 of the engine's greedy batch (token matrix saved by the parent) against the oracle: codebook 0 must be
     equal; refined tokens equal, or every deviating decision an audited near-tie (oracle.nar_audit)."""
@@ -118,9 +128,24 @@ def cpu_baseline(cfg, mc, wn, mn, n_utts: int):
             wav = O.synthesize(ids[i % len(ids)], ref, w, mw, cfg, mc, max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True)
             frames += wav.shape[-1] // 1920
         dt = time.perf_counter() - t0
-    return {"value": round(frames * FRAME_SEC / dt, 3), "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_utts} utterances x {FRAMES} frames, sequential synthesize() of oracle/sopro_oracle.py (torch fp32 CPU), "
-                      f"{dt:.1f} s wall"}
+        # time-to-first-audio of the oracle's stream() (reference: src/sopro/streaming.py:24-130), same arguments as the GPU leg
+        lat = []
+        n_ttfa = int(os.environ.get("SOPRO_BENCH_CPU_TTFA_RUNS", "20"))
+        for i in range(n_ttfa + 2):
+            t1 = time.perf_counter()
+            it = O.stream(ids[i % len(ids)], ref, w, mw, cfg, mc, max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True, chunk_frames=6)
+            next(it)
+            if i >= 2:
+                lat.append((time.perf_counter() - t1) * 1e3)
+            it.close()
+    out = {"value": round(frames * FRAME_SEC / dt, 3), "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n_utts} utterances x {FRAMES} frames, sequential synthesize() of oracle/sopro_oracle.py (torch fp32 CPU), "
+                     f"{dt:.1f} s wall"}
+    if lat:
+        out["ttfa_ms_p50"] = round(float(np.percentile(lat, 50)), 2)
+        out["ttfa_runs"] = len(lat)
+        out["ttfa_what"] = "first chunk of oracle stream(chunk_frames=6), same text / voice / sampling arguments as ttfa_ms_p50 of the GPU leg"
+    return out
 
 
 def ar_step_bytes(B: int, S: int, wbytes: int = 4, abytes: int = 4) -> float:

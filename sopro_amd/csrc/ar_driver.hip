@@ -90,6 +90,15 @@ __device__ __forceinline__ unsigned wave_nth_largest_u32(unsigned v, int n) {
   return r;
 }
 
+// Lanes of ONE wave exchanging data through LDS: the hardware executes a wave's LDS operations in issue order, so no barrier
+// is needed - but the compiler reasons per thread (it may forward a thread's own store to its later load, or move a load into
+// a branch).  A wavefront-scope fence pair + a scheduling barrier pins the order; it emits no instruction beyond a wait.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr int RECENT = 64;   // rolling token window per row: slot j = token sampled j+1 frames ago (-1 = none)
 constexpr int PER = 9;       // logits per thread: ceil(2049 / 256), element q*256 + tid
 constexpr int WREG = PER * 64;             // candidate slots of one wave's region (every logit of the wave may qualify)
@@ -204,7 +213,9 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
     const bool in_win = lane < 50 && r_mine >= 0 && r_mine < V1;
     unsigned* mine = pen_bits + wave * 64;
     mine[lane] = 0u;
+    wave_lds_sync();  // lanes talk to each other through LDS: the compiler must neither reorder nor forward across these points
     if (in_win && ((r_mine >> 6) & 3) == wave) atomicOr(&mine[r_mine & 63], 1u << (r_mine >> 8));
+    wave_lds_sync();
     const unsigned pm = mine[lane];
 #pragma unroll
     for (int q = 0; q < PER; ++q)
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
         if ((m >> lane) & 1ull) {
           const unsigned at = pos + (unsigned)__popcll(m & lt);
           cand_k[at] = ((u64)ov[q] << 12) | (u64)(4095 - (q * SAMP_THREADS + tid));
-          cand_e[at] = expf(xv[q] - xmax);
+          cand_e[at] = xv[q];  // the penalised logit; exp(x - max) is taken by whoever ranks the candidate (two per lane)
         }
         pos += (unsigned)__popcll(m);
       }
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
       // ---- all pairs in registers: lane l of every wave holds candidates l and l + 64; wave w broadcasts 32w .. 32w + 31
       const int ca = lane, cb = lane + 64;
       const u64 ka = ca < C ? cand_k[slot_of(ca)] : 0ull, kb = cb < C ? cand_k[slot_of(cb)] : 0ull;   // 0 sorts below every real key
-      const float ea = ca < C ? cand_e[slot_of(ca)] : 0.f, eb = cb < C ? cand_e[slot_of(cb)] : 0.f;
+      const float ea = ca < C ? expf(cand_e[slot_of(ca)] - xmax) : 0.f, eb = cb < C ? expf(cand_e[slot_of(cb)] - xmax) : 0.f;
       const unsigned src_lo = (wave & 2) ? (unsigned)kb : (unsigned)ka, src_hi = (wave & 2) ? (unsigned)(kb >> 32) : (unsigned)(ka >> 32);
       const float src_e = (wave & 2) ? eb : ea;
       int ra = 0, rb = 0;
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
         if (cb < C && rkb < kk) { selk[rkb] = kb; sele[rkb] = eb; selb[rkb] = ahb; }
       }
       // one wave wrote, the same wave reads: LDS executes a wave's operations in issue order (no barrier - the other waves are gone)
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_sync();
     } else {
       // ---- many ties at the bound (degenerate logits): the same ranks from LDS, any number of candidates
       for (int c = tid; c < C; c += SAMP_THREADS) {
@@ -331,9 +342,9 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
           const int sj = slot_of(j);
           const bool gt = cand_k[sj] > kc;
           rank += gt ? 1 : 0;
-          ahead += gt ? cand_e[sj] : 0.f;
+          ahead += gt ? expf(cand_e[sj] - xmax) : 0.f;
         }
-        if (rank < kk) { selk[rank] = kc; sele[rank] = cand_e[slot_of(c)]; selb[rank] = ahead; }
+        if (rank < kk) { selk[rank] = kc; sele[rank] = expf(cand_e[slot_of(c)] - xmax); selb[rank] = ahead; }
       }
       __syncthreads();
       SAMP_STAMP(5);
