@@ -169,6 +169,101 @@ def latest_profile(suffix: str) -> dict:
         return {}
 
 
+def profile_stamp(path: str) -> dict:
+    """Identity of a committed profile file whose numbers are REPLAYED into the line (not measured by this run): path +
+    content hash (there is no .git on the GPU box; `git log -- <file>` on the same content gives the commit)."""
+    import hashlib
+
+    try:
+        return {"file": os.path.relpath(path, ROOT), "sha256_16": hashlib.sha256(open(path, "rb").read()).hexdigest()[:16], "replayed": True}
+    except OSError:
+        return {"file": path, "replayed": True}
+
+
+def rocprof_family_table() -> dict:
+    """Per-launch kernel time of the instrumented families from the latest committed rocprofv3 --kernel-trace --stats summary of
+    this command (profiles/rNN_bench_lanes4_kernel_stats.csv): kernel time proper, where HIP events around a sub-50-us launch on
+    a shared partition mostly measure queueing."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_lanes4_kernel_stats.csv")))
+    if not files:
+        return {}
+    pat = {"gemm_f32_kernel": "gemm_f32_kernel", "gemm_bf16s_kernel<1,": "gemm_bf16x1_kernel", "gemm_bf16s_kernel<2,": "gemm_bf16x3_kernel",
+           "gemm_bf16s_kernel<3,": "gemm_bf16x6_kernel", "attention_kernel": "attention_kernel", "attn_window_mfma_kernel": "attention_kernel",
+           "attn_decode_kernel": "attention_kernel"}
+    out: dict = {}
+    try:
+        for r in csv.DictReader(open(files[-1])):
+            for k, fam in pat.items():
+                if k in r["Name"]:
+                    d = out.setdefault(fam, {"calls": 0, "ns": 0.0})
+                    d["calls"] += int(r["Calls"])
+                    d["ns"] += float(r["TotalDurationNs"])
+                    break
+    except Exception:  # noqa: BLE001
+        return {}
+    return {"families": {k: round(v["ns"] / max(1, v["calls"]) / 1e3, 2) for k, v in out.items()}, "stamp": profile_stamp(files[-1])}
+
+
+def run_leg(tts, ids, refs, *, frames: int, steps: int, lanes: int, args, seed: int = 20260924) -> dict:
+    """A short throughput run of another shape / voice set / engine right after the headline run, on the same box: warm-up
+    (eager pass + recording of the launch sequences), then `steps` timed steps bracketed by device syncs."""
+    B = len(ids)
+    job = dict(texts=[""] * B, refs=list(refs), max_frames=frames - 1, top_p=0.9, temperature=1.05, anti_loop=True, text_ids=list(ids), seed=seed)
+    pipe = None
+    if lanes > 1:
+        from sopro_amd.pipeline import PipelinedSynthesizer
+
+        pipe = PipelinedSynthesizer(tts, lanes=lanes, ar_cus=args.ar_cus, ar_parts=args.ar_parts, ar_shared=bool(args.ar_shared), bulk_slots=args.bulk_slots)
+
+    def go(n):
+        outs = pipe.run([job] * n) if pipe is not None else [tts.synthesize_batch(**job) for _ in range(n)]
+        for out in outs:
+            assert all(o.shape[-1] == frames * 1920 for o in out)
+
+    try:
+        go(max(2, 2 * lanes if pipe is not None else 2))
+        torch.cuda.synchronize()
+        c0, t0 = time.process_time(), time.perf_counter()
+        go(steps)
+        torch.cuda.synchronize()
+        dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+    finally:
+        if pipe is not None:
+            pipe.close()
+    return {"value": round(steps * B * frames * FRAME_SEC / dt, 2), "unit": "audio-s/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "batch": B, "frames": frames, "lanes": lanes, "voices": len({id(r) for r in refs}), "host_cpu_s_per_step": round(cpu / steps, 4)}
+
+
+def bf16_quality(tts, tts16, ids, refs, frames: int, cfg, n: int = 4) -> dict:
+    """What the bf16 mode costs in quality, measured against the fp32 engine on the same inputs (greedy decoding, n utterances):
+    how long free-running codebook-0 generation stays identical, how many refined tokens agree given the fp32 engine's
+    codebook 0 and conditioning, and the decoder's waveform error on the fp32 engine's tokens.  (tests/test_gpu_bf16_mode.py
+    measures the same things against the fp32 REFERENCE fixtures.)"""
+    kw = dict(max_frames=frames - 1, top_p=0.0, temperature=1.0, anti_loop=False, style_strength=float(cfg.style_strength))
+    g32 = tts.model.generate_tokens_batch(ids[:n], refs[:n], **kw)
+    g16 = tts16.model.generate_tokens_batch(ids[:n], refs[:n], **kw)
+    first = []
+    for a, b in zip(g32, g16):
+        m = min(int(a.shape[0]), int(b.shape[0]))
+        neq = (a[:m, 0] != b[:m, 0]).nonzero()
+        first.append(int(neq[0]) if neq.numel() else m)
+    T = min(int(g.shape[0]) for g in g32)
+    r32 = torch.stack([g[:T] for g in g32])
+    prep = tts.model.prepare_conditioning_batch(ids[:n], refs[:n], max_frames=frames - 1, style_strength=kw["style_strength"])
+    r16 = tts16.model.nar_refine(prep["cond_ar"][:, :T], r32[:, :, 0])
+    agree = float((r16[:, :, 1:] == r32[:, :, 1:]).float().mean())
+    w32, w16 = tts.codec.decode_batch(r32).float(), tts16.codec.decode_batch(r32).float()
+    torch.cuda.synchronize()
+    err = float((w16 - w32).abs().max() / w32.abs().max())
+    snr = 10.0 * float(torch.log10((w32 ** 2).mean() / ((w16 - w32) ** 2).mean()))
+    return {"against": "the fp32 engine on the same inputs", "utterances": n, "frames": T,
+            "greedy_codebook0_identical_frames": first, "refined_token_agreement_given_fp32_codebook0": round(agree, 4),
+            "waveform_max_err_of_peak": float(f"{err:.3e}"), "waveform_snr_db": round(snr, 1)}
+
+
 _T0 = time.perf_counter()
 
 
@@ -195,6 +290,8 @@ def main() -> None:
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 (default): the parity configuration; bf16: bf16 weights/operands with fp32 accumulation (BASELINE configs[1] wording)")
     ap.add_argument("--frames", type=int, default=FRAMES, help="frames per utterance (default: BASELINE configs[1]; 400 = the long-form case)")
+    ap.add_argument("--voices", type=int, default=-1, help="distinct reference voices per batch (default: one per utterance, SURVEY 8d; 1 = one shared voice)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra legs of the default run (one shared voice, 32x400 / 1x400 frames, bf16 mode)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--parity-tokens", type=str, default="", help=argparse.SUPPRESS)
     ap.add_argument("--input-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: a 1-GPU run on the inputs of rank R
@@ -245,9 +342,13 @@ def main() -> None:
 
     log("building engine")
     tts, cfg, mc, wn, mn = build_engine(device, args.precision)
-    ids, ref_tq = make_inputs(rank if args.input_rank < 0 else args.input_rank)
-    ref = tts.prepare_reference(ref_tokens_tq=ref_tq)  # per-voice, outside the timed region (README "precalculate" flow)
-    refs = [ref] * BATCH
+    in_rank = rank if args.input_rank < 0 else args.input_rank
+    ids, ref_tq = make_inputs(in_rank)
+    # per-voice preparation, outside the timed region (README "precalculate" flow); one voice per utterance
+    n_voices = BATCH if args.voices < 0 else max(1, min(BATCH, args.voices))
+    voices = [tts.prepare_reference(ref_tokens_tq=v) for v in make_voices(in_rank, n_voices)]
+    ref = voices[0]
+    refs = [voices[i % n_voices] for i in range(BATCH)]
     # one seed for every step: the steps are then the same job, and their outputs must be bit-identical (checked below)
     kw = dict(max_frames=FRAMES - 1, top_p=0.9, temperature=1.05, anti_loop=True, text_ids=ids, seed=20260924)
 
@@ -295,10 +396,12 @@ def main() -> None:
     log("timed steps")
     hip.phase_log = []  # two HIP events per AR phase, on the AR stream: the frame time of the timed region itself
     phases = {}
+    c0 = time.process_time()  # CPU time of every thread of this process (launch threads included)
     t0 = time.perf_counter()
     run_steps(args.steps, phases)
     fence()
     dt = time.perf_counter() - t0
+    host_cpu = time.process_time() - c0
     log(f"timed region done: {dt:.3f} s for {args.steps} steps; peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     if os.environ.get("SOPRO_BENCH_TRACE") and pipe is not None:  # developer aid: which lane ran which step when, and its phase times
         for rep in range(int(os.environ["SOPRO_BENCH_TRACE"])):
@@ -354,11 +457,14 @@ def main() -> None:
 
     # ---- rooflines of the instrumented families (HIP events recorded on the engine streams during the instrumented repeat)
     fam = prof.summary()
-    pmc, busy, ark = latest_profile("pmc_summary.json").get("families", {}), latest_profile("pmc_mfma_busy.json").get("families", {}), \
-        latest_profile("ar_kernels.json")
+    pmc_d, busy_d, ark = latest_profile("pmc_summary.json"), latest_profile("pmc_mfma_busy.json"), latest_profile("ar_kernels.json")
+    pmc, busy = pmc_d.get("families", {}), busy_d.get("families", {})
+    stamp_of = lambda d: profile_stamp(os.path.join(ROOT, d["source"])) if d.get("source") else None  # noqa: E731
+    rocf = rocprof_family_table()
     share = (256 - args.ar_cus * (1 if args.ar_shared else args.ar_parts)) / 256.0 if (args.lanes > 1 and args.ar_cus > 0) else 1.0  # CUs of the bulk partition
     ar_share = (args.ar_cus * (1 if args.ar_shared else args.ar_parts)) / 256.0 if (args.lanes > 1 and args.ar_cus > 0) else 1.0
-    measured = f"HIP events on the launch stream over an instrumented repeat of {nprof} steps right after the timed region"
+    measured = (f"HIP events on the launch stream over an instrumented repeat of {nprof} steps right after the timed region; samples whose "
+                "stream was idle at the first event (host-bound span) are excluded and the family time is scaled from the GPU-bound ones")
 
     def mfma_entry(key, title, peak, passes, extra_note):
         f = fam[key]
@@ -367,13 +473,20 @@ def main() -> None:
              "frac": round(ach / (peak * share), 5), "cu_share": share, "peak_full_chip": peak, "frac_full_chip": round(ach / peak, 5),
              "traffic": pmc.get(key, {}).get("traffic_bytes_per_launch"), "launches": f["launches"],
              "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2), "ms_per_step": round(f["ms"] / max(1, nprof), 3),
-             "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"])), "measured": measured}
+             "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"])), "measured": measured,
+             "gpu_bound_samples": f.get("gpu_bound"), "samples": f["launches"]}
         if passes > 1:
             e["mfma_passes_per_product"] = passes
             e["frac_of_pass_ceiling"] = round(ach / (peak * share / passes), 5)
             e["note"] = f"achieved = algorithmic (fp32-equivalent) flops / launch time; each product costs {passes} bf16 MFMA passes. " + extra_note
+        if e["traffic"] is not None:
+            e["traffic_profile"] = stamp_of(pmc_d)
         if key in busy:
             e["mfma_busy_pmc"] = busy[key].get("mfma_busy_share_at_2p4ghz")
+            e["mfma_busy_profile"] = stamp_of(busy_d)
+        if key in rocf.get("families", {}):
+            e["avg_launch_us_rocprof"] = rocf["families"][key]
+            e["rocprof_profile"] = rocf["stamp"]
         return e
 
     entries = []  # (summed ms, entry)
@@ -410,15 +523,38 @@ def main() -> None:
                           if ar_frames else measured),
              "note": ("one launch = one frame of one 32-row batch; in the pipeline two AR phases replay concurrently on the generation "
                       "partition, so the phase sum exceeds the wall time per step" if args.lanes > 1 else "sequential batches, whole chip")}
+        if tr:
+            e["traffic_profile"] = stamp_of(pmc_d)
         if ark.get("kernels"):
             e["per_kernel_us_rocprof"] = ark["kernels"]
-            e["per_kernel_source"] = ark.get("source")
+            e["per_kernel_profile"] = profile_stamp(os.path.join(ROOT, ark["source"])) if ark.get("source") and not os.path.isabs(ark["source"]) \
+                else {"file": ark.get("source"), "replayed": True}
         entries.append(((ar_ms * nprof / args.steps) if ar_frames else f["ms"], e))  # same basis as the others: ms over nprof steps
+    # a contraction family cannot have spent more than the phases that contain it (conditioning + refinement + decoding, from the
+    # un-instrumented phase timers of the timed region): caps what a host-bound instrumented repeat could inflate
+    bulk_cap = sum(phases.get(k, 0.0) for k in ("cond", "nar", "mimi")) / max(1, args.steps) * 1e3 * max(1, nprof)
+    entries = [((min(ms, bulk_cap) if (bulk_cap > 0 and not e["kernel"].startswith("AR frame")) else ms), e) for ms, e in entries]
     entries.sort(key=lambda t: -t[0])
+    # Families whose launches are short (rocprof average under 50 us) are NOT reported from HIP events: events around a short
+    # launch on a shared partition mostly measure queueing (r2: 187 us per launch by events, 32.8 us by rocprof).  They keep
+    # their launch count and the rocprof figure of the committed profile.
+    small = {k for k, us in rocf.get("families", {}).items() if us < 50.0}
+    dropped = [e["kernel"] for _, e in entries if any(e["kernel"].startswith(k) for k in small)]
+    entries = [(ms, e) for ms, e in entries if not any(e["kernel"].startswith(k) for k in small)]
     roof = entries[0][1] if entries else None
     roof_more = [e for _, e in entries[1:]]
-    families = {k: {"ms_per_step": round(v["ms"] / max(1, nprof), 3), "launches_per_step": v["launches"] // max(1, nprof),
-                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 3) if v["flops"] else None} for k, v in fam.items()}
+    families = {}
+    for k, v in fam.items():
+        d = {"launches_per_step": v["launches"] // max(1, nprof)}
+        if k in small:
+            d.update(timing="rocprof (committed profile): launches under 50 us are not timed with HIP events", avg_launch_us_rocprof=rocf["families"][k],
+                     ms_per_step_rocprof=round(rocf["families"][k] * d["launches_per_step"] / 1e3, 3), rocprof_profile=rocf["stamp"])
+        else:
+            d.update(timing="hip-events (instrumented repeat)", ms_per_step=round(v["ms"] / max(1, nprof), 3),
+                     tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 3) if v["flops"] else None)
+            if k in rocf.get("families", {}):
+                d["avg_launch_us_rocprof"] = rocf["families"][k]
+        families[k] = d
 
     if pipe is not None:
         pipe.close()  # the latency leg below runs on the whole chip
@@ -477,6 +613,36 @@ def main() -> None:
             del it, first
         ttfa = float(np.percentile(lat, 50))
 
+    # ---- extra legs of the default run (BASELINE.json configs the headline does not cover), rank 0 of a single-GPU run only
+    legs = None
+    default_shape = (BATCH, FRAMES) == (32, 200) and args.precision == "f32"
+    if rank == 0 and world == 1 and default_shape and not args.no_legs:
+        legs = {}
+        try:
+            log("leg: one shared voice")
+            legs["one_voice_32x200"] = run_leg(tts, ids, [ref] * BATCH, frames=FRAMES, steps=8, lanes=args.lanes, args=args)
+            log("leg: 32 x 400 frames")
+            legs["f32_32x400"] = run_leg(tts, ids, refs, frames=400, steps=6, lanes=args.lanes, args=args)
+            log("leg: 1 x 400 frames, strictly sequential")
+            legs["f32_1x400_sequential"] = run_leg(tts, ids[:1], refs[:1], frames=400, steps=8, lanes=1, args=args)
+            log("leg: bf16 mode")
+            tts16 = build_engine(device, "bf16")[0]
+            b16 = run_leg(tts16, ids, refs, frames=FRAMES, steps=12, lanes=args.lanes, args=args)
+            b16["dtype"] = "bf16"
+            b16["dtype_detail"] = ("bf16 mode: NAR + Mimi contractions with both operands rounded to bf16 once (one MFMA pass); the AR frame streams bf16 "
+                                   "weights with bf16 MFMA operands; fp32 accumulators, norms, softmax, ring buffers and residual streams; conditioning "
+                                   "stays fp32.  A throughput mode, not a parity mode: quote it with its quality block")
+            b16["quality"] = bf16_quality(tts, tts16, ids, refs, FRAMES, cfg)
+            legs["bf16_32x200"] = b16
+            b16_400 = run_leg(tts16, ids, refs, frames=400, steps=6, lanes=args.lanes, args=args)
+            b16_400["dtype"] = "bf16"
+            legs["bf16_32x400"] = b16_400
+            del tts16
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001  (a failed leg must not void the headline)
+            log(f"legs failed: {e!r}")
+            legs["error"] = repr(e)
+
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import subprocess
@@ -504,9 +670,10 @@ def main() -> None:
             "steps": args.steps, "warmup": args.warmup, "warmup_run": warm, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"Sopro-135M synthesize, {BATCH} utterances x {FRAMES} frames per GPU ({'BASELINE configs[1]' if (BATCH, FRAMES) == (32, 200) else 'non-default shape'}), "
-                                   f"S={TEXT_LEN} text tokens, {REF_FRAMES}-frame reference voice prepared outside the timed region, "
-                                   "top_p=0.9 T=1.05 anti_loop (reference defaults), synthetic weights with EOS suppressed",
-                       "batch_per_gpu": BATCH, "frames": FRAMES, "parallelism": f"replicas x{world} (utterance sharding, no collective)",
+                                   f"S={TEXT_LEN} text tokens, {n_voices} distinct {REF_FRAMES}-frame reference voice(s) per batch prepared outside the timed "
+                                   "region, top_p=0.9 T=1.05 anti_loop (reference defaults), synthetic weights with EOS suppressed",
+                       "batch_per_gpu": BATCH, "frames": FRAMES, "voices_per_batch": n_voices,
+                       "parallelism": f"replicas x{world} (utterance sharding, no collective)",
                        "lanes_per_gpu": args.lanes,
                        "pipelining": (f"{args.lanes} engines per GPU share the weights: up to {args.ar_parts} AR phases at a time on "
                                       f"{'one shared partition' if args.ar_shared else 'partitions'} of {args.ar_cus} CUs while conditioning, NAR and Mimi "
@@ -516,10 +683,15 @@ def main() -> None:
                              "three bf16 pieces (24 mantissa bits, 6 MFMA passes); Mimi decoder contractions with two pieces (16 bits, 3 passes)")
                             if args.precision == "f32" else
                             ("bf16 mode (SURVEY 8d config 2): NAR + Mimi contractions with both operands rounded to bf16 once, one MFMA pass, fp32 accumulators, "
-                             "norms, softmax and residual streams; conditioning and the AR frame stay fp32.  Not a parity line: see tests/test_gpu_bf16_mode.py"),
+                             "norms, softmax and residual streams; the AR frame streams bf16 weights with bf16 MFMA operands (fp32 accumulate, norms, ring buffers, residual); "
+                             "only conditioning stays fp32.  Not a parity line: see tests/test_gpu_bf16_mode.py"),
             "phase_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phases.items()},
             "kernel_families": families,
             "ttfa_ms_p50": None if ttfa is None else round(ttfa, 3),
+            "cpu_ttfa_ms_p50": (cpu or {}).get("ttfa_ms_p50"),
+            "host_cpu_s_per_step": round(host_cpu / args.steps, 4),
+            "host_cpu_note": "CPU time of all threads of this rank's process over the timed region / steps (launch threads of the lanes included)",
+            "legs": legs, "roofline_dropped": dropped,
             "roofline": roof, "roofline_more": roof_more, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
           if (epi == SOPRO_EPI_GELU) y = gelu_erf(y);
           else if (epi == SOPRO_EPI_TANH) y = tanhf(y);
         }
-        if (res_here) y = e_res[mt][nt] + e_scale[nt] * y;
+        if (res_here) y = fmaf(e_scale[nt], y, e_res[mt][nt]);  // (explicit: every workgroup shape must round alike)
         if (ok) yp[(int64_t)b_row[mt] * a.ldy + n_col[nt]] = y;
       } else {
         const float pre = v + e_bias[nt];                // lanes 0-7: value, lanes 8-15: gate pre-activation
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
         const float h = pre * sigmoidf_(gate);
         float y = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXTAPS - 1; ++j) y += tapw[nt][j] * tapv[mt][nt][j];
-        y += tapw[nt][MAXTAPS - 1] * h;
+        for (int j = 0; j < MAXTAPS - 1; ++j) y = fmaf(tapw[nt][j], tapv[mt][nt][j], y);  // explicit fma chain: the compiler must
+        y = fmaf(tapw[nt][MAXTAPS - 1], h, y);                                            // not pick mul + add in one shape
         y += e_dwb[nt];
         if (ok) {
           a.ring[((int64_t)slot_now * a.ring_bcap + b_row[mt]) * D + n_col[nt]] = h;

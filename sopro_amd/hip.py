@@ -217,36 +217,46 @@ def load() -> C.CDLL:
 
 class Profiler:
     """HIP-event timing of the heavy launches, recorded on the stream each launch is enqueued on
-    (bench.py's roofline leg).  Families: the fp32 GEMM kernel, the attention kernel, AR graph replays."""
+    (bench.py's roofline leg).  Families: the GEMM kernels, the attention kernel, AR graph replays.
+    A sample whose stream was IDLE when its first event was recorded is host-bound (the span then contains the host's
+    time between the record and the launch, not only the kernel): such samples are kept apart, and the family's time is
+    extrapolated from the GPU-bound ones."""
 
     def __init__(self):
-        self.rec = []  # (family, flops, ev0, ev1)
+        self.rec = []  # (family, flops, ev0, ev1, gpu_bound)
 
     def begin(self):
+        s = torch.cuda.current_stream()
         e = torch.cuda.Event(enable_timing=True)
-        e.record(torch.cuda.current_stream())
-        return e
+        e.record(s)
+        return (e, not s.query())  # work still queued in front of the launch: the span is GPU time
 
     def end(self, family: str, flops: float, e0) -> None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record(torch.cuda.current_stream())
-        self.rec.append((family, flops, e0, e1))
+        self.rec.append((family, flops, e0[0], e1, e0[1]))
 
     def summary(self) -> dict:
         torch.cuda.synchronize()
         out: dict = {}
-        for fam, fl, e0, e1 in self.rec:
-            d = out.setdefault(fam, {"ms": 0.0, "launches": 0, "flops": 0.0})
-            d["ms"] += e0.elapsed_time(e1)
+        for fam, fl, e0, e1, bound in self.rec:
+            d = out.setdefault(fam, {"ms": 0.0, "launches": 0, "flops": 0.0, "ms_all": 0.0, "gpu_bound": 0, "ms_bound": 0.0, "flops_bound": 0.0})
+            t = e0.elapsed_time(e1)
+            d["ms_all"] += t
             d["launches"] += 1
             d["flops"] += fl
+            if bound:
+                d["gpu_bound"] += 1
+                d["ms_bound"] += t
+                d["flops_bound"] += fl
+        for d in out.values():
+            # time of the family: GPU-bound samples scaled to all launches (by flops where the family has them)
+            if d["gpu_bound"] * 10 >= d["launches"] and d["ms_bound"] > 0:
+                scale = (d["flops"] / d["flops_bound"]) if d["flops_bound"] > 0 else d["launches"] / d["gpu_bound"]
+                d["ms"] = d["ms_bound"] * scale
+            else:
+                d["ms"] = d["ms_all"]
         return out
-
-
-_prof: Optional[Profiler] = None
-# bench.py: when a list, ar_generate_batch appends (frames, start event, end event) of every AR phase - two HIP events per
-# phase on the AR stream, cheap enough for the timed region itself
-phase_log: Optional[list] = None
 
 
 def set_profiler(p: Optional[Profiler]) -> None:
