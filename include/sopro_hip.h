@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 27
+#define SOPRO_ABI_VERSION 28
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -136,6 +136,7 @@ typedef struct sopro_gemm_split_ext {
    * (each XCD gets one contiguous range of the walk) share g row blocks of A and a few column blocks of W in its 4 MB L2
    * instead of streaming the whole W once per row tile.  Filled from sopro_gemm_set_group_m when 0. */
   int32_t group_m;
+  float acc_scale;     /* sopro_gemm_f16x3 only: 1 / (sopro_f16x3_a_scale() * the weight's pack scale), applied to the accumulator */
 } sopro_gemm_split_ext;
 int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
 /* Six-pass variant for token paths (NAR refinement, conditioning: src/sopro/nn/nar.py, blocks.py): operands split into
@@ -155,6 +156,15 @@ int sopro_gemm_bf16x1(const sopro_gemm_args* a, const void* packed_w, const sopr
 /* W [N, ldw] fp32 (device) -> `pieces` (2: bf16x3, 3: bf16x6) bf16 planes in MFMA fragment order
  * [n/32][k/16][piece][lane][8]; `packed` holds sopro_packed_w_bytes(N, K, pieces) bytes, 16-byte aligned. */
 int sopro_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t pieces, void* packed, void* stream);
+/* Three-pass variant for token paths ("f16x3", round 3): operands split into TWO fp16 pieces (22 mantissa bits; the dropped
+ * lo*lo term is <= 2^-22 relative), products lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16 - the forms of
+ * sopro_gemm_bf16x6 (fp32 rows in / out or arg-max partials, prologues NONE / ADDVEC, epilogues NONE / GELU / RES / GLU, fused
+ * RMSNorm) at half its passes.  fp16 has a narrow exponent: activations are scaled by sopro_f16x3_a_scale() (a power of two)
+ * while they are staged, the weight by `wscale` (a power of two chosen by the host so that max|W| * wscale <= ~2^14) when it is
+ * packed (sopro_packed_w_bytes(N, K, 2) bytes), and ext->acc_scale = 1 / (a_scale * wscale) undoes both exactly. */
+int sopro_pack_w_f16x2(const float* W, int64_t ldw, int32_t N, int32_t K, float wscale, void* packed, void* stream);
+float sopro_f16x3_a_scale(void);
+int sopro_gemm_f16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
 int64_t sopro_packed_w_bytes(int32_t N, int32_t K, int32_t pieces);
 int sopro_gemm_bf16_set_tile_override(int cfg); /* developer probe */
 int sopro_gemm_set_group_m(int g);              /* default tile-walk group of the split-bf16 contractions (see group_m) */

@@ -29,19 +29,37 @@ constexpr int BK = 32;
 constexpr int ABL = SOPRO_ABLATE;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ bf16x8 as_frag(const uint4& v) { return *reinterpret_cast<const bf16x8*>(&v); }
+__device__ __forceinline__ f16x8 as_frag16(const uint4& v) { return *reinterpret_cast<const f16x8*>(&v); }
 
-// two fp32 values -> NPL packed bf16 pairs (piece p of x in the low half, of y in the high half)
-template <int NPL>
+// F16 ("f16x3", round 3): the two pieces are fp16 (11 mantissa bits each -> 22 bits per operand, dropped lo*lo <= 2^-22) at the
+// same three MFMA passes as bf16x3: the token paths' accuracy class (NAR arg-max margins) at half of bf16x6's passes.  fp16
+// has 5 exponent bits, so both operands are scaled by powers of two into its range (activations by A16_SCALE while they are
+// staged, a weight matrix by its own power of two when it is packed; products are exact in the scale, the accumulator is
+// multiplied by 1 / (both) in the epilogue): below 2^-14 a piece goes subnormal and the absolute resolution stays 2^-24 of
+// the scaled value, i.e. ~7e-9 of the unscaled activation - small against 2^-22 of an O(1) row.
+constexpr float A16_SCALE = 8.0f;  // |activation| < 8188 stays finite; nothing on the NAR path is near it
+
+// two fp32 values -> NPL packed 16-bit pairs (piece p of x in the low half, of y in the high half)
+template <int NPL, bool F16 = false>
 __device__ __forceinline__ void split_pair(float x, float y, unsigned (&pc)[NPL]) {
 #pragma unroll
   for (int p = 0; p < NPL; ++p) {
     const f32x2_t v = {x, y};
-    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
-    pc[p] = *reinterpret_cast<const unsigned*>(&h);
-    x -= __uint_as_float(pc[p] << 16);  // exact
-    y -= __uint_as_float(pc[p] & 0xffff0000u);
+    if constexpr (F16) {
+      const f16x2_t h = __builtin_convertvector(v, f16x2_t);  // round to nearest even
+      pc[p] = *reinterpret_cast<const unsigned*>(&h);
+      x -= (float)h[0];  // exact
+      y -= (float)h[1];
+    } else {
+      const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+      pc[p] = *reinterpret_cast<const unsigned*>(&h);
+      x -= __uint_as_float(pc[p] << 16);  // exact
+      y -= __uint_as_float(pc[p] & 0xffff0000u);
+    }
   }
 }
 
@@ -50,7 +68,7 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned (&pc)[NPL]
 // 16-byte copies; 3 = fp32 rows + pro_vec[k] (PRO_ADDVEC); 4 = fp32 rows whose RMSNorm is fused: the row's sum of squares is
 // accumulated while it is staged and rsqrt(mean + eps) scales the accumulator in the epilogue (the norm's weight vector is
 // folded into W by the host; needs K % 32 == 0 and no split-K: every workgroup sees its rows' whole K).
-template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT, bool SK>
+template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT, bool SK, bool F16 = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gemm_args g, const uint4* __restrict__ Wp,
                                                                  int ksubs, const sopro_gemm_split_ext ext) {
   constexpr int AROW = NPL * 64 + 16;  // bytes per LDS row
@@ -156,8 +174,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
         unsigned c0[NPL], c1[NPL];
-        split_pair<NPL>(ra[i].x, ra[i].y, c0);
-        split_pair<NPL>(ra[i].z, ra[i].w, c1);
+        if constexpr (F16) {
+          split_pair<NPL, true>(ra[i].x * A16_SCALE, ra[i].y * A16_SCALE, c0);
+          split_pair<NPL, true>(ra[i].z * A16_SCALE, ra[i].w * A16_SCALE, c1);
+        } else {
+          split_pair<NPL>(ra[i].x, ra[i].y, c0);
+          split_pair<NPL>(ra[i].z, ra[i].w, c1);
+        }
 #pragma unroll
         for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(a + i * RSTEP * AROW + p * 64) = make_uint2(c0[p], c1[p]);
       }
@@ -195,6 +218,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
           for (int j = 0; j < TN; ++j)
             if constexpr (ABL & 1)
               acc[i][j][q & 15] += __uint_as_float((af[i][PA[q]].x ^ rb[j][s][PB[q]].y) & 0x3fffffffu);
+            else if constexpr (F16)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag16(af[i][PA[q]]), as_frag16(rb[j][s][PB[q]]), acc[i][j], 0, 0, 0);
             else
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af[i][PA[q]]), as_frag(rb[j][s][PB[q]]), acc[i][j], 0, 0, 0);
     }
@@ -289,6 +314,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
           }
     }
   }
+  if constexpr (F16) {  // undo the operand scales (powers of two: exact)
+    const float sc = ext.acc_scale;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= sc;
+  }
   const float* rs = nullptr;
   if constexpr (AMODE == 4) {
     // the 8 threads that staged a row hold its partial sums (consecutive lanes): reduce, publish one scale per tile row
@@ -310,9 +344,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
 }
 
 // W [N, ldw] fp32 -> fragment-ordered bf16 pieces; one thread per 16-byte fragment piece
-template <int NPL>
+template <int NPL, bool F16 = false>
 __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, uint4* __restrict__ out,
-                                                     int ksubs, int64_t total) {
+                                                     int ksubs, int64_t total, float wscale = 1.0f) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int lane = (int)(i & 63);
@@ -330,24 +364,28 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W
     const float x = (n < N && k < K) ? W[(int64_t)n * ldw + k] : 0.f;
     const float y = (n < N && k + 1 < K) ? W[(int64_t)n * ldw + k + 1] : 0.f;
     unsigned pc[NPL];
-    split_pair<NPL>(x, y, pc);
+    if constexpr (F16) split_pair<NPL, true>(x * wscale, y * wscale, pc);
+    else split_pair<NPL>(x, y, pc);
     w[e] = pc[p];
   }
   out[i] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT>
+template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT, bool F16 = false>
 int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds_main = (size_t)2 * BM * (NPL * 64 + 16), lds_epi = (size_t)BM * (BN + 4 + (AMODE == 4 ? 1 : 0)) * sizeof(float);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   const int ks = ext.ksplit > 1 ? ext.ksplit : 1;
-  static bool attr_done[2] = {false, false};
-  auto kern = ks > 1 ? gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT, true> : gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT, false>;
+  // (per device: a process may drive several GPUs; a repeated call from a racing thread is harmless)
+  static unsigned char attr_done[2][32] = {};
+  auto kern = ks > 1 ? gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT, true, F16> : gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT, false, F16>;
   constexpr size_t lds_cap = lds > (size_t)96 * 1024 ? lds : (size_t)96 * 1024;  // room for sopro_set_lds_floor
-  if (!attr_done[ks > 1]) {
+  int dev = 0;
+  SOPRO_HIP(hipGetDevice(&dev));
+  if (!attr_done[ks > 1][dev & 31]) {
     SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-    attr_done[ks > 1] = true;
+    attr_done[ks > 1][dev & 31] = 1;
   }
   const size_t lds_req = lds > (size_t)g_sopro_lds_floor ? lds : (size_t)g_sopro_lds_floor;
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
@@ -403,11 +441,11 @@ int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
   return -2;
 }
 
-template <int NPL, int WM, int WN, int TM, int TN>
+template <int NPL, int WM, int WN, int TM, int TN, bool F16 = false>
 int launch_cfg6(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
   const int key = g.epilogue * 10 + amode_of(g, ext);
 #define SOPRO_CASE(E, A) \
-  case (E) * 10 + (A): return launch_one<NPL, WM, WN, TM, TN, E, A, 0>(g, wp, ksubs, ext, s)
+  case (E) * 10 + (A): return launch_one<NPL, WM, WN, TM, TN, E, A, 0, F16>(g, wp, ksubs, ext, s)
   switch (key) {
     SOPRO_CASE(SOPRO_EPI_NONE, 0);  // plain projections
     SOPRO_CASE(SOPRO_EPI_GELU, 0);  // FF1
@@ -419,20 +457,20 @@ int launch_cfg6(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
   }
 #undef SOPRO_CASE
   if constexpr (WN * TN * 32 >= 64) {
-    if (key == SOPRO_EPI_GLU * 10) return launch_one<NPL, WM, WN, TM, TN, SOPRO_EPI_GLU, 0, 0>(g, wp, ksubs, ext, s);
-    if (key == SOPRO_EPI_GLU * 10 + 4) return launch_one<NPL, WM, WN, TM, TN, SOPRO_EPI_GLU, 4, 0>(g, wp, ksubs, ext, s);  // RMSNorm -> GLU
+    if (key == SOPRO_EPI_GLU * 10) return launch_one<NPL, WM, WN, TM, TN, SOPRO_EPI_GLU, 0, 0, F16>(g, wp, ksubs, ext, s);
+    if (key == SOPRO_EPI_GLU * 10 + 4) return launch_one<NPL, WM, WN, TM, TN, SOPRO_EPI_GLU, 4, 0, F16>(g, wp, ksubs, ext, s);  // RMSNorm -> GLU
   }
-  sopro_set_error("sopro_gemm_bf16x%d: (epilogue %d, prologue %d) is not an available combination", NPL == 3 ? 6 : NPL, g.epilogue, g.prologue);
+  sopro_set_error("sopro_gemm_%s: (epilogue %d, prologue %d) is not an available combination", F16 ? "f16x3" : (NPL == 3 ? "bf16x6" : "bf16x1"), g.epilogue, g.prologue);
   return -2;
 }
 
 // c_mode 5: per-row arg-max partials instead of C (64x64 tiles: 32 partials per 2048 columns)
-template <int NPL>
+template <int NPL, bool F16 = false>
 int launch_argmax(sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
   SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE && g.prologue == SOPRO_PRO_NONE && !ext.rms_norm && ext.a_format == 0,
                   "arg-max output takes a plain contraction (no prologue / epilogue / fused norm)");
   SOPRO_CHECK_ARG(ext.C2 && ext.ldc2 >= (g.N + 63) / 64, "arg-max output: C2 = [M][ldc2 >= ceil(N / 64)] (value, index) pairs");
-  return launch_one<NPL, 2, 2, 1, 1, SOPRO_EPI_NONE, 0, 5>(g, wp, ksubs, ext, s);
+  return launch_one<NPL, 2, 2, 1, 1, SOPRO_EPI_NONE, 0, 5, F16>(g, wp, ksubs, ext, s);
 }
 
 int check_common(sopro_gemm_args& g, sopro_gemm_split_ext& ext, const void* packed_w) {
@@ -601,4 +639,46 @@ extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w,
   // measured on the NAR shapes (tools/gemm_x6_probe.py): a few thousand rows, K <= 1536 -> the small tiles win
   if (g.epilogue == SOPRO_EPI_GLU) return launch_cfg6<3, 2, 2, 1, 2>(g, wp, ksubs, ext, s);
   return launch_cfg6<3, 2, 2, 1, 1>(g, wp, ksubs, ext, s);
+}
+
+// ---- f16x3: the token paths at three passes (see A16_SCALE above)
+extern "C" int sopro_pack_w_f16x2(const float* W, int64_t ldw, int32_t N, int32_t K, float wscale, void* packed, void* stream) {
+  SOPRO_CHECK_ARG(W && packed && N > 0 && K > 0 && ldw >= K, "bad pointers or sizes");
+  SOPRO_CHECK_ARG(aligned16(packed), "packed must be 16-byte aligned");
+  int ex = 0;
+  SOPRO_CHECK_ARG(wscale > 0.f && frexpf(wscale, &ex) == 0.5f, "wscale must be a power of two (the scaling has to be exact)");
+  const int ksubs = (K + 31) / 32 * 2;
+  const int64_t total = (int64_t)((N + 31) / 32) * ksubs * 2 * 64;
+  hipLaunchKernelGGL((pack_w_kernel<2, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K,
+                     reinterpret_cast<uint4*>(packed), ksubs, total, wscale);
+  SOPRO_LAUNCH_CHECK();
+}
+
+extern "C" float sopro_f16x3_a_scale(void) { return A16_SCALE; }
+
+extern "C" int sopro_gemm_f16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* x, void* stream) {
+  SOPRO_CHECK_ARG(a != nullptr && x != nullptr, "args / ext is NULL (ext carries acc_scale)");
+  sopro_gemm_args g = *a;
+  sopro_gemm_split_ext ext = *x;
+  if (ext.group_m == 0) ext.group_m = g_group_m;
+  SOPRO_CHECK_ARG(ext.acc_scale > 0.f, "acc_scale = 1 / (sopro_f16x3_a_scale() * the weight's pack scale) must be set");
+  SOPRO_CHECK_ARG(ext.a_format == 0 && (ext.c_mode == 0 || ext.c_mode == 5),
+                  "the f16 three-pass path reads fp32 rows and writes fp32 rows, or arg-max partials (c_mode 5)");
+  SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f),
+                  "fused RMSNorm needs K % 32 == 0, no split-K, no prologue and eps > 0");
+  if (int rc = check_common(g, ext, packed_w)) return rc;
+  SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ADDVEC, "prologue must be NONE or ADDVEC");
+  SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES || g.epilogue == SOPRO_EPI_GLU,
+                  "epilogue must be NONE, GELU, RES or GLU");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const uint4* wp = reinterpret_cast<const uint4*>(packed_w);
+  const int ksubs = (g.K + 31) / 32 * 2;
+  if (ext.c_mode == 5) return launch_argmax<2, true>(g, wp, ksubs, ext, s);
+  switch (g_tile_override) {
+    case 1: return launch_cfg6<2, 2, 2, 2, 2, true>(g, wp, ksubs, ext, s);
+    case 4: return launch_cfg6<2, 2, 2, 1, 2, true>(g, wp, ksubs, ext, s);
+    default: break;
+  }
+  if (g.epilogue == SOPRO_EPI_GLU) return launch_cfg6<2, 2, 2, 1, 2, true>(g, wp, ksubs, ext, s);
+  return launch_cfg6<2, 2, 2, 1, 1, true>(g, wp, ksubs, ext, s);
 }

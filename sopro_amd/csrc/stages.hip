@@ -18,10 +18,12 @@ struct Ten {
   const float* f() const { return reinterpret_cast<const float*>(p); }
 };
 
-struct Wt {  // weight operand of a contraction: fp32 [N, K] row-major and / or its packed bf16 pieces
+struct Wt {  // weight operand of a contraction: fp32 [N, K] row-major and / or its packed 16-bit pieces
   const float* f32 = nullptr;
   const void* packed = nullptr;
   int pieces = 0;
+  bool f16 = false;        // two fp16 pieces (sopro_gemm_f16x3) instead of bf16 ones
+  float acc_scale = 1.f;   // f16: 1 / (activation scale * pack scale)
 };
 
 constexpr float RMS_EPS = 1e-6f;  // src/sopro/nn/blocks.py:27
@@ -115,6 +117,8 @@ int dev_upload(sopro_engine* e, const std::vector<T>& h, T** out) {
   return 0;
 }
 
+constexpr int F16X2 = 22;  // pack_pieces: two fp16 pieces (the NAR contractions, sopro_gemm_f16x3)
+
 // [N, K] fp32 device matrix (optionally with its columns scaled by a device vector: an RMSNorm weight folded in) -> bf16 pieces
 int pack_pieces(sopro_engine* e, const std::string& key, const std::string& out_key, int pieces, const char* fold_vec, hipStream_t s) {
   const Ten* t;
@@ -133,11 +137,27 @@ int pack_pieces(sopro_engine* e, const std::string& key, const std::string& out_
     STG(dev_upload(e, hw, &d));
     src = d;
   }
+  const bool f16 = pieces == F16X2;
+  if (f16) pieces = 2;
   const int64_t bytes = sopro_packed_w_bytes(N, K, pieces);
   char* dst;
   STG(dev_alloc(e, (size_t)bytes, &dst));
-  STG(sopro_pack_w_bf16(src, K, N, K, pieces, dst, s));
   Wt w;
+  if (f16) {
+    // scale the matrix by a power of two so that max |w| lands in [2^13, 2^14) (see sopro_pack_w_f16x2)
+    std::vector<float> hw((size_t)N * K);
+    SOPRO_HIP(hipMemcpy(hw.data(), src, hw.size() * 4, hipMemcpyDeviceToHost));
+    float amax = 0.f;
+    for (float v : hw) amax = fmaxf(amax, fabsf(v));
+    int ex = 0;
+    (void)frexpf(amax, &ex);
+    const float wscale = amax > 0.f ? ldexpf(1.0f, 13 - ex + 1) : 1.0f;
+    STG(sopro_pack_w_f16x2(src, K, N, K, wscale, dst, s));
+    w.f16 = true;
+    w.acc_scale = 1.0f / (sopro_f16x3_a_scale() * wscale);
+  } else {
+    STG(sopro_pack_w_bf16(src, K, N, K, pieces, dst, s));
+  }
   w.f32 = fold_vec ? nullptr : t->f();
   w.packed = dst;
   w.pieces = pieces;
@@ -195,6 +215,10 @@ int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override
     x.ldc2 = o.ldc2 < 0 ? n_out : o.ldc2;
     x.c2_seg_stride = o.c2_seg;
     if (o.rms_eps > 0.f) { x.rms_norm = 1; x.rms_eps = o.rms_eps; }
+    if (w.f16) {
+      x.acc_scale = w.acc_scale;
+      return sopro_gemm_f16x3(&g, w.packed, &x, s);
+    }
     if (w.pieces == 3) return sopro_gemm_bf16x6(&g, w.packed, &x, s);
     if (w.pieces == 1) return sopro_gemm_bf16x1(&g, w.packed, &x, s);
     return sopro_gemm_bf16x3(&g, w.packed, &x, s);
@@ -287,20 +311,20 @@ int sopro_engine_finalize(sopro_engine* e, void* stream) {
     STG(need(e, "ar.head.b", &t));
     STG(need(e, "cb_embed", &t, 2));
   }
-  // ---- NAR: six-pass operands, the two RMSNorm weights of a block folded into the projections they feed
+  // ---- NAR: two fp16 pieces / three passes (22 mantissa bits), the two RMSNorm weights of a block folded into the projections they feed
   for (int i = 0; i < c.n_layers_nar; ++i) {
     const std::string p = "nar.blocks." + std::to_string(i);
-    STG(pack_pieces(e, p + ".glu.w", p + ".glu.wn", 3, (p + ".norm.weight").c_str(), s));
-    STG(pack_pieces(e, p + ".ff1.w", p + ".ff1.wn", 3, (p + ".ff.norm.weight").c_str(), s));
-    STG(pack_pieces(e, p + ".ff2.w", p + ".ff2.w", 3, nullptr, s));
+    STG(pack_pieces(e, p + ".glu.w", p + ".glu.wn", F16X2, (p + ".norm.weight").c_str(), s));
+    STG(pack_pieces(e, p + ".ff1.w", p + ".ff1.wn", F16X2, (p + ".ff.norm.weight").c_str(), s));
+    STG(pack_pieces(e, p + ".ff2.w", p + ".ff2.w", F16X2, nullptr, s));
     for (const char* nm : {".glu.b", ".dw.w", ".dw.b", ".ff1.b", ".ff2.b"}) STG(need(e, p + nm, &t));
   }
-  STG(pack_pieces(e, "nar.pre.w", "nar.pre.w", 3, nullptr, s));
+  STG(pack_pieces(e, "nar.pre.w", "nar.pre.w", F16X2, nullptr, s));
   const char* stage_names[8] = {"B", "C", "D", "E", "F", "G", "H", "I"};
   std::vector<int> known = {0};
   for (int sgi = 0; sgi < c.n_stages; ++sgi) {
     const std::string hk = std::string("nar.heads.") + stage_names[sgi];
-    STG(pack_pieces(e, hk + ".w", hk + ".w", 3, nullptr, s));
+    STG(pack_pieces(e, hk + ".w", hk + ".w", F16X2, nullptr, s));
     STG(need(e, hk + ".b", &t));
     // prev = sum_j softmax(w[known])_j * E[cb_j * V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
     std::vector<int32_t> cols(known.begin(), known.end()), offs;

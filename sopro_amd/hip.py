@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
 class SplitExt(C.Structure):
     _fields_ = [("a_format", _i32), ("c_mode", _i32), ("C2", _p), ("ldc2", _i64), ("c2_seg_stride", _i64),
                 ("rms_norm", _i32), ("rms_eps", _f32), ("ksplit", _i32), ("n_tickets", _i32), ("ws", _p), ("ws_bytes", _i64),
-                ("tickets", _p), ("group_m", _i32)]
+                ("tickets", _p), ("group_m", _i32), ("acc_scale", _f32)]
 
 
 class SkinnyArgs(C.Structure):
@@ -128,6 +128,9 @@ SYMBOLS = {
     "sopro_gemm_bf16x6": (C.c_int, [_p, _p, _p, _p]),
     "sopro_gemm_bf16x1": (C.c_int, [_p, _p, _p, _p]),
     "sopro_pack_w_bf16": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
+    "sopro_pack_w_f16x2": (C.c_int, [_p, _i64, _i32, _i32, _f32, _p, _p]),
+    "sopro_f16x3_a_scale": (C.c_float, []),
+    "sopro_gemm_f16x3": (C.c_int, [_p, _p, _p, _p]),
     "sopro_packed_w_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "sopro_gemm_bf16_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_gemm_set_group_m": (C.c_int, [C.c_int]),
@@ -259,6 +262,10 @@ class Profiler:
         return out
 
 
+_prof: Optional[Profiler] = None
+phase_log = None  # bench.py: list receiving (frames, rows, ev0, ev1) per AR phase while set
+
+
 def set_profiler(p: Optional[Profiler]) -> None:
     global _prof
     _prof = p
@@ -326,14 +333,21 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     if packed:
         x = SplitExt()
         if rms_eps > 0.0:  # fused RMSNorm of the A rows (W must carry the norm's weight vector)
-            if W.pieces == 2:
-                raise SoproHipError("fused RMSNorm is a six-pass (pieces = 3) or one-pass (pieces = 1) feature")
+            if W.pieces == 2 and not W.f16:
+                raise SoproHipError("fused RMSNorm is a six-pass (pieces = 3), f16 three-pass or one-pass (pieces = 1) feature")
             x.rms_norm, x.rms_eps = 1, float(rms_eps)
-        ks = _auto_ksplit(M, N, K, W.pieces, epilogue) if (dbg is None and _splitk_enabled and rms_eps <= 0.0) else 1
+        ks = _auto_ksplit(M, N, K, 3 if W.f16 else W.pieces, epilogue) if (dbg is None and _splitk_enabled and rms_eps <= 0.0) else 1
         if ks > 1:
             ws, tk = _splitk_buffers()
             x.ksplit, x.n_tickets, x.ws, x.ws_bytes, x.tickets = ks, int(tk.numel()), ptr(ws), int(ws.numel()) * 4, ptr(tk, torch.int32)
-    if packed and W.pieces == 1:
+    if packed and W.f16:  # two fp16 pieces, three passes: the forms of the six-pass path
+        if a_split or c_mode not in (0, 5):
+            raise SoproHipError("split-form operands belong to the bf16 three-pass (pieces = 2) path")
+        if c_mode == 5:
+            x.c_mode, x.C2, x.ldc2 = 5, ptr(C2) + 4 * c2_off, (-(-N // 64) if ldc2 is None else ldc2)
+        x.acc_scale = W.acc_scale
+        _check(load().sopro_gemm_f16x3(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_f16x3")
+    elif packed and W.pieces == 1:
         if a_split or c_mode in (1, 2):
             raise SoproHipError("split-form operands belong to the three-pass (pieces = 2) path")
         x.c_mode = c_mode
@@ -356,7 +370,8 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     else:
         _check(load().sopro_gemm_f32(C.byref(g), _stream()), "sopro_gemm_f32")
     if e0 is not None:
-        _prof.end({1: "gemm_bf16x1_kernel", 2: "gemm_bf16x3_kernel", 3: "gemm_bf16x6_kernel"}[W.pieces] if packed else "gemm_f32_kernel", 2.0 * M * N * K, e0)
+        fam = "gemm_f32_kernel" if not packed else ("gemm_f16x3_kernel" if W.f16 else {1: "gemm_bf16x1_kernel", 2: "gemm_bf16x3_kernel", 3: "gemm_bf16x6_kernel"}[W.pieces])
+        _prof.end(fam, 2.0 * M * N * K, e0)
 
 
 _splitk_enabled = os.environ.get("SOPRO_NO_SPLITK", "0") != "1"
@@ -401,10 +416,10 @@ def _splitk_buffers():
 class PackedW:
     """A weight matrix [N, K] as 1, 2 or 3 bf16 pieces in MFMA fragment order (sopro_pack_w_bf16)."""
 
-    __slots__ = ("data", "N", "K", "pieces")
+    __slots__ = ("data", "N", "K", "pieces", "f16", "acc_scale")
 
-    def __init__(self, data: torch.Tensor, N: int, K: int, pieces: int):
-        self.data, self.N, self.K, self.pieces = data, N, K, pieces
+    def __init__(self, data: torch.Tensor, N: int, K: int, pieces: int, f16: bool = False, acc_scale: float = 1.0):
+        self.data, self.N, self.K, self.pieces, self.f16, self.acc_scale = data, N, K, pieces, f16, acc_scale
 
 
 def pack_w_bf16(W: torch.Tensor, pieces: int) -> PackedW:
@@ -421,6 +436,22 @@ def pack_w_bf16(W: torch.Tensor, pieces: int) -> PackedW:
 
 def pack_w_bf16x3(W: torch.Tensor) -> PackedW:
     return pack_w_bf16(W, 2)
+
+
+def pack_w_f16x3(W: torch.Tensor) -> PackedW:
+    """Two fp16 pieces (22 mantissa bits), three MFMA passes: the token paths' accuracy class at half the passes of bf16x6.
+    The matrix is scaled by a power of two into fp16's range (max |w| lands in [2^13, 2^14)); gemm undoes it exactly."""
+    if W.dim() != 2 or not W.is_contiguous():
+        raise SoproHipError("pack_w_f16x3 wants a contiguous [N, K] matrix")
+    import math
+
+    N, K = int(W.shape[0]), int(W.shape[1])
+    lib = load()
+    amax = float(W.abs().max())
+    wscale = 2.0 ** (13 - math.frexp(amax)[1] + 1) if amax > 0.0 else 1.0  # amax * wscale in [2^13, 2^14)
+    data = torch.empty(int(lib.sopro_packed_w_bytes(N, K, 2)) // 4, dtype=torch.int32, device=W.device)
+    _check(lib.sopro_pack_w_f16x2(ptr(W), K, N, K, wscale, ptr(data, torch.int32), _stream()), "sopro_pack_w_f16x2")
+    return PackedW(data, N, K, 2, f16=True, acc_scale=1.0 / (float(lib.sopro_f16x3_a_scale()) * wscale))
 
 
 def pack_w_bf16x6(W: torch.Tensor) -> PackedW:

@@ -121,7 +121,10 @@ class SoproTTSModel:
         # operand: the accuracy class of the fp32 MFMA kernel at ~1.5x its speed on these shapes); SOPRO_NAR_F32=1 keeps fp32.
         self.wx: Dict[str, hip.PackedW] = {}
         # (the text / reference encoders feed the AR loop's conditioning: they keep their six-pass form in both modes)
-        pack_for = lambda key: hip.pack_w_bf16x1 if (precision == "bf16" and key.startswith("nar.")) else hip.pack_w_bf16x6  # noqa: E731
+        # NAR (round 3): two fp16 pieces / three passes ("f16x3": 22 mantissa bits, the arg-max margins' accuracy class at half
+        # the passes of bf16x6; SOPRO_NAR_X6=1 keeps the six-pass form).  The encoders feed the AR loop's conditioning and keep x6.
+        nar_pack = hip.pack_w_bf16x6 if os.environ.get("SOPRO_NAR_X6", "0") == "1" else hip.pack_w_f16x3
+        pack_for = lambda key: (hip.pack_w_bf16x1 if precision == "bf16" else nar_pack) if key.startswith("nar.") else hip.pack_w_bf16x6  # noqa: E731
         if os.environ.get("SOPRO_NAR_F32", "0") != "1":
             unfused = os.environ.get("SOPRO_NORM_UNFUSED", "0") == "1"
             with torch.cuda.device(self.device):

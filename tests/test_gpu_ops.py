@@ -256,6 +256,57 @@ def test_gemm_bf16x6_fused_rmsnorm(M, K):
         hip.gemm(dev(X), hip.pack_w_bf16x3(dev(Wf)), C, M=M, N=N, K=K, rms_eps=eps)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (129, 64, 64), (6400, 384, 1536), (6400, 1536, 384), (6, 768, 384), (12, 2048, 1024), (1, 64, 1536), (33, 96, 320)])
+def test_gemm_f16x3_is_fp32_class(M, N, K):
+    """Two fp16 pieces per operand, three MFMA passes (round 3: the NAR contractions): 22 mantissa bits, so the error against
+    fp64 must stay within a few 2^-22 of |A||W| - the class of the six-pass bf16 form (2^-24) and of an fp32 fma chain - for
+    operands of very different magnitudes (the power-of-two scales must not cost precision), with every form NAR uses."""
+    g = torch.Generator().manual_seed(7)
+    A = rnd(M, K, seed=71) * torch.exp(2.0 * torch.randn(M, 1, generator=g))  # rows from ~0.02 to ~50
+    A[0] *= 1e-4
+    W, b = rnd(N, K, seed=72, scale=K ** -0.5), rnd(N, seed=73)
+    W[: N // 4] *= 1e-3  # small and large weights in one matrix
+    Wp = hip.pack_w_f16x3(dev(W))
+    ref = A.double() @ W.double().t() + b.double()
+    bound = (A.double().abs() @ W.double().abs().t()) * 2.0 ** -20 + b.double().abs() * 2.0 ** -22 + 1e-30
+    C = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b))
+    torch.cuda.synchronize()
+    err = (C.cpu().double() - ref).abs()
+    assert bool(torch.isfinite(C).all()) and bool((err <= bound).all()), f"{M}x{N}x{K}: worst {float((err / bound).max()):.2f} of the bound"
+    # typical error: a fraction of 2^-22 |A||W| (zero-mean pieces)
+    assert float((err / (A.double().abs() @ W.double().abs().t())).mean()) < 2.0 ** -23
+    # the forms: GELU, residual, head-id prologue, fused RMSNorm, GLU, arg-max partials
+    R, pv = rnd(M, N, seed=74), rnd(K, seed=75)
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_GELU)
+    close(C, F.gelu(ref.float()), 3e-5 * max(1.0, float(ref.abs().max())), "gelu")
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_RES, R=dev(R))
+    close(C, R + ref.float(), 3e-5 * max(1.0, float(ref.abs().max())), "res")
+    hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b), prologue=hip.PRO_ADDVEC, pro_vec=dev(pv))
+    close(C, ((A + pv).double() @ W.double().t() + b.double()).float(), 3e-5 * max(1.0, float(ref.abs().max())), "addvec")
+    if K % 32 == 0:
+        eps, nw = 1e-6, 1.0 + 0.3 * rnd(K, seed=76)
+        Wf = (W * nw[None, :]).contiguous()
+        xn = (A.double() * torch.rsqrt((A.double() ** 2).mean(-1, keepdim=True) + eps)) * nw.double()
+        refn = (xn @ W.double().t() + b.double()).float()
+        Wfp = hip.pack_w_f16x3(dev(Wf))
+        hip.gemm(dev(A), Wfp, C, M=M, N=N, K=K, bias=dev(b), rms_eps=eps)
+        close(C, refn, 2e-5 * max(1.0, float(refn.abs().max())), "fused rmsnorm")
+        if N % 64 == 0:
+            wg, bg = pack.pack_glu(Wf, b)
+            G = torch.full((M, N // 2), float("nan"), device=DEV)
+            hip.gemm(dev(A), hip.pack_w_f16x3(dev(wg)), G, M=M, N=N, K=K, bias=dev(bg), epilogue=hip.EPI_GLU, rms_eps=eps)
+            close(G, refn[:, : N // 2] * torch.sigmoid(refn[:, N // 2:]), 2e-5 * max(1.0, float(refn.abs().max())), "rmsnorm + glu")
+    if N % 64 == 0:
+        part = torch.full((M, N // 64, 2), float("nan"), device=DEV)
+        got = torch.full((M, 1), -1, dtype=torch.int32, device=DEV)
+        hip.gemm(dev(A), Wp, None, M=M, N=N, K=K, bias=dev(b), c_mode=5, C2=part, ldc2=N // 64)
+        hip.argmax_partials(part, got, rows=M, heads=1, per_head=N // 64, V=N, ldp=N // 64, ldo=1, o_off=0)
+        hip.gemm(dev(A), Wp, C, M=M, N=N, K=K, bias=dev(b))
+        torch.cuda.synchronize()
+        assert torch.equal(got[:, 0].cpu().long(), C.cpu().argmax(-1))
+
+
 @pytest.mark.parametrize("pieces,M,N,K,epi", [(3, 6, 384, 1536, "res"), (3, 6, 768, 1152, "glu"), (3, 12, 2048, 1024, "none"), (2, 12, 512, 2048, "res"),
                                               (2, 12, 1024, 3584, "none"), (2, 33, 4096, 2048, "none"), (3, 1, 64, 1536, "gelu")])
 def test_gemm_split_k_small_m_is_exact_class_and_deterministic(pieces, M, N, K, epi):
