@@ -40,8 +40,9 @@ __device__ __forceinline__ f16x8 as_frag16(const uint4& v) { return *reinterpret
 // has 5 exponent bits, so both operands are scaled by powers of two into its range (activations by A16_SCALE while they are
 // staged, a weight matrix by its own power of two when it is packed; products are exact in the scale, the accumulator is
 // multiplied by 1 / (both) in the epilogue): below 2^-14 a piece goes subnormal and the absolute resolution stays 2^-24 of
-// the scaled value, i.e. ~7e-9 of the unscaled activation - small against 2^-22 of an O(1) row.
-constexpr float A16_SCALE = 8.0f;  // |activation| < 8188 stays finite; nothing on the NAR path is near it
+// the scaled value, i.e. ~7e-9 of the unscaled activation - small against 2^-22 of an O(1) row (the NAR stream is O(1-10): its
+// contraction inputs are RMS-normalised or GELU outputs; rows of energy << 1e-2 lose relative precision to that floor).
+constexpr float A16_SCALE = 8.0f;  // |activation| <= 8188 is exact in range; beyond it the operand saturates (finite, wrong)
 
 // two fp32 values -> NPL packed 16-bit pairs (piece p of x in the low half, of y in the high half)
 template <int NPL, bool F16 = false>
@@ -174,9 +175,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
         unsigned c0[NPL], c1[NPL];
-        if constexpr (F16) {
-          split_pair<NPL, true>(ra[i].x * A16_SCALE, ra[i].y * A16_SCALE, c0);
-          split_pair<NPL, true>(ra[i].z * A16_SCALE, ra[i].w * A16_SCALE, c1);
+        if constexpr (F16) {  // scaled, and saturated at fp16's largest finite value (|a| > 8188: no inf / NaN downstream)
+          const float F16MAX = 65504.0f;
+          split_pair<NPL, true>(__builtin_amdgcn_fmed3f(ra[i].x * A16_SCALE, -F16MAX, F16MAX), __builtin_amdgcn_fmed3f(ra[i].y * A16_SCALE, -F16MAX, F16MAX), c0);
+          split_pair<NPL, true>(__builtin_amdgcn_fmed3f(ra[i].z * A16_SCALE, -F16MAX, F16MAX), __builtin_amdgcn_fmed3f(ra[i].w * A16_SCALE, -F16MAX, F16MAX), c1);
         } else {
           split_pair<NPL>(ra[i].x, ra[i].y, c0);
           split_pair<NPL>(ra[i].z, ra[i].w, c1);

@@ -76,6 +76,39 @@ def test_c_stages_on_a_ragged_sampled_batch(eng, tts_noeos):
     assert float((wav - pw).abs().max()) < 2e-5 * float(pw.abs().max())
 
 
+def test_c_stages_on_a_32x200_batch(eng, tts_noeos, cfg, w_noeos):
+    """BASELINE configs[1] through the C stage API alone: 32 utterances x 200 frames, 4 voices, greedy.  Every row's tokens
+    equal the Python host's (same kernels, same order); rows 2 and 29 are checked against their own oracle runs."""
+    tts = tts_noeos
+    torch.set_num_threads(8)
+    rng = np.random.default_rng(93)
+    B, maxf = 32, 199
+    ids = [torch.from_numpy(rng.integers(0, 512, size=64)) for _ in range(B)]
+    refs_tq = [torch.from_numpy(rng.integers(0, 2048, size=(150, 32))) for _ in range(4)]
+    voices = [tts.prepare_reference(ref_tokens_tq=r) for r in refs_tq]
+    refs = [voices[b % 4] for b in range(B)]
+    prep = tts.model.prepare_conditioning_batch(ids, refs, max_frames=maxf, style_strength=1.0)
+    hist, feos = eng.ar_generate(prep["cond_ar"], prep["txt_seq"], prep["text_lens"], **GREEDY)
+    assert hist.shape == (B, maxf + 1) and bool((feos < 0).all())
+    toks = eng.nar_refine(prep["cond_ar"], hist)
+    ptoks = tts.model.generate_tokens_batch(ids, refs, max_frames=maxf, style_strength=1.0, **GREEDY)
+    for b in range(B):
+        assert torch.equal(toks[b].cpu().long(), ptoks[b].cpu()), b
+    wav = eng.mimi_decode(toks)
+    pw = tts.codec.decode_batch(torch.stack(ptoks))
+    assert tuple(wav.shape) == (B, (maxf + 1) * 1920)
+    assert float((wav - pw).abs().max()) < 2e-5 * float(pw.abs().max())
+    for b in (2, 29):
+        oref = O.prepare_reference(refs_tq[b % 4], w_noeos, cfg)
+        want = O.generate_tokens(ids[b], oref, w_noeos, cfg, max_frames=maxf, style_strength=1.0, **GREEDY)
+        got = toks[b].cpu().long()
+        assert torch.equal(got[:, 0], want[:, 0]), b
+        if not torch.equal(got, want):
+            oprep = O.prepare_conditioning(ids[b], oref, w_noeos, cfg, max_frames=maxf, style_strength=1.0)
+            n_off, gap = O.nar_audit(oprep["cond_ar"][:, : maxf + 1], got.unsqueeze(0), w_noeos, cfg)
+            assert gap < 1e-4, (b, n_off, gap)
+
+
 @pytest.mark.parametrize("trim", ["none", "legacy"])
 def test_streaming_decode_through_the_c_stage(eng, tts_noeos, trim):
     """sopro_mimi_decode_stream (+ _trim for the legacy policy) against the Python host's MimiStreamDecoder over 40 chunks of

@@ -59,3 +59,14 @@ def test_stream_legacy_trim_policy(cfg, mc, w_noeos, mw):
     assert float((leg - _t(g["stream"])).abs().max()) < 1e-5 * scale
     plain = torch.cat(list(O.stream(_t(gi["ids"]), ref, w_noeos, mw, cfg, mc, **kw)), dim=1).reshape(-1)
     assert float((plain - _t(g["stream"])).abs().max()) > 1e-3 * scale  # the two policies really differ
+
+
+@pytest.mark.parametrize("name,cf", [("stream_c1", 1), ("stream_c16", 16)])
+def test_stream_other_chunk_sizes(cfg, mc, w_noeos, mw, name, cf):
+    """chunk_frames 1 and 16 against the reference's own stream() runs (tests/golden/make_golden_stream_chunks.py)."""
+    g, gi = golden(name), golden("full200")
+    ref = O.prepare_reference(_t(gi["ref_tq"]), w_noeos, cfg)
+    chunks = list(O.stream(_t(gi["ids"]), ref, w_noeos, mw, cfg, mc, max_frames=int(g["max_frames"]), style_strength=1.0, chunk_frames=cf, **GREEDY))
+    assert [int(c.shape[1]) for c in chunks] == g["chunk_sizes"].tolist()
+    cat = torch.cat(chunks, dim=1).reshape(-1)
+    assert float((cat - _t(g["stream"])).abs().max()) < 1e-5 * float(np.abs(g["stream"]).max())
