@@ -276,7 +276,7 @@ def test_gemm_f16x3_is_fp32_class(M, N, K):
     torch.cuda.synchronize()
     err = (C.cpu().double() - ref).abs()
     assert bool(torch.isfinite(C).all()) and bool((err <= bound).all()), f"{M}x{N}x{K}: worst {float((err / bound).max()):.2f} of the bound"
-    assert float((err / aw).mean()) < 2.0 ** -22  # typical error: a fraction of the bound (zero-mean pieces)
+    assert float((err / (aw + b.double().abs())).mean()) < 2.0 ** -23  # typical error: a fraction of the bound (measured 1.3e-8: tools/f16x3_probe.py)
     # outside the domain: a low-energy row keeps the absolute floor, a huge one saturates instead of producing inf / NaN
     A2 = A.clone()
     A2[0] *= 1e-3

@@ -1,0 +1,1 @@
+python tools/f16x3_probe.py 2>&1 | grep -v amdgpu.ids
