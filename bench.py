@@ -327,6 +327,17 @@ def main() -> None:
     device = f"cuda:{dev_index}"
     import torch.distributed as dist
 
+    # One rank per GPU means 1 + lanes host threads per rank, all latency-sensitive (they keep the AR launch queues fed).  With
+    # N ranks on one host every rank gets its own slice of the cores, so that no rank's launch threads are descheduled behind
+    # another rank's; intra-op CPU threads are of no use to this path.  SOPRO_BENCH_PIN=0 leaves the placement to the OS.
+    pinned = None
+    if world > 1:
+        torch.set_num_threads(1)
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // world
+        if os.environ.get("SOPRO_BENCH_PIN", "1") != "0" and per >= 1:
+            pinned = cores[local_rank * per:(local_rank + 1) * per]
+            os.sched_setaffinity(0, pinned)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
@@ -440,7 +451,11 @@ def main() -> None:
         dist.all_gather_object(allh, rank_hashes[0])
         rank_hashes = allh
     kept.clear()
+    host_cpu_ranks = [round(host_cpu / args.steps, 4)]
     if world > 1:
+        allc = [None] * world
+        dist.all_gather_object(allc, host_cpu_ranks[0])
+        host_cpu_ranks = allc
         t = torch.tensor([dt], device="cpu" if share_gpu else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -690,6 +705,9 @@ def main() -> None:
             "ttfa_ms_p50": None if ttfa is None else round(ttfa, 3),
             "cpu_ttfa_ms_p50": (cpu or {}).get("ttfa_ms_p50"),
             "host_cpu_s_per_step": round(host_cpu / args.steps, 4),
+            "host_cpu_s_per_step_by_rank": host_cpu_ranks,
+            "host_threads": {"per_rank": 1 + (args.lanes if args.lanes > 1 else 0), "torch_intra_op": torch.get_num_threads(),
+                             "pinned_cores_rank0": (len(pinned) if pinned else None)},
             "host_cpu_note": "CPU time of all threads of this rank's process over the timed region / steps (launch threads of the lanes included)",
             "legs": legs, "roofline_dropped": dropped,
             "roofline": roof, "roofline_more": roof_more, "cpu_baseline": cpu, "parity": parity,

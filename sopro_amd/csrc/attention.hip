@@ -148,12 +148,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const sopro_attn_args a)
 template <int DH>
 int launch_attn(const sopro_attn_args& a, hipStream_t s) {
   constexpr size_t lds = sizeof(float) * (TQ * DH + TK * (DH + 1) + TK * DH + TQ * (TK + 1));
-  static bool attr_done = false;
   auto kern = attention_kernel<DH>;
-  if (!attr_done) {
-    SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  SOPRO_SET_MAX_LDS_ONCE(kern, lds);
   dim3 grid((a.Tq + TQ - 1) / TQ, a.H, a.B);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   SOPRO_LAUNCH_CHECK();

@@ -45,6 +45,19 @@ extern int g_sopro_lds_floor;
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize must be set per device: `done` is one flag byte per device of the calling site (a
+// process may drive several GPUs; two threads racing on the first call both set the attribute, which is harmless).
+#define SOPRO_SET_MAX_LDS_ONCE(kern, bytes)                                                                              \
+  do {                                                                                                                   \
+    static unsigned char done_[64] = {};                                                                                 \
+    int dev_ = 0;                                                                                                        \
+    SOPRO_HIP(hipGetDevice(&dev_));                                                                                      \
+    if (!done_[dev_ & 63]) {                                                                                             \
+      SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      done_[dev_ & 63] = 1;                                                                                              \
+    }                                                                                                                    \
+  } while (0)
+
 __device__ __forceinline__ float gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 // ELU(alpha=1).  exp(v)-1 with the hardware exponential: absolute error <= ~2e-7 on v <= 0 (fp32 round-off of the

@@ -379,16 +379,10 @@ int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro
   constexpr size_t lds_main = (size_t)2 * BM * (NPL * 64 + 16), lds_epi = (size_t)BM * (BN + 4 + (AMODE == 4 ? 1 : 0)) * sizeof(float);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   const int ks = ext.ksplit > 1 ? ext.ksplit : 1;
-  // (per device: a process may drive several GPUs; a repeated call from a racing thread is harmless)
-  static unsigned char attr_done[2][32] = {};
   auto kern = ks > 1 ? gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT, true, F16> : gemm_bf16s_kernel<NPL, WM, WN, TM, TN, EPI, AMODE, OUT, false, F16>;
   constexpr size_t lds_cap = lds > (size_t)96 * 1024 ? lds : (size_t)96 * 1024;  // room for sopro_set_lds_floor
-  int dev = 0;
-  SOPRO_HIP(hipGetDevice(&dev));
-  if (!attr_done[ks > 1][dev & 31]) {
-    SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-    attr_done[ks > 1][dev & 31] = 1;
-  }
+  if (ks > 1) SOPRO_SET_MAX_LDS_ONCE(kern, lds_cap);
+  else SOPRO_SET_MAX_LDS_ONCE(kern, lds_cap);
   const size_t lds_req = lds > (size_t)g_sopro_lds_floor ? lds : (size_t)g_sopro_lds_floor;
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   if (ks > 1) {

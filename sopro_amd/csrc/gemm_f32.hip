@@ -159,12 +159,8 @@ int launch_epi(const sopro_gemm_args& g, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
   static_assert((size_t)BM * (BN + 4) * sizeof(float) <= lds, "the epilogue tile must fit in the main-loop buffers");
-  static bool attr_done = false;
   auto kern = gemm_f32_kernel<WM, WN, TM, TN, EPI>;
-  if (!attr_done) {
-    SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  SOPRO_SET_MAX_LDS_ONCE(kern, lds);
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, g);
   SOPRO_LAUNCH_CHECK();

@@ -166,18 +166,16 @@ extern "C" int sopro_seanet_up128_f32(const float* x, int64_t x_seg_stride, cons
   SOPRO_CHECK_ARG(passes == 1 || passes == 3, "passes must be 3 (three-pass split-bf16) or 1 (bf16 mode)");
   SOPRO_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(out) && (x_seg_stride & 3) == 0 && (out_seg_stride & 3) == 0,
                   "x, w, out must be 16-byte aligned with segment strides % 4 == 0");
+  SOPRO_CHECK_ARG(B == 1 || (x_seg_stride >= (int64_t)(T + 1) * UC && out_seg_stride >= (int64_t)T * UN),
+                  "segment strides: x holds T + 1 rows of 128 per utterance (one pad row in front), out T rows of 256");
   const int ntile = (T + UTO - 1) / UTO;
   // enough workgroups for ~4 per CU, as many tiles per workgroup as that leaves (the weight fragments are split once per workgroup)
   int tiles = g_up_tiles ? g_up_tiles : (int)(((int64_t)ntile * B + 1023) / 1024);
   if (tiles < 1) tiles = 1;
   const dim3 grid((unsigned)((ntile + tiles - 1) / tiles), (unsigned)B);
   constexpr int lds = 2 * UHR * UROW;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_up128_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    SOPRO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_up128_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_done = true;
-  }
+  SOPRO_SET_MAX_LDS_ONCE(seanet_up128_kernel<3>, lds);
+  SOPRO_SET_MAX_LDS_ONCE(seanet_up128_kernel<1>, lds);
   if (passes == 3)
     hipLaunchKernelGGL(seanet_up128_kernel<3>, grid, dim3(512), lds, (hipStream_t)stream, x, x_seg_stride, w, bias, out, out_seg_stride, T, tiles);
   else

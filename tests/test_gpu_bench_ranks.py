@@ -33,3 +33,23 @@ def test_two_ranks_reproduce_two_single_gpu_runs():
         assert one["n_gpus"] == 1 and one["parity"]["rank_output_sha16"] == [hashes[r]], r
     # whole-job aggregate: two ranks' audio over the slower rank's time
     assert two["value"] > 0 and abs(two["value"] * two["ms_per_step"] - 2 * 4 * 24 * 0.08 * 1e3) < 1e-3 * two["value"] * two["ms_per_step"]
+
+
+def test_eight_ranks_on_the_shared_gpu():
+    """The 8-GPU launch shape without an 8-GPU box: eight ranks through torch.distributed.run on the one device,
+    each with its own inputs, pinned to its own slice of the host cores.  n_gpus == 8, eight distinct output hashes that equal
+    the single-rank runs on the same inputs (ranks 0, 3, 7 re-run alone), per-rank host CPU time reported and below the wall
+    time of a step (no rank's launch threads are starved)."""
+    eight = _bench(["--gpus", "8"], env={"SOPRO_BENCH_SHARE_GPU": "1", "MASTER_PORT": "29549"})
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "weak" and eight["steps"] == 2
+    assert eight["parity"]["timed_steps_identical"] and eight["parity"]["timed_outputs_finite"]
+    hashes = eight["parity"]["rank_output_sha16"]
+    assert len(hashes) == 8 and len(set(hashes)) == 8
+    for r in (0, 3, 7):
+        one = _bench(["--gpus", "1", "--input-rank", str(r)])
+        assert one["parity"]["rank_output_sha16"] == [hashes[r]], r
+    cpu = eight["host_cpu_s_per_step_by_rank"]
+    assert len(cpu) == 8 and all(0.0 < c for c in cpu)
+    assert max(cpu) < 4.0 * eight["ms_per_step"] * 1e-3 + 0.05  # CPU seconds per step of any rank stay of the order of the step's wall time
+    assert abs(eight["value"] * eight["ms_per_step"] - 8 * 4 * 24 * 0.08 * 1e3) < 1e-3 * eight["value"] * eight["ms_per_step"]
+    assert eight["host_threads"]["torch_intra_op"] == 1
