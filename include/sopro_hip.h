@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 28
+#define SOPRO_ABI_VERSION 29
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -471,13 +471,24 @@ typedef struct sopro_engine_cfg {
   int32_t mimi_n_ratios, mimi_ratios[8], mimi_num_filters, mimi_kernel, mimi_res_kernel, mimi_last_kernel, mimi_compress;
   int32_t mimi_n_semantic, mimi_rope_positions;
   float mimi_norm_eps, mimi_final_bias;
+  int32_t precision;                 /* 0: the fp32 parity configuration (AR exact fp32, NAR f16x3, Mimi bf16x3); 1: the bf16 mode
+                                      * (bf16 AR weights, one-pass NAR / Mimi contractions, fp32 accumulators / norms / residuals) */
 } sopro_engine_cfg;
 int sopro_engine_create(const sopro_engine_cfg* cfg, sopro_engine** out);
 /* name: a key of sopro_amd.pack.pack_sopro / pack_mimi ("ar.blocks.0.glu.w", "nar.heads.B.w", "tr.3.qkv.w", "sea.up1.w", ...)
  * plus "rope.cos" / "rope.sin" [positions, head_dim / 2].  The engine keeps the pointer; the caller keeps the memory. */
 int sopro_engine_set_tensor(sopro_engine* e, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim);
-/* checks that every tensor the three stages need is present and builds the packed operand forms (allocates device memory) */
+/* builds the packed operand forms (allocates device memory).  A stage family takes part when its marker tensor was given -
+ * "ar.head.w" (AR), "nar.pre.w" (NAR), "rvq_proj.w" (Mimi decoder) - and must then be complete; a stage call on an engine
+ * without its family is refused.  After this call the engine is read-only except for its AR plan: NAR / Mimi calls of several
+ * host threads (lanes with their own workspaces and streams) may share it. */
 int sopro_engine_finalize(sopro_engine* e, void* stream);
+/* The folded text operands of ONE cross-attention layer of the AR loop for B utterances of S text positions
+ * (src/sopro/nn/text.py:75-83 with q_proj / out_proj folded in: K'_h = K_h Wq_h, V'_h = V_h Wo_h^T): txt [B*S, D] ->
+ * kp, vp [B, H, S_cap, D].  q_wT: [H, D, D/H] (RMSNorm_nq folded in), o_w: [D, D]; nkv [B*S, D], kvd [B*S, 2D] scratch.
+ * The one place this preparation is written down: sopro_ar_begin and the Python host (batched and slot admission) call it. */
+int sopro_ar_fold_text(const float* txt, const float* nkv_weight, const float* kv_w, const float* q_wT, const float* o_w, float* nkv, float* kvd,
+                       float* kp, float* vp, int32_t B, int32_t S, int32_t S_cap, int32_t D, int32_t H, float eps, void* stream);
 int sopro_engine_destroy(sopro_engine* e);
 /* workgroup shapes of the AR-step stage kinds, (mt << 4) | nt each (see sopro_skinny_args; 0 = 1 x 1).  Drops a recorded frame graph. */
 int sopro_engine_set_ar_tiles(sopro_engine* e, int32_t glu, int32_t ff1, int32_t ff2, int32_t head);

@@ -2,12 +2,14 @@
 ``MimiStreamDecoder`` (reference: src/sopro/codec/mimi.py:18-181), whose arithmetic lives in the
 third-party HuggingFace ``MimiModel`` (HF:modeling_mimi.py:1388-1406 ``_decode_frame``).
 
-Pipeline, all channels-last fp32 on HIP kernels:
+Decoding (the hot path), all channels-last fp32 on HIP kernels, is ONE call into the library per batch
+(``sopro_mimi_decode`` / ``sopro_mimi_decode_stream``, csrc/stages.hip):
   tokens [B, T, 32] -> RVQ gather-sum (semantic | acoustic, HF:1128-1137) -> output projections as
   one K=512 contraction -> depthwise ConvTranspose upsample x2 (HF:1208-1216) -> 8 pre-LN transformer
-  layers with RoPE and a causal sliding window of 250 (HF:729-928) -> SEANet decoder: every Conv1d /
-  ConvTranspose1d is the overlapping-row contraction of ``sopro_gemm_f32`` with ELU fused on the
-  operand load and the residual add fused on the store (HF:931-961, 408-447) -> last 64->1 conv.
+  layers with RoPE and a causal sliding window of 250 (HF:729-928) -> SEANet decoder (HF:931-961, 408-447):
+  overlapping-row contractions on the three-pass split-bf16 path, the 128-channel residual block, the last
+  transposed convolution and the 24 kHz tail as fused weight-stationary kernels.
+This module stages the codes, records / replays the call per (B, T) shape and keeps the streaming state.
 
 Decoding is the hot path.  Encoding a reference WAV (``encode_file`` / ``encode_waveform``) runs the
 Mimi encoder through the same kernels: first conv and resampler = ``sopro_fir1_f32``; residual blocks, strided
@@ -30,15 +32,26 @@ from .pack import pack_mimi, rope_tables
 
 @dataclass
 class MimiDecodeState:
-    """reference: src/sopro/codec/mimi.py:75-80 (kv = decoder-transformer cache)."""
+    """reference: src/sopro/codec/mimi.py:75-80 (kv = decoder-transformer cache).  The cache itself is the C side's
+    ``sopro_mimi_stream_state`` (post-RoPE (k | v) rows per layer in a device buffer of ``cap_rows`` rows)."""
 
-    kv: Optional[List[torch.Tensor]] = None  # per layer [len, 1024] rows of (k | v), post-RoPE
-    kv_len: int = 0
-    pos: int = 0  # transformer position of the next row
-    evict: bool = True  # sliding-window layers drop all but the last window-1 rows; False after a legacy-policy trim
+    cst: Optional["hip.MimiStreamState"] = None
+    kv_buf: Optional[torch.Tensor] = None
     frames_seen: int = 0
     samples_emitted: int = 0
     tail_codes_tq: Optional[torch.Tensor] = None
+
+    @property
+    def kv_len(self) -> int:
+        return int(self.cst.kv_len) if self.cst is not None else 0
+
+    @property
+    def pos(self) -> int:  # transformer position of the next row
+        return int(self.cst.pos) if self.cst is not None else 0
+
+    @property
+    def evict(self) -> bool:  # sliding-window layers drop all but the last window-1 rows; False after a legacy-policy trim
+        return bool(self.cst.evict) if self.cst is not None else True
 
 
 class MimiCodec:
@@ -59,42 +72,16 @@ class MimiCodec:
         self.num_quantizers = int(self.mc.num_quantizers)
         self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "32")) << 30  # scratch kept per batch shape, per engine
         self.use_graph = os.environ.get("SOPRO_NO_BULK_GRAPH", "0") != "1"
-        self._graphs = hip.GraphCache("mimi_graph", cap=32)  # recorded decode launch sequences per (B, T)
-        self.fuse_tail = os.environ.get("SOPRO_UNFUSED_TAIL", "0") != "1"
-        self.fuse_res = os.environ.get("SOPRO_UNFUSED_RES", "0") != "1"  # 128-channel residual block as one kernel
-        self.ws_up = os.environ.get("SOPRO_GEMM_UP", "0") != "1"  # last transposed convolution weight-stationary (seanet_up.hip)
-        self.passes = 1 if precision == "bf16" else 3
-        # Decoder contractions run on the split-bf16 matrix-core path (16 mantissa bits per operand, fp32 accumulate:
-        # waveform error ~1e-5 of peak, inside the 1e-4 contract); SOPRO_MIMI_F32=1 keeps them on the fp32 MFMA kernel.
-        self.split_bf16 = os.environ.get("SOPRO_MIMI_F32", "0") != "1"
-        # SOPRO_MIMI_SPLIT_FORM=1: keep SEANet activations in split form between convolutions (producer-side ELU + split);
-        # measured slower than splitting while staging with the current kernel, so it is off by default.
-        self.split_form = os.environ.get("SOPRO_MIMI_SPLIT_FORM", "0") == "1"
-        # Activated-copy flow (default): a producer's epilogue writes ELU(x) as fp32 next to / instead of x, so the consumer's
-        # main loop has no activation work (measured: 4.9k -> 2.9k cycles per K-step); SOPRO_MIMI_ELU_PROLOGUE=1 disables it.
-        self.act_copy = os.environ.get("SOPRO_MIMI_ELU_PROLOGUE", "0") != "1"
-        self.wd: Dict[str, object] = {}
-        if self.split_bf16:
-            with torch.cuda.device(self.device):
-                for k, v in self.w.items():
-                    if v.dim() == 2 and k.endswith(".w") and (k.startswith(("tr.", "sea.conv0", "sea.up", "sea.res", "rvq_proj")))\
-                            and int(v.shape[0]) >= 64 and int(v.shape[1]) % 32 == 0:
-                        self.wd[k] = hip.pack_w_bf16x1(v) if precision == "bf16" else hip.pack_w_bf16x3(v)
-                torch.cuda.synchronize(self.device)
-            n_st = len(self.mc.upsampling_ratios)
-            need = ["rvq_proj.w", "sea.conv0.w"] + [f"sea.up{i}.w" for i in range(n_st)] + \
-                   [f"sea.res{i}.c{j}.w" for i in range(n_st - 1) for j in (1, 2)]
-            if any(k not in self.wd for k in need):  # unusual channel counts: stay on the fp32 kernels
-                self.split_bf16, self.wd = False, {}
+        self._graphs = hip.GraphCache("mimi_graph", cap=32)  # recorded decode calls per (B, T)
+        self.stream_cap_rows = 1024  # cache rows of a streaming state (MimiStreamDecoder sets it per policy)
         self._rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._rope_n = 0
         self._rope_old: List[Tuple[torch.Tensor, torch.Tensor]] = []  # outgrown tables stay alive: recorded graphs point at them
         self._banks: Dict[Tuple[int, int], tuple] = {}
-        Q, V = self.num_quantizers, int(self.mc.codebook_size)
-        ns = int(self.mc.num_semantic_quantizers)
-        i32 = lambda v: torch.tensor(list(v), dtype=torch.int32, device=self.device)  # noqa: E731
-        self._sem = (i32(range(ns)), i32([q * V for q in range(ns)]), torch.ones(ns, device=self.device))
-        self._ac = (i32(range(ns, Q)), i32([q * V for q in range(ns, Q)]), torch.ones(Q - ns, device=self.device))
+        # the stage engine (csrc/stages.hip): the decoder's launch sequence and its packed operands live in the library
+        from .stages import codec_engine
+
+        self.eng = codec_engine(self) if "rvq_proj.w" in self.w else None
 
     def on_stream(self):
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -248,274 +235,82 @@ class MimiCodec:
     @torch.inference_mode()
     def decode_batch(self, codes_btq: torch.Tensor, state: Optional[MimiDecodeState] = None,
                      timings: Optional[Dict[str, float]] = None) -> torch.Tensor:
-        """[B, T, Q] integer codes -> [B, T*1920] fp32 waveform.  With ``state`` (B == 1) the transformer
-        attends over the cached keys/values of earlier calls, as MimiModel.decode(decoder_past_key_values=...)."""
-        mc, w, dev, ws = self.mc, self.w, self.device, self.ws
-        gw = self._gw
+        """[B, T, Q] integer codes -> [B, T*1920] fp32 waveform: ``sopro_mimi_decode`` (csrc/stages.hip), recorded per (B, T)
+        shape and replayed.  With ``state`` (B == 1) the transformer attends over the cached keys / values of earlier calls, as
+        MimiModel.decode(decoder_past_key_values=...): ``sopro_mimi_decode_stream``."""
+        mc, dev, ws = self.mc, self.device, self.ws
         B, T, Q = codes_btq.shape
         if Q != self.num_quantizers:
             raise ValueError(f"expected {self.num_quantizers} codebooks, got {Q}")
         if T == 0:
             return torch.zeros(B, 0, device=dev)
-        HS, CD = int(mc.hidden_size), int(mc.codebook_dim)
-        N2 = 2 * T
-        PADX = int(mc.kernel_size) - 1  # 6 zero rows in front of the first SEANet conv's input
         if state is not None and B != 1:
             raise ValueError("streaming decode state is single-utterance")
+        if self.eng is None:
+            raise hip.SoproHipError("this Mimi checkpoint was loaded without its decoder-side tensors")
         if ws.over(self.ws_budget) and (B, T) not in self._graphs.graphs:  # many batch shapes seen: start over
             torch.cuda.synchronize(self.device)
             self._graphs.clear()
             ws.clear()
+        lib, eng = hip.load(), self.eng
         with self.on_stream():
-            # codes land in a persistent buffer so that the launch sequence of a (B, T) shape can be recorded once
+            # codes land in a persistent buffer so that the call of a (B, T) shape can be recorded once
             tok = ws.get("rvq.tok", (B * T, Q), dtype=torch.int32)
             tok.copy_(codes_btq.to(dev).reshape(B * T, Q))
-            if state is None and self.use_graph:
-                self._graphs.run((B, T), lambda: self._decode_issue(B, T, tok, None))
+            out = ws.get("sea.wav", (B, T * int(mc.frame_samples)))
+            scratch = ws.get(f"mimi.stage_ws.{B}x{T}", (int(lib.sopro_mimi_workspace_bytes(eng.h, B, T)),), dtype=torch.uint8)
+            if state is None:
+                def issue():
+                    hip._check(lib.sopro_mimi_decode(eng.h, scratch.data_ptr(), tok.data_ptr(), B, T, out.data_ptr(), hip._stream()), "sopro_mimi_decode")
+
+                if self.use_graph:
+                    self._graphs.run((B, T), issue)
+                else:
+                    issue()
             else:
-                self._decode_issue(B, T, tok, state)
-            wav = ws.get("sea.wav", (B, T * int(mc.frame_samples))).clone()  # the caller owns its result
+                if state.cst is None:  # first call of a stream: the cache buffer (window + chunk rows under the evicting policy)
+                    import ctypes as C
+
+                    cap = self.stream_cap_rows
+                    state.kv_buf = torch.empty(int(lib.sopro_mimi_stream_kv_bytes(eng.h, cap)), dtype=torch.uint8, device=dev)
+                    state.cst = hip.MimiStreamState()
+                    hip._check(lib.sopro_mimi_stream_init(eng.h, C.byref(state.cst), state.kv_buf.data_ptr(), cap), "sopro_mimi_stream_init")
+                import ctypes as C
+
+                hip._check(lib.sopro_mimi_decode_stream(eng.h, scratch.data_ptr(), C.byref(state.cst), tok.data_ptr(), T, out.data_ptr(), hip._stream()),
+                           "sopro_mimi_decode_stream")
+            wav = out.clone()  # the caller owns its result
         self.stream.synchronize()
         return wav
 
-    def _decode_issue(self, B: int, T: int, tok: torch.Tensor, state: Optional[MimiDecodeState]) -> None:
-        """The decoder's launch sequence for [B*T, Q] int32 codes -> ws["sea.wav"]: launches only (recordable when
-        ``state`` is None)."""
-        mc, w, ws = self.mc, self.w, self.ws
-        gw = self._gw
-        Q = self.num_quantizers
-        HS, CD = int(mc.hidden_size), int(mc.codebook_dim)
-        N2 = 2 * T
-        PADX = int(mc.kernel_size) - 1  # 6 zero rows in front of the first SEANet conv's input
-        # ---- RVQ decode + output projections (HF:modeling_mimi.py:1128-1137)
-        emb = ws.get("rvq.emb", (B * T, 2 * CD))
-        hip.codebook_sum(tok, Q, *self._sem, w["codebooks"], emb, rows=B * T, D=CD, ldo=2 * CD)
-        hip.codebook_sum(tok, Q, *self._ac, w["codebooks"], emb, rows=B * T, D=CD, ldo=2 * CD, o_off=CD)
-        q = ws.get("rvq.q", (B * T, HS))
-        hip.gemm(emb, gw("rvq_proj.w"), q, M=B * T, N=HS, K=2 * CD)
-        # ---- upsample into the (zero-padded) transformer stream
-        xs_stride = (PADX + N2) * HS
-        X = ws.get("tr.x", (B, PADX + N2, HS), zero=True)
-        hip.upsample2(q, w["upsample.w"], X, B=B, T=T, C_=HS, y_seg_stride=xs_stride, y_off=PADX * HS)
-        # ---- transformer
-        self._transformer("tr", X, B, N2, PADX, xs_stride, state)
-        # ---- SEANet decoder (HF:modeling_mimi.py:931-961)
-        wav = ws.get("sea.wav", (B, T * int(mc.frame_samples)))
-        if self.split_bf16 and self.split_form:
-            self._seanet_split(X, B, N2, xs_stride, wav)
-        elif self.split_bf16 and self.act_copy:
-            self._seanet_act(X, B, N2, xs_stride, wav)
-        else:
-            self._seanet_f32(X, B, N2, xs_stride, wav)
-
-    def _seanet_f32(self, X: torch.Tensor, B: int, N2: int, xs_stride: int, wav: torch.Tensor) -> None:
-        """SEANet decoder with fp32 activations and ELU as a GEMM prologue: on the split-bf16 kernel (operands split while
-        they are staged) or, with SOPRO_MIMI_F32=1, on the fp32 MFMA kernel."""
-        mc, w, dev, ws = self.mc, self.w, self.device, self.ws
-        HS = int(mc.hidden_size)
-        gwf = self._gw
-        ch = int(mc.num_filters) * (2 ** len(mc.upsampling_ratios))  # 1024
-        rows = N2
-        # first conv k=7: window = 7 consecutive rows starting 6 rows before (the zero pad)
-        Hc = ws.get("sea.h0", (B, 1 + rows, ch), zero=True)  # 1 zero row: x[t-1] of the transposed conv
-        hip.gemm(X, gwf("sea.conv0.w"), Hc, M=B * rows, N=ch, K=int(mc.kernel_size) * HS, lda=HS, bias=w["sea.conv0.b"],
-                 rows_per_seg=rows, a_seg_stride=xs_stride, c_off=ch, c_seg_stride=(1 + rows) * ch, ldc=ch)
-        pad_in = 1
-        for si, r in enumerate(mc.upsampling_ratios):
-            r = int(r)
-            co = ch // 2
-            orow = rows * r
-            Ho = ws.get(f"sea.h{si + 1}", (B, 2 + orow, co), zero=True)  # 2 zero rows: left pad of the k=3 conv
-            # ELU -> ConvTranspose1d(ch -> co, k=2r, s=r): row t of A = [x[t-1] | x[t]]
-            hip.gemm(Hc, gwf(f"sea.up{si}.w"), Ho, M=B * rows, N=r * co, K=2 * ch, lda=ch, bias=w[f"sea.up{si}.b"],
-                     prologue=hip.PRO_ELU, rows_per_seg=rows, a_seg_stride=(pad_in + rows) * ch, a_off=(pad_in - 1) * ch,
-                     c_off=2 * co, c_seg_stride=(2 + orow) * co, ldc=r * co)
-            hid = co // int(mc.compress)
-            last = si == len(mc.upsampling_ratios) - 1
-            if last and self.fuse_tail and co == 64 and hid == 32 and int(mc.residual_kernel_size) == 3 and int(mc.last_kernel_size) == 3:
-                # last residual block + last conv in one kernel: the 64-channel 24 kHz activation is read once
-                hip.seanet_tail(Ho, w[f"sea.res{si}.c1.w"], w[f"sea.res{si}.c1.b"], w[f"sea.res{si}.c2.w"], w[f"sea.res{si}.c2.b"],
-                                w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
-                Hc, ch, rows, pad_in = Ho, co, orow, 2
-                break
-            # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x))))
-            Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
-            hip.gemm(Ho, gwf(f"sea.res{si}.c1.w"), Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"],
-                     prologue=hip.PRO_ELU, rows_per_seg=orow, a_seg_stride=(2 + orow) * co)
-            hip.gemm(Y1, gwf(f"sea.res{si}.c2.w"), Ho, M=B * orow, N=co, K=hid, bias=w[f"sea.res{si}.c2.b"], prologue=hip.PRO_ELU,
-                     epilogue=hip.EPI_RES, R=Ho, rows_per_seg=orow, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co,
-                     r_seg_stride=(2 + orow) * co, ldc=co, ldr=co)
-            Hc, ch, rows, pad_in = Ho, co, orow, 2
-        else:
-            hip.final_conv(Hc, w["sea.final.w"], self.final_bias, wav, B=B, T=rows, h_seg_stride=(2 + rows) * ch, wav_seg_stride=rows)
-
-    def _seanet_act(self, X: torch.Tensor, B: int, N2: int, xs_stride: int, wav: torch.Tensor) -> None:
-        """SEANet decoder on the split-bf16 kernel with the activation applied ONCE, by the producer: every convolution
-        input is stored as ELU(x) (fp32) by the epilogue that made it; the raw tensor is written too only where the
-        residual block needs it as its skip operand (transposed-conv outputs)."""
-        mc, w, ws = self.mc, self.w, self.ws
-        gw = self._gw
-        HS = int(mc.hidden_size)
-        ratios = [int(r) for r in mc.upsampling_ratios]
-        ch = int(mc.num_filters) * (2 ** len(ratios))  # 1024
-        rows = N2
-        # first conv k=7 -> ELU; 1 zero row in front = x[t-1] of the transposed conv
-        He = ws.get("sea.e0", (B, 1 + rows, ch), zero=True)
-        hip.gemm(X, gw("sea.conv0.w"), He, M=B * rows, N=ch, K=int(mc.kernel_size) * HS, lda=HS, bias=w["sea.conv0.b"],
-                 rows_per_seg=rows, a_seg_stride=xs_stride, c_off=ch, c_seg_stride=(1 + rows) * ch, ldc=ch, c_mode=3)
-        pad_in = 1
-        for si, r in enumerate(ratios):
-            co, orow = ch // 2, rows * r
-            hid = co // int(mc.compress)
-            last = si == len(ratios) - 1
-            Ho = ws.get(f"sea.h{si + 1}", (B, 2 + orow, co), zero=True)  # raw fp32 (skip operand / tail input)
-            up = dict(M=B * rows, N=r * co, K=2 * ch, lda=ch, bias=w[f"sea.up{si}.b"], rows_per_seg=rows, a_seg_stride=(pad_in + rows) * ch,
-                      a_off=(pad_in - 1) * ch, c_off=2 * co, c_seg_stride=(2 + orow) * co, ldc=r * co)
-            if last:
-                # ConvTranspose1d -> raw fp32 only: the last stage runs in the fused tail (or on the fp32 kernels)
-                if self.ws_up and ch == 128 and co == 64 and r == 4:  # weight-stationary form of this K = 256, N = 256 contraction
-                    hip.seanet_up128(He, w[f"sea.up{si}.w"], w[f"sea.up{si}.b"], Ho, B=B, T=rows, x_seg_stride=(pad_in + rows) * ch,
-                                     x_off=(pad_in - 1) * ch, out_seg_stride=(2 + orow) * co, out_off=2 * co, passes=self.passes)
-                else:
-                    hip.gemm(He, gw(f"sea.up{si}.w"), Ho, **up)
-                if self.fuse_tail and co == 64 and hid == 32 and int(mc.residual_kernel_size) == 3 and int(mc.last_kernel_size) == 3:
-                    hip.seanet_tail(Ho, w[f"sea.res{si}.c1.w"], w[f"sea.res{si}.c1.b"], w[f"sea.res{si}.c2.w"], w[f"sea.res{si}.c2.b"],
-                                    w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
-                    return
-                Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
-                hip.gemm(Ho, w[f"sea.res{si}.c1.w"], Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"],
-                         prologue=hip.PRO_ELU, rows_per_seg=orow, a_seg_stride=(2 + orow) * co)
-                hip.gemm(Y1, w[f"sea.res{si}.c2.w"], Ho, M=B * orow, N=co, K=hid, bias=w[f"sea.res{si}.c2.b"], prologue=hip.PRO_ELU,
-                         epilogue=hip.EPI_RES, R=Ho, rows_per_seg=orow, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co,
-                         r_seg_stride=(2 + orow) * co, ldc=co, ldr=co)
-                hip.final_conv(Ho, w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
-                return
-            # ConvTranspose1d(ch -> co, k=2r, s=r): row t of A = [x[t-1] | x[t]] of the activated input; raw to Ho, ELU to Hn
-            Hn = ws.get(f"sea.e{si + 1}", (B, 2 + orow, co), zero=True)  # 2 zero rows: left pad of the k=3 conv
-            if self.fuse_res and co == 128 and hid == 64 and int(mc.residual_kernel_size) == 3:
-                # one kernel for the whole residual block (+ the next layer's ELU): the producer writes the raw tensor only,
-                # the block reads it once and writes the activated result once (sopro_seanet_res128_f32)
-                hip.gemm(He, gw(f"sea.up{si}.w"), Ho, **up)
-                hip.seanet_res128(Ho, w[f"sea.res{si}.c1.w"], w[f"sea.res{si}.c1.b"], w[f"sea.res{si}.c2.w"], w[f"sea.res{si}.c2.b"], Hn,
-                                  B=B, T=orow, h_seg_stride=(2 + orow) * co, out_seg_stride=(2 + orow) * co)
-                He, ch, rows, pad_in = Hn, co, orow, 2
-                continue
-            hip.gemm(He, gw(f"sea.up{si}.w"), Ho, c_mode=4, C2=Hn, ldc2=r * co, c2_seg_stride=(2 + orow) * co, c2_off=2 * co, **up)
-            # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x)))); its output is only ever read through ELU
-            Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
-            hip.gemm(Hn, gw(f"sea.res{si}.c1.w"), Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"], rows_per_seg=orow,
-                     a_seg_stride=(2 + orow) * co, c_mode=3)
-            hip.gemm(Y1, gw(f"sea.res{si}.c2.w"), Hn, M=B * orow, N=co, K=hid, bias=w[f"sea.res{si}.c2.b"], epilogue=hip.EPI_RES, R=Ho,
-                     rows_per_seg=orow, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co, r_seg_stride=(2 + orow) * co,
-                     ldc=co, ldr=co, c_mode=3)
-            He, ch, rows, pad_in = Hn, co, orow, 2
-        raise AssertionError("unreachable: the last stage returns")
-
-    def _seanet_split(self, X: torch.Tensor, B: int, N2: int, xs_stride: int, wav: torch.Tensor) -> None:
-        """SEANet decoder on the split-bf16 matrix-core path.  Between convolutions an activation lives as ELU(x) in
-        split form (every 32 channels = [32 hi bf16 | 32 lo bf16], same bytes, lines and strides as fp32), written by the producer's
-        epilogue, so the consumer's main loop stages it with plain copies.  The raw fp32 tensor is written next to it
-        only where the residual block needs it as its skip operand (transposed-conv outputs)."""
-        mc, w, dev, ws = self.mc, self.w, self.device, self.ws
-        gw = self._gw
-        HS = int(mc.hidden_size)
-        ratios = [int(r) for r in mc.upsampling_ratios]
-        ch = int(mc.num_filters) * (2 ** len(ratios))  # 1024
-        rows = N2
-        # first conv k=7 over the fp32 transformer stream -> ELU, split planes; 1 zero row = x[t-1] of the transposed conv
-        He = ws.get("sea.e0", (B, 1 + rows, ch), zero=True)
-        hip.gemm(X, gw("sea.conv0.w"), He, M=B * rows, N=ch, K=int(mc.kernel_size) * HS, lda=HS, bias=w["sea.conv0.b"],
-                 rows_per_seg=rows, a_seg_stride=xs_stride, c_off=ch, c_seg_stride=(1 + rows) * ch, ldc=ch, c_mode=1)
-        pad_in = 1
-        for si, r in enumerate(ratios):
-            co, orow = ch // 2, rows * r
-            hid = co // int(mc.compress)
-            last = si == len(ratios) - 1
-            Ho = ws.get(f"sea.h{si + 1}", (B, 2 + orow, co), zero=True)  # raw fp32 (skip operand / tail input)
-            up = dict(M=B * rows, N=r * co, K=2 * ch, lda=ch, bias=w[f"sea.up{si}.b"], rows_per_seg=rows, a_seg_stride=(pad_in + rows) * ch,
-                      a_off=(pad_in - 1) * ch, a_split=True, c_off=2 * co, c_seg_stride=(2 + orow) * co, ldc=r * co)
-            if last:
-                # ConvTranspose1d -> raw fp32 only: the last stage runs in the fused tail (or on the fp32 kernels)
-                hip.gemm(He, gw(f"sea.up{si}.w"), Ho, **up)
-                if self.fuse_tail and co == 64 and hid == 32 and int(mc.residual_kernel_size) == 3 and int(mc.last_kernel_size) == 3:
-                    hip.seanet_tail(Ho, w[f"sea.res{si}.c1.w"], w[f"sea.res{si}.c1.b"], w[f"sea.res{si}.c2.w"], w[f"sea.res{si}.c2.b"],
-                                    w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
-                    return
-                Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
-                hip.gemm(Ho, w[f"sea.res{si}.c1.w"], Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"],
-                         prologue=hip.PRO_ELU, rows_per_seg=orow, a_seg_stride=(2 + orow) * co)
-                hip.gemm(Y1, w[f"sea.res{si}.c2.w"], Ho, M=B * orow, N=co, K=hid, bias=w[f"sea.res{si}.c2.b"], prologue=hip.PRO_ELU,
-                         epilogue=hip.EPI_RES, R=Ho, rows_per_seg=orow, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co,
-                         r_seg_stride=(2 + orow) * co, ldc=co, ldr=co)
-                hip.final_conv(Ho, w["sea.final.w"], self.final_bias, wav, B=B, T=orow, h_seg_stride=(2 + orow) * co, wav_seg_stride=orow)
-                return
-            # ELU -> ConvTranspose1d(ch -> co, k=2r, s=r): row t of A = [x[t-1] | x[t]]; raw to Ho, ELU split to Hn
-            Hn = ws.get(f"sea.e{si + 1}", (B, 2 + orow, co), zero=True)  # 2 zero rows: left pad of the k=3 conv
-            hip.gemm(He, gw(f"sea.up{si}.w"), Ho, c_mode=2, C2=Hn, ldc2=r * co, c2_seg_stride=(2 + orow) * co, c2_off=2 * co, **up)
-            # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x)))); its output is only ever read through ELU
-            Y1 = ws.get(f"sea.y{si + 1}", (B * orow, hid))
-            hip.gemm(Hn, gw(f"sea.res{si}.c1.w"), Y1, M=B * orow, N=hid, K=3 * co, lda=co, bias=w[f"sea.res{si}.c1.b"], rows_per_seg=orow,
-                     a_seg_stride=(2 + orow) * co, a_split=True, c_mode=1)
-            hip.gemm(Y1, gw(f"sea.res{si}.c2.w"), Hn, M=B * orow, N=co, K=hid, bias=w[f"sea.res{si}.c2.b"], epilogue=hip.EPI_RES, R=Ho,
-                     rows_per_seg=orow, a_split=True, c_off=2 * co, r_off=2 * co, c_seg_stride=(2 + orow) * co, r_seg_stride=(2 + orow) * co,
-                     ldc=co, ldr=co, c_mode=1)
-            He, ch, rows, pad_in = Hn, co, orow, 2
-        raise AssertionError("unreachable: the last stage returns")
-
-    def _transformer(self, pre: str, X: torch.Tensor, B: int, n: int, pad: int, xs_stride: int,
-                     state: Optional[MimiDecodeState] = None) -> None:
+    def _transformer(self, pre: str, X: torch.Tensor, B: int, n: int, pad: int, xs_stride: int) -> None:
         """Pre-norm causal sliding-window RoPE transformer over the residual stream ``X`` [B, pad + n (+ tail), HS], in place
-        (HF:modeling_mimi.py MimiTransformerModel; ``pre`` = "tr" for the decoder side, "etr" for the encoder side)."""
+        (HF:modeling_mimi.py MimiTransformerModel).  The ENCODER side's ("etr"): the decoder side's runs inside
+        ``sopro_mimi_decode``."""
         mc, w, ws = self.mc, self.w, self.ws
-        gw = self._gw
         HS, H, dh, win = int(mc.hidden_size), int(mc.num_attention_heads), int(mc.head_dim), int(mc.sliding_window)
         inter = int(mc.intermediate_size)
-        past = state.pos if state is not None else 0
-        cos_t, sin_t = self._rope_tables(past + n)
+        cos_t, sin_t = self._rope_tables(n)
         y = ws.get("tr.y", (B * n, HS))
         qkv = ws.get("tr.qkv", (B * n, 3 * HS))
         ao = ws.get("tr.ao", (B * n, HS))
         hd = ws.get("tr.hd", (B * n, inter))
         seg = dict(rows_per_seg=n)
-        new_kv: List[torch.Tensor] = []
         for li in range(int(mc.num_hidden_layers)):
             p = f"{pre}.{li}"
             self._ln_stream(X, y, w[p + ".ln1.w"], w[p + ".ln1.b"], B, n, pad, HS, xs_stride)
-            hip.gemm(y, gw(p + ".qkv.w"), qkv, M=B * n, N=3 * HS, K=HS)
-            hip.rope(qkv, cos_t, sin_t, rows=B * n, rows_per_seg=n, pos0=past, H=H, dh=dh, ldx=3 * HS)
-            hip.rope(qkv, cos_t, sin_t, rows=B * n, rows_per_seg=n, pos0=past, H=H, dh=dh, ldx=3 * HS, x_off=HS)
-            if state is None:
-                hip.attention(qkv, qkv, qkv, ao, B=B, H=H, dh=dh, Tq=n, Tk=n, ldq=3 * HS, ldk=3 * HS, ldv=3 * HS, ldo=HS,
-                              q_bstride=n * 3 * HS, k_bstride=n * 3 * HS, v_bstride=n * 3 * HS, o_bstride=n * HS,
-                              causal=True, window=win, k_off=HS, v_off=2 * HS)
-            else:
-                # keys/values of earlier calls (post-RoPE) followed by this call's
-                cur = qkv[:, HS:].contiguous()  # [n, 2*HS] = (k | v)
-                if state.kv is not None and state.kv_len > 0:
-                    allkv = torch.cat([state.kv[li], cur], dim=0)
-                else:
-                    allkv = cur
-                Tk = int(allkv.shape[0])
-                hip.attention(qkv, allkv, allkv, ao, B=1, H=H, dh=dh, Tq=n, Tk=Tk, ldq=3 * HS, ldk=2 * HS, ldv=2 * HS, ldo=HS,
-                              q_bstride=0, k_bstride=0, v_bstride=0, o_bstride=0, causal=True, window=win, q_pos0=past,
-                              k_pos0=past + n - Tk, v_off=HS)
-                # DynamicSlidingWindowLayer keeps the last window-1 positions (installed transformers 5.x); the plain layers
-                # a legacy-policy trim rebuilds the cache from keep everything (the window then acts through the mask only)
-                new_kv.append((allkv[-(win - 1):] if state.evict else allkv).clone())
-            hip.gemm(ao, gw(p + ".o.w"), X, M=B * n, N=HS, K=HS, epilogue=hip.EPI_RES, R=X, scale=w[p + ".ls1"],
+            hip.gemm(y, w[p + ".qkv.w"], qkv, M=B * n, N=3 * HS, K=HS)
+            hip.rope(qkv, cos_t, sin_t, rows=B * n, rows_per_seg=n, pos0=0, H=H, dh=dh, ldx=3 * HS)
+            hip.rope(qkv, cos_t, sin_t, rows=B * n, rows_per_seg=n, pos0=0, H=H, dh=dh, ldx=3 * HS, x_off=HS)
+            hip.attention(qkv, qkv, qkv, ao, B=B, H=H, dh=dh, Tq=n, Tk=n, ldq=3 * HS, ldk=3 * HS, ldv=3 * HS, ldo=HS,
+                          q_bstride=n * 3 * HS, k_bstride=n * 3 * HS, v_bstride=n * 3 * HS, o_bstride=n * HS,
+                          causal=True, window=win, k_off=HS, v_off=2 * HS)
+            hip.gemm(ao, w[p + ".o.w"], X, M=B * n, N=HS, K=HS, epilogue=hip.EPI_RES, R=X, scale=w[p + ".ls1"],
                      c_off=pad * HS, r_off=pad * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
             self._ln_stream(X, y, w[p + ".ln2.w"], w[p + ".ln2.b"], B, n, pad, HS, xs_stride)
-            hip.gemm(y, gw(p + ".fc1.w"), hd, M=B * n, N=inter, K=HS, epilogue=hip.EPI_GELU)
-            hip.gemm(hd, gw(p + ".fc2.w"), X, M=B * n, N=HS, K=inter, epilogue=hip.EPI_RES, R=X,
+            hip.gemm(y, w[p + ".fc1.w"], hd, M=B * n, N=inter, K=HS, epilogue=hip.EPI_GELU)
+            hip.gemm(hd, w[p + ".fc2.w"], X, M=B * n, N=HS, K=inter, epilogue=hip.EPI_RES, R=X,
                      scale=w[p + ".ls2"], c_off=pad * HS, r_off=pad * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
-        if state is not None:
-            state.kv = new_kv
-            state.kv_len = int(new_kv[0].shape[0])
-            state.pos = past + n
-
-    def _gw(self, key: str):
-        """GEMM weight operand: the split-bf16 packed form where one was made, else the fp32 matrix."""
-        return self.wd.get(key) or self.w[key]
 
     def _ln_stream(self, X: torch.Tensor, y: torch.Tensor, wt: torch.Tensor, bs: torch.Tensor, B: int, N2: int, pad: int, HS: int,
                    xs_stride: int) -> None:
@@ -556,10 +351,12 @@ class MimiStreamDecoder:
         if self.overlap_frames > 0 and st.tail_codes_tq is not None and st.tail_codes_tq.numel() > 0:
             ov = min(self.overlap_frames, int(st.tail_codes_tq.shape[0]))
             codes_in = torch.cat([st.tail_codes_tq[-ov:], chunk], dim=0)
-        if self.trim == "legacy" and ov > 0 and st.kv is not None and st.kv_len > 0:
-            keep = max(0, st.kv_len - ov)
-            st.kv = [t[:keep] for t in st.kv]
-            st.kv_len, st.pos, st.evict = keep, keep, False
+        if self.trim == "legacy" and ov > 0 and st.cst is not None and st.kv_len > 0:
+            import ctypes as C
+
+            hip._check(hip.load().sopro_mimi_stream_trim(C.byref(st.cst), ov), "sopro_mimi_stream_trim")
+        # the evicting policy keeps window - 1 rows + the call's own; the legacy policy's plain layers keep everything
+        self.codec.stream_cap_rows = 4096 if self.trim == "legacy" else 1024
         wav = self.codec.decode_batch(codes_in.unsqueeze(0), state=st)
         wav = wav[:, : (ov + n_new) * hop][:, ov * hop:]
         st.frames_seen += n_new

@@ -114,7 +114,7 @@ class ContinuousSynthesizer:
         ss = items[0]["ss"]
         prep = m.prepare_conditioning_batch(ids, [it["ref"] for it in items], max_frames=mf, style_strength=ss)
         n, S = len(items), int(prep["txt_seq"].shape[1])
-        H, dh = 4, D // 4
+        H = 4
         with m.on_stream(prep=True):
             ts = prep["txt_seq"].contiguous().view(n * S, D)
             nkv = torch.empty(n * S, D, device=m.device)
@@ -124,12 +124,8 @@ class ContinuousSynthesizer:
                 pa = f"ar.x_attns.{i}"
                 kp = torch.zeros(n, H, self.S_cap, D, device=m.device)
                 vp = torch.zeros(n, H, self.S_cap, D, device=m.device)
-                hip.norm(ts, nkv, w[pa + ".nkv.weight"], rows=n * S, C_=D, eps=RMS_EPS)
-                hip.gemm(nkv, w[pa + ".kv.w"], kvd, M=n * S, N=2 * D, K=D)
-                seg = dict(M=n * S, N=D, K=dh, lda=2 * D, rows_per_seg=S, ldc=D, c_seg_stride=H * self.S_cap * D)
-                for h in range(H):
-                    hip.gemm(kvd, w[pa + ".q.wT"][h], kp, a_off=h * dh, c_off=h * self.S_cap * D, **seg)
-                    hip.gemm(kvd, w[pa + ".o.w"][:, h * dh:], vp, a_off=D + h * dh, c_off=h * self.S_cap * D, ldw=D, **seg)
+                hip.ar_fold_text(ts, w[pa + ".nkv.weight"], w[pa + ".kv.w"], w[pa + ".q.wT"], w[pa + ".o.w"], nkv, kvd, kp, vp,
+                                 B=n, S=S, S_cap=self.S_cap, D=D, H=H, eps=RMS_EPS)
                 kps[i], vps[i] = kp, vp
             ev = torch.cuda.Event()
             ev.record(m.prep_stream)

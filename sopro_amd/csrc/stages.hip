@@ -63,6 +63,7 @@ struct sopro_engine {
   std::map<std::string, const float*> sk;  // AR-step weights in skinny fragment order
   std::vector<void*> owned;
   bool final = false;
+  bool has_ar = false, has_nar = false, has_mimi = false;  // families whose tensors were given before sopro_engine_finalize
   // NAR constants
   std::vector<int32_t*> nar_cols, nar_offs;
   std::vector<float*> nar_cw, ad_mul, ad_add;
@@ -94,6 +95,12 @@ int need(const sopro_engine* e, const std::string& name, const Ten** out, int nd
   }
   *out = &it->second;
   return 0;
+}
+
+const Wt& WT(const sopro_engine* e, const std::string& key) {  // a packed operand made by sopro_engine_finalize (read-only: lanes share an engine)
+  static const Wt none;
+  auto it = e->w.find(key);
+  return it == e->w.end() ? none : it->second;
 }
 
 const float* F(const sopro_engine* e, const std::string& name) {
@@ -174,6 +181,39 @@ int plain(sopro_engine* e, const std::string& key) {
   return 0;
 }
 
+// Split-K scratch of a stage call (carved from the caller's workspace; belongs to the call's stream): problems with too few output
+// tiles to occupy the chip (streaming chunks, batch 1) run their K loop on `ksplit` workgroups per tile (sopro_gemm_split_ext).
+constexpr size_t SPLITK_WS_BYTES = (size_t)32 << 20;
+constexpr int SPLITK_TICKETS = 1024;
+struct SplitK {
+  float* ws = nullptr;
+  int32_t* tickets = nullptr;
+};
+
+// K slices for a problem of M x N x K on tiles of the kernel family `pieces` selects (3: six-pass / f16 three-pass rules,
+// 1: one-pass, 2: three-pass).  The split costs ~10 us (device-scope release / acquire around the ticket): it pays from ~32
+// K-steps up; a slice costs ~0.9 us per K-step, the reducing workgroup ~0.36 us per slice: ks ~ sqrt(2.5 * K-steps).
+int auto_ksplit(int M, int N, int K, int pieces, int epi) {
+  int bm, bn;
+  if (pieces == 3) {
+    bm = 64; bn = epi == SOPRO_EPI_GLU ? 128 : 64;
+  } else if (pieces == 1) {
+    const bool small = N <= 64 || M <= 64 || (int64_t)((M + 127) / 128) * ((N + 127) / 128) < 256;
+    if (small) { bm = 64; bn = epi == SOPRO_EPI_GLU ? 128 : 64; } else { bm = bn = 128; }
+  } else {
+    if (N <= 64 || M <= 64) bm = bn = 64; else bm = bn = 128;
+  }
+  const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  const int kt = (K + 31) / 32;
+  if (tiles >= 96 || kt < 32 || tiles > SPLITK_TICKETS) return 1;
+  int ks = (int)lrint(sqrt(2.5 * kt));
+  if (ks > 16) ks = 16;
+  if (ks > 512 / (int)tiles) ks = 512 / (int)tiles;
+  if (ks < 1) ks = 1;
+  while (ks > 1 && (size_t)ks * tiles * bm * bn * 4 > SPLITK_WS_BYTES) --ks;
+  return ks;
+}
+
 struct G {  // one contraction: mirrors sopro_amd.hip.gemm's keyword arguments
   int M = 0, N = 0, K = 0;
   int64_t lda = -1, ldc = -1, ldr = -1, ldw = -1;
@@ -184,6 +224,7 @@ struct G {  // one contraction: mirrors sopro_amd.hip.gemm's keyword arguments
   float* C2 = nullptr;
   int64_t ldc2 = -1, c2_seg = 0;
   float rms_eps = 0.f;
+  const SplitK* sk = nullptr;  // non-NULL: few-row problems may run split-K on this scratch
 };
 
 int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override, float* C, const G& o) {
@@ -215,6 +256,12 @@ int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override
     x.ldc2 = o.ldc2 < 0 ? n_out : o.ldc2;
     x.c2_seg_stride = o.c2_seg;
     if (o.rms_eps > 0.f) { x.rms_norm = 1; x.rms_eps = o.rms_eps; }
+    if (o.sk && o.sk->ws && o.rms_eps <= 0.f && o.c_mode != 5) {
+      const int ks = auto_ksplit(o.M, o.N, o.K, w.f16 ? 3 : w.pieces, o.epi);
+      if (ks > 1) {
+        x.ksplit = ks; x.n_tickets = SPLITK_TICKETS; x.ws = o.sk->ws; x.ws_bytes = (int64_t)SPLITK_WS_BYTES; x.tickets = o.sk->tickets;
+      }
+    }
     if (w.f16) {
       x.acc_scale = w.acc_scale;
       return sopro_gemm_f16x3(&g, w.packed, &x, s);
@@ -285,119 +332,161 @@ int sopro_engine_finalize(sopro_engine* e, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const sopro_engine_cfg& c = e->c;
   const Ten* t;
-  // ---- AR step: skinny fragment order for the four big projections of every block and the head
-  for (int i = 0; i < c.n_layers_ar; ++i) {
-    const std::string p = "ar.blocks." + std::to_string(i);
-    for (const char* nm : {".glu.w", ".ff1.w", ".ff2.w"}) {
-      STG(need(e, p + nm, &t, 2));
-      const int N = (int)t->shape[0], K = (int)t->shape[1], glu = std::string(nm) == ".glu.w";
-      float* d;
-      STG(dev_alloc(e, (size_t)sopro_skinny_packed_floats(N, K, glu), &d));
-      STG(sopro_pack_skinny_w(t->f(), K, N, K, glu, d, s));
-      e->sk[p + nm] = d;
-    }
-    for (const char* nm : {".glu.b", ".dw.w", ".dw.b", ".ff1.b", ".ff2.b"}) STG(need(e, p + nm, &t));
-    if (c.ar_xattn[i]) {
-      const std::string pa = "ar.x_attns." + std::to_string(i);
-      for (const char* nm : {".nkv.weight", ".kv.w", ".q.wT", ".o.w"}) STG(need(e, pa + nm, &t));
-    }
+  const bool bf16 = c.precision == 1;
+  // A stage family is present when its marker tensor was given; a family that is present must be complete.
+  e->has_ar = e->t.count("ar.head.w") != 0;
+  e->has_nar = e->t.count("nar.pre.w") != 0;
+  e->has_mimi = e->t.count("rvq_proj.w") != 0;
+  if (!e->has_ar && !e->has_nar && !e->has_mimi) {
+    // report the first tensor of the first stage by name (what a host that forgot sopro_engine_set_tensor wants to read)
+    STG(need(e, "ar.blocks.0.glu.w", &t, 2));
   }
-  {
-    STG(need(e, "ar.head.w", &t, 2));
-    float* d;
-    STG(dev_alloc(e, (size_t)sopro_skinny_packed_floats((int)t->shape[0], (int)t->shape[1], 0), &d));
-    STG(sopro_pack_skinny_w(t->f(), t->shape[1], (int)t->shape[0], (int)t->shape[1], 0, d, s));
-    e->sk["ar.head.w"] = d;
+  // ---- AR step: skinny fragment order for the four big projections of every block and the head (bf16 mode: bf16 weights)
+  if (e->has_ar) {
+    auto pack_skinny = [&](const std::string& key, int glu) -> int {
+      STG(need(e, key, &t, 2));
+      const int N = (int)t->shape[0], K = (int)t->shape[1];
+      const int64_t nfl = sopro_skinny_packed_floats(N, K, glu);
+      float* d;
+      STG(dev_alloc(e, (size_t)(bf16 ? nfl / 2 : nfl), &d));
+      if (bf16) STG(sopro_pack_skinny_w_bf16(t->f(), K, N, K, glu, d, s));
+      else STG(sopro_pack_skinny_w(t->f(), K, N, K, glu, d, s));
+      e->sk[key] = d;
+      return 0;
+    };
+    for (int i = 0; i < c.n_layers_ar; ++i) {
+      const std::string p = "ar.blocks." + std::to_string(i);
+      STG(pack_skinny(p + ".glu.w", 1));
+      STG(pack_skinny(p + ".ff1.w", 0));
+      STG(pack_skinny(p + ".ff2.w", 0));
+      for (const char* nm : {".glu.b", ".dw.w", ".dw.b", ".ff1.b", ".ff2.b"}) STG(need(e, p + nm, &t));
+      if (c.ar_xattn[i]) {
+        const std::string pa = "ar.x_attns." + std::to_string(i);
+        for (const char* nm : {".nkv.weight", ".kv.w", ".q.wT", ".o.w"}) STG(need(e, pa + nm, &t));
+      }
+    }
+    STG(pack_skinny("ar.head.w", 0));
     STG(need(e, "ar.head.b", &t));
     STG(need(e, "cb_embed", &t, 2));
   }
-  // ---- NAR: two fp16 pieces / three passes (22 mantissa bits), the two RMSNorm weights of a block folded into the projections they feed
-  for (int i = 0; i < c.n_layers_nar; ++i) {
-    const std::string p = "nar.blocks." + std::to_string(i);
-    STG(pack_pieces(e, p + ".glu.w", p + ".glu.wn", F16X2, (p + ".norm.weight").c_str(), s));
-    STG(pack_pieces(e, p + ".ff1.w", p + ".ff1.wn", F16X2, (p + ".ff.norm.weight").c_str(), s));
-    STG(pack_pieces(e, p + ".ff2.w", p + ".ff2.w", F16X2, nullptr, s));
-    for (const char* nm : {".glu.b", ".dw.w", ".dw.b", ".ff1.b", ".ff2.b"}) STG(need(e, p + nm, &t));
-  }
-  STG(pack_pieces(e, "nar.pre.w", "nar.pre.w", F16X2, nullptr, s));
-  const char* stage_names[8] = {"B", "C", "D", "E", "F", "G", "H", "I"};
-  std::vector<int> known = {0};
-  for (int sgi = 0; sgi < c.n_stages; ++sgi) {
-    const std::string hk = std::string("nar.heads.") + stage_names[sgi];
-    STG(pack_pieces(e, hk + ".w", hk + ".w", F16X2, nullptr, s));
-    STG(need(e, hk + ".b", &t));
-    // prev = sum_j softmax(w[known])_j * E[cb_j * V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
-    std::vector<int32_t> cols(known.begin(), known.end()), offs;
-    std::vector<float> cw;
-    float mx = -1e30f, sum = 0.f;
-    for (int k : known) mx = fmaxf(mx, c.nar_prev_cb_weights[k]);
-    for (int k : known) { cw.push_back(expf(c.nar_prev_cb_weights[k] - mx)); sum += cw.back(); }
-    for (float& v : cw) v /= sum;
-    for (int k : known) offs.push_back(k * c.codebook_size);
-    int32_t *dc, *dofs;
-    float* dw;
-    STG(dev_upload(e, cols, &dc));
-    STG(dev_upload(e, offs, &dofs));
-    STG(dev_upload(e, cw, &dw));
-    e->nar_cols.push_back(dc); e->nar_offs.push_back(dofs); e->nar_cw.push_back(dw);
-    e->nar_known.push_back((int)known.size());
-    for (int j = 0; j < c.stage_n_cb[sgi]; ++j) known.push_back(c.stage_first_cb[sgi] + j);
-  }
-  for (const char* nm : {"nar.norm.weight", "nar.pre.b", "nar.stage_emb", "nar.adapter.norm.weight", "nar.adapter.mlp.0.w", "nar.adapter.mlp.0.b",
-                         "nar.adapter.mlp.2.w", "nar.adapter.mlp.2.b"})
-    STG(need(e, nm, &t));
-  {  // per-stage adapter coefficients (1 + tanh g, tanh b): input independent (src/sopro/nn/nar.py:25-32)
-    const int ns = c.n_stages, D = c.d_model;
-    float *h, *gb;
-    STG(dev_alloc(e, (size_t)ns * 256, &h));
-    STG(dev_alloc(e, (size_t)ns * 2 * D, &gb));
-    G o; o.M = ns; o.N = 256; o.K = D; o.bias = F(e, "nar.adapter.mlp.0.b"); o.epi = SOPRO_EPI_GELU;
-    Wt w0; w0.f32 = F(e, "nar.adapter.mlp.0.w");
-    STG(gemm(s, F(e, "nar.stage_emb"), w0, nullptr, h, o));
-    G o2; o2.M = ns; o2.N = 2 * D; o2.K = 256; o2.bias = F(e, "nar.adapter.mlp.2.b");
-    Wt w2; w2.f32 = F(e, "nar.adapter.mlp.2.w");
-    STG(gemm(s, h, w2, nullptr, gb, o2));
-    for (int sg = 0; sg < ns; ++sg) {
-      float *mul, *add;
-      STG(dev_alloc(e, (size_t)D, &mul));
-      STG(dev_alloc(e, (size_t)D, &add));
-      STG(sopro_tanh_affine_f32(gb + (size_t)sg * 2 * D, mul, 1.0f, 1.0f, D, s));
-      STG(sopro_tanh_affine_f32(gb + (size_t)sg * 2 * D + D, add, 0.0f, 1.0f, D, s));
-      e->ad_mul.push_back(mul); e->ad_add.push_back(add);
+  // ---- NAR: two fp16 pieces / three passes (22 mantissa bits), the two RMSNorm weights of a block folded into the
+  // projections they feed; bf16 mode: one bf16 piece
+  if (e->has_nar) {
+    const int np = bf16 ? 1 : F16X2;
+    for (int i = 0; i < c.n_layers_nar; ++i) {
+      const std::string p = "nar.blocks." + std::to_string(i);
+      STG(pack_pieces(e, p + ".glu.w", p + ".glu.wn", np, (p + ".norm.weight").c_str(), s));
+      STG(pack_pieces(e, p + ".ff1.w", p + ".ff1.wn", np, (p + ".ff.norm.weight").c_str(), s));
+      STG(pack_pieces(e, p + ".ff2.w", p + ".ff2.w", np, nullptr, s));
+      for (const char* nm : {".glu.b", ".dw.w", ".dw.b", ".ff1.b", ".ff2.b"}) STG(need(e, p + nm, &t));
+    }
+    STG(pack_pieces(e, "nar.pre.w", "nar.pre.w", np, nullptr, s));
+    const char* stage_names[8] = {"B", "C", "D", "E", "F", "G", "H", "I"};
+    std::vector<int> known = {0};
+    for (int sgi = 0; sgi < c.n_stages; ++sgi) {
+      const std::string hk = std::string("nar.heads.") + stage_names[sgi];
+      STG(pack_pieces(e, hk + ".w", hk + ".w", np, nullptr, s));
+      STG(need(e, hk + ".b", &t));
+      // prev = sum_j softmax(w[known])_j * E[cb_j * V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
+      std::vector<int32_t> cols(known.begin(), known.end()), offs;
+      std::vector<float> cw;
+      float mx = -1e30f, sum = 0.f;
+      for (int k : known) mx = fmaxf(mx, c.nar_prev_cb_weights[k]);
+      for (int k : known) { cw.push_back(expf(c.nar_prev_cb_weights[k] - mx)); sum += cw.back(); }
+      for (float& v : cw) v /= sum;
+      for (int k : known) offs.push_back(k * c.codebook_size);
+      int32_t *dc, *dofs;
+      float* dw;
+      STG(dev_upload(e, cols, &dc));
+      STG(dev_upload(e, offs, &dofs));
+      STG(dev_upload(e, cw, &dw));
+      e->nar_cols.push_back(dc); e->nar_offs.push_back(dofs); e->nar_cw.push_back(dw);
+      e->nar_known.push_back((int)known.size());
+      for (int j = 0; j < c.stage_n_cb[sgi]; ++j) known.push_back(c.stage_first_cb[sgi] + j);
+    }
+    for (const char* nm : {"nar.norm.weight", "nar.pre.b", "nar.stage_emb", "nar.adapter.norm.weight", "nar.adapter.mlp.0.w", "nar.adapter.mlp.0.b",
+                           "nar.adapter.mlp.2.w", "nar.adapter.mlp.2.b", "cb_embed"})
+      STG(need(e, nm, &t));
+    {  // per-stage adapter coefficients (1 + tanh g, tanh b): input independent (src/sopro/nn/nar.py:25-32)
+      const int ns = c.n_stages, D = c.d_model;
+      float *h, *gb;
+      STG(dev_alloc(e, (size_t)ns * 256, &h));
+      STG(dev_alloc(e, (size_t)ns * 2 * D, &gb));
+      G o; o.M = ns; o.N = 256; o.K = D; o.bias = F(e, "nar.adapter.mlp.0.b"); o.epi = SOPRO_EPI_GELU;
+      Wt w0; w0.f32 = F(e, "nar.adapter.mlp.0.w");
+      STG(gemm(s, F(e, "nar.stage_emb"), w0, nullptr, h, o));
+      G o2; o2.M = ns; o2.N = 2 * D; o2.K = 256; o2.bias = F(e, "nar.adapter.mlp.2.b");
+      Wt w2; w2.f32 = F(e, "nar.adapter.mlp.2.w");
+      STG(gemm(s, h, w2, nullptr, gb, o2));
+      for (int sg = 0; sg < ns; ++sg) {
+        float *mul, *add;
+        STG(dev_alloc(e, (size_t)D, &mul));
+        STG(dev_alloc(e, (size_t)D, &add));
+        STG(sopro_tanh_affine_f32(gb + (size_t)sg * 2 * D, mul, 1.0f, 1.0f, D, s));
+        STG(sopro_tanh_affine_f32(gb + (size_t)sg * 2 * D + D, add, 0.0f, 1.0f, D, s));
+        e->ad_mul.push_back(mul); e->ad_add.push_back(add);
+      }
     }
   }
-  // ---- Mimi decoder: three-pass operands (16 mantissa bits: waveform contract), raw fp32 for the two fused SEANet kernels
-  STG(pack_pieces(e, "rvq_proj.w", "rvq_proj.w", 2, nullptr, s));
-  for (int l = 0; l < c.mimi_layers; ++l) {
-    const std::string p = "tr." + std::to_string(l);
-    for (const char* nm : {".qkv.w", ".o.w", ".fc1.w", ".fc2.w"}) STG(pack_pieces(e, p + nm, p + nm, 2, nullptr, s));
-    for (const char* nm : {".ln1.w", ".ln1.b", ".ln2.w", ".ln2.b", ".ls1", ".ls2"}) STG(need(e, p + nm, &t));
-  }
-  STG(pack_pieces(e, "sea.conv0.w", "sea.conv0.w", 2, nullptr, s));
-  STG(need(e, "sea.conv0.b", &t));
-  for (int si = 0; si < c.mimi_n_ratios; ++si) {
-    const std::string u = "sea.up" + std::to_string(si), r = "sea.res" + std::to_string(si);
-    STG(pack_pieces(e, u + ".w", u + ".w", 2, nullptr, s));
-    STG(need(e, u + ".b", &t));
-    for (const char* nm : {".c1.w", ".c1.b", ".c2.w", ".c2.b"}) STG(need(e, r + nm, &t));
-    STG(need(e, r + ".c1.w", &t, 2));
-    if ((int)t->shape[0] >= 64 && (int)t->shape[0] != 64) {  // hidden > 64: generic contractions (64 = the fused 128-channel block)
-      STG(pack_pieces(e, r + ".c1.w", r + ".c1.w", 2, nullptr, s));
-      STG(pack_pieces(e, r + ".c2.w", r + ".c2.w", 2, nullptr, s));
+  // ---- Mimi decoder: three-pass operands (16 mantissa bits: waveform contract; bf16 mode: one piece), raw fp32 for the fused
+  // SEANet kernels
+  if (e->has_mimi) {
+    const int mp = bf16 ? 1 : 2;
+    STG(pack_pieces(e, "rvq_proj.w", "rvq_proj.w", mp, nullptr, s));
+    for (int l = 0; l < c.mimi_layers; ++l) {
+      const std::string p = "tr." + std::to_string(l);
+      for (const char* nm : {".qkv.w", ".o.w", ".fc1.w", ".fc2.w"}) STG(pack_pieces(e, p + nm, p + nm, mp, nullptr, s));
+      for (const char* nm : {".ln1.w", ".ln1.b", ".ln2.w", ".ln2.b", ".ls1", ".ls2"}) STG(need(e, p + nm, &t));
     }
-  }
-  for (const char* nm : {"codebooks", "upsample.w", "sea.final.w", "rope.cos", "rope.sin"}) STG(need(e, nm, &t));
-  {
-    const int Q = c.num_codebooks, V = c.codebook_size, ns = c.mimi_n_semantic;
-    std::vector<int32_t> sc, so, ac, ao;
-    for (int q = 0; q < ns; ++q) { sc.push_back(q); so.push_back(q * V); }
-    for (int q = ns; q < Q; ++q) { ac.push_back(q); ao.push_back(q * V); }
-    STG(dev_upload(e, sc, &e->sem_col)); STG(dev_upload(e, so, &e->sem_off));
-    STG(dev_upload(e, ac, &e->ac_col)); STG(dev_upload(e, ao, &e->ac_off));
-    std::vector<float> one((size_t)Q, 1.0f);
-    STG(dev_upload(e, one, &e->ones));
+    STG(pack_pieces(e, "sea.conv0.w", "sea.conv0.w", mp, nullptr, s));
+    STG(need(e, "sea.conv0.b", &t));
+    for (int si = 0; si < c.mimi_n_ratios; ++si) {
+      const std::string u = "sea.up" + std::to_string(si), r = "sea.res" + std::to_string(si);
+      STG(pack_pieces(e, u + ".w", u + ".w", mp, nullptr, s));
+      STG(need(e, u + ".b", &t));
+      for (const char* nm : {".c1.w", ".c1.b", ".c2.w", ".c2.b"}) STG(need(e, r + nm, &t));
+      STG(need(e, r + ".c1.w", &t, 2));
+      if ((int)t->shape[0] >= 64 && (int)t->shape[0] != 64) {  // hidden > 64: generic contractions (64 = the fused 128-channel block)
+        STG(pack_pieces(e, r + ".c1.w", r + ".c1.w", mp, nullptr, s));
+        STG(pack_pieces(e, r + ".c2.w", r + ".c2.w", mp, nullptr, s));
+      }
+    }
+    for (const char* nm : {"codebooks", "upsample.w", "sea.final.w", "rope.cos", "rope.sin"}) STG(need(e, nm, &t));
+    {
+      const int Q = c.num_codebooks, V = c.codebook_size, ns = c.mimi_n_semantic;
+      std::vector<int32_t> sc, so, ac, ao;
+      for (int q = 0; q < ns; ++q) { sc.push_back(q); so.push_back(q * V); }
+      for (int q = ns; q < Q; ++q) { ac.push_back(q); ao.push_back(q * V); }
+      STG(dev_upload(e, sc, &e->sem_col)); STG(dev_upload(e, so, &e->sem_off));
+      STG(dev_upload(e, ac, &e->ac_col)); STG(dev_upload(e, ao, &e->ac_off));
+      std::vector<float> one((size_t)Q, 1.0f);
+      STG(dev_upload(e, one, &e->ones));
+    }
   }
   e->final = true;
+  return 0;
+}
+
+// The per-utterance operands of one text cross-attention layer of the AR loop (src/sopro/nn/text.py:75-83: k / v projections of
+// the normalised text), with the layer's query and output projections folded in: K'_h = K_h Wq_h, V'_h = V_h Wo_h^T, written
+// as [B, H, S_cap, D] (rows past S of a block are left untouched).  Launches only; nkv [B*S, D] and kvd [B*S, 2D] are scratch.
+int sopro_ar_fold_text(const float* txt, const float* nkv_weight, const float* kv_w, const float* q_wT, const float* o_w, float* nkv, float* kvd,
+                       float* kp, float* vp, int32_t B, int32_t S, int32_t S_cap, int32_t D, int32_t H, float eps, void* stream) {
+  SOPRO_CHECK_ARG(txt && nkv_weight && kv_w && q_wT && o_w && nkv && kvd && kp && vp, "NULL pointer");
+  SOPRO_CHECK_ARG(B > 0 && S > 0 && S_cap >= S && D > 0 && H > 0 && D % H == 0, "bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const int dh = D / H;
+  STG(norm(s, txt, nkv, nkv_weight, B * S, D, eps));
+  G o; o.M = B * S; o.N = 2 * D; o.K = D;
+  Wt kv; kv.f32 = kv_w;
+  STG(gemm(s, nkv, kv, nullptr, kvd, o));
+  for (int h = 0; h < H; ++h) {
+    G f; f.M = B * S; f.N = D; f.K = dh; f.lda = 2 * D; f.rows_per_seg = S; f.ldc = D; f.c_seg = (int64_t)H * S_cap * D;
+    Wt none;
+    STG(gemm(s, kvd + h * dh, none, q_wT + (size_t)h * D * dh, kp + (size_t)h * S_cap * D, f));
+    f.ldw = D;
+    STG(gemm(s, kvd + D + h * dh, none, o_w + h * dh, vp + (size_t)h * S_cap * D, f));
+  }
   return 0;
 }
 
@@ -458,7 +547,7 @@ static int ar_issue_step(sopro_engine* e, hipStream_t s) {
   f.head_w = e->sk["ar.head.w"]; f.head_b = F(e, "ar.head.b");
   f.x0 = p.x[0]; f.xa = p.x[1]; f.xb = p.x[2]; f.part = p.part; f.u = p.u; f.xp = p.xp; f.logits = p.logits; f.klens = p.klens;
   f.n_layers = c.n_layers_ar; f.B = p.B; f.D = c.d_model; f.S_cap = p.S_cap; f.V1 = c.codebook_size + 1; f.H = 4; f.ksize = c.ar_kernel;
-  f.w_layout = 1;
+  f.w_layout = c.precision == 1 ? 2 : 1;
   f.tile_glu = e->ar_tiles[0]; f.tile_ff1 = e->ar_tiles[1]; f.tile_ff2 = e->ar_tiles[2]; f.tile_head = e->ar_tiles[3];
   f.eps = RMS_EPS;
   f.st = p.st;
@@ -467,12 +556,13 @@ static int ar_issue_step(sopro_engine* e, hipStream_t s) {
 
 int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* cond_ar, const float* txt_seq, const int32_t* text_lens,
                    int32_t S, int32_t Tar, const float params[8], uint64_t seed, uint32_t nonce, void* stream) {
-  SOPRO_CHECK_ARG(e && e->final && workspace && cond_ar && txt_seq && params && B > 0 && S > 0 && Tar > 0, "bad arguments (finalize the engine first)");
+  SOPRO_CHECK_ARG(e && e->final && e->has_ar && workspace && cond_ar && txt_seq && params && B > 0 && S > 0 && Tar > 0,
+                  "bad arguments (finalize the engine with the AR tensors first)");
   SOPRO_CHECK_ARG(params[6] >= 1.f && params[6] <= 64.f, "top_k must be in [1, 64] (the reference uses 50)");
   hipStream_t s = (hipStream_t)stream;
   const sopro_engine_cfg& c = e->c;
   ArPlan& p = e->ar;
-  const int D = c.d_model, H = 4, dh = D / H;
+  const int D = c.d_model, H = 4;
   ar_carve(e, p, workspace, B, S, Tar);
   p.B = B; p.S = S; p.S_cap = (S + 63) / 64 * 64; p.Tar = Tar; p.ws = workspace;
   SOPRO_HIP(hipMemcpyAsync(p.cond, cond_ar, (size_t)B * Tar * D * 4, hipMemcpyDeviceToDevice, s));
@@ -485,17 +575,8 @@ int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* con
   for (int i = 0; i < c.n_layers_ar; ++i) {
     if (!c.ar_xattn[i]) continue;
     const std::string pa = "ar.x_attns." + std::to_string(i);
-    STG(norm(s, txt_seq, p.nkv, F(e, pa + ".nkv.weight"), B * S, D, RMS_EPS));
-    G o; o.M = B * S; o.N = 2 * D; o.K = D;
-    Wt kv; kv.f32 = F(e, pa + ".kv.w");
-    STG(gemm(s, p.nkv, kv, nullptr, p.kvd, o));
-    for (int h = 0; h < H; ++h) {
-      G f; f.M = B * S; f.N = D; f.K = dh; f.lda = 2 * D; f.rows_per_seg = S; f.ldc = D; f.c_seg = (int64_t)H * p.S_cap * D;
-      Wt none;
-      STG(gemm(s, p.kvd + h * dh, none, F(e, pa + ".q.wT") + (size_t)h * D * dh, p.kp[i] + (size_t)h * p.S_cap * D, f));
-      f.ldw = D;
-      STG(gemm(s, p.kvd + D + h * dh, none, F(e, pa + ".o.w") + h * dh, p.vp[i] + (size_t)h * p.S_cap * D, f));
-    }
+    STG(sopro_ar_fold_text(txt_seq, F(e, pa + ".nkv.weight"), F(e, pa + ".kv.w"), F(e, pa + ".q.wT"), F(e, pa + ".o.w"), p.nkv, p.kvd, p.kp[i],
+                           p.vp[i], B, S, p.S_cap, D, H, RMS_EPS, s));
   }
   for (int i = 0; i < c.n_layers_ar; ++i)
     SOPRO_HIP(hipMemsetAsync(p.rings[i], 0, (size_t)((c.ar_kernel - 1) * c.ar_dilations[i] + 1) * B * D * 4, s));
@@ -547,7 +628,7 @@ int sopro_ar_tokens(sopro_engine* e, int32_t* hist, int32_t* first_eos, int32_t*
 }
 
 // ------------------------------------------------------------------------------------------------ NAR refinement
-struct NarWs { float *xa, *xb, *h, *x1, *u, *z, *part, *cond; int32_t* lens; };
+struct NarWs { float *xa, *xb, *h, *x1, *u, *z, *part, *cond; int32_t* lens; SplitK sk; };
 static size_t nar_carve(const sopro_engine* e, NarWs& w, void* ws, int B, int T) {
   const sopro_engine_cfg& c = e->c;
   const size_t M = (size_t)B * T, D = c.d_model;
@@ -559,6 +640,8 @@ static size_t nar_carve(const sopro_engine* e, NarWs& w, void* ws, int B, int T)
   w.part = cv.take<float>(M * nh_max * (c.codebook_size / 64) * 2);
   w.cond = cv.take<float>(M * D);
   w.lens = cv.take<int32_t>(B);
+  w.sk.tickets = cv.take<int32_t>(SPLITK_TICKETS);
+  w.sk.ws = M <= 1024 ? cv.take<float>(SPLITK_WS_BYTES / 4) : nullptr;  // few rows (streaming windows, batch 1): K loops may be split
   return cv.off;
 }
 
@@ -574,23 +657,25 @@ static int ssm_block_seq(sopro_engine* e, hipStream_t s, const NarWs& w, const f
   const int D = e->c.d_model, M = B * T;
   const int total = (ksize - 1) * dil, left = total / 2;  // non-causal: symmetric zero padding (blocks.py:68-72)
   G g; g.M = M; g.N = 2 * D; g.K = D; g.bias = F(e, p + ".glu.b"); g.epi = SOPRO_EPI_GLU; g.rms_eps = RMS_EPS;
-  STG(gemm(s, x, e->w[p + ".glu.wn"], nullptr, w.h, g));
+  STG(gemm(s, x, WT(e, p + ".glu.wn"), nullptr, w.h, g));
   STG(sopro_dwconv_f32(w.h, F(e, p + ".dw.w"), F(e, p + ".dw.b"), x, w.x1, lens, B, T, D, ksize, dil, left, 1, s));
   G f1; f1.M = M; f1.N = 4 * D; f1.K = D; f1.bias = F(e, p + ".ff1.b"); f1.epi = SOPRO_EPI_GELU; f1.rms_eps = RMS_EPS;
-  STG(gemm(s, w.x1, e->w[p + ".ff1.wn"], nullptr, w.u, f1));
-  G f2; f2.M = M; f2.N = D; f2.K = 4 * D; f2.bias = F(e, p + ".ff2.b"); f2.epi = SOPRO_EPI_RES; f2.R = w.x1;
-  return gemm(s, w.u, e->w[p + ".ff2.w"], nullptr, out, f2);
+  STG(gemm(s, w.x1, WT(e, p + ".ff1.wn"), nullptr, w.u, f1));
+  G f2; f2.M = M; f2.N = D; f2.K = 4 * D; f2.bias = F(e, p + ".ff2.b"); f2.epi = SOPRO_EPI_RES; f2.R = w.x1; f2.sk = &w.sk;
+  return gemm(s, w.u, WT(e, p + ".ff2.w"), nullptr, out, f2);
 }
 
 int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_t cond_bstride, const int32_t* rvq1, const int32_t* lens,
                      int32_t B, int32_t T, int32_t* tokens, void* stream) {
-  SOPRO_CHECK_ARG(e && e->final && workspace && cond && rvq1 && tokens && B > 0 && T > 0, "bad arguments (finalize the engine first)");
+  SOPRO_CHECK_ARG(e && e->final && e->has_nar && workspace && cond && rvq1 && tokens && B > 0 && T > 0,
+                  "bad arguments (finalize the engine with the NAR tensors first)");
   hipStream_t s = (hipStream_t)stream;
   const sopro_engine_cfg& c = e->c;
   const int D = c.d_model, V = c.codebook_size, Q = c.num_codebooks, HD = c.nar_head_dim, M = B * T;
   SOPRO_CHECK_ARG(V % 64 == 0, "codebook_size must be a multiple of 64 (arg-max partials per 64 columns)");
   NarWs w;
   nar_carve(e, w, workspace, B, T);
+  if (w.sk.ws) SOPRO_HIP(hipMemsetAsync(w.sk.tickets, 0, SPLITK_TICKETS * sizeof(int32_t), s));  // split-K tickets start (and are left) at zero
   int nh_max = 0;
   for (int i = 0; i < c.n_stages; ++i) nh_max = c.stage_n_cb[i] > nh_max ? c.stage_n_cb[i] : nh_max;
   const float* cnd = cond;
@@ -618,12 +703,12 @@ int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_
     }
     STG(norm(s, xa, xb, F(e, "nar.norm.weight"), M, D, RMS_EPS));
     G pz; pz.M = M; pz.N = HD; pz.K = D; pz.bias = F(e, "nar.pre.b");
-    STG(gemm(s, xb, e->w["nar.pre.w"], nullptr, w.z, pz));
+    STG(gemm(s, xb, WT(e, "nar.pre.w"), nullptr, w.z, pz));
     // all heads of the stage in one contraction, arg-max in its epilogue (head-id embeddings live in the bias)
     const int nh = c.stage_n_cb[sid];
     const std::string hk = std::string("nar.heads.") + stage_names[sid];
     G hg; hg.M = M; hg.N = nh * V; hg.K = HD; hg.bias = F(e, hk + ".b"); hg.c_mode = 5; hg.C2 = w.part; hg.ldc2 = (int64_t)nh_max * (V / 64);
-    STG(gemm(s, w.z, e->w[hk + ".w"], nullptr, nullptr, hg));
+    STG(gemm(s, w.z, WT(e, hk + ".w"), nullptr, nullptr, hg));
     STG(sopro_argmax_partials_i32(w.part, (int64_t)nh_max * (V / 64), tokens + c.stage_first_cb[sid], Q, nh, V / 64, V, M, s));
   }
   return 0;
@@ -633,12 +718,15 @@ int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_
 struct MimiWs {
   int32_t* tok;
   float *emb, *q, *X, *y, *qkv, *ao, *hd, *e0, *hraw[8], *hact[8], *y1[8];
+  SplitK sk;
 };
 static size_t mimi_carve(const sopro_engine* e, MimiWs& w, void* ws, int B, int T) {
   const sopro_engine_cfg& c = e->c;
   const size_t HS = c.mimi_hidden, CD = c.mimi_codebook_dim, N2 = 2 * (size_t)T, PADX = c.mimi_kernel - 1;
   Carver cv(ws);
   w.tok = cv.take<int32_t>((size_t)B * T * c.num_codebooks);
+  w.sk.tickets = cv.take<int32_t>(SPLITK_TICKETS);
+  w.sk.ws = (size_t)B * N2 <= 512 ? cv.take<float>(SPLITK_WS_BYTES / 4) : nullptr;  // few rows (streaming chunks): K loops may be split
   w.emb = cv.take<float>((size_t)B * T * 2 * CD);
   w.q = cv.take<float>((size_t)B * T * HS);
   w.X = cv.take<float>((size_t)B * (PADX + N2) * HS);
@@ -666,7 +754,8 @@ int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T) 
 
 static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream,
                             sopro_mimi_stream_state* sst) {
-  SOPRO_CHECK_ARG(e && e->final && workspace && tokens && wav && B > 0 && T > 0, "bad arguments (finalize the engine first)");
+  SOPRO_CHECK_ARG(e && e->final && e->has_mimi && workspace && tokens && wav && B > 0 && T > 0,
+                  "bad arguments (finalize the engine with the Mimi tensors first)");
   hipStream_t s = (hipStream_t)stream;
   const sopro_engine_cfg& c = e->c;
   const int Q = c.num_codebooks, HS = c.mimi_hidden, CD = c.mimi_codebook_dim, N2 = 2 * T, PADX = c.mimi_kernel - 1;
@@ -677,6 +766,7 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   SOPRO_CHECK_ARG(c.mimi_res_kernel == 3 && c.mimi_last_kernel == 3 && c.mimi_compress == 2, "the SEANet sequence is written for k = 3 residual / last convs, compress 2");
   MimiWs w;
   mimi_carve(e, w, workspace, B, T);
+  if (w.sk.ws) SOPRO_HIP(hipMemsetAsync(w.sk.tickets, 0, SPLITK_TICKETS * sizeof(int32_t), s));
   // the zero rows in front of every segment of a convolution input are never written by the kernels: clear just those
   {
     SOPRO_HIP(hipMemset2DAsync(w.X, (size_t)(PADX + N2) * HS * 4, 0, (size_t)PADX * HS * 4, B, s));
@@ -695,8 +785,8 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
                              B * T, B * T, CD, s));
   STG(sopro_codebook_sum_f32(tokens, Q, e->ac_col, e->ac_off, e->ones, Q - ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb + CD, 2 * CD,
                              0, B * T, B * T, CD, s));
-  G pj; pj.M = B * T; pj.N = HS; pj.K = 2 * CD;
-  STG(gemm(s, w.emb, e->w["rvq_proj.w"], nullptr, w.q, pj));
+  G pj; pj.sk = &w.sk; pj.M = B * T; pj.N = HS; pj.K = 2 * CD;
+  STG(gemm(s, w.emb, WT(e, "rvq_proj.w"), nullptr, w.q, pj));
   // ---- upsample into the zero-padded transformer stream (HF:1208-1216)
   const int64_t xs = (int64_t)(PADX + N2) * HS;
   STG(sopro_upsample2_f32(w.q, F(e, "upsample.w"), w.X + (size_t)PADX * HS, xs, B, T, HS, s));
@@ -705,8 +795,8 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   for (int l = 0; l < c.mimi_layers; ++l) {
     const std::string p = "tr." + std::to_string(l);
     STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln1.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln1.b"), nullptr, nullptr, n, xs));
-    G qg; qg.M = B * n; qg.N = 3 * HS; qg.K = HS;
-    STG(gemm(s, w.y, e->w[p + ".qkv.w"], nullptr, w.qkv, qg));
+    G qg; qg.sk = &w.sk; qg.M = B * n; qg.N = 3 * HS; qg.K = HS;
+    STG(gemm(s, w.y, WT(e, p + ".qkv.w"), nullptr, w.qkv, qg));
     STG(sopro_rope_f32(w.qkv, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, past, H, dh, s));
     STG(sopro_rope_f32(w.qkv + HS, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, past, H, dh, s));
     sopro_attn_args a;
@@ -739,22 +829,22 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     }
     STG(sopro_attention_f32(&a, s));
   attended:;
-    G og; og.M = B * n; og.N = HS; og.K = HS; og.epi = SOPRO_EPI_RES; og.R = w.X + (size_t)PADX * HS; og.scale = F(e, p + ".ls1");
+    G og; og.sk = &w.sk; og.M = B * n; og.N = HS; og.K = HS; og.epi = SOPRO_EPI_RES; og.R = w.X + (size_t)PADX * HS; og.scale = F(e, p + ".ls1");
     og.c_seg = xs; og.r_seg = xs; og.rows_per_seg = n;
-    STG(gemm(s, w.ao, e->w[p + ".o.w"], nullptr, w.X + (size_t)PADX * HS, og));
+    STG(gemm(s, w.ao, WT(e, p + ".o.w"), nullptr, w.X + (size_t)PADX * HS, og));
     STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln2.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln2.b"), nullptr, nullptr, n, xs));
-    G f1; f1.M = B * n; f1.N = c.mimi_inter; f1.K = HS; f1.epi = SOPRO_EPI_GELU;
-    STG(gemm(s, w.y, e->w[p + ".fc1.w"], nullptr, w.hd, f1));
-    G f2; f2.M = B * n; f2.N = HS; f2.K = c.mimi_inter; f2.epi = SOPRO_EPI_RES; f2.R = w.X + (size_t)PADX * HS; f2.scale = F(e, p + ".ls2");
+    G f1; f1.sk = &w.sk; f1.M = B * n; f1.N = c.mimi_inter; f1.K = HS; f1.epi = SOPRO_EPI_GELU;
+    STG(gemm(s, w.y, WT(e, p + ".fc1.w"), nullptr, w.hd, f1));
+    G f2; f2.sk = &w.sk; f2.M = B * n; f2.N = HS; f2.K = c.mimi_inter; f2.epi = SOPRO_EPI_RES; f2.R = w.X + (size_t)PADX * HS; f2.scale = F(e, p + ".ls2");
     f2.c_seg = xs; f2.r_seg = xs; f2.rows_per_seg = n;
-    STG(gemm(s, w.hd, e->w[p + ".fc2.w"], nullptr, w.X + (size_t)PADX * HS, f2));
+    STG(gemm(s, w.hd, WT(e, p + ".fc2.w"), nullptr, w.X + (size_t)PADX * HS, f2));
   }
   // ---- SEANet decoder (HF:931-961), activated-copy flow of sopro_amd.codec.MimiCodec._seanet_act
   int ch = c.mimi_num_filters << c.mimi_n_ratios, rows = N2, pad_in = 1;
   {  // first conv k = 7 -> ELU; one zero row in front = x[t-1] of the transposed conv
-    G g; g.M = B * rows; g.N = ch; g.K = c.mimi_kernel * HS; g.lda = HS; g.bias = F(e, "sea.conv0.b"); g.rows_per_seg = rows; g.a_seg = xs;
+    G g; g.sk = &w.sk; g.M = B * rows; g.N = ch; g.K = c.mimi_kernel * HS; g.lda = HS; g.bias = F(e, "sea.conv0.b"); g.rows_per_seg = rows; g.a_seg = xs;
     g.c_seg = (int64_t)(1 + rows) * ch; g.ldc = ch; g.c_mode = 3;
-    STG(gemm(s, w.X, e->w["sea.conv0.w"], nullptr, w.e0 + ch, g));
+    STG(gemm(s, w.X, WT(e, "sea.conv0.w"), nullptr, w.e0 + ch, g));
   }
   const float* He = w.e0;
   for (int si = 0; si < c.mimi_n_ratios; ++si) {
@@ -762,33 +852,33 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     const bool last = si == c.mimi_n_ratios - 1;
     const std::string u = "sea.up" + std::to_string(si), rs = "sea.res" + std::to_string(si);
     float* Ho = w.hraw[si];
-    G up; up.M = B * rows; up.N = r * co; up.K = 2 * ch; up.lda = ch; up.bias = F(e, u + ".b"); up.rows_per_seg = rows;
+    G up; up.sk = &w.sk; up.M = B * rows; up.N = r * co; up.K = 2 * ch; up.lda = ch; up.bias = F(e, u + ".b"); up.rows_per_seg = rows;
     up.a_seg = (int64_t)(pad_in + rows) * ch; up.c_seg = (int64_t)(2 + orow) * co; up.ldc = (int64_t)r * co;
     const float* A = He + (size_t)(pad_in - 1) * ch;
     if (last) {
       SOPRO_CHECK_ARG(co == 64 && hid == 32, "the fused tail is written for a 64-channel last stage");
       if (ch == 128 && r == 4)  // weight-stationary form of the K = 256, N = 256 contraction (same results)
-        STG(sopro_seanet_up128_f32(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), Ho + 2 * co, up.c_seg, B, rows, 3, s));
+        STG(sopro_seanet_up128_f32(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), Ho + 2 * co, up.c_seg, B, rows, c.precision == 1 ? 1 : 3, s));
       else
-        STG(gemm(s, A, e->w[u + ".w"], nullptr, Ho + 2 * co, up));
+        STG(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
       return sopro_seanet_tail_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"),
                                    F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, orow, s);
     }
     float* Hn = w.hact[si];
     if (co == 128 && hid == 64) {
-      STG(gemm(s, A, e->w[u + ".w"], nullptr, Ho + 2 * co, up));
+      STG(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
       STG(sopro_seanet_res128_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
                                   (int64_t)(2 + orow) * co, B, orow, s));
     } else {
       up.c_mode = 4; up.C2 = Hn + 2 * co; up.ldc2 = (int64_t)r * co; up.c2_seg = (int64_t)(2 + orow) * co;
-      STG(gemm(s, A, e->w[u + ".w"], nullptr, Ho + 2 * co, up));
+      STG(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
       // residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x)))); its output is only ever read through ELU
-      G c1; c1.M = B * orow; c1.N = hid; c1.K = 3 * co; c1.lda = co; c1.bias = F(e, rs + ".c1.b"); c1.rows_per_seg = orow;
+      G c1; c1.sk = &w.sk; c1.M = B * orow; c1.N = hid; c1.K = 3 * co; c1.lda = co; c1.bias = F(e, rs + ".c1.b"); c1.rows_per_seg = orow;
       c1.a_seg = (int64_t)(2 + orow) * co; c1.c_mode = 3;
-      STG(gemm(s, Hn, e->w[rs + ".c1.w"], nullptr, w.y1[si], c1));
-      G c2; c2.M = B * orow; c2.N = co; c2.K = hid; c2.bias = F(e, rs + ".c2.b"); c2.epi = SOPRO_EPI_RES; c2.R = Ho + 2 * co; c2.rows_per_seg = orow;
+      STG(gemm(s, Hn, WT(e, rs + ".c1.w"), nullptr, w.y1[si], c1));
+      G c2; c2.sk = &w.sk; c2.M = B * orow; c2.N = co; c2.K = hid; c2.bias = F(e, rs + ".c2.b"); c2.epi = SOPRO_EPI_RES; c2.R = Ho + 2 * co; c2.rows_per_seg = orow;
       c2.c_seg = (int64_t)(2 + orow) * co; c2.r_seg = (int64_t)(2 + orow) * co; c2.ldc = co; c2.ldr = co; c2.c_mode = 3;
-      STG(gemm(s, w.y1[si], e->w[rs + ".c2.w"], nullptr, Hn + 2 * co, c2));
+      STG(gemm(s, w.y1[si], WT(e, rs + ".c2.w"), nullptr, Hn + 2 * co, c2));
     }
     He = Hn; ch = co; rows = orow; pad_in = 2;
   }

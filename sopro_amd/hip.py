@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -98,7 +98,7 @@ class EngineCfg(C.Structure):
                 ("mimi_hidden", _i32), ("mimi_codebook_dim", _i32), ("mimi_heads", _i32), ("mimi_head_dim", _i32), ("mimi_layers", _i32),
                 ("mimi_window", _i32), ("mimi_inter", _i32), ("mimi_n_ratios", _i32), ("mimi_ratios", _i32 * 8), ("mimi_num_filters", _i32),
                 ("mimi_kernel", _i32), ("mimi_res_kernel", _i32), ("mimi_last_kernel", _i32), ("mimi_compress", _i32),
-                ("mimi_n_semantic", _i32), ("mimi_rope_positions", _i32), ("mimi_norm_eps", _f32), ("mimi_final_bias", _f32)]
+                ("mimi_n_semantic", _i32), ("mimi_rope_positions", _i32), ("mimi_norm_eps", _f32), ("mimi_final_bias", _f32), ("precision", _i32)]
 
 
 class MimiStreamState(C.Structure):
@@ -185,6 +185,7 @@ SYMBOLS = {
     "sopro_ar_sample": (C.c_int, [C.POINTER(ArState), _p, _i64, _p]),
     "sopro_ar_admit": (C.c_int, [C.POINTER(ArState), _i32, _p]),
     "sopro_ar_issue_frame": (C.c_int, [C.POINTER(ArFrame), _p]),
+    "sopro_ar_fold_text": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p]),
     "sopro_engine_set_ar_tiles": (C.c_int, [_p, _i32, _i32, _i32, _i32]),
 }
 
@@ -697,6 +698,14 @@ def ar_sample(st: ArState, logits: torch.Tensor, ld: int) -> None:
 def ar_issue_frame(frame: ArFrame) -> None:
     """One autoregressive frame (23 launches) on the current stream: the sequence lives in csrc/ar_frame.hip."""
     _check(load().sopro_ar_issue_frame(C.byref(frame), _stream()), "sopro_ar_issue_frame")
+
+
+def ar_fold_text(txt: torch.Tensor, nkv_weight: torch.Tensor, kv_w: torch.Tensor, q_wT: torch.Tensor, o_w: torch.Tensor, nkv: torch.Tensor,
+                 kvd: torch.Tensor, kp: torch.Tensor, vp: torch.Tensor, *, B: int, S: int, S_cap: int, D: int, H: int, eps: float,
+                 out_off: int = 0) -> None:
+    """Folded text operands of one AR cross-attention layer (sopro_ar_fold_text); ``out_off``: float offset into kp / vp."""
+    _check(load().sopro_ar_fold_text(ptr(txt), ptr(nkv_weight), ptr(kv_w), ptr(q_wT), ptr(o_w), ptr(nkv), ptr(kvd), ptr(kp) + 4 * out_off,
+                                     ptr(vp) + 4 * out_off, B, S, S_cap, D, H, eps, _stream()), "sopro_ar_fold_text")
 
 
 def ar_tile_code(spec: str) -> int:

@@ -91,17 +91,7 @@ class SoproTTSModel:
         self.Q = int(cfg.num_codebooks)
         packed = pack_sopro(weights, cfg)
         self.gates = {i: float(packed[f"ar.x_attns.{i}.gate_scale"][0]) for i in cfg.ar_xattn_layers}  # tanh(gate), text.py:131
-        # per-stage constants of nar_refine, resolved once on the host (no device round trips on the hot path)
-        sc0 = cfg.stage_codebooks()
-        self._nar_const = []
-        known: List[int] = [0]
-        for stage in cfg.stage_order():
-            cw = torch.softmax(packed["nar_prev_cb_weights"][torch.tensor(known)].float(), dim=0)  # embeddings.py:77-112
-            mix = packed[f"nar.mix.{stage}"]
-            self._nar_const.append({"cols": torch.tensor(known, dtype=torch.int32).to(self.device),
-                                    "offs": torch.tensor([c * self.V for c in known], dtype=torch.int32).to(self.device),
-                                    "cw": cw.contiguous().to(self.device), "mix0": float(mix[0]), "mix1": float(mix[1])})
-            known = known + list(sc0[stage])
+        self._nar_mix = [(float(packed[f"nar.mix.{st}"][0]), float(packed[f"nar.mix.{st}"][1])) for st in cfg.stage_order()]  # nar.py:95-97
         self.w: Dict[str, torch.Tensor] = {k: v.to(self.device) for k, v in packed.items()}
         npos = int(cfg.pos_emb_max) + 8  # reference: src/sopro/model.py:62-64
         self.pe = sinusoid_table(npos, self.D).to(self.device)
@@ -117,32 +107,25 @@ class SoproTTSModel:
         self._runs = [0]  # generation runs started so far (shared by the lanes of clone_lane): the sampler's default nonce
         self._nar_graphs = hip.GraphCache("nar_graph", cap=64)  # recorded NAR launch sequences per (B, T)
         self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "16")) << 30  # scratch kept per batch shape, per engine
-        # NAR and text / reference encoder contractions on the six-pass split-bf16 matrix-core path (24 mantissa bits per
-        # operand: the accuracy class of the fp32 MFMA kernel at ~1.5x its speed on these shapes); SOPRO_NAR_F32=1 keeps fp32.
+        # Text / reference encoder contractions (they feed the AR loop's conditioning) on the six-pass split-bf16 matrix-core path
+        # (24 mantissa bits per operand: the accuracy class of the fp32 MFMA kernel at ~1.5x its speed on these shapes), their two
+        # RMSNorms fused into the contractions they feed (the norm's weight vector folded into W here, once).  The NAR and AR
+        # operands are made by the stage engine below (csrc/stages.hip).
         self.wx: Dict[str, hip.PackedW] = {}
-        # (the text / reference encoders feed the AR loop's conditioning: they keep their six-pass form in both modes)
-        # NAR (round 3): two fp16 pieces / three passes ("f16x3": 22 mantissa bits, the arg-max margins' accuracy class at half
-        # the passes of bf16x6; SOPRO_NAR_X6=1 keeps the six-pass form).  The encoders feed the AR loop's conditioning and keep x6.
-        nar_pack = hip.pack_w_bf16x6 if os.environ.get("SOPRO_NAR_X6", "0") == "1" else hip.pack_w_f16x3
-        pack_for = lambda key: (hip.pack_w_bf16x1 if precision == "bf16" else nar_pack) if key.startswith("nar.") else hip.pack_w_bf16x6  # noqa: E731
-        if os.environ.get("SOPRO_NAR_F32", "0") != "1":
-            unfused = os.environ.get("SOPRO_NORM_UNFUSED", "0") == "1"
-            with torch.cuda.device(self.device):
-                for k, v in self.w.items():
-                    if k.startswith(("nar.", "text_enc.layers.", "ref_enc_blocks.")) and v.dim() == 2 and k.endswith(".w") \
-                            and int(v.shape[1]) % 32 == 0 and int(v.shape[0]) >= 64 and not k.startswith("nar.adapter"):
-                        # the two RMSNorms of an SSMLite block are fused into the GEMMs they feed (sopro_gemm_split_ext.rms_norm):
-                        # their weight vectors are folded into the columns of W here, once
-                        nk = None
-                        if k.endswith(".glu.w"):
-                            nk = k[: -len("glu.w")] + "norm.weight"
-                        elif k.endswith(".ff1.w"):
-                            nk = k[: -len("ff1.w")] + "ff.norm.weight"
-                        if nk is not None and nk in self.w and not unfused:
-                            self.wx[k + "n"] = pack_for(k)((v * self.w[nk][None, :]).contiguous())
-                            continue
-                        self.wx[k] = pack_for(k)(v)
-                torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            for k, v in self.w.items():
+                if k.startswith(("text_enc.layers.", "ref_enc_blocks.")) and v.dim() == 2 and k.endswith(".w") \
+                        and int(v.shape[1]) % 32 == 0 and int(v.shape[0]) >= 64:
+                    nk = None
+                    if k.endswith(".glu.w"):
+                        nk = k[: -len("glu.w")] + "norm.weight"
+                    elif k.endswith(".ff1.w"):
+                        nk = k[: -len("ff1.w")] + "ff.norm.weight"
+                    if nk is not None and nk in self.w:
+                        self.wx[k + "n"] = hip.pack_w_bf16x6((v * self.w[nk][None, :]).contiguous())
+                    else:
+                        self.wx[k] = hip.pack_w_bf16x6(v)
+            torch.cuda.synchronize(self.device)
         # AR-step weights in the fragment order of the skinny kernel (1 KiB of consecutive memory per load instruction)
         self.wk: Dict[str, hip.SkinnyW] = {}
         with torch.cuda.device(self.device):
@@ -155,11 +138,11 @@ class SoproTTSModel:
         # not depend on them).  SOPRO_AR_TILES="glu:2x1,ff1:2x2,..." or "2x2" for all.
         self.ar_tiles = {"glu": "1x1", "ff1": "1x1", "ff2": "1x1", "head": "1x1"}
         self.set_ar_tiles(os.environ.get("SOPRO_AR_TILES", ""))
-        self._ones: Dict[int, torch.Tensor] = {}
-        sc = cfg.stage_codebooks()
-        self._stage_cbs = [(s, sc[s]) for s in cfg.stage_order()]
-        # per-stage adapter coefficients do not depend on the input: computed lazily on the device
-        self._adapter: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None
+        # the stage engine (csrc/stages.hip): the NAR launch sequence and its packed operands live in the library; the lanes of a
+        # pipeline share it (read-only after finalize), each with its own workspace and stream
+        from .stages import model_engine
+
+        self.eng = model_engine(self)
 
     # ------------------------------------------------------------------ helpers
     def set_ar_tiles(self, spec: str) -> None:
@@ -566,32 +549,12 @@ class SoproTTSModel:
             run.done = True  # also when the consumer abandons the generator: the plan is free again
 
     # ------------------------------------------------------------------ NAR refinement
-    def _adapter_coeffs(self) -> List[Tuple[torch.Tensor, torch.Tensor]]:
-        """(1 + tanh g, tanh b) per stage (reference: src/sopro/nn/nar.py:25-32)."""
-        if self._adapter is None:
-            w, dev, D = self.w, self.device, self.D
-            ns = len(self._stage_cbs)
-            h = torch.empty(ns, 256, device=dev)
-            hip.gemm(w["nar.stage_emb"], w["nar.adapter.mlp.0.w"], h, M=ns, N=256, K=D, bias=w["nar.adapter.mlp.0.b"], epilogue=hip.EPI_GELU)
-            gb = torch.empty(ns, 2 * D, device=dev)
-            hip.gemm(h, w["nar.adapter.mlp.2.w"], gb, M=ns, N=2 * D, K=256, bias=w["nar.adapter.mlp.2.b"])
-            out = []
-            for s in range(ns):
-                g = gb[s, :D].contiguous()
-                b = gb[s, D:].contiguous()
-                mul = torch.empty(D, device=dev)
-                add = torch.empty(D, device=dev)
-                hip.tanh_affine(g, mul, 1.0, 1.0, D)
-                hip.tanh_affine(b, add, 0.0, 1.0, D)
-                out.append((mul, add))
-            self._adapter = out
-        return self._adapter
-
     @torch.inference_mode()
     def nar_refine(self, cond_seq: torch.Tensor, tokens_A_1xT: torch.Tensor, lens: Optional[Sequence[int]] = None) -> torch.Tensor:
         """Codebooks 1..Q-1 from codebook 0: [B, T, D], [B, T] -> [B, T, Q] int64
-        (reference: src/sopro/model.py:307-347 and src/sopro/nn/nar.py:89-116; B = 1 there)."""
-        cfg, w, dev, D, V, Q = self.cfg, self.w, self.device, self.D, self.V, self.Q
+        (reference: src/sopro/model.py:307-347 and src/sopro/nn/nar.py:89-116; B = 1 there).  The launch sequence is
+        ``sopro_nar_refine`` (csrc/stages.hip); this method stages the inputs and records / replays it per (B, T) shape."""
+        dev, D, Q = self.device, self.D, self.Q
         B, T, _ = cond_seq.shape
         M = B * T
         lens_l = [T] * B if lens is None else [int(n) for n in lens]
@@ -599,63 +562,29 @@ class SoproTTSModel:
             torch.cuda.synchronize(self.device)
             self._nar_graphs.clear()
             self.ws.clear()
+        lib, eng = hip.load(), self.eng
         with self.on_stream(bulk=True):
             # inputs land in persistent buffers so that the launch sequence of a (B, T) shape can be recorded once
             cond = self.ws.get("nar.cond", (M, D))
             cond.view(B, T, D).copy_(cond_seq.to(dev).float())
-            toks = self.ws.get("nar.toks", (M, Q), dtype=torch.int32)
-            toks.view(B, T, Q)[:, :, 0] = tokens_A_1xT.to(dev).reshape(B, T).to(torch.int32)
+            rvq1 = self.ws.get("nar.rvq1", (B, T), dtype=torch.int32)
+            rvq1.copy_(tokens_A_1xT.to(dev).reshape(B, T).to(torch.int32))
             lens_d = self.ws.get("nar.lens", (B,), dtype=torch.int32)
             lens_d.copy_(torch.tensor(lens_l, dtype=torch.int32), non_blocking=False)
-            adapters = self._adapter_coeffs()
+            toks = self.ws.get("nar.toks", (M, Q), dtype=torch.int32)
+            scratch = self.ws.get(f"nar.stage_ws.{B}x{T}", (int(lib.sopro_nar_workspace_bytes(eng.h, B, T)),), dtype=torch.uint8)
+
+            def issue():
+                hip._check(lib.sopro_nar_refine(eng.h, scratch.data_ptr(), cond.data_ptr(), T * D, rvq1.data_ptr(), lens_d.data_ptr(), B, T,
+                                                toks.data_ptr(), hip._stream()), "sopro_nar_refine")
+
             if self.use_graph:
-                self._nar_graphs.run((B, T), lambda: self._nar_issue(B, T, cond, toks, lens_d, adapters))
+                self._nar_graphs.run((B, T), issue)
             else:
-                self._nar_issue(B, T, cond, toks, lens_d, adapters)
+                issue()
             out = toks.view(B, T, Q).long()
         self.bulk_stream.synchronize()
         return out
-
-    def _nar_issue(self, B: int, T: int, cond: torch.Tensor, toks: torch.Tensor, lens_d: torch.Tensor, adapters) -> None:
-        """The NAR launch sequence for a [B, T] batch: launches only (recordable)."""
-        cfg, w, D, V, Q = self.cfg, self.w, self.D, self.V, self.Q
-        M = B * T
-        xa = self.ws.get("nar.xa", (M, D))
-        xb = self.ws.get("nar.xb", (M, D))
-        z = self.ws.get("nar.z", (M, int(cfg.nar_head_dim)))
-        nh_max = max(len(c) for _, c in self._stage_cbs)
-        fused_argmax = bool(self.wx) and V % 64 == 0 and os.environ.get("SOPRO_NAR_LOGITS", "0") != "1"
-        if fused_argmax:  # (max, column) per row and 64-column tile instead of the logits: 1/32 of their bytes
-            part = self.ws.get("nar.part", (M, nh_max * (V // 64), 2))
-        else:
-            logits = self.ws.get("nar.logits", (M, nh_max * V))
-        HD = int(cfg.nar_head_dim)
-        for sid, (stage, cbs) in enumerate(self._stage_cbs):
-            # prev = sum_j softmax(w[known])_j * E[cb_j*V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
-            nc = self._nar_const[sid]
-            hip.codebook_sum(toks, Q, nc["cols"], nc["offs"], nc["cw"], w["cb_embed"], xa,
-                             rows=M, D=D, base=cond, alpha=nc["mix0"], beta=nc["mix1"])
-            mul, add = adapters[sid]
-            hip.norm(xa, xb, w["nar.adapter.norm.weight"], rows=M, C_=D, eps=RMS_EPS, mul=mul, add=add, rows_per_seg=M)
-            xa, xb = xb, xa
-            for i, dil in enumerate(cfg.nar_dilations):
-                self._ssm_block_seq(xa, xb, f"nar.blocks.{i}", B=B, T=T, ksize=int(cfg.nar_kernel_size), dil=int(dil),
-                                    causal=False, lens=lens_d)
-                xa, xb = xb, xa
-            hip.norm(xa, xb, w["nar.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
-            hip.gemm(xb, self.wx.get("nar.pre.w") or w["nar.pre.w"], z, M=M, N=HD, K=D, bias=w["nar.pre.b"])
-            # all heads of the stage in one contraction (head-id embeddings live in the bias), one arg-max launch
-            nh = len(cbs)
-            hw = self.wx.get(f"nar.heads.{stage}.w")
-            if fused_argmax and hw is not None:
-                # the arg-max runs in the contraction's epilogue (per 64-column tile) + one small reduction: no logits in HBM
-                hip.gemm(z, hw, None, M=M, N=nh * V, K=HD, bias=w[f"nar.heads.{stage}.b"], c_mode=5, C2=part, ldc2=nh_max * (V // 64))
-                hip.argmax_partials(part, toks, rows=M, heads=nh, per_head=V // 64, V=V, ldp=nh_max * (V // 64), ldo=Q, o_off=cbs[0])
-            else:
-                if fused_argmax:
-                    logits = self.ws.get("nar.logits", (M, nh_max * V))
-                hip.gemm(z, hw or w[f"nar.heads.{stage}.w"], logits, M=M, N=nh * V, K=HD, bias=w[f"nar.heads.{stage}.b"])
-                hip.argmax_rows(logits, toks, rows=M * nh, N=V, ldo=Q, o_off=cbs[0], inner=nh)
 
     # ------------------------------------------------------------------ text + reference -> tokens
     @torch.inference_mode()
@@ -853,16 +782,10 @@ class _ARPlan:
         nkv = m.ws.get("ar.row.nkv", (S, D))
         kvd = m.ws.get("ar.row.kvd", (S, 2 * D))
         ts = txt_row.contiguous()
-        H, dh = 4, D // 4
         for i in cfg.ar_xattn_layers:
             pa = f"ar.x_attns.{i}"
-            hip.norm(ts, nkv, w[pa + ".nkv.weight"], rows=S, C_=D, eps=RMS_EPS)
-            hip.gemm(nkv, w[pa + ".kv.w"], kvd, M=S, N=2 * D, K=D)
-            seg = dict(M=S, N=D, K=dh, lda=2 * D, ldc=D)
-            for h in range(H):
-                off = (row * H + h) * self.S_cap * D
-                hip.gemm(kvd, w[pa + ".q.wT"][h], self.kp[i], a_off=h * dh, c_off=off, **seg)
-                hip.gemm(kvd, w[pa + ".o.w"][:, h * dh:], self.vp[i], a_off=D + h * dh, c_off=off, ldw=D, **seg)
+            hip.ar_fold_text(ts, w[pa + ".nkv.weight"], w[pa + ".kv.w"], w[pa + ".q.wT"], w[pa + ".o.w"], nkv, kvd, self.kp[i], self.vp[i],
+                             B=1, S=S, S_cap=self.S_cap, D=D, H=4, eps=RMS_EPS, out_off=row * 4 * self.S_cap * D)
         for r in self.rings:
             r[:, row].zero_()
 
@@ -938,20 +861,15 @@ class _ARRun:
                 plan.klens.fill_(S)
             else:
                 plan.klens.copy_(text_lens.to(dev).to(torch.int32))
-            # K/V of the text for the three cross-attention layers (src/sopro/nn/text.py:75-83)
+            # K/V of the text for the three cross-attention layers with the query / output projections folded in, once per
+            # utterance (src/sopro/nn/text.py:75-83; the sequence is sopro_ar_fold_text, csrc/stages.hip)
             nkv = m.ws.get("ar.nkv", (B * S, D))
             kvd = m.ws.get("ar.kvd", (B * S, 2 * D))
             ts = txt_seq.to(dev).float().contiguous().view(B * S, D)
-            H, dh = 4, D // 4
             for i in cfg.ar_xattn_layers:
                 pa = f"ar.x_attns.{i}"
-                hip.norm(ts, nkv, w[pa + ".nkv.weight"], rows=B * S, C_=D, eps=RMS_EPS)
-                hip.gemm(nkv, w[pa + ".kv.w"], kvd, M=B * S, N=2 * D, K=D)
-                # fold the query / output projections into the cached operands (once per utterance)
-                seg = dict(M=B * S, N=D, K=dh, lda=2 * D, rows_per_seg=S, ldc=D, c_seg_stride=H * S_cap * D)
-                for h in range(H):
-                    hip.gemm(kvd, w[pa + ".q.wT"][h], plan.kp[i], a_off=h * dh, c_off=h * S_cap * D, **seg)
-                    hip.gemm(kvd, w[pa + ".o.w"][:, h * dh:], plan.vp[i], a_off=D + h * dh, c_off=h * S_cap * D, ldw=D, **seg)
+                hip.ar_fold_text(ts, w[pa + ".nkv.weight"], w[pa + ".kv.w"], w[pa + ".q.wT"], w[pa + ".o.w"], nkv, kvd, plan.kp[i], plan.vp[i],
+                                 B=B, S=S, S_cap=S_cap, D=D, H=4, eps=RMS_EPS)
             for r in plan.rings:
                 r.zero_()
             plan.hist.zero_()

@@ -1,8 +1,8 @@
-"""ctypes driver of the stage-level C entry points (include/sopro_hip.h: sopro_engine_*, sopro_ar_*, sopro_nar_refine,
-sopro_mimi_decode) - what a host that is NOT this Python package would write, in ~100 lines: hand the repacked weights
-to the engine by name, then three calls per stage.  The Python host (model.py / codec.py) issues the same launch sequences
-itself; ``tests/test_gpu_stages.py`` checks the two against each other and against the oracle.  INTEGRATION.md shows the
-same calls from C."""
+"""ctypes side of the stage-level C entry points (include/sopro_hip.h: sopro_engine_*, sopro_ar_*, sopro_nar_refine,
+sopro_mimi_decode[_stream]).  The launch sequences of the hot path live in the library (csrc/stages.hip, csrc/ar_frame.hip);
+``model_engine`` / ``codec_engine`` give the Python host (model.py / codec.py) its engines, and ``StageEngine`` drives all three
+stages directly - what a host that is NOT this package writes in ~100 lines (tests/test_gpu_stages.py; INTEGRATION.md shows
+the same calls from C)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -46,37 +46,29 @@ def engine_cfg(cfg, mc, gates: Dict[int, float], nar_mix, prev_w, final_bias: fl
     return c
 
 
-class StageEngine:
-    """The C engine over the device weights of an existing ``SoproTTS`` (no copies: the engine keeps pointers)."""
+class EngineHandle:
+    """A ``sopro_engine`` over device tensors that stay owned by the caller (no copies: the engine keeps pointers and builds
+    its packed operand forms in ``sopro_engine_finalize``).  ``tensors``: name -> device tensor, the keys of
+    ``pack_sopro`` / ``pack_mimi`` (+ "rope.cos" / "rope.sin"); a stage family takes part when its tensors are there."""
 
-    def __init__(self, tts):
-        m, codec = tts.model, tts.codec
-        self.tts, self.device = tts, m.device
+    def __init__(self, cfg: hip.EngineCfg, tensors: Dict[str, torch.Tensor], device: torch.device):
         self.lib = lib = hip.load()
-        cos, sin = codec._rope_tables(1)
-        order = m.cfg.stage_order()
-        mix = [(c["mix0"], c["mix1"]) for c in m._nar_const]
-        cfg = engine_cfg(m.cfg, codec.mc, m.gates, mix, m.w["nar_prev_cb_weights"].float().cpu().tolist(), codec.final_bias, int(cos.shape[0]))
+        self.device = device
         h = C.c_void_p()
         hip._check(lib.sopro_engine_create(C.byref(cfg), C.byref(h)), "sopro_engine_create")
         self.h = h
-        self._keep = [cos, sin]
-        tensors = dict(m.w)
-        for i, s in enumerate(order):  # the C side names the stages by position
-            tensors[f"nar.heads.{_POS[i]}.w"], tensors[f"nar.heads.{_POS[i]}.b"] = m.w[f"nar.heads.{s}.w"], m.w[f"nar.heads.{s}.b"]
-        tensors.update({k: v for k, v in codec.w.items()})
-        tensors["rope.cos"], tensors["rope.sin"] = cos, sin
+        self._keep = []
         for name, t in tensors.items():
-            if not (t.is_cuda and t.dtype in (torch.float32, torch.int32) and t.dim() >= 1 and t.dim() <= 4):
+            if not (t.is_cuda and t.dtype in (torch.float32, torch.int32) and 1 <= t.dim() <= 4):
                 continue
             t = t.contiguous()
             self._keep.append(t)
             shape = (C.c_int64 * t.dim())(*[int(x) for x in t.shape])
             hip._check(lib.sopro_engine_set_tensor(h, name.encode(), t.data_ptr(), shape, t.dim()), "sopro_engine_set_tensor")
-        self.stream = torch.cuda.Stream(device=self.device)
-        hip._check(lib.sopro_engine_finalize(h, self.stream.cuda_stream), "sopro_engine_finalize")
-        self.stream.synchronize()
-        self._ws: Dict[str, torch.Tensor] = {}
+        with torch.cuda.device(device):
+            st = torch.cuda.Stream(device=device)
+            hip._check(lib.sopro_engine_finalize(h, st.cuda_stream), "sopro_engine_finalize")
+            st.synchronize()
 
     def close(self) -> None:
         if self.h:
@@ -89,6 +81,55 @@ class StageEngine:
             self.close()
         except Exception:
             pass
+
+
+def _sopro_tensors(m) -> Dict[str, torch.Tensor]:
+    tensors = dict(m.w)
+    for i, s in enumerate(m.cfg.stage_order()):  # the C side names the stages by position
+        tensors[f"nar.heads.{_POS[i]}.w"], tensors[f"nar.heads.{_POS[i]}.b"] = m.w[f"nar.heads.{s}.w"], m.w[f"nar.heads.{s}.b"]
+    return tensors
+
+
+def _cfg_of(m, codec, precision: str) -> hip.EngineCfg:
+    """sopro_engine_cfg from the hosts' configs; a side that is absent contributes its config defaults (unused)."""
+    from .config import MimiDecoderConfig, SoproTTSConfig
+
+    scfg = m.cfg if m is not None else SoproTTSConfig()
+    mc = codec.mc if codec is not None else MimiDecoderConfig()
+    gates = m.gates if m is not None else {i: 0.0 for i in scfg.ar_xattn_layers}
+    mix = list(m._nar_mix) if m is not None else [(1.0, 0.0)] * len(scfg.stage_order())
+    prev = m.w["nar_prev_cb_weights"].float().cpu().tolist() if m is not None else [0.0] * int(scfg.num_codebooks)
+    rope_n = int(codec._rope_tables(1)[0].shape[0]) if codec is not None else 1024
+    c = engine_cfg(scfg, mc, gates, mix, prev, codec.final_bias if codec is not None else 0.0, rope_n)
+    c.precision = 1 if precision == "bf16" else 0
+    return c
+
+
+def model_engine(m) -> EngineHandle:
+    """The engine of a ``SoproTTSModel``: AR + NAR families (the lanes of a pipeline share it; it is read-only after finalize)."""
+    return EngineHandle(_cfg_of(m, None, m.precision), _sopro_tensors(m), m.device)
+
+
+def codec_engine(codec) -> EngineHandle:
+    """The engine of a ``MimiCodec``: the decoder family + its RoPE tables."""
+    tensors = dict(codec.w)
+    tensors["rope.cos"], tensors["rope.sin"] = codec._rope_tables(1)
+    return EngineHandle(_cfg_of(None, codec, codec.precision), tensors, codec.device)
+
+
+class StageEngine(EngineHandle):
+    """All three stage families in ONE engine over the device weights of an existing ``SoproTTS``, driven directly: what a host
+    that is not this package writes (tests/test_gpu_stages.py)."""
+
+    def __init__(self, tts):
+        m, codec = tts.model, tts.codec
+        self.tts = tts
+        tensors = _sopro_tensors(m)
+        tensors.update(codec.w)
+        tensors["rope.cos"], tensors["rope.sin"] = codec._rope_tables(1)
+        super().__init__(_cfg_of(m, codec, m.precision), tensors, m.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._ws: Dict[str, torch.Tensor] = {}
 
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
         ws = self._ws.get(key)
