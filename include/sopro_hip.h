@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 29
+#define SOPRO_ABI_VERSION 30
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -219,6 +219,10 @@ int64_t sopro_skinny_packed_floats(int32_t N, int32_t K, int32_t glu);
 int sopro_pack_skinny_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t glu, void* out, void* stream);
 
 /* ---- normalisation / elementwise ------------------------------------------------------- */
+/* rows x width 32-bit words, pitches in words: fills and device-to-device copies as kernels.  The stage sequences use them
+ * instead of hipMemset* / hipMemcpy* so that a recorded sequence holds kernel nodes only. */
+int sopro_fill2d_u32(void* p, int64_t pitch, int32_t rows, int32_t width, uint32_t value, void* stream);
+int sopro_copy2d_u32(void* dst, int64_t dpitch, const void* src, int64_t spitch, int32_t rows, int32_t width, void* stream);
 enum { SOPRO_NORM_RMS = 0, SOPRO_NORM_LN = 1 };
 /* out[r, :] = (norm(x[r, :]) * w (+ b)) * mul[seg(r), :] + add[seg(r), :]   (mul/add optional, one
  * row per segment of rows_per_seg rows).  RMS: src/sopro/nn/blocks.py:26-37 (eps inside rsqrt);

@@ -422,6 +422,22 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
 
 inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+
+// rows x width 32-bit words with row pitches: the stage sequences' pad clears, ticket resets and strided copies as KERNELS
+// (a recorded launch sequence must not hold memset / memcpy nodes: a hipMemsetAsync captured into a hipGraph was measured to
+// corrupt the split-K tickets of the replayed sequence once other allocations had happened - profiles/r03_experiments.md)
+__global__ __launch_bounds__(256) void fill2d_kernel(unsigned* __restrict__ p, int64_t pitch, int rows, int width, unsigned v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * width) return;
+  p[(i / width) * pitch + (i % width)] = v;
+}
+__global__ __launch_bounds__(256) void copy2d_kernel(unsigned* __restrict__ d, int64_t dpitch, const unsigned* __restrict__ s, int64_t spitch, int rows,
+                                                     int width) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * width) return;
+  d[(i / width) * dpitch + (i % width)] = s[(i / width) * spitch + (i % width)];
+}
+
 }  // namespace
 
 extern "C" {
@@ -565,6 +581,20 @@ int sopro_stats_pool_f32(const float* h, const float* logit, const int32_t* lens
 int sopro_l2norm_f32(const float* x, float* out, int32_t rows, int32_t C, float eps, void* stream) {
   SOPRO_CHECK_ARG(x && out && rows > 0 && C > 0, "bad pointers or sizes");
   hipLaunchKernelGGL(l2norm_kernel, dim3(nblk(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, out, rows, C, eps);
+  SOPRO_LAUNCH_CHECK();
+}
+
+int sopro_fill2d_u32(void* p, int64_t pitch, int32_t rows, int32_t width, uint32_t value, void* stream) {
+  SOPRO_CHECK_ARG(p && rows > 0 && width > 0 && pitch >= width, "bad pointers or sizes");
+  hipLaunchKernelGGL(fill2d_kernel, dim3(nblk((int64_t)rows * width, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<unsigned*>(p), pitch, rows,
+                     width, value);
+  SOPRO_LAUNCH_CHECK();
+}
+
+int sopro_copy2d_u32(void* dst, int64_t dpitch, const void* src, int64_t spitch, int32_t rows, int32_t width, void* stream) {
+  SOPRO_CHECK_ARG(dst && src && rows > 0 && width > 0 && dpitch >= width && spitch >= width, "bad pointers or sizes");
+  hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)rows * width, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<unsigned*>(dst), dpitch,
+                     reinterpret_cast<const unsigned*>(src), spitch, rows, width);
   SOPRO_LAUNCH_CHECK();
 }
 

@@ -3,6 +3,8 @@
 // sequences are the ones sopro_amd/model.py (_ARRun / _ARPlan.issue_step / _nar_issue) and sopro_amd/codec.py
 // (_decode_issue / _transformer / _seanet_act) issue; tests/test_gpu_stages.py checks the two hosts against each other
 // and against the oracle.
+#include <stdlib.h>
+
 #include <map>
 #include <string>
 #include <vector>
@@ -256,7 +258,8 @@ int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override
     x.ldc2 = o.ldc2 < 0 ? n_out : o.ldc2;
     x.c2_seg_stride = o.c2_seg;
     if (o.rms_eps > 0.f) { x.rms_norm = 1; x.rms_eps = o.rms_eps; }
-    if (o.sk && o.sk->ws && o.rms_eps <= 0.f && o.c_mode != 5) {
+    static const bool no_splitk = getenv("SOPRO_NO_SPLITK") && getenv("SOPRO_NO_SPLITK")[0] == '1';  // developer switch
+    if (!no_splitk && o.sk && o.sk->ws && o.rms_eps <= 0.f && o.c_mode != 5) {
       const int ks = auto_ksplit(o.M, o.N, o.K, w.f16 ? 3 : w.pieces, o.epi);
       if (ks > 1) {
         x.ksplit = ks; x.n_tickets = SPLITK_TICKETS; x.ws = o.sk->ws; x.ws_bytes = (int64_t)SPLITK_WS_BYTES; x.tickets = o.sk->tickets;
@@ -675,19 +678,18 @@ int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_
   SOPRO_CHECK_ARG(V % 64 == 0, "codebook_size must be a multiple of 64 (arg-max partials per 64 columns)");
   NarWs w;
   nar_carve(e, w, workspace, B, T);
-  if (w.sk.ws) SOPRO_HIP(hipMemsetAsync(w.sk.tickets, 0, SPLITK_TICKETS * sizeof(int32_t), s));  // split-K tickets start (and are left) at zero
+  if (w.sk.ws) STG(sopro_fill2d_u32(w.sk.tickets, SPLITK_TICKETS, 1, SPLITK_TICKETS, 0u, s));  // split-K tickets start (and are left) at zero
   int nh_max = 0;
   for (int i = 0; i < c.n_stages; ++i) nh_max = c.stage_n_cb[i] > nh_max ? c.stage_n_cb[i] : nh_max;
   const float* cnd = cond;
   if (cond_bstride != (int64_t)T * D) {  // the first T rows of longer conditioning blocks (cond_ar has max_frames + 1 rows): densify once
-    SOPRO_HIP(hipMemcpy2DAsync(w.cond, (size_t)T * D * 4, cond, (size_t)cond_bstride * 4, (size_t)T * D * 4, B, hipMemcpyDeviceToDevice, s));
+    STG(sopro_copy2d_u32(w.cond, (int64_t)T * D, cond, cond_bstride, B, T * D, s));
     cnd = w.cond;
   }
-  SOPRO_HIP(hipMemcpy2DAsync(tokens, (size_t)Q * 4, rvq1, 4, 4, (size_t)M, hipMemcpyDeviceToDevice, s));  // column 0 <- codebook 0
+  STG(sopro_copy2d_u32(tokens, Q, rvq1, 1, M, 1, s));  // column 0 <- codebook 0
   const int32_t* lens_d = nullptr;
   if (lens) {
-    SOPRO_HIP(hipMemcpyAsync(w.lens, lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-    lens_d = w.lens;
+    lens_d = lens;  // (a device pointer of the caller: read by the kernels of this call, stream-ordered)
   }
   const char* stage_names[8] = {"B", "C", "D", "E", "F", "G", "H", "I"};
   for (int sid = 0; sid < c.n_stages; ++sid) {
@@ -766,16 +768,16 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   SOPRO_CHECK_ARG(c.mimi_res_kernel == 3 && c.mimi_last_kernel == 3 && c.mimi_compress == 2, "the SEANet sequence is written for k = 3 residual / last convs, compress 2");
   MimiWs w;
   mimi_carve(e, w, workspace, B, T);
-  if (w.sk.ws) SOPRO_HIP(hipMemsetAsync(w.sk.tickets, 0, SPLITK_TICKETS * sizeof(int32_t), s));
+  if (w.sk.ws) STG(sopro_fill2d_u32(w.sk.tickets, SPLITK_TICKETS, 1, SPLITK_TICKETS, 0u, s));
   // the zero rows in front of every segment of a convolution input are never written by the kernels: clear just those
   {
-    SOPRO_HIP(hipMemset2DAsync(w.X, (size_t)(PADX + N2) * HS * 4, 0, (size_t)PADX * HS * 4, B, s));
+    STG(sopro_fill2d_u32(w.X, (int64_t)(PADX + N2) * HS, B, PADX * HS, 0u, s));
     size_t chz = (size_t)c.mimi_num_filters << c.mimi_n_ratios, rowz = (size_t)N2;
-    SOPRO_HIP(hipMemset2DAsync(w.e0, (1 + rowz) * chz * 4, 0, chz * 4, B, s));
+    STG(sopro_fill2d_u32(w.e0, (int64_t)((1 + rowz) * chz), B, (int)chz, 0u, s));
     for (int si = 0; si < c.mimi_n_ratios; ++si) {
       const size_t co = chz / 2, orow = rowz * c.mimi_ratios[si];
-      SOPRO_HIP(hipMemset2DAsync(w.hraw[si], (2 + orow) * co * 4, 0, 2 * co * 4, B, s));
-      if (w.hact[si]) SOPRO_HIP(hipMemset2DAsync(w.hact[si], (2 + orow) * co * 4, 0, 2 * co * 4, B, s));
+      STG(sopro_fill2d_u32(w.hraw[si], (int64_t)((2 + orow) * co), B, (int)(2 * co), 0u, s));
+      if (w.hact[si]) STG(sopro_fill2d_u32(w.hact[si], (int64_t)((2 + orow) * co), B, (int)(2 * co), 0u, s));
       chz = co; rowz = orow;
     }
   }
@@ -811,8 +813,7 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     } else {
       // keys / values of earlier calls (post-RoPE) followed by this call's: append the (k | v) rows to the layer's cache
       float* cache = sst->kv + ((size_t)(l * 2 + sst->half) * sst->cap_rows) * 2 * HS;
-      SOPRO_HIP(hipMemcpy2DAsync(cache + (size_t)sst->kv_len * 2 * HS, (size_t)2 * HS * 4, w.qkv + HS, (size_t)3 * HS * 4, (size_t)2 * HS * 4, n,
-                                 hipMemcpyDeviceToDevice, s));
+      STG(sopro_copy2d_u32(cache + (size_t)sst->kv_len * 2 * HS, 2 * HS, w.qkv + HS, 3 * HS, n, 2 * HS, s));
       const int Tk = sst->kv_len + n;
       a.K = cache; a.ldk = 2 * HS; a.V = cache + HS; a.ldv = 2 * HS; a.Tk = Tk;
       a.q_pos0 = past; a.k_pos0 = past + n - Tk;
@@ -823,7 +824,7 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
         const int keep = c.mimi_window - 1;
         float* other = sst->kv + ((size_t)(l * 2 + (sst->half ^ 1)) * sst->cap_rows) * 2 * HS;
         STG(sopro_attention_f32(&a, s));
-        SOPRO_HIP(hipMemcpyAsync(other, cache + (size_t)(Tk - keep) * 2 * HS, (size_t)keep * 2 * HS * 4, hipMemcpyDeviceToDevice, s));
+        STG(sopro_copy2d_u32(other, 2 * HS, cache + (size_t)(Tk - keep) * 2 * HS, 2 * HS, keep, 2 * HS, s));
         goto attended;
       }
     }

@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -128,6 +128,8 @@ SYMBOLS = {
     "sopro_gemm_bf16x6": (C.c_int, [_p, _p, _p, _p]),
     "sopro_gemm_bf16x1": (C.c_int, [_p, _p, _p, _p]),
     "sopro_pack_w_bf16": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
+    "sopro_fill2d_u32": (C.c_int, [_p, _i64, _i32, _i32, C.c_uint32, _p]),
+    "sopro_copy2d_u32": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _p]),
     "sopro_pack_w_f16x2": (C.c_int, [_p, _i64, _i32, _i32, _f32, _p, _p]),
     "sopro_f16x3_a_scale": (C.c_float, []),
     "sopro_gemm_f16x3": (C.c_int, [_p, _p, _p, _p]),

@@ -578,7 +578,7 @@ class SoproTTSModel:
                 hip._check(lib.sopro_nar_refine(eng.h, scratch.data_ptr(), cond.data_ptr(), T * D, rvq1.data_ptr(), lens_d.data_ptr(), B, T,
                                                 toks.data_ptr(), hip._stream()), "sopro_nar_refine")
 
-            if self.use_graph:
+            if self.use_graph and os.environ.get("SOPRO_NO_BULK_GRAPH", "0") != "1":
                 self._nar_graphs.run((B, T), issue)
             else:
                 issue()
