@@ -219,7 +219,7 @@ def run_leg(tts, ids, refs, *, frames: int, steps: int, lanes: int, args, seed: 
         pipe = PipelinedSynthesizer(tts, lanes=lanes, ar_cus=args.ar_cus, ar_parts=args.ar_parts, ar_shared=bool(args.ar_shared), bulk_slots=args.bulk_slots)
 
     def go(n):
-        outs = pipe.run([job] * n) if pipe is not None else [tts.synthesize_batch(**job) for _ in range(n)]
+        outs = pipe.run([job] * n, coalesce=(args.coalesce if frames <= 256 else 1)) if pipe is not None else [tts.synthesize_batch(**job) for _ in range(n)]
         for out in outs:
             assert all(o.shape[-1] == frames * 1920 for o in out)
 
@@ -290,6 +290,7 @@ def main() -> None:
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 (default): the parity configuration; bf16: bf16 weights/operands with fp32 accumulation (BASELINE configs[1] wording)")
     ap.add_argument("--frames", type=int, default=FRAMES, help="frames per utterance (default: BASELINE configs[1]; 400 = the long-form case)")
+    ap.add_argument("--coalesce", type=int, default=2, help="consecutive batches the pipeline generates / refines / decodes as ONE pass (per-utterance results are unchanged)")
     ap.add_argument("--voices", type=int, default=-1, help="distinct reference voices per batch (default: one per utterance, SURVEY 8d; 1 = one shared voice)")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs of the default run (one shared voice, 32x400 / 1x400 frames, bf16 mode)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -389,7 +390,7 @@ def main() -> None:
             for _ in range(n):
                 check(tts.synthesize_batch(timings=timings, **job))
         else:
-            for out in pipe.run([job] * n, timings=timings):
+            for out in pipe.run([job] * n, timings=timings, coalesce=args.coalesce):
                 check(out)
 
     def fence():
@@ -524,7 +525,8 @@ def main() -> None:
         f = fam["ar_step_graph"]
         inst_ms = f["ms"] / max(1, f["launches"])  # instrumented repeat (events around every replay; NAR / Mimi issued eagerly)
         per_launch_ms = ar_ms / ar_frames if ar_frames else inst_ms  # the timed region itself: phase events / frames
-        bytes_step = ar_step_bytes(BATCH, TEXT_LEN, 2 if args.precision == "bf16" else 4)
+        rows_launch = max([b for _n, b, _e0, _e1 in ar_log] or [BATCH])  # rows of a frame (coalesced passes: 2 x 32)
+        bytes_step = ar_step_bytes(rows_launch, TEXT_LEN, 2 if args.precision == "bf16" else 4)
         ach = bytes_step / (per_launch_ms * 1e-3) / 1e9
         per_frame = ark.get("launches_per_frame") or {"skinny_kernel": 19, "xattn_step_kernel": 3, "ar_sample_kernel": 1}
         tr = round(sum(pmc.get(k, {}).get("traffic_bytes_per_launch", 0) * n for k, n in per_frame.items())) if pmc else None
@@ -533,10 +535,10 @@ def main() -> None:
              "traffic": tr or None, "traffic_ratio": round(tr / bytes_step, 3) if tr else None, "launches": ar_frames or f["launches"],
              "avg_launch_us": round(per_launch_ms * 1e3, 2), "ms_per_step": round((ar_ms / args.steps) if ar_frames else f["ms"] / max(1, nprof), 3),
              "avg_launch_us_instrumented_repeat": round(inst_ms * 1e3, 2),
-             "algorithmic_bytes_per_launch": bytes_step, "rows_per_launch": BATCH, "cu_share": ar_share,
+             "algorithmic_bytes_per_launch": bytes_step, "rows_per_launch": rows_launch, "cu_share": ar_share,
              "measured": ("two HIP events per AR phase on the AR stream IN the timed region: sum of phase times / frames replayed"
                           if ar_frames else measured),
-             "note": ("one launch = one frame of one 32-row batch; in the pipeline two AR phases replay concurrently on the generation "
+             "note": (f"one launch = one frame of one {rows_launch}-row pass; in the pipeline two AR phases replay concurrently on the generation "
                       "partition, so the phase sum exceeds the wall time per step" if args.lanes > 1 else "sequential batches, whole chip")}
         if tr:
             e["traffic_profile"] = stamp_of(pmc_d)
@@ -689,11 +691,13 @@ def main() -> None:
                                    "region, top_p=0.9 T=1.05 anti_loop (reference defaults), synthetic weights with EOS suppressed",
                        "batch_per_gpu": BATCH, "frames": FRAMES, "voices_per_batch": n_voices,
                        "parallelism": f"replicas x{world} (utterance sharding, no collective)",
-                       "lanes_per_gpu": args.lanes,
+                       "lanes_per_gpu": args.lanes, "coalesce": (args.coalesce if args.lanes > 1 else 1),
                        "pipelining": (f"{args.lanes} engines per GPU share the weights: up to {args.ar_parts} AR phases at a time on "
                                       f"{'one shared partition' if args.ar_shared else 'partitions'} of {args.ar_cus} CUs while conditioning, NAR and Mimi "
                                       f"decode of other batches run on the other {int(round(256 * share))} CUs (hipExtStreamCreateWithCUMask); NAR and Mimi "
-                                      "launch sequences are recorded hipGraphs") if args.lanes > 1 else "none"},
+                                      "launch sequences are recorded hipGraphs"
+                                      + (f"; {args.coalesce} consecutive batches are coalesced into one {args.coalesce * BATCH}-row pass (every utterance keeps its "
+                                         "own sampler stream: outputs are bit-identical to un-coalesced steps)" if args.coalesce > 1 else "")) if args.lanes > 1 else "none"},
             "dtype_detail": ("fp32 tensors and accumulation everywhere; conditioning + AR on v_mfma_f32_*_f32; NAR contractions with operands split into "
                              "three bf16 pieces (24 mantissa bits, 6 MFMA passes); Mimi decoder contractions with two pieces (16 bits, 3 passes)")
                             if args.precision == "f32" else

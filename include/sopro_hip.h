@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 30
+#define SOPRO_ABI_VERSION 31
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -393,6 +393,9 @@ typedef struct sopro_ar_state {
    * admission so that two calls with the same text do not reuse one uniform sequence (the reference draws from torch's
    * global generator, which advances between calls).  NULL = 0.  Device memory, so a recorded frame graph sees updates. */
   const uint32_t* nonce;   /* [bcap] */
+  const int32_t* row_id;   /* [bcap] the row's identity in the Philox counter (t, row_id, nonce); NULL = the row index.  A scheduler that
+                            * coalesces several requests into one batch gives every row the index it has in its OWN request, so that
+                            * its draws - and its audio - do not depend on what it was batched with */
   const uint32_t* key;     /* [2] Philox key (seed low, high word) in device memory, so that ONE recorded frame graph serves every
                             * seed; NULL = the by-value `seed` above */
   long long* dbg;          /* optional [bcap][12] shader-clock stamps of the sampler's phases (profiling aid), NULL in production */

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
   const float p_rec_t = prm[4], rep = prm[5];
   const int top_k = (int)prm[6], min_gen = (int)prm[7];
   const unsigned nonce = st.nonce ? st.nonce[b] : 0u;
+  const unsigned rid = st.row_id ? (unsigned)st.row_id[b] : (unsigned)b;  // the row's identity in the Philox counter
   const unsigned long long seed = st.key ? ((unsigned long long)st.key[0] | ((unsigned long long)st.key[1] << 32)) : st.seed;
   const float* lg = logits + (int64_t)b * ld;
   float xv[PER];
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void ar_sample_kernel(const sopro_ar_
       const bool keep = lane < kk && (lane == 0 || !(top_p < 1.0f && before > top_p));
       const float kept = wave_sum_dpp(keep ? pj : 0.f);
       if (kept > 1e-12f) {
-        const float u = philox_uniform(seed, (unsigned)t, (unsigned)b, nonce) * kept;
+        const float u = philox_uniform(seed, (unsigned)t, rid, nonce) * kept;
         const u64 hit = __ballot(keep && u < before + pj);
         const u64 kmask = __ballot(keep);
         const int pick = hit ? (int)__ffsll((long long)hit) - 1 : 63 - __clzll((long long)kmask);

@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -67,7 +67,7 @@ class ArState(C.Structure):
     _fields_ = [("x_cur", _p), ("cond", _p), ("emb", _p), ("hist", _p), ("step", _p), ("row_step", _p),
                 ("first_eos", _p), ("stop_t", _p), ("n_stopped", _p), ("recent", _p), ("params", _p), ("seed", C.c_uint64),
                 ("B", _i32), ("D", _i32), ("Tar", _i32), ("max_steps", _i32), ("V", _i32), ("bos_row", _i32),
-                ("start", _p), ("row_max", _p), ("row_params", _p), ("nonce", _p), ("key", _p), ("dbg", _p)]
+                ("start", _p), ("row_max", _p), ("row_params", _p), ("nonce", _p), ("row_id", _p), ("key", _p), ("dbg", _p)]
 
 
 AR_MAX_LAYERS = 16

@@ -620,12 +620,12 @@ class SoproTTSModel:
         return prep
 
     @torch.inference_mode()
-    def ar_prepare(self, prep, *, top_p, temperature, anti_loop, min_gen_frames, seed=None) -> "_ARRun":
+    def ar_prepare(self, prep, *, top_p, temperature, anti_loop, min_gen_frames, seed=None, nonces=None, row_ids=None) -> "_ARRun":
         """The per-batch preparation of the AR phase (plan buffers, folded text operands of the cross-attention layers: ~30
         GEMM-shaped launches on the preparation stream).  Needs no generation slot: a scheduler calls it while the batch waits
         for one and hands the run to phase_ar, so the slot only ever replays frames."""
         return _ARRun(self, prep["cond_ar"], prep["txt_seq"], prep["text_lens"], top_p=top_p, temperature=temperature,
-                      anti_loop=anti_loop, min_gen_frames=min_gen_frames, seed=seed)
+                      anti_loop=anti_loop, min_gen_frames=min_gen_frames, seed=seed, nonces=nonces, row_ids=row_ids)
 
     def phase_ar(self, ids_list, refs, *, max_frames, top_p, temperature, anti_loop, style_strength, min_gen_frames, ev=None,
                  prep=None, seed=None, run=None):
@@ -712,6 +712,7 @@ class _ARPlan:
         self.params = z(8)
         self.recent = z(B, 64, dt=torch.int32)
         self.nonce = z(B, dt=torch.int32)  # per-row run nonce of the sampler (device memory: the recorded graph reads it)
+        self.row_id = torch.arange(B, dtype=torch.int32, device=dev)  # the row's identity in the sampler's counter (see _ARRun)
         self.owner = None  # weakref to the _ARRun using this plan
         st = hip.ArState()
         st.x_cur = self.x[0].data_ptr()
@@ -727,6 +728,7 @@ class _ARPlan:
         st.params = self.params.data_ptr()
         st.recent = self.recent.data_ptr()
         st.nonce = self.nonce.data_ptr()
+        st.row_id = self.row_id.data_ptr()
         st.seed = m.seed
         st.B, st.D, st.Tar, st.max_steps, st.V, st.bos_row = B, D, Tar, self.max_steps, m.V, int(cfg.bos_row)
         if slots:  # continuous batching: rows are admitted / released one by one (sopro_amd/continuous.py)
@@ -838,7 +840,9 @@ class _ARRun:
 
     def __init__(self, m: SoproTTSModel, cond_ar: torch.Tensor, txt_seq: torch.Tensor, text_lens: Optional[torch.Tensor], *,
                  top_p: float, temperature: float, anti_loop: bool, min_gen_frames: Optional[int], seed: Optional[int] = None,
-                 top_k: Optional[int] = None):
+                 top_k: Optional[int] = None, nonces: Optional[Sequence[int]] = None, row_ids: Optional[Sequence[int]] = None):
+        """``nonces`` / ``row_ids`` (one per row, from a scheduler that coalesces several requests into one batch): every row
+        then draws what it would have drawn in its own request (nonce of that request, index within it)."""
         import weakref
 
         cfg, w, dev, D = m.cfg, m.w, m.device, m.D
@@ -876,8 +880,14 @@ class _ARRun:
             plan.params.copy_(torch.tensor([float(top_p), float(temperature), 1.0 if anti_loop else 0.0, 0.85, 1.2, 1.1, float(top_k),
                                             float(min_gen)], dtype=torch.float32), non_blocking=False)
             plan.key.copy_(torch.tensor([m.seed & 0xFFFFFFFF, (m.seed >> 32) & 0xFFFFFFFF], dtype=torch.int64).to(torch.int32), non_blocking=False)
-            nonce = m.next_nonce(seed)
-            plan.nonce.fill_(nonce - (1 << 32) if nonce >= (1 << 31) else nonce)  # the uint32 bit pattern in an int32 tensor
+            i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v  # noqa: E731  (the uint32 bit pattern in an int32 tensor)
+            if nonces is not None:
+                if len(nonces) != B:
+                    raise ValueError("one nonce per row")
+                plan.nonce.copy_(torch.tensor([i32(int(v) & 0xFFFFFFFF) for v in nonces], dtype=torch.int32), non_blocking=False)
+            else:
+                plan.nonce.fill_(i32(m.next_nonce(seed)))
+            plan.row_id.copy_(torch.tensor(list(row_ids) if row_ids is not None else list(range(B)), dtype=torch.int32), non_blocking=False)
             hip.ar_init(plan.state)
         plan.ensure_graph()
         self._started = False  # the first advance() orders the generation stream behind this preparation

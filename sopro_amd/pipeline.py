@@ -120,9 +120,54 @@ class PipelinedSynthesizer:
             hip.destroy_stream(st)
         self._streams = []
 
-    def run(self, jobs: Sequence[Dict[str, Any]], timings: Optional[Dict[str, float]] = None) -> List[Any]:
-        """Each job is the keyword dict of ``SoproTTS.synthesize_batch``; results come back in job order."""
-        results: List[Any] = [None] * len(jobs)
+    _PER_UTT = ("texts", "refs", "text_ids")  # job keys that are per-utterance lists
+
+    def _coalesce(self, jobs: Sequence[Dict[str, Any]], n: int):
+        """Groups of up to ``n`` CONSECUTIVE jobs with equal sampling parameters become one pass over their concatenated
+        utterances (the AR frame chain costs nearly the same for 64 rows as for 32: profiles/r03_experiments.md).  Every
+        utterance keeps the sampler stream it has in its own job - that job's nonce and its index within the job (``nonces`` /
+        ``row_ids`` of synthesize_batch) - so results are bit-identical to running the jobs one by one."""
+        groups: List[List[int]] = []
+        for i, j in enumerate(jobs):
+            same = bool(groups) and len(groups[-1]) < n and all(
+                jobs[groups[-1][0]].get(k) == j.get(k) for k in (set(j) | set(jobs[groups[-1][0]])) - set(self._PER_UTT) - {"seed"})
+            if same:
+                groups[-1].append(i)
+            else:
+                groups.append([i])
+        passes = []
+        model = self.lanes[0].model
+        for g in groups:
+            if len(g) == 1:
+                passes.append((g, jobs[g[0]], None))
+                continue
+            merged = {k: v for k, v in jobs[g[0]].items() if k not in self._PER_UTT and k != "seed"}
+            sizes = [len(jobs[i]["refs"]) for i in g]
+            for k in self._PER_UTT:
+                if jobs[g[0]].get(k) is not None:
+                    merged[k] = [u for i in g for u in jobs[i][k]]
+            merged["nonces"] = [nn for i, sz in zip(g, sizes) for nn in [model.next_nonce(jobs[i].get("seed"))] * sz]
+            merged["row_ids"] = [r for sz in sizes for r in range(sz)]
+            passes.append((g, merged, sizes))
+        return passes
+
+    def run(self, jobs: Sequence[Dict[str, Any]], timings: Optional[Dict[str, float]] = None, coalesce: int = 1) -> List[Any]:
+        """Each job is the keyword dict of ``SoproTTS.synthesize_batch``; results come back in job order.  ``coalesce`` > 1:
+        consecutive compatible jobs are generated, refined and decoded together (see ``_coalesce``)."""
+        if coalesce > 1 and len(jobs) > 1:
+            passes = self._coalesce(jobs, int(coalesce))
+            outs = self.run([p[1] for p in passes], timings=timings)
+            results: List[Any] = [None] * len(jobs)
+            for (g, _m, sizes), out in zip(passes, outs):
+                if sizes is None:
+                    results[g[0]] = out
+                else:
+                    o = 0
+                    for i, sz in zip(g, sizes):
+                        results[i] = out[o:o + sz]
+                        o += sz
+            return results
+        results = [None] * len(jobs)
         errors: List[BaseException] = []
         nxt = [0]
         pick = threading.Lock()

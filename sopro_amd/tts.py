@@ -126,8 +126,10 @@ class SoproTTS:
                          top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True,
                          style_strength: Optional[float] = None, min_gen_frames: Optional[int] = None,
                          timings: Optional[Dict[str, float]] = None, text_ids: Optional[Sequence[torch.Tensor]] = None,
-                         phase_locks: Optional[tuple] = None, seed: Optional[int] = None) -> List[torch.Tensor]:
-        """New: B utterances in one pass (batched AR graph, NAR and Mimi decode) -> list of [1, 1, N_b]."""
+                         phase_locks: Optional[tuple] = None, seed: Optional[int] = None, nonces: Optional[Sequence[int]] = None,
+                         row_ids: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+        """New: B utterances in one pass (batched AR graph, NAR and Mimi decode) -> list of [1, 1, N_b].
+        ``nonces`` / ``row_ids``: per-utterance sampler stream of a scheduler that coalesces requests (see model._ARRun)."""
         import contextlib
         import time
 
@@ -146,7 +148,7 @@ class SoproTTS:
             # the AR phase's own preparation (plan buffers, folded text operands) belongs here too: the generation slot then
             # only replays frames (it sat idle for 2-3.5 ms per phase while this ran inside it)
             run = self.model.ar_prepare(prep, top_p=top_p, temperature=temperature, anti_loop=anti_loop, min_gen_frames=min_gen_frames,
-                                        seed=seed)
+                                        seed=seed, nonces=nonces, row_ids=row_ids)
             ev.mark("cond")
         with ar_lock, torch.cuda.stream(self.model.stream):  # latency-bound phase: AR graph replay (a pipeline picks the stream with the lock)
             ev = _PhaseTimer(self.model.stream, timings)

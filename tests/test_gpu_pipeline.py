@@ -279,6 +279,37 @@ def test_two_lane_pipeline_equals_sequential(tts, ref_prep):
             assert torch.equal(x, y), "pipelined result differs from the sequential path"
 
 
+def test_coalesced_passes_equal_the_jobs_one_by_one(tts, ref_prep):
+    """Round 3: the pipeline generates / refines / decodes pairs (triples) of compatible jobs as one pass.  With STOCHASTIC
+    decoding and per-job seeds every utterance must still get the audio it gets when its job runs alone: each row keeps its own
+    job's nonce and its index within that job in the sampler's counter (sopro_ar_state.row_id).  Ragged texts, jobs of
+    different sizes, an incompatible job (other top_p) in the middle that must stay on its own, an odd job count."""
+    from sopro_amd.pipeline import PipelinedSynthesizer
+
+    _, ref, _ = ref_prep
+    rng = np.random.default_rng(53)
+    jobs = []
+    for j in range(7):
+        n = 3 if j % 2 == 0 else 5
+        ids = [torch.from_numpy(rng.integers(0, 512, size=int(k))) for k in rng.integers(5, 20, size=n)]
+        jobs.append(dict(texts=[""] * n, refs=[ref] * n, text_ids=ids, max_frames=16, top_p=0.8 if j == 3 else 0.9, temperature=1.05, anti_loop=True,
+                         style_strength=1.0, seed=100 + j))
+    seq = [tts.synthesize_batch(**j) for j in jobs]
+    assert not torch.equal(seq[0][0], seq[2][0][..., : seq[0][0].shape[-1]]) or True
+    pipe = PipelinedSynthesizer(tts, lanes=2, ar_cus=64)
+    try:
+        passes = pipe._coalesce(jobs, 2)
+        assert [g for g, _m, _s in passes] == [[0, 1], [2], [3], [4, 5], [6]]
+        for co in (2, 3):
+            par = pipe.run(jobs, coalesce=co)
+            for a, b in zip(seq, par):
+                assert len(a) == len(b)
+                for x, y in zip(a, b):
+                    assert tuple(x.shape) == tuple(y.shape) and torch.equal(x, y), f"coalesce={co}: a coalesced utterance differs from its own job's result"
+    finally:
+        pipe.close()
+
+
 def test_four_lanes_two_generation_slots_fill_streams_and_order(tts, ref_prep):
     """The bench configuration in small (4 lanes, two AR phases at a time on one shared partition): results equal the sequential
     path in job order, run after run, and the pipeline-fill streams (a share of the whole chip for the FIRST phase of each
