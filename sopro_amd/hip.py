@@ -740,9 +740,24 @@ class Graph:
         _check(load().sopro_graph_launch_n(self.handle, _stream(), int(n)), "sopro_graph_launch_n")
 
     def __del__(self):
+        # Never destroy here: the collector may run this INSIDE another recording (any allocation can trigger it), and
+        # hipGraphExecDestroy during a stream capture invalidates that capture ("operation failed due to a previous error
+        # during capture", seen once in a few suite runs).  The handle is parked and destroyed at the next safe point.
+        if self.handle:
+            _dead_graphs.append(self.handle)
+            self.handle = 0
+
+
+_dead_graphs: list = []
+
+
+def reap_graphs() -> None:
+    """Destroy the graphs whose owners are gone; called where no recording can be open (capture_begin takes the lock first)."""
+    while _dead_graphs:
+        h = _dead_graphs.pop()
         try:
-            if self.handle and _lib is not None:
-                _lib.sopro_graph_destroy(self.handle)
+            if _lib is not None:
+                _lib.sopro_graph_destroy(h)
         except Exception:
             pass
 
@@ -801,6 +816,7 @@ _capture_lock = threading.RLock()
 def capture_begin() -> None:
     _capture_lock.acquire()
     try:
+        reap_graphs()
         _check(load().sopro_capture_begin(_stream()), "sopro_capture_begin")
     except BaseException:
         _capture_lock.release()
