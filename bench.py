@@ -191,13 +191,15 @@ def rocprof_family_table() -> dict:
     if not files:
         return {}
     pat = {"gemm_f32_kernel": "gemm_f32_kernel", "gemm_bf16s_kernel<1,": "gemm_bf16x1_kernel", "gemm_bf16s_kernel<2,": "gemm_bf16x3_kernel",
-           "gemm_bf16s_kernel<3,": "gemm_bf16x6_kernel", "attention_kernel": "attention_kernel", "attn_window_mfma_kernel": "attention_kernel",
+           "gemm_bf16s_kernel<3,": "gemm_bf16x6_kernel",  # (<2, ..., true> = the fp16 pieces of the NAR path: told apart below) "attention_kernel": "attention_kernel", "attn_window_mfma_kernel": "attention_kernel",
            "attn_decode_kernel": "attention_kernel"}
     out: dict = {}
     try:
         for r in csv.DictReader(open(files[-1])):
             for k, fam in pat.items():
                 if k in r["Name"]:
+                    if fam == "gemm_bf16x3_kernel" and r["Name"].split(">(")[0].rstrip().endswith("true"):
+                        fam = "gemm_f16x3_kernel"
                     d = out.setdefault(fam, {"calls": 0, "ns": 0.0})
                     d["calls"] += int(r["Calls"])
                     d["ns"] += float(r["TotalDurationNs"])
@@ -514,6 +516,10 @@ def main() -> None:
         entries.append((fam["gemm_bf16x6_kernel"]["ms"], mfma_entry(
             "gemm_bf16x6_kernel", "gemm_bf16x6_kernel (NAR contractions; v_mfma_f32_32x32x16_bf16, 6 passes per product, 24-bit operands)",
             PEAK_BF16_MFMA_TFLOPS, 6, "fp32-class products: refined tokens must equal the fp32 reference's")))
+    if "gemm_f16x3_kernel" in fam:
+        entries.append((fam["gemm_f16x3_kernel"]["ms"], mfma_entry(
+            "gemm_f16x3_kernel", "gemm_f16x3_kernel (NAR contractions; v_mfma_f32_32x32x16_f16, 3 passes per product, two fp16 pieces = 22-bit operands)",
+            PEAK_BF16_MFMA_TFLOPS, 3, "fp32-class products (as accurate as the six-pass bf16 form: profiles/r03_f16x3_probe.txt): refined tokens must equal the fp32 reference's")))
     if "gemm_bf16x1_kernel" in fam:
         entries.append((fam["gemm_bf16x1_kernel"]["ms"], mfma_entry(
             "gemm_bf16x1_kernel", "gemm_bf16x1_kernel (bf16 mode: NAR + Mimi contractions, bf16 operands, fp32 accumulate, one MFMA pass)",
@@ -637,14 +643,14 @@ def main() -> None:
         legs = {}
         try:
             log("leg: one shared voice")
-            legs["one_voice_32x200"] = run_leg(tts, ids, [ref] * BATCH, frames=FRAMES, steps=8, lanes=args.lanes, args=args)
+            legs["one_voice_32x200"] = run_leg(tts, ids, [ref] * BATCH, frames=FRAMES, steps=args.steps, lanes=args.lanes, args=args)
             log("leg: 32 x 400 frames")
             legs["f32_32x400"] = run_leg(tts, ids, refs, frames=400, steps=6, lanes=args.lanes, args=args)
             log("leg: 1 x 400 frames, strictly sequential")
             legs["f32_1x400_sequential"] = run_leg(tts, ids[:1], refs[:1], frames=400, steps=8, lanes=1, args=args)
             log("leg: bf16 mode")
             tts16 = build_engine(device, "bf16")[0]
-            b16 = run_leg(tts16, ids, refs, frames=FRAMES, steps=12, lanes=args.lanes, args=args)
+            b16 = run_leg(tts16, ids, refs, frames=FRAMES, steps=args.steps, lanes=args.lanes, args=args)
             b16["dtype"] = "bf16"
             b16["dtype_detail"] = ("bf16 mode: NAR + Mimi contractions with both operands rounded to bf16 once (one MFMA pass); the AR frame streams bf16 "
                                    "weights with bf16 MFMA operands; fp32 accumulators, norms, softmax, ring buffers and residual streams; conditioning "

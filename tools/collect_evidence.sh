@@ -3,12 +3,12 @@
 #   tools/collect_evidence.sh r02 profiles    -> rocprofv3 kernel stats (pipelined / sequential), PMC passes, AR kernel table
 #   tools/collect_evidence.sh r02 bench       -> the bench lines (driver's form, default, bf16 mode, other shapes)
 # Results land in gpurun_out/<tag>/; copy what is to be kept into profiles/ (see profiles/README.md for the names).
-TAG=${1:-r02}; WHAT=${2:-bench}
+TAG=${1:-r03}; WHAT=${2:-bench}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 if [ "$WHAT" = profiles ]; then
   cd /tmp && export TMPDIR=/tmp
-  B="python $R/bench.py --no-cpu-baseline --ttfa-runs 0 --profile-steps 0"
+  B="python $R/bench.py --no-cpu-baseline --ttfa-runs 0 --profile-steps 0 --no-legs"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/l4 -o l4 -- $B --steps 8 --warmup 5 > $O/l4.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/l1 -o l1 -- $B --lanes 1 --steps 4 --warmup 2 > $O/l1.log 2>&1
   # counters in passes of their own, with the kernel trace only (no --stats, no sys / runtime traces)

@@ -18,8 +18,8 @@ import sys
 def fam(name: str) -> str:
     if "gemm_bf16s_kernel<1" in name:
         return "gemm_bf16x1_kernel"
-    if "gemm_bf16s_kernel<2" in name:
-        return "gemm_bf16x3_kernel"
+    if "gemm_bf16s_kernel<2" in name:  # the last template argument tells the fp16 pieces (f16x3: NAR) from the bf16 ones (bf16x3: Mimi)
+        return "gemm_f16x3_kernel" if name.split(">(")[0].rstrip().endswith("true") else "gemm_bf16x3_kernel"
     if "gemm_bf16s_kernel<3" in name:
         return "gemm_bf16x6_kernel"
     if "attn_window_mfma_kernel" in name:
