@@ -191,8 +191,10 @@ def rocprof_family_table() -> dict:
     if not files:
         return {}
     pat = {"gemm_f32_kernel": "gemm_f32_kernel", "gemm_bf16s_kernel<1,": "gemm_bf16x1_kernel", "gemm_bf16s_kernel<2,": "gemm_bf16x3_kernel",
-           "gemm_bf16s_kernel<3,": "gemm_bf16x6_kernel",  # (<2, ..., true> = the fp16 pieces of the NAR path: told apart below) "attention_kernel": "attention_kernel", "attn_window_mfma_kernel": "attention_kernel",
-           "attn_decode_kernel": "attention_kernel"}
+           "gemm_bf16s_kernel<3,": "gemm_bf16x6_kernel",  # (<2, ..., true> = the fp16 pieces of the NAR path: told apart below)
+           "attention_kernel": "attention_kernel", "attn_window_mfma_kernel": "attention_kernel", "attn_mfma_kernel": "attention_kernel",
+           "attn_decode_kernel": "attention_kernel", "seanet_tail_kernel": "seanet_tail_kernel", "seanet_res128_kernel": "seanet_res128_kernel",
+           "seanet_up128_kernel": "seanet_up128_kernel"}
     out: dict = {}
     try:
         for r in csv.DictReader(open(files[-1])):
@@ -527,6 +529,17 @@ def main() -> None:
     if "gemm_f32_kernel" in fam:
         entries.append((fam["gemm_f32_kernel"]["ms"], mfma_entry(
             "gemm_f32_kernel", "gemm_f32_kernel (all tile shapes; v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1, "")))
+    mimi_passes = 1 if args.precision == "bf16" else 3
+    for key, what in (("seanet_tail_kernel", "fused 24 kHz tail: last residual block + final convolution"),
+                      ("seanet_res128_kernel", "fused residual block of the 128-channel level"),
+                      ("seanet_up128_kernel", "weight-stationary last transposed convolution")):
+        if key in fam:
+            entries.append((fam[key]["ms"], mfma_entry(key, f"{key} ({what}; v_mfma_f32_32x32x16_bf16, {mimi_passes} pass(es) per product)",
+                                                       PEAK_BF16_MFMA_TFLOPS, mimi_passes, "16-bit operands, waveform contract 1e-4 of peak")))
+    if "attention_kernel" in fam and fam["attention_kernel"]["flops"] > 0:
+        entries.append((fam["attention_kernel"]["ms"], mfma_entry(
+            "attention_kernel", "attention_kernel family (attn_mfma_kernel: codec transformer window attention + reference cross-attention; v_mfma_f32_32x32x2_f32)",
+            PEAK_F32_MFMA_TFLOPS, 1, "")))
     if "ar_step_graph" in fam:
         f = fam["ar_step_graph"]
         inst_ms = f["ms"] / max(1, f["launches"])  # instrumented repeat (events around every replay; NAR / Mimi issued eagerly)

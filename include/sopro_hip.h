@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 31
+#define SOPRO_ABI_VERSION 32
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -366,6 +366,20 @@ int sopro_seanet_up128_f32(const float* x, int64_t x_seg_stride, const float* w,
                            int64_t out_seg_stride, int32_t B, int32_t T, int32_t passes, void* stream);
 int sopro_seanet_up_set_tiles(int tiles); /* developer probe / tests: 64-row tiles per workgroup, 0 = by size */
 int sopro_seanet_tail_set_tiles(int tiles); /* developer probe / tests: 126-sample tiles per workgroup, 0 = by size */
+
+/* ---- launch timing of the stage sequences (csrc/prof.hip) -------------------------------------
+ * bench.py's roofline leg (the reference has no counterpart: its profiler is torch's).  While enabled, every heavy launch
+ * of sopro_nar_refine / sopro_mimi_decode* / sopro_ar_fold_text is bracketed by two HIP events on its stream (never while the
+ * stream is capturing).  sopro_prof_collect waits for the events recorded so far, sums them per kernel family and forgets
+ * them.  gpu_bound / ms_bound / flops_bound cover the samples whose stream still had work queued when the first event was
+ * recorded (their span is GPU time only). */
+typedef struct sopro_prof_row {
+  char family[40];
+  int64_t launches, gpu_bound;
+  double flops, flops_bound, ms_all, ms_bound;
+} sopro_prof_row;
+int sopro_prof_enable(int on);
+int sopro_prof_collect(sopro_prof_row* rows, int32_t cap, int32_t* n_rows);
 
 /* ---- autoregressive driver state ----------------------------------------------------------- */
 /* Device-resident state of ar_stream (src/sopro/model.py:218-305) for up to `bcap` rows. All

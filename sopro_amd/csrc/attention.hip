@@ -157,7 +157,7 @@ int launch_attn(const sopro_attn_args& a, hipStream_t s) {
 
 }  // namespace
 
-int sopro_attn_window_mfma(const sopro_attn_args& a, hipStream_t s);  // attention_mfma.hip
+int sopro_attn_mfma(const sopro_attn_args& a, hipStream_t s);  // attention_mfma.hip
 
 extern "C" int sopro_attention_f32(const sopro_attn_args* p, void* stream) {
   SOPRO_CHECK_ARG(p != nullptr, "args is NULL");
@@ -169,10 +169,11 @@ extern "C" int sopro_attention_f32(const sopro_attn_args* p, void* stream) {
                       (a.v_bstride & 3) == 0,
                   "K/V must be 16-byte aligned with strides % 4 == 0");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // causal sliding-window self-attention with 64-wide heads (the codec transformers) runs on the matrix cores
-  if (a.dh == 64 && a.causal && a.Tq >= 16 && aligned16(a.Q) && aligned16(a.O) && (a.ldq & 3) == 0 && (a.ldo & 3) == 0 &&
-      (a.q_bstride & 3) == 0 && (a.o_bstride & 3) == 0)
-    return sopro_attn_window_mfma(a, s);
+  // causal sliding-window self-attention with 64-wide heads (the codec transformers) and dense attention (the reference
+  // cross-attention of the conditioning) run on the matrix cores
+  if ((a.causal ? a.dh == 64 : (a.dh == 64 || a.dh == 96 || a.dh == 192)) && a.Tq >= 16 && aligned16(a.Q) && aligned16(a.O) &&
+      (a.ldq & 3) == 0 && (a.ldo & 3) == 0 && (a.q_bstride & 3) == 0 && (a.o_bstride & 3) == 0 && !getenv("SOPRO_ATTN_VALU"))
+    return sopro_attn_mfma(a, s);
   switch (a.dh) {
     case 64: return launch_attn<64>(a, s);
     case 96: return launch_attn<96>(a, s);

@@ -1,8 +1,9 @@
-// Causal sliding-window self-attention with head dim 64 on the matrix cores (Mimi decoder / encoder transformers,
-// HF:modeling_mimi.py MimiAttention + sliding-window mask): exact fp32 v_mfma_f32_32x32x2_f32 in "transposed" form so
-// that a lane owns ONE query for the whole kernel:
+// Attention on the matrix cores: causal sliding-window self-attention with head dim 64 (Mimi decoder / encoder transformers,
+// HF:modeling_mimi.py MimiAttention + sliding-window mask) and the dense cross-attention over the reference voice with head dim
+// 192 / 96 (src/sopro/nn/xattn.py RefXAttnBlock; per-row key counts).  Exact fp32 v_mfma_f32_32x32x2_f32 in "transposed" form
+// so that a lane owns ONE query for the whole kernel:
 //     S^T [32 keys x 32 queries] = K_tile . Q^T        (A = K rows, B = Q rows: both read straight from HBM/L2)
-//     O^T [64 dims x 32 queries] += V_tile^T . P       (A = V columns; B = P = exp(S^T - m), the S^T accumulators as they are)
+//     O^T [DH dims x 32 queries] += V_tile^T . P       (A = V columns; B = P = exp(S^T - m), the S^T accumulators as they are)
 // In the MFMA C layout a lane holds column (lane & 31) = its query and 16 of the 32 key rows, which is exactly the B
 // operand layout of the second product (MFMA step r multiplies key rows k(r), k(r)+4), so P never leaves the registers;
 // the online-softmax statistics of a query are per lane plus one exchange with lane ^ 32; no LDS is used at all.
@@ -11,9 +12,9 @@
 
 namespace {
 
-constexpr int DH = 64;
-
-__global__ __launch_bounds__(256) void attn_window_mfma_kernel(const sopro_attn_args a) {
+template <int DH, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const sopro_attn_args a) {
+  constexpr int NC = DH / 8, NT = DH / 32;  // float4 fragments of a query / key row per lane; 32-wide output tiles
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qt = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
   const int q0 = qt * 32;
@@ -27,42 +28,45 @@ __global__ __launch_bounds__(256) void attn_window_mfma_kernel(const sopro_attn_
   // Q fragments of this lane's query: k = 8c + 4*half + s  (the same k order as the K fragments below)
   const int qi = min(q0 + col, a.Tq - 1);
   const int qabs = a.q_pos0 + qi;
-  float4 qf[8];
+  float4 qf[NC];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const float4*>(Qb + (int64_t)qi * a.ldq + c * 8 + half * 4);
+  for (int c = 0; c < NC; ++c) qf[c] = *reinterpret_cast<const float4*>(Qb + (int64_t)qi * a.ldq + c * 8 + half * 4);
 
-  f32x16 o0, o1;
+  f32x16 o[NT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // key range any query of the tile can see: q_abs - window < k_abs <= q_abs
-  const int q_lo_abs = a.q_pos0 + q0, q_hi_abs = a.q_pos0 + min(q0 + 31, a.Tq - 1);
-  int k_first = q_lo_abs - a.window + 1 - a.k_pos0;
-  int k_last = q_hi_abs - a.k_pos0;
-  k_first = max(k_first, 0);
-  k_last = min(k_last, klen - 1);
+  // key range any query of the tile can see: q_abs - window < k_abs <= q_abs (causal), every valid key otherwise
+  int k_first = 0, k_last = klen - 1;
+  if constexpr (CAUSAL) {
+    const int q_lo_abs = a.q_pos0 + q0, q_hi_abs = a.q_pos0 + min(q0 + 31, a.Tq - 1);
+    k_first = max(q_lo_abs - a.window + 1 - a.k_pos0, 0);
+    k_last = min(q_hi_abs - a.k_pos0, klen - 1);
+  }
   for (int k0 = (k_first / 32) * 32; k0 <= k_last; k0 += 32) {
     // ---- S^T = K_tile . Q^T
     const int kr = min(k0 + col, klen - 1);  // clamped: rows past the end are masked below
     const float* kp = Kb + (int64_t)kr * a.ldk + half * 4;
-    float4 kf[8];
+    float4 kf[NC];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) kf[c] = *reinterpret_cast<const float4*>(kp + c * 8);
+    for (int c = 0; c < NC; ++c) kf[c] = *reinterpret_cast<const float4*>(kp + c * 8);
     // V^T fragments: MFMA step r of the second product multiplies key rows k(r) + 4*half; lane reads column `col`
-    float vf0[16], vf1[16];
+    float vf[NT][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = min(k0 + (r & 3) + 8 * (r >> 2) + 4 * half, klen - 1);
       const float* vp = Vb + (int64_t)key * a.ldv + col;
-      vf0[r] = vp[0];
-      vf1[r] = vp[32];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) vf[t][r] = vp[32 * t];
     }
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < NC; ++c) {
       st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].x, qf[c].x, st, 0, 0, 0);
       st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].y, qf[c].y, st, 0, 0, 0);
       st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].z, qf[c].z, st, 0, 0, 0);
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void attn_window_mfma_kernel(const sopro_attn_
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int kabs = a.k_pos0 + key;
-      const bool ok = key < klen && kabs <= qabs && kabs > qabs - a.window;
+      const bool ok = key < klen && (!CAUSAL || (kabs <= qabs && kabs > qabs - a.window));
       st[r] = ok ? st[r] * a.scale : -INFINITY;
       mx = fmaxf(mx, st[r]);
     }
@@ -93,31 +97,41 @@ __global__ __launch_bounds__(256) void attn_window_mfma_kernel(const sopro_attn_
     l_run = l_run * alpha + ps;
     m_run = m_new;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) o[t][r] *= alpha;
     // ---- O^T += V_tile^T . P
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf0[r], st[r], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf1[r], st[r], o1, 0, 0, 0);
-    }
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t][r], st[r], o[t], 0, 0, 0);
   }
   // ---- O[q][d]: lane holds d = 32t + (r&3) + 8(r>>2) + 4*half of its query: four consecutive d per (t, r>>2)
   if (q0 + col < a.Tq) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     float* op = a.O + (int64_t)b * a.o_bstride + (int64_t)(q0 + col) * a.ldo + h * DH + half * 4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      *reinterpret_cast<float4*>(op + g * 8) = make_float4(o0[g * 4] * inv, o0[g * 4 + 1] * inv, o0[g * 4 + 2] * inv, o0[g * 4 + 3] * inv);
-      *reinterpret_cast<float4*>(op + 32 + g * 8) = make_float4(o1[g * 4] * inv, o1[g * 4 + 1] * inv, o1[g * 4 + 2] * inv, o1[g * 4 + 3] * inv);
-    }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(op + 32 * t + g * 8) =
+            make_float4(o[t][g * 4] * inv, o[t][g * 4 + 1] * inv, o[t][g * 4 + 2] * inv, o[t][g * 4 + 3] * inv);
   }
 }
 
 }  // namespace
 
-// called by sopro_attention_f32 for dh == 64 causal-window problems with 16-byte aligned rows
-int sopro_attn_window_mfma(const sopro_attn_args& a, hipStream_t s) {
+// called by sopro_attention_f32 for problems with 16-byte aligned rows: dh == 64 causal window, dh in {64, 96, 192} dense
+int sopro_attn_mfma(const sopro_attn_args& a, hipStream_t s) {
   dim3 grid(((a.Tq + 31) / 32 + 3) / 4, a.H, a.B);
-  hipLaunchKernelGGL(attn_window_mfma_kernel, grid, dim3(256), 0, s, a);
+  if (a.causal) {
+    hipLaunchKernelGGL((attn_mfma_kernel<64, true>), grid, dim3(256), 0, s, a);
+  } else if (a.dh == 64) {
+    hipLaunchKernelGGL((attn_mfma_kernel<64, false>), grid, dim3(256), 0, s, a);
+  } else if (a.dh == 96) {
+    hipLaunchKernelGGL((attn_mfma_kernel<96, false>), grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((attn_mfma_kernel<192, false>), grid, dim3(256), 0, s, a);
+  }
   SOPRO_LAUNCH_CHECK();
 }

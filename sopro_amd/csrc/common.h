@@ -96,3 +96,13 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// library-side launch timing (prof.hip): a scope around one heavy launch of a stage sequence; a no-op unless sopro_prof_enable(1)
+struct sopro_prof_scope {
+  void* rec;
+  hipStream_t s;
+  sopro_prof_scope(const char* family, double flops, hipStream_t s);
+  ~sopro_prof_scope();
+  sopro_prof_scope(const sopro_prof_scope&) = delete;
+  sopro_prof_scope& operator=(const sopro_prof_scope&) = delete;
+};

@@ -105,15 +105,42 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-      const unsigned char* a = es + (mt * 32 + frow) * REROW + fg * 16;
+    }
+    {
+      // both row tiles advance together (two independent accumulator chains) and the fragment reads run DEPTH substeps ahead
+      // of the MFMAs that consume them (left to itself the compiler emits read -> wait -> MFMA per substep: every LDS latency
+      // exposed); the scheduling barriers pin that order
+      constexpr int DEPTH = 2;
+      const unsigned char* a = es + frow * REROW + fg * 16;
+      auto fptr = [&](int s, int mt) { const int sg = kh * 12 + s; return a + mt * 32 * REROW + (sg >> 3) * REROW + (sg & 7) * 32; };
+      uint4 ah[DEPTH][2], al[DEPTH][2];
+#pragma unroll
+      for (int s = 0; s < DEPTH; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          ah[s][mt] = *reinterpret_cast<const uint4*>(fptr(s, mt));
+          al[s][mt] = *reinterpret_cast<const uint4*>(fptr(s, mt) + 2 * RC);
+        }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 12; ++s) {
-        const int sg = kh * 12 + s;
-        const unsigned char* p = a + (sg >> 3) * REROW + (sg & 7) * 32;
-        const uint4 ah = *reinterpret_cast<const uint4*>(p), al = *reinterpret_cast<const uint4*>(p + 2 * RC);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(al), rfrag(w1h[s]), acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w1l[s]), acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w1h[s]), acc[mt], 0, 0, 0);
+        uint4 ch[2], cl[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) { ch[mt] = ah[s % DEPTH][mt]; cl[mt] = al[s % DEPTH][mt]; }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(cl[mt]), rfrag(w1h[s]), acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ch[mt]), rfrag(w1l[s]), acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ch[mt]), rfrag(w1h[s]), acc[mt], 0, 0, 0);
+        if (s + DEPTH < 12) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            ah[s % DEPTH][mt] = *reinterpret_cast<const uint4*>(fptr(s + DEPTH, mt));
+            al[s % DEPTH][mt] = *reinterpret_cast<const uint4*>(fptr(s + DEPTH, mt) + 2 * RC);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // the two K halves of a block meet through LDS: wave (nt, kh) keeps row tile kh and hands row tile 1-kh to wave (nt, 1-kh)

@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256, 2) void seanet_tail_kernel(const float* __rest
       const int idx = tid + q * 256;       // float4 index: 16 per row
       const int r = idx >> 4, c4 = idx & 15;
       const int p = s0 - 2 + r;            // padded row
-      v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < HR && p >= 0 && p < T + 2) v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)p * 64 + c4 * 4);
+      const int pc = (r < HR && p >= 0 && p < T + 2) ? p : 0;  // outside the segment: padded row 0, a zero row (branch-free loads)
+      v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)pc * 64 + c4 * 4);
     }
   };
   if (!LOOP) load_tile((int)blockIdx.x * TO);  // looped variant: requested per tile (the weight fragments fill the registers here)
@@ -88,19 +88,6 @@ __global__ __launch_bounds__(256, 2) void seanet_tail_kernel(const float* __rest
   if (s0 >= T) break;  // uniform over the workgroup
   if (it > 0) __syncthreads();  // the previous tile's last phase is done with the LDS tiles
   if (LOOP) load_tile(s0);
-  // skip operand of the residual block in the accumulator layout of the second convolution (row mr, column frow / 32+frow),
-  // (an L2-resident re-read of rows the tile request brought in), consumed two phases later
-  float skip[2][16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
-    const int p = s0 + mr;  // padded row of sample s0-2+mr
-    const bool in = p >= 2 && p < T + 2;
-    const float* hp = hb + (int64_t)(in ? p : 2) * 64 + frow;
-    skip[0][r] = in ? hp[0] : 0.f;
-    skip[1][r] = in ? hp[32] : 0.f;
-  }
-
   // ELU + split once per element
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
@@ -116,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void seanet_tail_kernel(const float* __rest
   }
   __syncthreads();
 
+  float skip[2][16];
   // ---- conv k=3, 64 -> 32: intermediate row m (sample s0-2+m) reads tile rows m, m+1, m+2; wave w owns rows 32w..32w+31.
   // K index = tap*64 + channel; substep s covers tap s/4, channels 16*(s%4) .. +15
   {
@@ -123,13 +111,41 @@ __global__ __launch_bounds__(256, 2) void seanet_tail_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const unsigned char* a = es + (wave * 32 + frow) * EROW + fg * 16;
+    // the fragment reads run DEPTH substeps ahead of the MFMAs that consume them (left to itself the compiler emits
+    // read -> wait -> MFMA per substep); the scheduling barriers pin that order
+    constexpr int DEPTH = 4;
+    uint4 ah[DEPTH], al[DEPTH];
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+      const unsigned char* p = a + (s >> 2) * EROW + (s & 3) * 32;
+      ah[s] = *reinterpret_cast<const uint4*>(p);
+      al[s] = *reinterpret_cast<const uint4*>(p + 128);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 12; ++s) {
-      const unsigned char* p = a + (s >> 2) * EROW + (s & 3) * 32;
-      const uint4 ah = *reinterpret_cast<const uint4*>(p), al = *reinterpret_cast<const uint4*>(p + 128);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(al), frag(w1h[s]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah), frag(w1l[s]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah), frag(w1h[s]), acc, 0, 0, 0);
+      const uint4 ch = ah[s % DEPTH], cl = al[s % DEPTH];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(cl), frag(w1h[s]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ch), frag(w1l[s]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ch), frag(w1h[s]), acc, 0, 0, 0);
+      if (s + DEPTH < 12) {
+        const unsigned char* p = a + ((s + DEPTH) >> 2) * EROW + ((s + DEPTH) & 3) * 32;
+        ah[s % DEPTH] = *reinterpret_cast<const uint4*>(p);
+        al[s % DEPTH] = *reinterpret_cast<const uint4*>(p + 128);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // skip operand of the residual block in the accumulator layout of the second convolution (row mr, column frow / 32+frow):
+    // an L2-resident re-read of rows the tile request brought in, requested here - behind this phase's matrix-core work, so that
+    // its 32 registers are free for the fragment reads that run ahead of the MFMAs - and consumed behind the next phase's
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+      const int p = s0 + mr;  // padded row of sample s0-2+mr
+      const bool in = p >= 2 && p < T + 2;
+      const float* hp = hb + (int64_t)(in ? p : 0) * 64 + frow;  // outside: padded row 0, a zero row
+      skip[0][r] = hp[0];
+      skip[1][r] = hp[32];
     }
     // D[r]: row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 -> ELU, split, one bf16 per plane
 #pragma unroll

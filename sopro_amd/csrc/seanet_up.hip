@@ -110,24 +110,36 @@ __global__ __launch_bounds__(512, 1) void seanet_up128_kernel(const float* __res
       for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
     // K index = tap * 128 + channel; substep s covers tap s / 8 (LDS row + tap), channels 16 * (s % 8) .. + 15
     const unsigned char* a0 = es_all + cur * (UHR * UROW) + frow * UROW + fg * 16;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {  // (reading the fragments a substep ahead in the source, or pinning read / MFMA groups with
-      // sched_group_barrier, compiles to the same dependent read -> MFMA order; two waves per SIMD cover for each other)
+    // the fragment reads run DEPTH substeps ahead of the MFMAs that consume them; the scheduling barriers pin that order (left
+    // to itself - or with sched_group_barrier - the compiler emits read -> wait -> MFMA per substep: every LDS latency exposed)
+    constexpr int DEPTH = 2;
+    uint4 ah[DEPTH][2], al[DEPTH][2];
+    auto fread = [&](int s, int slot) {
       const unsigned char* p = a0 + (s >> 3) * UROW + (s & 7) * 32;
-      uint4 ah[2], al[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        ah[mt] = *reinterpret_cast<const uint4*>(p + mt * 32 * UROW);
-        if (PASSES == 3) al[mt] = *reinterpret_cast<const uint4*>(p + mt * 32 * UROW + 2 * UC);
+        ah[slot][mt] = *reinterpret_cast<const uint4*>(p + mt * 32 * UROW);
+        if (PASSES == 3) al[slot][mt] = *reinterpret_cast<const uint4*>(p + mt * 32 * UROW + 2 * UC);
       }
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) fread(s, s);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      uint4 ch[2], cl[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) { ch[mt] = ah[s % DEPTH][mt]; if (PASSES == 3) cl[mt] = al[s % DEPTH][mt]; }
       if (PASSES == 3) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag(al[mt]), ufrag(wh[s]), acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag(cl[mt]), ufrag(wh[s]), acc[mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag(ah[mt]), ufrag(wl[s]), acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag(ch[mt]), ufrag(wl[s]), acc[mt], 0, 0, 0);
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag(ah[mt]), ufrag(wh[s]), acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag(ch[mt]), ufrag(wh[s]), acc[mt], 0, 0, 0);
+      if (s + DEPTH < 16) fread(s + DEPTH, s % DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- store: register r of a lane is row 8 * (r / 4) + 4 * (lane >> 5) + r % 4 of its 32-row block, column lane & 31
     float* ot = ob + (int64_t)t0 * UN;  // wave-uniform base + a 32-bit lane offset: no 64-bit address per store

@@ -5,6 +5,7 @@
 // and against the oracle.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -229,6 +230,20 @@ struct G {  // one contraction: mirrors sopro_amd.hip.gemm's keyword arguments
   const SplitK* sk = nullptr;  // non-NULL: few-row problems may run split-K on this scratch
 };
 
+// attention launch with its timing scope: 4 * dh flops per visible (query, key) pair
+int attend(const sopro_attn_args& a, hipStream_t s) {
+  double pairs = (double)a.Tq * a.Tk;
+  if (a.causal) {
+    pairs = 0;
+    for (int q = 0; q < a.Tq; ++q) {
+      const int hi = std::min(a.Tk - 1, a.q_pos0 + q - a.k_pos0), lo = std::max(0, a.q_pos0 + q - a.window + 1 - a.k_pos0);
+      pairs += std::max(0, hi - lo + 1);
+    }
+  }
+  sopro_prof_scope prof("attention_kernel", 4.0 * a.dh * pairs * a.B * a.H, s);
+  return sopro_attention_f32(&a, s);
+}
+
 int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override, float* C, const G& o) {
   const int n_out = o.epi == SOPRO_EPI_GLU ? o.N / 2 : o.N;
   sopro_gemm_args g;
@@ -250,7 +265,10 @@ int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override
   g.M = o.M; g.N = o.N; g.K = o.K;
   g.rows_per_seg = o.rows_per_seg < 0 ? o.M : o.rows_per_seg;
   g.prologue = o.pro; g.epilogue = o.epi;
-  if (!w_f32_override && w.packed) {
+  const bool split = !w_f32_override && w.packed;
+  sopro_prof_scope prof(!split ? "gemm_f32_kernel" : w.f16 ? "gemm_f16x3_kernel" : w.pieces == 3 ? "gemm_bf16x6_kernel"
+                        : w.pieces == 1 ? "gemm_bf16x1_kernel" : "gemm_bf16x3_kernel", 2.0 * o.M * o.N * o.K, s);
+  if (split) {
     sopro_gemm_split_ext x;
     memset(&x, 0, sizeof(x));
     x.c_mode = o.c_mode;
@@ -823,12 +841,12 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
       if (sst->evict && Tk > c.mimi_window - 1) {
         const int keep = c.mimi_window - 1;
         float* other = sst->kv + ((size_t)(l * 2 + (sst->half ^ 1)) * sst->cap_rows) * 2 * HS;
-        STG(sopro_attention_f32(&a, s));
+        STG(attend(a, s));
         STG(sopro_copy2d_u32(other, 2 * HS, cache + (size_t)(Tk - keep) * 2 * HS, 2 * HS, keep, 2 * HS, s));
         goto attended;
       }
     }
-    STG(sopro_attention_f32(&a, s));
+    STG(attend(a, s));
   attended:;
     G og; og.sk = &w.sk; og.M = B * n; og.N = HS; og.K = HS; og.epi = SOPRO_EPI_RES; og.R = w.X + (size_t)PADX * HS; og.scale = F(e, p + ".ls1");
     og.c_seg = xs; og.r_seg = xs; og.rows_per_seg = n;
@@ -858,16 +876,21 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     const float* A = He + (size_t)(pad_in - 1) * ch;
     if (last) {
       SOPRO_CHECK_ARG(co == 64 && hid == 32, "the fused tail is written for a 64-channel last stage");
-      if (ch == 128 && r == 4)  // weight-stationary form of the K = 256, N = 256 contraction (same results)
+      if (ch == 128 && r == 4) {  // weight-stationary form of the K = 256, N = 256 contraction (same results)
+        sopro_prof_scope prof("seanet_up128_kernel", 2.0 * B * rows * 256 * 256, s);
         STG(sopro_seanet_up128_f32(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), Ho + 2 * co, up.c_seg, B, rows, c.precision == 1 ? 1 : 3, s));
-      else
+      } else {
         STG(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
+      }
+      // last residual block (k=3 conv 64->32, k=1 conv 32->64) + final k=3 conv 64->1 per output sample
+      sopro_prof_scope prof("seanet_tail_kernel", 2.0 * B * orow * (3 * 64 * 32 + 32 * 64 + 3 * 64), s);
       return sopro_seanet_tail_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"),
                                    F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, orow, s);
     }
     float* Hn = w.hact[si];
     if (co == 128 && hid == 64) {
       STG(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
+      sopro_prof_scope prof("seanet_res128_kernel", 2.0 * B * orow * (3 * 128 * 64 + 64 * 128), s);
       STG(sopro_seanet_res128_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
                                   (int64_t)(2 + orow) * co, B, orow, s));
     } else {

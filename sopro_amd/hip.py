@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -189,6 +189,8 @@ SYMBOLS = {
     "sopro_ar_issue_frame": (C.c_int, [C.POINTER(ArFrame), _p]),
     "sopro_ar_fold_text": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p]),
     "sopro_engine_set_ar_tiles": (C.c_int, [_p, _i32, _i32, _i32, _i32]),
+    "sopro_prof_enable": (C.c_int, [C.c_int]),
+    "sopro_prof_collect": (C.c_int, [_p, _i32, _p]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -221,6 +223,11 @@ def load() -> C.CDLL:
     return lib
 
 
+class ProfRow(C.Structure):  # sopro_prof_row
+    _fields_ = [("family", C.c_char * 40), ("launches", C.c_int64), ("gpu_bound", C.c_int64), ("flops", C.c_double),
+                ("flops_bound", C.c_double), ("ms_all", C.c_double), ("ms_bound", C.c_double)]
+
+
 class Profiler:
     """HIP-event timing of the heavy launches, recorded on the stream each launch is enqueued on
     (bench.py's roofline leg).  Families: the GEMM kernels, the attention kernel, AR graph replays.
@@ -245,8 +252,21 @@ class Profiler:
     def summary(self) -> dict:
         torch.cuda.synchronize()
         out: dict = {}
+        new = lambda: {"ms": 0.0, "launches": 0, "flops": 0.0, "ms_all": 0.0, "gpu_bound": 0, "ms_bound": 0.0, "flops_bound": 0.0}  # noqa: E731
+        # the launches of the stage sequences (NAR refinement, Mimi decoding, text folding) are timed inside the library
+        rows = (ProfRow * 32)()
+        n = C.c_int32(0)
+        _check(load().sopro_prof_collect(rows, 32, C.byref(n)), "sopro_prof_collect")
+        for r in rows[: n.value]:
+            d = out.setdefault(r.family.decode(), new())
+            d["launches"] += r.launches
+            d["flops"] += r.flops
+            d["ms_all"] += r.ms_all
+            d["gpu_bound"] += r.gpu_bound
+            d["ms_bound"] += r.ms_bound
+            d["flops_bound"] += r.flops_bound
         for fam, fl, e0, e1, bound in self.rec:
-            d = out.setdefault(fam, {"ms": 0.0, "launches": 0, "flops": 0.0, "ms_all": 0.0, "gpu_bound": 0, "ms_bound": 0.0, "flops_bound": 0.0})
+            d = out.setdefault(fam, new())
             t = e0.elapsed_time(e1)
             d["ms_all"] += t
             d["launches"] += 1
@@ -272,6 +292,7 @@ phase_log = None  # bench.py: list receiving (frames, rows, ev0, ev1) per AR pha
 def set_profiler(p: Optional[Profiler]) -> None:
     global _prof
     _prof = p
+    load().sopro_prof_enable(1 if p is not None else 0)
 
 
 def _check(rc: int, what: str) -> None:
@@ -628,7 +649,8 @@ def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor
     e0 = _prof.begin() if _prof is not None else None
     _check(load().sopro_attention_f32(C.byref(a), _stream()), "sopro_attention_f32")
     if e0 is not None:
-        _prof.end("attention_kernel", 0.0, e0)
+        pairs = float(Tq) * Tk if not causal else float(sum(max(0, min(Tk - 1, q_pos0 + q - k_pos0) - max(0, q_pos0 + q - window + 1 - k_pos0) + 1) for q in range(Tq)))
+        _prof.end("attention_kernel", 4.0 * dh * pairs * B * H, e0)
 
 
 def xattn_step(X: torch.Tensor, Y: torch.Tensor, norm_w: Optional[torch.Tensor], Kp: torch.Tensor, Vp: torch.Tensor, klens: Optional[torch.Tensor], *,
@@ -743,7 +765,7 @@ class Graph:
         # Never destroy here: the collector may run this INSIDE another recording (any allocation can trigger it), and
         # hipGraphExecDestroy during a stream capture invalidates that capture ("operation failed due to a previous error
         # during capture", seen once in a few suite runs).  The handle is parked and destroyed at the next safe point.
-        if self.handle:
+        if self.handle and _dead_graphs is not None:  # (None: module globals already torn down at interpreter exit)
             _dead_graphs.append(self.handle)
             self.handle = 0
 

@@ -138,6 +138,9 @@ class SoproTTSModel:
         # not depend on them).  SOPRO_AR_TILES="glu:2x1,ff1:2x2,..." or "2x2" for all.
         self.ar_tiles = {"glu": "1x1", "ff1": "1x1", "ff2": "1x1", "head": "1x1"}
         self.set_ar_tiles(os.environ.get("SOPRO_AR_TILES", ""))
+        # shape used instead for frames of more than 32 rows; a pipeline sets "1x2" on its 64-CU generation partition, where two
+        # column tiles per workgroup are 5 % faster at 64 rows (profiles/r03_ar_tile_sweep_64rows.txt) and slower on the whole chip
+        self.ar_tiles_wide: Optional[str] = None
         # the stage engine (csrc/stages.hip): the NAR launch sequence and its packed operands live in the library; the lanes of a
         # pipeline share it (read-only after finalize), each with its own workspace and stream
         from .stages import model_engine
@@ -762,7 +765,8 @@ class _ARPlan:
         f.klens = hip.ptr(self.klens, torch.int32)
         f.n_layers, f.B, f.D, f.S_cap, f.V1, f.H, f.ksize = len(cfg.ar_dilations), self.B, D, self.S_cap, m.V + 1, 4, int(cfg.ar_kernel)
         f.w_layout = 2 if bf16 else 1
-        f.tile_glu, f.tile_ff1, f.tile_ff2, f.tile_head = (hip.ar_tile_code(m.ar_tiles[k]) for k in ("glu", "ff1", "ff2", "head"))
+        wide = m.ar_tiles_wide if self.B > 32 else None
+        f.tile_glu, f.tile_ff1, f.tile_ff2, f.tile_head = (hip.ar_tile_code(wide or m.ar_tiles[k]) for k in ("glu", "ff1", "ff2", "head"))
         f.eps = RMS_EPS
         f.st = self.state
         return f

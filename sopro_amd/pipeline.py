@@ -12,6 +12,7 @@ lanes; results are identical to the sequential path (same kernels, same order pe
 """
 from __future__ import annotations
 
+import os
 import threading
 from typing import Any, Callable, Dict, List, Optional, Sequence
 
@@ -57,6 +58,8 @@ class PipelinedSynthesizer:
             lane.model._ar_cache.clear()  # recorded graphs belong to the stream they were captured on
             lane.model._nar_graphs.clear()
             lane.codec._graphs.clear()
+            if os.environ.get("SOPRO_AR_TILES_WIDE", "1x2") not in ("", "0"):
+                lane.model.ar_tiles_wide = os.environ.get("SOPRO_AR_TILES_WIDE", "1x2")  # coalesced (64-row) frames on the small partition
             self.lanes.append(lane)
         # An empty pipeline has nothing on the throughput partition yet: the first AR phase of each partition lock gets an equal
         # share of the WHOLE chip (the recorded frame graph replays on any stream), which shortens the fill of the pipeline.
@@ -113,6 +116,7 @@ class PipelinedSynthesizer:
             lane.codec.ws.clear()
         lane0 = self.lanes[0]
         lane0.model._driver = None
+        lane0.model.ar_tiles_wide = None
         lane0.model.stream, lane0.model.bulk_stream, lane0.codec.stream, lane0.model.prep_stream = self._saved
         self.lanes = []
         torch.cuda.synchronize(self.device)

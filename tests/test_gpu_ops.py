@@ -710,7 +710,7 @@ def test_gathers():
 
 
 # ---------------------------------------------------------------------------------------- attention
-@pytest.mark.parametrize("H,dh,Tq,Tk", [(4, 96, 1, 19), (4, 96, 1, 130), (2, 192, 49, 30), (2, 192, 401, 150), (8, 64, 40, 40)])
+@pytest.mark.parametrize("H,dh,Tq,Tk", [(4, 96, 1, 19), (4, 96, 1, 130), (2, 192, 49, 30), (2, 192, 401, 150), (8, 64, 40, 40), (4, 96, 33, 70), (2, 192, 201, 150), (2, 192, 16, 2)])
 def test_attention_cross(H, dh, Tq, Tk):
     B, D = 3, H * dh
     q, k, v = rnd(B, Tq, D, seed=70), rnd(B, Tk, D, seed=71), rnd(B, Tk, D, seed=72)

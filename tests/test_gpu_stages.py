@@ -130,6 +130,31 @@ def test_streaming_decode_through_the_c_stage(eng, tts_noeos, trim):
     assert cdec.st.pos == pst.pos and cdec.st.kv_len == pst.kv_len and cdec.st.evict == int(pst.evict)
 
 
+def test_library_profiler_times_the_stage_launches(tts_noeos):
+    """sopro_prof_enable / sopro_prof_collect (csrc/prof.hip): while bench.py's profiler is attached the launches of the NAR
+    and Mimi sequences are bracketed inside the library and come back per kernel family with their algorithmic flops."""
+    from sopro_amd import hip
+
+    tts = tts_noeos
+    rng = np.random.default_rng(5)
+    toks = torch.from_numpy(rng.integers(0, 2048, size=(2, 40, 32))).to(tts.device)
+    want = tts.codec.decode_batch(toks).clone()
+    cond = torch.randn(2, 40, 384, device=tts.device)
+    p = hip.Profiler()
+    hip.set_profiler(p)
+    try:
+        got = tts.codec.decode_batch(toks).clone()
+        tts.model.nar_refine(cond, toks[:, :, 0].contiguous())
+    finally:
+        hip.set_profiler(None)
+    fam = p.summary()
+    assert torch.equal(got, want)  # the timed (eager) sequence is the recorded one
+    for k in ("gemm_bf16x3_kernel", "gemm_f16x3_kernel", "attention_kernel", "seanet_tail_kernel", "seanet_res128_kernel", "seanet_up128_kernel"):
+        assert k in fam and fam[k]["launches"] > 0 and fam[k]["flops"] > 0 and fam[k]["ms_all"] > 0, (k, fam.get(k))
+    assert fam["seanet_tail_kernel"]["launches"] == 1 and fam["seanet_tail_kernel"]["flops"] == 2.0 * 2 * 40 * 1920 * (3 * 64 * 32 + 32 * 64 + 3 * 64)
+    assert hip.Profiler().summary() == {}  # collected records are gone
+
+
 def test_missing_tensor_is_reported_by_name(tts_noeos):
     import ctypes as C
     from sopro_amd import hip

@@ -25,7 +25,8 @@ ids, ref_tq = make_inputs(0)
 ref = tts.prepare_reference(ref_tokens_tq=ref_tq)
 lanes = [tts, tts.clone_lane()]
 kw = dict(top_p=0.9, temperature=1.05, anti_loop=True)
-preps = [l.model.prepare_conditioning_batch(ids[:B], [ref] * B, max_frames=steps - 1) for l in lanes]
+idsB = [ids[i % len(ids)] for i in range(B)]
+preps = [l.model.prepare_conditioning_batch(idsB, [ref] * B, max_frames=steps - 1) for l in lanes]
 part = [hip.cu_range_stream(0, 64, dev) for _ in lanes]
 whole = torch.cuda.Stream()
 bulk = hip.cu_range_stream(64, 192, dev)

@@ -22,7 +22,7 @@ def fam(name: str) -> str:
         return "gemm_f16x3_kernel" if name.split(">(")[0].rstrip().endswith("true") else "gemm_bf16x3_kernel"
     if "gemm_bf16s_kernel<3" in name:
         return "gemm_bf16x6_kernel"
-    if "attn_window_mfma_kernel" in name:
+    if "attn_window_mfma_kernel" in name or "attn_mfma_kernel" in name:
         return "attention_kernel"
     for k in ("gemm_f32_kernel", "skinny_kernel", "xattn_step_kernel", "ar_sample_kernel", "seanet_tail_kernel", "seanet_res128_kernel", "seanet_up128_kernel",
               "attention_kernel", "argmax_partials_kernel"):
