@@ -733,6 +733,8 @@ def main() -> None:
                              "pinned_cores_rank0": (len(pinned) if pinned else None)},
             "host_cpu_note": "CPU time of all threads of this rank's process over the timed region / steps (launch threads of the lanes included)",
             "legs": legs, "roofline_dropped": dropped,
+            "unpinned": ["sinc_resample of the reference-audio front end (SURVEY 8f rank 1, outside this line's timed path): pinned by derivation "
+                         "only - torchaudio is not in the image to generate a fixture from"],
             "roofline": roof, "roofline_more": roof_more, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)
