@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 32
+#define SOPRO_ABI_VERSION 33
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -307,6 +307,8 @@ typedef struct sopro_attn_args {
   int32_t B, H, dh, Tq, Tk;
   int32_t causal, q_pos0, k_pos0, window;
   float scale;
+  const int32_t* kv_index;  /* NULL, or [B]: batch row b reads K / V block kv_index[b] (x k_bstride / v_bstride) instead of block b:
+                             * rows that share a voice share one copy of its keys (sopro_attention_f32 only) */
 } sopro_attn_args;
 int sopro_attention_f32(const sopro_attn_args* args, void* stream);
 /* Tq == 1 form for the AR frame (cached text K/V, src/sopro/nn/text.py:85-132): one workgroup per
@@ -494,13 +496,16 @@ typedef struct sopro_engine_cfg {
   float mimi_norm_eps, mimi_final_bias;
   int32_t precision;                 /* 0: the fp32 parity configuration (AR exact fp32, NAR f16x3, Mimi bf16x3); 1: the bf16 mode
                                       * (bf16 AR weights, one-pass NAR / Mimi contractions, fp32 accumulators / norms / residuals) */
+  /* conditioning side (src/sopro/config.py): text encoder, reference encoder, reference cross-attention, Token2SV */
+  int32_t n_layers_text, ref_enc_layers, ref_xattn_layers, ref_xattn_heads, sv_student_dim, enc_kernel /* 7: both encoders */;
 } sopro_engine_cfg;
 int sopro_engine_create(const sopro_engine_cfg* cfg, sopro_engine** out);
 /* name: a key of sopro_amd.pack.pack_sopro / pack_mimi ("ar.blocks.0.glu.w", "nar.heads.B.w", "tr.3.qkv.w", "sea.up1.w", ...)
  * plus "rope.cos" / "rope.sin" [positions, head_dim / 2].  The engine keeps the pointer; the caller keeps the memory. */
 int sopro_engine_set_tensor(sopro_engine* e, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim);
 /* builds the packed operand forms (allocates device memory).  A stage family takes part when its marker tensor was given -
- * "ar.head.w" (AR), "nar.pre.w" (NAR), "rvq_proj.w" (Mimi decoder) - and must then be complete; a stage call on an engine
+ * "ar.head.w" (AR), "nar.pre.w" (NAR), "rvq_proj.w" (Mimi decoder), "text_enc.embed" (conditioning + reference preparation,
+ * with the position table "pe" [positions, D]) - and must then be complete; a stage call on an engine
  * without its family is refused.  After this call the engine is read-only except for its AR plan: NAR / Mimi calls of several
  * host threads (lanes with their own workspaces and streams) may share it. */
 int sopro_engine_finalize(sopro_engine* e, void* stream);
@@ -513,6 +518,28 @@ int sopro_ar_fold_text(const float* txt, const float* nkv_weight, const float* k
 int sopro_engine_destroy(sopro_engine* e);
 /* workgroup shapes of the AR-step stage kinds, (mt << 4) | nt each (see sopro_skinny_args; 0 = 1 x 1).  Drops a recorded frame graph. */
 int sopro_engine_set_ar_tiles(sopro_engine* e, int32_t glu, int32_t ff1, int32_t ff2, int32_t head);
+
+/* ---- conditioning stage (src/sopro/model.py:172-216 for B utterances at once): text encoder (src/sopro/nn/text.py:29-44),
+ * pooled text + frame positions (model.py:200-202), SpeakerFiLM with per-row coefficients (src/sopro/nn/speaker.py:76-85; made
+ * once per voice by sopro_film_coeffs), the reference cross-attention blocks over the voices' cached K / V
+ * (src/sopro/nn/ref.py:54-108), cond_norm (model.py:208).  ids [B, S] int32 (rows padded with anything past lens[b]), lens [B],
+ * ragged != 0 when some lens[b] < S; film_mul / film_add [B, D]; ref_k[i] / ref_v[i] (host arrays of ref_xattn_layers device
+ * pointers): dense [*, Tr, D] keys / values per layer, block of row b = (kv_index ? kv_index[b] : b) * kv_bstride floats in
+ * (kv_bstride 0: one voice for all rows); ref_klens [B] or NULL (= Tr).  Out: txt_seq [B, S, D], txt_pool [B, D],
+ * cond_ar [B, Tar, D].  Launches only. */
+int64_t sopro_cond_workspace_bytes(const sopro_engine* e, int32_t B, int32_t S, int32_t Tar);
+int sopro_cond_prepare(sopro_engine* e, void* workspace, const int32_t* ids, const int32_t* lens, int32_t ragged, const float* film_mul, const float* film_add,
+                       const float* const* ref_k, const float* const* ref_v, int64_t kv_bstride, const int32_t* kv_index, const int32_t* ref_klens,
+                       int32_t B, int32_t S, int32_t Tar, int32_t Tr, float* txt_seq, float* txt_pool, float* cond_ar, void* stream);
+/* SpeakerFiLM coefficients of n voices (speaker.py:76-85): sv [n, sv_student_dim] -> mul = 1 + style * tanh(gamma), add = style *
+ * tanh(beta), both [n, D]; scratch: n * 5 * D floats. */
+int sopro_film_coeffs(sopro_engine* e, const float* sv, float style, int32_t n, float* scratch, float* mul, float* add, void* stream);
+/* Reference preparation of one voice from its codec tokens (src/sopro/model.py:151-170): Token2SV (src/sopro/nn/speaker.py:37-61)
+ * -> sv [sv_student_dim]; reference sequence encoder (model.py:133-149) -> ref_seq [T, D]; K | V rows of every reference
+ * cross-attention block (src/sopro/nn/ref.py:120-128) -> kv[i] [T, 2 D] (host array of ref_xattn_layers device pointers).
+ * tokens [T, Q] int32.  Launches only. */
+int64_t sopro_ref_workspace_bytes(const sopro_engine* e, int32_t T);
+int sopro_ref_prepare(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t T, float* sv, float* ref_seq, float* const* kv, void* stream);
 
 /* ---- autoregressive stage.  S_cap = S rounded up to 64.  The workspace must stay alive (and untouched) until the tokens
  * have been read; one generation at a time per engine. */

@@ -27,8 +27,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const sopro_attn_args a)
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int q0 = qt * TQ;
   const float* Qb = a.Q + (int64_t)b * a.q_bstride + h * DH;
-  const float* Kb = a.K + (int64_t)b * a.k_bstride + h * DH;
-  const float* Vb = a.V + (int64_t)b * a.v_bstride + h * DH;
+  const int kb = a.kv_index ? a.kv_index[b] : b;  // rows that share a voice share one copy of its keys / values
+  const float* Kb = a.K + (int64_t)kb * a.k_bstride + h * DH;
+  const float* Vb = a.V + (int64_t)kb * a.v_bstride + h * DH;
   const int klen = a.klens ? min(a.klens[b], a.Tk) : a.Tk;
 
   for (int idx = tid; idx < TQ * DH; idx += 256) {
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const sopro_attn_args 
 }  // namespace
 
 extern "C" int sopro_attn_decode_f32(const sopro_attn_args* p, void* stream) {
+  SOPRO_CHECK_ARG(p == nullptr || p->kv_index == nullptr, "kv_index is a sopro_attention_f32 feature");
   SOPRO_CHECK_ARG(p != nullptr, "args is NULL");
   const sopro_attn_args& a = *p;
   SOPRO_CHECK_ARG(a.Q && a.K && a.V && a.O, "Q, K, V, O must be non-NULL");

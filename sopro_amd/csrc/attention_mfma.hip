@@ -21,8 +21,9 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const sopro_attn_args a)
   if (q0 >= a.Tq) return;  // whole wave
   const int col = lane & 31, half = lane >> 5;
   const float* Qb = a.Q + (int64_t)b * a.q_bstride + h * DH;
-  const float* Kb = a.K + (int64_t)b * a.k_bstride + h * DH;
-  const float* Vb = a.V + (int64_t)b * a.v_bstride + h * DH;
+  const int kb = a.kv_index ? a.kv_index[b] : b;  // rows that share a voice share one copy of its keys / values
+  const float* Kb = a.K + (int64_t)kb * a.k_bstride + h * DH;
+  const float* Vb = a.V + (int64_t)kb * a.v_bstride + h * DH;
   const int klen = a.klens ? min(a.klens[b], a.Tk) : a.Tk;
 
   // Q fragments of this lane's query: k = 8c + 4*half + s  (the same k order as the K fragments below)

@@ -66,7 +66,8 @@ struct sopro_engine {
   std::map<std::string, const float*> sk;  // AR-step weights in skinny fragment order
   std::vector<void*> owned;
   bool final = false;
-  bool has_ar = false, has_nar = false, has_mimi = false;  // families whose tensors were given before sopro_engine_finalize
+  bool has_ar = false, has_nar = false, has_mimi = false, has_cond = false;  // families whose tensors were given before sopro_engine_finalize
+  int32_t *q_col = nullptr, *q_off = nullptr;  // conditioning: codebook columns 0..Q-1 and their table offsets q * V
   // NAR constants
   std::vector<int32_t*> nar_cols, nar_offs;
   std::vector<float*> nar_cw, ad_mul, ad_add;
@@ -358,7 +359,8 @@ int sopro_engine_finalize(sopro_engine* e, void* stream) {
   e->has_ar = e->t.count("ar.head.w") != 0;
   e->has_nar = e->t.count("nar.pre.w") != 0;
   e->has_mimi = e->t.count("rvq_proj.w") != 0;
-  if (!e->has_ar && !e->has_nar && !e->has_mimi) {
+  e->has_cond = e->t.count("text_enc.embed") != 0;
+  if (!e->has_ar && !e->has_nar && !e->has_mimi && !e->has_cond) {
     // report the first tensor of the first stage by name (what a host that forgot sopro_engine_set_tensor wants to read)
     STG(need(e, "ar.blocks.0.glu.w", &t, 2));
   }
@@ -449,6 +451,34 @@ int sopro_engine_finalize(sopro_engine* e, void* stream) {
       }
     }
   }
+  // ---- conditioning + reference preparation: the two encoders' contractions on three bf16 pieces / six passes (24 mantissa
+  // bits: they feed the AR loop's conditioning), their RMSNorm weights folded into the projections they feed
+  if (e->has_cond) {
+    SOPRO_CHECK_ARG(c.n_layers_text >= 1 && c.ref_enc_layers >= 1 && c.ref_xattn_layers >= 1 && c.ref_xattn_layers <= 8 && c.ref_xattn_heads >= 1 &&
+                        c.sv_student_dim >= 1 && c.enc_kernel >= 1, "conditioning fields of sopro_engine_cfg are not set");
+    auto enc_block = [&](const std::string& p) -> int {
+      STG(pack_pieces(e, p + ".glu.w", p + ".glu.wn", 3, (p + ".norm.weight").c_str(), s));
+      STG(pack_pieces(e, p + ".ff1.w", p + ".ff1.wn", 3, (p + ".ff.norm.weight").c_str(), s));
+      STG(pack_pieces(e, p + ".ff2.w", p + ".ff2.w", 3, nullptr, s));
+      for (const char* nm : {".glu.b", ".dw.w", ".dw.b", ".ff1.b", ".ff2.b"}) STG(need(e, p + nm, &t));
+      return 0;
+    };
+    for (int i = 0; i < c.n_layers_text; ++i) STG(enc_block("text_enc.layers." + std::to_string(i)));
+    for (int i = 0; i < c.ref_enc_layers; ++i) STG(enc_block("ref_enc_blocks." + std::to_string(i)));
+    for (int i = 0; i < c.ref_xattn_layers; ++i) {
+      const std::string p = "ref_xattn.blocks." + std::to_string(i);
+      for (const char* nm : {".nq.weight", ".q.w", ".o.w", ".gate_scale", ".nkv.weight", ".kv.w"}) STG(need(e, p + nm, &t));
+    }
+    for (const char* nm : {"text_enc.embed", "text_enc.norm.weight", "pe", "spk_film.mlp.0.w", "spk_film.mlp.0.b", "spk_film.mlp.2.w", "spk_film.mlp.2.b",
+                           "spk_film.norm.weight", "spk_film.norm.bias", "cond_norm.weight", "token2sv.emb", "token2sv.cw", "token2sv.enc.0.w",
+                           "token2sv.enc.0.b", "token2sv.enc.3.w", "token2sv.enc.3.b", "token2sv.pool.attn.0.w", "token2sv.pool.attn.0.b",
+                           "token2sv.pool.attn.2.w", "token2sv.pool.attn.2.b", "token2sv.proj.w", "token2sv.proj.b", "ref_cw", "ref_enc_norm.weight", "cb_embed"})
+      STG(need(e, nm, &t));
+    std::vector<int32_t> col, off;
+    for (int q = 0; q < c.num_codebooks; ++q) { col.push_back(q); off.push_back(q * c.codebook_size); }
+    STG(dev_upload(e, col, &e->q_col));
+    STG(dev_upload(e, off, &e->q_off));
+  }
   // ---- Mimi decoder: three-pass operands (16 mantissa bits: waveform contract; bf16 mode: one piece), raw fp32 for the fused
   // SEANet kernels
   if (e->has_mimi) {
@@ -507,6 +537,160 @@ int sopro_ar_fold_text(const float* txt, const float* nkv_weight, const float* k
     STG(gemm(s, kvd + h * dh, none, q_wT + (size_t)h * D * dh, kp + (size_t)h * S_cap * D, f));
     f.ldw = D;
     STG(gemm(s, kvd + D + h * dh, none, o_w + h * dh, vp + (size_t)h * S_cap * D, f));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ conditioning stage
+static int ssm_block_bufs(sopro_engine* e, hipStream_t s, float* h, float* x1, float* u, const SplitK* sk, const float* x, float* out,
+                          const std::string& p, int B, int T, int ksize, int dil, const int32_t* lens);  // (with the NAR stage below)
+struct CondWs { float *xa, *xb, *h, *x1, *u, *base, *cond, *nq, *q, *a, *am; SplitK sk; };
+static size_t cond_carve(const sopro_engine* e, CondWs& w, void* ws, int B, int S, int Tar) {
+  const size_t M = (size_t)B * S, R = (size_t)B * Tar, D = e->c.d_model;
+  Carver cv(ws);
+  w.xa = cv.take<float>(M * D); w.xb = cv.take<float>(M * D); w.h = cv.take<float>(M * D); w.x1 = cv.take<float>(M * D);
+  w.u = cv.take<float>(M * 4 * D);
+  w.base = cv.take<float>(R * D); w.cond = cv.take<float>(R * D); w.nq = cv.take<float>(R * D); w.q = cv.take<float>(R * D);
+  w.a = cv.take<float>(R * D); w.am = cv.take<float>(R * D);
+  w.sk.tickets = cv.take<int32_t>(SPLITK_TICKETS);
+  w.sk.ws = M <= 1024 ? cv.take<float>(SPLITK_WS_BYTES / 4) : nullptr;
+  return cv.off;
+}
+
+int64_t sopro_cond_workspace_bytes(const sopro_engine* e, int32_t B, int32_t S, int32_t Tar) {
+  if (!e || B <= 0 || S <= 0 || Tar <= 0) return 0;
+  CondWs w;
+  return (int64_t)cond_carve(e, w, nullptr, B, S, Tar);
+}
+
+int sopro_cond_prepare(sopro_engine* e, void* workspace, const int32_t* ids, const int32_t* lens, int32_t ragged, const float* film_mul,
+                       const float* film_add, const float* const* ref_k, const float* const* ref_v, int64_t kv_bstride, const int32_t* kv_index,
+                       const int32_t* ref_klens, int32_t B, int32_t S, int32_t Tar, int32_t Tr, float* txt_seq, float* txt_pool, float* cond_ar,
+                       void* stream) {
+  SOPRO_CHECK_ARG(e && e->final && e->has_cond && workspace && ids && lens && film_mul && film_add && ref_k && ref_v && txt_seq && txt_pool && cond_ar,
+                  "bad arguments (finalize the engine with the conditioning tensors first)");
+  SOPRO_CHECK_ARG(B > 0 && S > 0 && Tar > 0 && Tr > 0, "bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const sopro_engine_cfg& c = e->c;
+  const int D = c.d_model, M = B * S, R = B * Tar, H = c.ref_xattn_heads, dh = D / H;
+  SOPRO_CHECK_ARG(Tar <= e->t["pe"].shape[0] && S <= e->t["pe"].shape[0], "more positions than the position table holds");
+  CondWs w;
+  cond_carve(e, w, workspace, B, S, Tar);
+  if (w.sk.ws) STG(sopro_fill2d_u32(w.sk.tickets, SPLITK_TICKETS, 1, SPLITK_TICKETS, 0u, s));
+  // ---- text encoder (src/sopro/nn/text.py:29-44)
+  float *xa = w.xa, *xb = w.xb;
+  STG(sopro_text_embed_f32(ids, lens, F(e, "text_enc.embed"), e->t["text_enc.embed"].shape[0], F(e, "pe"), xa, B, S, D, s));
+  for (int i = 0; i < c.n_layers_text; ++i) {
+    STG(ssm_block_bufs(e, s, w.h, w.x1, w.u, &w.sk, xa, xb, "text_enc.layers." + std::to_string(i), B, S, c.enc_kernel, 1, ragged ? lens : nullptr));
+    std::swap(xa, xb);
+  }
+  STG(norm(s, xa, txt_seq, F(e, "text_enc.norm.weight"), M, D, RMS_EPS));
+  STG(sopro_masked_mean_f32(txt_seq, lens, txt_pool, B, S, D, s));
+  // ---- base = pooled text + frame positions (model.py:200-202), SpeakerFiLM on its LayerNorm (speaker.py:76-85)
+  STG(sopro_add_pos_f32(txt_pool, F(e, "pe"), w.base, B, Tar, D, 0, s));
+  STG(norm(s, w.base, w.cond, F(e, "spk_film.norm.weight"), R, D, 1e-5f, SOPRO_NORM_LN, F(e, "spk_film.norm.bias"), film_mul, film_add, Tar));
+  // ---- reference cross-attention stack (src/sopro/nn/ref.py:54-108)
+  for (int i = 0; i < c.ref_xattn_layers; ++i) {
+    const std::string p = "ref_xattn.blocks." + std::to_string(i);
+    STG(norm(s, w.cond, w.nq, F(e, p + ".nq.weight"), R, D, RMS_EPS));
+    G qg; qg.M = R; qg.N = D; qg.K = D;
+    Wt wq; wq.f32 = F(e, p + ".q.w");
+    STG(gemm(s, w.nq, wq, nullptr, w.q, qg));
+    sopro_attn_args a;
+    memset(&a, 0, sizeof(a));
+    a.Q = w.q; a.ldq = D; a.q_bstride = (int64_t)Tar * D;
+    a.K = ref_k[i]; a.ldk = D; a.k_bstride = kv_bstride;
+    a.V = ref_v[i]; a.ldv = D; a.v_bstride = kv_bstride;
+    a.O = w.a; a.ldo = D; a.o_bstride = (int64_t)Tar * D;
+    a.klens = ref_klens; a.kv_index = kv_index;
+    a.B = B; a.H = H; a.dh = dh; a.Tq = Tar; a.Tk = Tr; a.scale = 1.0f / sqrtf((float)dh);
+    STG(attend(a, s));
+    STG(sopro_rms_match_f32(w.a, w.cond, w.am, R, D, s));
+    G og; og.M = R; og.N = D; og.K = D; og.epi = SOPRO_EPI_RES; og.R = w.cond; og.scale = F(e, p + ".gate_scale");
+    Wt wo; wo.f32 = F(e, p + ".o.w");
+    STG(gemm(s, w.am, wo, nullptr, w.cond, og));
+  }
+  return norm(s, w.cond, cond_ar, F(e, "cond_norm.weight"), R, D, RMS_EPS);
+}
+
+int sopro_film_coeffs(sopro_engine* e, const float* sv, float style, int32_t n, float* scratch, float* mul, float* add, void* stream) {
+  SOPRO_CHECK_ARG(e && e->final && e->has_cond && sv && scratch && mul && add && n > 0, "bad arguments (finalize the engine with the conditioning tensors first)");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = e->c.d_model, svd = e->c.sv_student_dim;
+  float *f1 = scratch, *film = f1 + (size_t)n * D, *gam = film + (size_t)n * 2 * D, *bet = gam + (size_t)n * D;
+  G g1; g1.M = n; g1.N = D; g1.K = svd; g1.bias = F(e, "spk_film.mlp.0.b"); g1.epi = SOPRO_EPI_GELU;
+  Wt w0; w0.f32 = F(e, "spk_film.mlp.0.w");
+  STG(gemm(s, sv, w0, nullptr, f1, g1));
+  G g2; g2.M = n; g2.N = 2 * D; g2.K = D; g2.bias = F(e, "spk_film.mlp.2.b");
+  Wt w2; w2.f32 = F(e, "spk_film.mlp.2.w");
+  STG(gemm(s, f1, w2, nullptr, film, g2));
+  STG(sopro_copy2d_u32(gam, D, film, 2 * D, n, D, s));
+  STG(sopro_copy2d_u32(bet, D, film + D, 2 * D, n, D, s));
+  STG(sopro_tanh_affine_f32(gam, mul, 1.0f, style, (int64_t)n * D, s));
+  return sopro_tanh_affine_f32(bet, add, 0.0f, style, (int64_t)n * D, s);
+}
+
+// ------------------------------------------------------------------------------------------------ reference preparation
+struct RefWs { float *x, *h1, *h2, *a1, *lg, *st, *ev, *xa, *xb, *h, *x1, *u, *nkv; SplitK sk; };
+static size_t ref_carve(const sopro_engine* e, RefWs& w, void* ws, int T) {
+  const size_t D = e->c.d_model, SD = e->t.count("token2sv.emb") ? (size_t)e->t.at("token2sv.emb").shape[1] : 0;
+  Carver cv(ws);
+  w.x = cv.take<float>(T * SD); w.h1 = cv.take<float>(T * SD); w.h2 = cv.take<float>(T * SD); w.a1 = cv.take<float>(T * SD);
+  w.lg = cv.take<float>(T); w.st = cv.take<float>(2 * SD); w.ev = cv.take<float>(e->c.sv_student_dim);
+  w.xa = cv.take<float>(T * D); w.xb = cv.take<float>(T * D); w.h = cv.take<float>(T * D); w.x1 = cv.take<float>(T * D);
+  w.u = cv.take<float>(T * 4 * D); w.nkv = cv.take<float>(T * D);
+  w.sk.tickets = cv.take<int32_t>(SPLITK_TICKETS);
+  w.sk.ws = (size_t)T <= 1024 ? cv.take<float>(SPLITK_WS_BYTES / 4) : nullptr;
+  return cv.off;
+}
+
+int64_t sopro_ref_workspace_bytes(const sopro_engine* e, int32_t T) {
+  if (!e || T <= 0) return 0;
+  RefWs w;
+  return (int64_t)ref_carve(e, w, nullptr, T);
+}
+
+int sopro_ref_prepare(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t T, float* sv, float* ref_seq, float* const* kv, void* stream) {
+  SOPRO_CHECK_ARG(e && e->final && e->has_cond && workspace && tokens && sv && ref_seq && kv && T > 0,
+                  "bad arguments (finalize the engine with the conditioning tensors first)");
+  hipStream_t s = (hipStream_t)stream;
+  const sopro_engine_cfg& c = e->c;
+  const int D = c.d_model, Q = c.num_codebooks, SD = (int)e->t["token2sv.emb"].shape[1], svd = c.sv_student_dim;
+  RefWs w;
+  ref_carve(e, w, workspace, T);
+  if (w.sk.ws) STG(sopro_fill2d_u32(w.sk.tickets, SPLITK_TICKETS, 1, SPLITK_TICKETS, 0u, s));
+  // ---- Token2SV (src/sopro/nn/speaker.py:37-61)
+  STG(sopro_codebook_sum_f32(tokens, Q, e->q_col, e->q_off, F(e, "token2sv.cw"), Q, F(e, "token2sv.emb"), e->t["token2sv.emb"].shape[0], nullptr, 0.f,
+                             1.f, w.x, SD, 0, T, T, SD, s));
+  STG(sopro_dwconv_f32(w.x, F(e, "token2sv.enc.0.w"), F(e, "token2sv.enc.0.b"), nullptr, w.h1, nullptr, 1, T, SD, 7, 1, 3, 2, s));
+  STG(sopro_dwconv_f32(w.h1, F(e, "token2sv.enc.3.w"), F(e, "token2sv.enc.3.b"), nullptr, w.h2, nullptr, 1, T, SD, 7, 1, 3, 2, s));
+  G ga; ga.M = T; ga.N = SD; ga.K = SD; ga.bias = F(e, "token2sv.pool.attn.0.b"); ga.epi = SOPRO_EPI_TANH;
+  Wt wa; wa.f32 = F(e, "token2sv.pool.attn.0.w");
+  STG(gemm(s, w.h2, wa, nullptr, w.a1, ga));
+  G gl; gl.M = T; gl.N = 1; gl.K = SD; gl.bias = F(e, "token2sv.pool.attn.2.b");
+  Wt wl; wl.f32 = F(e, "token2sv.pool.attn.2.w");
+  STG(gemm(s, w.a1, wl, nullptr, w.lg, gl));
+  STG(sopro_stats_pool_f32(w.h2, w.lg, nullptr, w.st, 1, T, SD, s));
+  G gp; gp.M = 1; gp.N = svd; gp.K = 2 * SD; gp.bias = F(e, "token2sv.proj.b");
+  Wt wp; wp.f32 = F(e, "token2sv.proj.w");
+  STG(gemm(s, w.st, wp, nullptr, w.ev, gp));
+  STG(sopro_l2norm_f32(w.ev, sv, 1, svd, 1e-6f, s));
+  // ---- reference sequence encoder (model.py:133-149)
+  float *xa = w.xa, *xb = w.xb;
+  STG(sopro_codebook_sum_f32(tokens, Q, e->q_col, e->q_off, F(e, "ref_cw"), Q, F(e, "cb_embed"), e->t["cb_embed"].shape[0], nullptr, 0.f, 1.f, xa, D, 0,
+                             T, T, D, s));
+  for (int i = 0; i < c.ref_enc_layers; ++i) {
+    STG(ssm_block_bufs(e, s, w.h, w.x1, w.u, &w.sk, xa, xb, "ref_enc_blocks." + std::to_string(i), 1, T, c.enc_kernel, 1, nullptr));
+    std::swap(xa, xb);
+  }
+  STG(norm(s, xa, ref_seq, F(e, "ref_enc_norm.weight"), T, D, RMS_EPS));
+  // ---- K | V rows of the reference cross-attention blocks (src/sopro/nn/ref.py:120-128)
+  for (int i = 0; i < c.ref_xattn_layers; ++i) {
+    const std::string p = "ref_xattn.blocks." + std::to_string(i);
+    STG(norm(s, ref_seq, w.nkv, F(e, p + ".nkv.weight"), T, D, RMS_EPS));
+    G gk; gk.M = T; gk.N = 2 * D; gk.K = D;
+    Wt wk; wk.f32 = F(e, p + ".kv.w");
+    STG(gemm(s, w.nkv, wk, nullptr, kv[i], gk));
   }
   return 0;
 }
@@ -672,18 +856,23 @@ int64_t sopro_nar_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T) {
   return (int64_t)nar_carve(e, w, nullptr, B, T);
 }
 
-// full-sequence SSMLiteBlock over dense [B*T, D] rows (reference: src/sopro/nn/blocks.py:143-148), norms fused into the contractions
-static int ssm_block_seq(sopro_engine* e, hipStream_t s, const NarWs& w, const float* x, float* out, const std::string& p, int B, int T,
-                         int ksize, int dil, const int32_t* lens) {
+// full-sequence SSMLiteBlock over dense [B*T, D] rows (reference: src/sopro/nn/blocks.py:143-148), norms fused into the contractions;
+// h, x1 [B*T, D] and u [B*T, 4D] are scratch, sk the split-K scratch of the last contraction (few-row problems)
+static int ssm_block_bufs(sopro_engine* e, hipStream_t s, float* h, float* x1, float* u, const SplitK* sk, const float* x, float* out,
+                          const std::string& p, int B, int T, int ksize, int dil, const int32_t* lens) {
   const int D = e->c.d_model, M = B * T;
   const int total = (ksize - 1) * dil, left = total / 2;  // non-causal: symmetric zero padding (blocks.py:68-72)
   G g; g.M = M; g.N = 2 * D; g.K = D; g.bias = F(e, p + ".glu.b"); g.epi = SOPRO_EPI_GLU; g.rms_eps = RMS_EPS;
-  STG(gemm(s, x, WT(e, p + ".glu.wn"), nullptr, w.h, g));
-  STG(sopro_dwconv_f32(w.h, F(e, p + ".dw.w"), F(e, p + ".dw.b"), x, w.x1, lens, B, T, D, ksize, dil, left, 1, s));
+  STG(gemm(s, x, WT(e, p + ".glu.wn"), nullptr, h, g));
+  STG(sopro_dwconv_f32(h, F(e, p + ".dw.w"), F(e, p + ".dw.b"), x, x1, lens, B, T, D, ksize, dil, left, 1, s));
   G f1; f1.M = M; f1.N = 4 * D; f1.K = D; f1.bias = F(e, p + ".ff1.b"); f1.epi = SOPRO_EPI_GELU; f1.rms_eps = RMS_EPS;
-  STG(gemm(s, w.x1, WT(e, p + ".ff1.wn"), nullptr, w.u, f1));
-  G f2; f2.M = M; f2.N = D; f2.K = 4 * D; f2.bias = F(e, p + ".ff2.b"); f2.epi = SOPRO_EPI_RES; f2.R = w.x1; f2.sk = &w.sk;
-  return gemm(s, w.u, WT(e, p + ".ff2.w"), nullptr, out, f2);
+  STG(gemm(s, x1, WT(e, p + ".ff1.wn"), nullptr, u, f1));
+  G f2; f2.M = M; f2.N = D; f2.K = 4 * D; f2.bias = F(e, p + ".ff2.b"); f2.epi = SOPRO_EPI_RES; f2.R = x1; f2.sk = sk;
+  return gemm(s, u, WT(e, p + ".ff2.w"), nullptr, out, f2);
+}
+static int ssm_block_seq(sopro_engine* e, hipStream_t s, const NarWs& w, const float* x, float* out, const std::string& p, int B, int T,
+                         int ksize, int dil, const int32_t* lens) {
+  return ssm_block_bufs(e, s, w.h, w.x1, w.u, &w.sk, x, out, p, B, T, ksize, dil, lens);
 }
 
 int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_t cond_bstride, const int32_t* rvq1, const int32_t* lens,

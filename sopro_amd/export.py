@@ -34,6 +34,9 @@ def export_packed(weights: Dict[str, np.ndarray], mimi_weights: Dict[str, np.nda
     tensors = dict(ps)
     tensors.update(pm)
     tensors["rope.cos"], tensors["rope.sin"] = cos, sin
+    from .pack import sinusoid_table
+
+    tensors["pe"] = sinusoid_table(int(cfg.pos_emb_max) + 8, int(cfg.d_model))  # position table of the conditioning family (src/sopro/model.py:62-64)
     order, sc = cfg.stage_order(), cfg.stage_codebooks()
     if len(order) > len(_POS):
         raise ValueError(f"{len(order)} NAR stages, the stage-level C API names at most {len(_POS)}")
@@ -53,7 +56,9 @@ def export_packed(weights: Dict[str, np.ndarray], mimi_weights: Dict[str, np.nda
         "mimi_inter": int(mc.intermediate_size), "mimi_n_ratios": len(mc.upsampling_ratios), "mimi_ratios": [int(r) for r in mc.upsampling_ratios],
         "mimi_num_filters": int(mc.num_filters), "mimi_kernel": int(mc.kernel_size), "mimi_res_kernel": int(mc.residual_kernel_size),
         "mimi_last_kernel": int(mc.last_kernel_size), "mimi_compress": int(mc.compress), "mimi_n_semantic": int(mc.num_semantic_quantizers),
-        "mimi_rope_positions": int(rope_positions), "mimi_norm_eps": float(mc.norm_eps), "mimi_final_bias": float(pm["sea.final.b"][0]),
+        "mimi_rope_positions": int(rope_positions), "mimi_norm_eps": float(mc.norm_eps), "mimi_final_bias": float(pm["sea.final.b"][0]), "precision": 0,
+        "n_layers_text": int(cfg.n_layers_text), "ref_enc_layers": int(cfg.ref_enc_layers), "ref_xattn_layers": int(cfg.ref_xattn_layers),
+        "ref_xattn_heads": int(cfg.ref_xattn_heads), "sv_student_dim": int(cfg.sv_student_dim), "enc_kernel": 7,
     }
     table, off = [], 0
     with open(out_prefix + ".bin", "wb") as f:

@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -54,7 +54,7 @@ class AttnArgs(C.Structure):
     _fields_ = [("Q", _p), ("ldq", _i64), ("q_bstride", _i64), ("K", _p), ("ldk", _i64), ("k_bstride", _i64),
                 ("V", _p), ("ldv", _i64), ("v_bstride", _i64), ("O", _p), ("ldo", _i64), ("o_bstride", _i64),
                 ("klens", _p), ("B", _i32), ("H", _i32), ("dh", _i32), ("Tq", _i32), ("Tk", _i32),
-                ("causal", _i32), ("q_pos0", _i32), ("k_pos0", _i32), ("window", _i32), ("scale", _f32)]
+                ("causal", _i32), ("q_pos0", _i32), ("k_pos0", _i32), ("window", _i32), ("scale", _f32), ("kv_index", _p)]
 
 
 class XattnArgs(C.Structure):
@@ -98,7 +98,9 @@ class EngineCfg(C.Structure):
                 ("mimi_hidden", _i32), ("mimi_codebook_dim", _i32), ("mimi_heads", _i32), ("mimi_head_dim", _i32), ("mimi_layers", _i32),
                 ("mimi_window", _i32), ("mimi_inter", _i32), ("mimi_n_ratios", _i32), ("mimi_ratios", _i32 * 8), ("mimi_num_filters", _i32),
                 ("mimi_kernel", _i32), ("mimi_res_kernel", _i32), ("mimi_last_kernel", _i32), ("mimi_compress", _i32),
-                ("mimi_n_semantic", _i32), ("mimi_rope_positions", _i32), ("mimi_norm_eps", _f32), ("mimi_final_bias", _f32), ("precision", _i32)]
+                ("mimi_n_semantic", _i32), ("mimi_rope_positions", _i32), ("mimi_norm_eps", _f32), ("mimi_final_bias", _f32), ("precision", _i32),
+                ("n_layers_text", _i32), ("ref_enc_layers", _i32), ("ref_xattn_layers", _i32), ("ref_xattn_heads", _i32), ("sv_student_dim", _i32),
+                ("enc_kernel", _i32)]
 
 
 class MimiStreamState(C.Structure):
@@ -189,6 +191,11 @@ SYMBOLS = {
     "sopro_ar_issue_frame": (C.c_int, [C.POINTER(ArFrame), _p]),
     "sopro_ar_fold_text": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p]),
     "sopro_engine_set_ar_tiles": (C.c_int, [_p, _i32, _i32, _i32, _i32]),
+    "sopro_cond_workspace_bytes": (_i64, [_p, _i32, _i32, _i32]),
+    "sopro_cond_prepare": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    "sopro_film_coeffs": (C.c_int, [_p, _p, _f32, _i32, _p, _p, _p, _p]),
+    "sopro_ref_workspace_bytes": (_i64, [_p, _i32]),
+    "sopro_ref_prepare": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p]),
     "sopro_prof_enable": (C.c_int, [C.c_int]),
     "sopro_prof_collect": (C.c_int, [_p, _i32, _p]),
 }
@@ -633,8 +640,9 @@ def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor
               Tk: int, ldq: int, ldk: int, ldv: int, ldo: int, q_bstride: int, k_bstride: int, v_bstride: int,
               o_bstride: int, klens: Optional[torch.Tensor] = None, causal: bool = False, q_pos0: int = 0, k_pos0: int = 0,
               window: int = 0, scale: Optional[float] = None, q_off: int = 0, k_off: int = 0, v_off: int = 0,
-              o_off: int = 0, decode: bool = False) -> None:
+              o_off: int = 0, decode: bool = False, kv_index: Optional[torch.Tensor] = None) -> None:
     a = AttnArgs()
+    a.kv_index = ptr(kv_index, torch.int32)
     a.Q, a.ldq, a.q_bstride = ptr(Q) + 4 * q_off, ldq, q_bstride
     a.K, a.ldk, a.k_bstride = ptr(K) + 4 * k_off, ldk, k_bstride
     a.V, a.ldv, a.v_bstride = ptr(V) + 4 * v_off, ldv, v_bstride
@@ -739,6 +747,27 @@ def ar_tile_code(spec: str) -> int:
         raise ValueError(f"AR tile shape must be 1x1, 1x2, 2x1 or 2x2, got {spec!r}")
     return (mt << 4) | nt
 
+
+
+def cond_prepare(engine, ws: torch.Tensor, ids: torch.Tensor, lens: torch.Tensor, ragged: bool, film_mul: torch.Tensor, film_add: torch.Tensor,
+                 ref_k, ref_v, kv_bstride: int, kv_index: Optional[torch.Tensor], ref_klens: Optional[torch.Tensor], B: int, S: int, Tar: int,
+                 Tr: int, txt_seq: torch.Tensor, txt_pool: torch.Tensor, cond_ar: torch.Tensor) -> None:
+    """sopro_cond_prepare: the conditioning launch sequence of B utterances (csrc/stages.hip)."""
+    ka = (C.c_void_p * len(ref_k))(*[ptr(t) for t in ref_k])
+    va = (C.c_void_p * len(ref_v))(*[ptr(t) for t in ref_v])
+    _check(load().sopro_cond_prepare(engine, ptr(ws), ptr(ids, torch.int32), ptr(lens, torch.int32), int(bool(ragged)), ptr(film_mul), ptr(film_add),
+                                     ka, va, int(kv_bstride), ptr(kv_index, torch.int32), ptr(ref_klens, torch.int32), B, S, Tar, Tr,
+                                     ptr(txt_seq), ptr(txt_pool), ptr(cond_ar), _stream()), "sopro_cond_prepare")
+
+
+def film_coeffs(engine, sv: torch.Tensor, style: float, n: int, scratch: torch.Tensor, mul: torch.Tensor, add: torch.Tensor) -> None:
+    _check(load().sopro_film_coeffs(engine, ptr(sv), float(style), n, ptr(scratch), ptr(mul), ptr(add), _stream()), "sopro_film_coeffs")
+
+
+def ref_prepare(engine, ws: torch.Tensor, tokens: torch.Tensor, T: int, sv: torch.Tensor, ref_seq: torch.Tensor, kvs) -> None:
+    """sopro_ref_prepare: Token2SV, reference encoder and the K | V rows of the reference cross-attention blocks of one voice."""
+    ka = (C.c_void_p * len(kvs))(*[ptr(t) for t in kvs])
+    _check(load().sopro_ref_prepare(engine, ptr(ws), ptr(tokens, torch.int32), T, ptr(sv), ptr(ref_seq), ka, _stream()), "sopro_ref_prepare")
 
 class Graph:
     """A recorded launch sequence (hipGraphExec) replayable on any stream."""

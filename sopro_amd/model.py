@@ -107,25 +107,6 @@ class SoproTTSModel:
         self._runs = [0]  # generation runs started so far (shared by the lanes of clone_lane): the sampler's default nonce
         self._nar_graphs = hip.GraphCache("nar_graph", cap=64)  # recorded NAR launch sequences per (B, T)
         self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "16")) << 30  # scratch kept per batch shape, per engine
-        # Text / reference encoder contractions (they feed the AR loop's conditioning) on the six-pass split-bf16 matrix-core path
-        # (24 mantissa bits per operand: the accuracy class of the fp32 MFMA kernel at ~1.5x its speed on these shapes), their two
-        # RMSNorms fused into the contractions they feed (the norm's weight vector folded into W here, once).  The NAR and AR
-        # operands are made by the stage engine below (csrc/stages.hip).
-        self.wx: Dict[str, hip.PackedW] = {}
-        with torch.cuda.device(self.device):
-            for k, v in self.w.items():
-                if k.startswith(("text_enc.layers.", "ref_enc_blocks.")) and v.dim() == 2 and k.endswith(".w") \
-                        and int(v.shape[1]) % 32 == 0 and int(v.shape[0]) >= 64:
-                    nk = None
-                    if k.endswith(".glu.w"):
-                        nk = k[: -len("glu.w")] + "norm.weight"
-                    elif k.endswith(".ff1.w"):
-                        nk = k[: -len("ff1.w")] + "ff.norm.weight"
-                    if nk is not None and nk in self.w:
-                        self.wx[k + "n"] = hip.pack_w_bf16x6((v * self.w[nk][None, :]).contiguous())
-                    else:
-                        self.wx[k] = hip.pack_w_bf16x6(v)
-            torch.cuda.synchronize(self.device)
         # AR-step weights in the fragment order of the skinny kernel (1 KiB of consecutive memory per load instruction)
         self.wk: Dict[str, hip.SkinnyW] = {}
         with torch.cuda.device(self.device):
@@ -247,88 +228,28 @@ class SoproTTSModel:
     def rf_nar(self) -> int:
         return self.cfg.rf_nar()
 
-    def _ssm_block_seq(self, x: torch.Tensor, out: torch.Tensor, p: str, *, B: int, T: int, ksize: int, dil: int,
-                       causal: bool, lens: Optional[torch.Tensor], ws: Optional[Workspace] = None) -> None:
-        """Full-sequence SSMLiteBlock over dense [B*T, D] rows (reference: src/sopro/nn/blocks.py:143-148)."""
-        D, M, w = self.D, B * T, self.w
-        ws = ws if ws is not None else self.ws
-        h = ws.get("ssm.h", (M, D))
-        x1 = ws.get("ssm.x1", (M, D))
-        u = ws.get("ssm.u", (M, 4 * D))
-        gw = lambda k: self.wx.get(k) or w[k]  # noqa: E731
-        total = (ksize - 1) * dil
-        left = total if causal else total // 2
-        gn, fn = self.wx.get(p + ".glu.wn"), self.wx.get(p + ".ff1.wn")
-        if gn is not None:  # RMSNorm inside the GEMM (norm weight folded into W)
-            hip.gemm(x, gn, h, M=M, N=2 * D, K=D, bias=w[p + ".glu.b"], epilogue=hip.EPI_GLU, rms_eps=RMS_EPS)
-        else:
-            nrm = ws.get("ssm.nrm", (M, D))
-            hip.norm(x, nrm, w[p + ".norm.weight"], rows=M, C_=D, eps=RMS_EPS)
-            hip.gemm(nrm, gw(p + ".glu.w"), h, M=M, N=2 * D, K=D, bias=w[p + ".glu.b"], epilogue=hip.EPI_GLU)
-        hip.dwconv(h, w[p + ".dw.w"], w[p + ".dw.b"], x1, B=B, T=T, C_=D, ksize=ksize, dil=dil, left=left, mode=1, res=x, lens=lens)
-        if fn is not None:
-            hip.gemm(x1, fn, u, M=M, N=4 * D, K=D, bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU, rms_eps=RMS_EPS)
-        else:
-            nrm = ws.get("ssm.nrm", (M, D))
-            hip.norm(x1, nrm, w[p + ".ff.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
-            hip.gemm(nrm, gw(p + ".ff1.w"), u, M=M, N=4 * D, K=D, bias=w[p + ".ff1.b"], epilogue=hip.EPI_GELU)
-        hip.gemm(u, gw(p + ".ff2.w"), out, M=M, N=D, K=4 * D, bias=w[p + ".ff2.b"], epilogue=hip.EPI_RES, R=x1)
-
     # ------------------------------------------------------------------ per-voice preparation
     @torch.inference_mode()
     def prepare_reference(self, ref_tokens_tq: torch.Tensor) -> PreparedReference:
-        """reference: src/sopro/model.py:151-170 (Token2SV src/sopro/nn/speaker.py:37-61,
-        reference encoder model.py:133-149, K/V caches src/sopro/nn/ref.py:120-128)."""
-        cfg, w, dev, D = self.cfg, self.w, self.device, self.D
+        """reference: src/sopro/model.py:151-170 (Token2SV src/sopro/nn/speaker.py:37-61, reference encoder model.py:133-149,
+        K/V caches src/sopro/nn/ref.py:120-128).  The launch sequence is ``sopro_ref_prepare`` (csrc/stages.hip)."""
+        cfg, dev, D = self.cfg, self.device, self.D
         if ref_tokens_tq.dim() != 2 or ref_tokens_tq.shape[1] != self.Q:
             raise ValueError(f"ref_tokens_tq must be [T, {self.Q}], got {tuple(ref_tokens_tq.shape)}")
-        T = int(ref_tokens_tq.shape[0])
+        T, L, H = int(ref_tokens_tq.shape[0]), int(cfg.ref_xattn_layers), int(cfg.ref_xattn_heads)
         with self.on_stream():
             tok64 = ref_tokens_tq.to(dev).long()
             tok = tok64.to(torch.int32).contiguous()
-            col = _i32(range(self.Q), dev)
-            off = _i32([q * self.V for q in range(self.Q)], dev)
-            # --- Token2SV
-            SD = int(w["token2sv.emb"].shape[1])
-            x = torch.empty(T, SD, device=dev)
-            hip.codebook_sum(tok, self.Q, col, off, w["token2sv.cw"], w["token2sv.emb"], x, rows=T, D=SD)
-            h1 = torch.empty_like(x)
-            h2 = torch.empty_like(x)
-            hip.dwconv(x, w["token2sv.enc.0.w"], w["token2sv.enc.0.b"], h1, B=1, T=T, C_=SD, ksize=7, dil=1, left=3, mode=2)
-            hip.dwconv(h1, w["token2sv.enc.3.w"], w["token2sv.enc.3.b"], h2, B=1, T=T, C_=SD, ksize=7, dil=1, left=3, mode=2)
-            a1 = torch.empty(T, SD, device=dev)
-            hip.gemm(h2, w["token2sv.pool.attn.0.w"], a1, M=T, N=SD, K=SD, bias=w["token2sv.pool.attn.0.b"], epilogue=hip.EPI_TANH)
-            lg = torch.empty(T, 1, device=dev)
-            hip.gemm(a1, w["token2sv.pool.attn.2.w"], lg, M=T, N=1, K=SD, bias=w["token2sv.pool.attn.2.b"])
-            st = torch.empty(1, 2 * SD, device=dev)
-            hip.stats_pool(h2, lg, None, st, 1, T, SD)
-            svd = int(cfg.sv_student_dim)
-            e = torch.empty(1, svd, device=dev)
-            hip.gemm(st, w["token2sv.proj.w"], e, M=1, N=svd, K=2 * SD, bias=w["token2sv.proj.b"])
-            sv = torch.empty(1, svd, device=dev)
-            hip.l2norm(e, sv, 1, svd, 1e-6)
-            # --- reference sequence encoder
-            xa = torch.empty(T, D, device=dev)
-            xb = torch.empty(T, D, device=dev)
-            hip.codebook_sum(tok, self.Q, col, off, w["ref_cw"], w["cb_embed"], xa, rows=T, D=D)
-            for i in range(int(cfg.ref_enc_layers)):
-                # own scratch: a client thread may prepare a voice while a scheduler drives this engine's other streams
-                self._ssm_block_seq(xa, xb, f"ref_enc_blocks.{i}", B=1, T=T, ksize=7, dil=1, causal=False, lens=None, ws=self._ref_ws)
-                xa, xb = xb, xa
+            sv = torch.empty(1, int(cfg.sv_student_dim), device=dev)
             ref_seq = torch.empty(1, T, D, device=dev)
-            hip.norm(xa, ref_seq, w["ref_enc_norm.weight"], rows=T, C_=D, eps=RMS_EPS)
-            # --- K/V of the three reference cross-attention blocks
-            H = int(cfg.ref_xattn_heads)
+            kvs = [torch.empty(T, 2 * D, device=dev) for _ in range(L)]
+            # own scratch: a client thread may prepare a voice while a scheduler drives this engine's other streams
+            wsb = self._ref_ws.get("ref.ws", (int(hip.load().sopro_ref_workspace_bytes(self.eng.h, T)) // 4 + 64,))
+            hip.ref_prepare(self.eng.h, wsb, tok, T, sv, ref_seq, kvs)
             caches: List[Dict[str, Optional[torch.Tensor]]] = []
-            nkv = torch.empty(T, D, device=dev)
-            for i in range(int(cfg.ref_xattn_layers)):
-                p = f"ref_xattn.blocks.{i}"
-                hip.norm(ref_seq, nkv, w[p + ".nkv.weight"], rows=T, C_=D, eps=RMS_EPS)
-                kv = torch.empty(T, 2 * D, device=dev)
-                hip.gemm(nkv, w[p + ".kv.w"], kv, M=T, N=2 * D, K=D)
-                k = kv[:, :D].reshape(1, T, H, D // H).permute(0, 2, 1, 3)  # [1, H, T, dh] view, as the reference stores it
-                v = kv[:, D:].reshape(1, T, H, D // H).permute(0, 2, 1, 3)
-                caches.append({"k": k, "v": v, "key_padding_mask": None})
+            for kv in kvs:  # [1, H, T, dh] views, as the reference stores them
+                caches.append({"k": kv[:, :D].reshape(1, T, H, D // H).permute(0, 2, 1, 3), "v": kv[:, D:].reshape(1, T, H, D // H).permute(0, 2, 1, 3),
+                               "key_padding_mask": None})
         self.stream.synchronize()
         return PreparedReference(ref_tokens_btq=tok64.unsqueeze(0), sv_ref=sv, ref_seq=ref_seq, ref_kv_caches=caches)
 
@@ -345,10 +266,11 @@ class SoproTTSModel:
     @torch.inference_mode()
     def prepare_conditioning_batch(self, ids_list: Sequence[torch.Tensor], refs: Sequence[PreparedReference], *,
                                    max_frames: int, style_strength: float = 1.0) -> Dict[str, Any]:
-        """B utterances at once (new): text encoder (src/sopro/nn/text.py:29-44), base = pooled text +
-        frame positions (model.py:200-202), SpeakerFiLM (src/sopro/nn/speaker.py:76-85), three reference
-        cross-attention blocks (src/sopro/nn/ref.py:54-108), cond_norm (model.py:208)."""
-        cfg, w, dev, D = self.cfg, self.w, self.device, self.D
+        """B utterances at once (new): text encoder (src/sopro/nn/text.py:29-44), base = pooled text + frame positions
+        (model.py:200-202), SpeakerFiLM (src/sopro/nn/speaker.py:76-85), three reference cross-attention blocks
+        (src/sopro/nn/ref.py:54-108), cond_norm (model.py:208).  The launch sequence is ``sopro_cond_prepare`` (csrc/stages.hip);
+        this method pads the ids, keeps what depends on the voices only (FiLM coefficients, dense K / V) and marshals."""
+        cfg, dev, D = self.cfg, self.device, self.D
         B = len(ids_list)
         if B == 0 or len(refs) != B:
             raise ValueError("need one reference per utterance")
@@ -362,25 +284,10 @@ class SoproTTSModel:
         ids = torch.zeros(B, S, dtype=torch.int32)
         for b, x in enumerate(ids_list):
             ids[b, : lens_h[b]] = x.detach().to("cpu", torch.int32).view(-1)
+        lib, eng = hip.load(), self.eng
         with self.on_stream(prep=True):
             ids = ids.to(dev)
             lens = _i32(lens_h, dev)
-            ragged = min(lens_h) != S
-            M = B * S
-            xa = torch.empty(M, D, device=dev)
-            xb = torch.empty(M, D, device=dev)
-            hip.text_embed(ids, lens, w["text_enc.embed"], self.pe, xa, B, S, D)
-            for i in range(int(cfg.n_layers_text)):
-                self._ssm_block_seq(xa, xb, f"text_enc.layers.{i}", B=B, T=S, ksize=7, dil=1, causal=False,
-                                    lens=lens if ragged else None)
-                xa, xb = xb, xa
-            txt_seq = torch.empty(B, S, D, device=dev)
-            hip.norm(xa, txt_seq, w["text_enc.norm.weight"], rows=M, C_=D, eps=RMS_EPS)
-            txt_pool = torch.empty(B, D, device=dev)
-            hip.masked_mean(txt_seq, lens, txt_pool, B, S, D)
-            # base + FiLM
-            base = torch.empty(B * Tar, D, device=dev)
-            hip.add_pos(txt_pool, self.pe, base, B, Tar, D, 0)
             sv = torch.cat([r.sv_ref.to(dev).reshape(1, -1) for r in refs], dim=0).contiguous()
             s = float(style_strength)
             # SpeakerFiLM coefficients depend on the voice (and the style strength) only: computed once per voice and kept
@@ -389,16 +296,9 @@ class SoproTTSModel:
             todo = [i for i, vc in enumerate(vcs) if s not in vc["film"]]
             if todo:
                 uniq = list({id(vcs[i]): i for i in todo}.values())
-                svu = sv[uniq].contiguous()
-                n, svd = len(uniq), int(sv.shape[1])
-                f1 = torch.empty(n, D, device=dev)
-                hip.gemm(svu, w["spk_film.mlp.0.w"], f1, M=n, N=D, K=svd, bias=w["spk_film.mlp.0.b"], epilogue=hip.EPI_GELU)
-                film = torch.empty(n, 2 * D, device=dev)
-                hip.gemm(f1, w["spk_film.mlp.2.w"], film, M=n, N=2 * D, K=D, bias=w["spk_film.mlp.2.b"])
-                gam, bet = film[:, :D].contiguous(), film[:, D:].contiguous()
+                n = len(uniq)
                 mul_u, add_u = torch.empty(n, D, device=dev), torch.empty(n, D, device=dev)
-                hip.tanh_affine(gam, mul_u, 1.0, s, n * D)
-                hip.tanh_affine(bet, add_u, 0.0, s, n * D)
+                hip.film_coeffs(eng.h, sv[uniq].contiguous(), s, n, torch.empty(n * 5 * D, device=dev), mul_u, add_u)
                 for j, i in enumerate(uniq):
                     vcs[i]["film"][s] = (mul_u[j], add_u[j])
             if all(vc is vcs[0] for vc in vcs):
@@ -406,49 +306,28 @@ class SoproTTSModel:
             else:
                 mul = torch.stack([vc["film"][s][0] for vc in vcs]).contiguous()
                 add = torch.stack([vc["film"][s][1] for vc in vcs]).contiguous()
-            cond = torch.empty(B * Tar, D, device=dev)
-            hip.norm(base, cond, w["spk_film.norm.weight"], rows=B * Tar, C_=D, eps=1e-5, kind=hip.NORM_LN,
-                     b=w["spk_film.norm.bias"], mul=mul, add=add, rows_per_seg=Tar)
-            # reference cross-attention stack
-            H = int(cfg.ref_xattn_heads)
-            dh = D // H
             tr_h = [int(r.ref_kv_caches[0]["k"].shape[2]) for r in refs]
             Tr = max(tr_h)
             klens = _i32(tr_h, dev) if min(tr_h) != Tr else None
-            nq = torch.empty(B * Tar, D, device=dev)
-            q = torch.empty(B * Tar, D, device=dev)
-            a = torch.empty(B * Tar, D, device=dev)
-            am = torch.empty(B * Tar, D, device=dev)
             # rows that share a voice (the same PreparedReference object) share its cached K / V: one dense copy per voice and
-            # layer; a single-voice batch reads it through a zero batch stride, a mixed one through one gather
+            # layer, read through a zero batch stride (one voice), the rows' own blocks (B voices) or an index per row
             order: List[PreparedReference] = []
             seen: Dict[int, int] = {}
             for r in refs:
                 if id(r) not in seen:
                     seen[id(r)] = len(order)
                     order.append(r)
-            row_u = [seen[id(r)] for r in refs]
             U = len(order)
-            sel = None if U in (1, B) else torch.tensor(row_u, dtype=torch.long, device=dev)
-            kv_bstride = 0 if (U == 1 and B > 1) else Tr * D
-            stacks = self._voice_stack(order, Tr) if U > 1 else None
-            for i in range(int(cfg.ref_xattn_layers)):
-                p = f"ref_xattn.blocks.{i}"
-                if U == 1:  # the voice's own dense [Tr, D] copies, made once (self._voice)
-                    Ku, Vu = self._voice_entry(order[0])["kv"][i]
-                    Ku, Vu = Ku.unsqueeze(0), Vu.unsqueeze(0)
-                else:  # one [U, Tr, D] stack per layer, made once per set of voices
-                    Ku, Vu = stacks[i]
-                Kb = Ku if sel is None else Ku.index_select(0, sel)
-                Vb = Vu if sel is None else Vu.index_select(0, sel)
-                hip.norm(cond, nq, w[p + ".nq.weight"], rows=B * Tar, C_=D, eps=RMS_EPS)
-                hip.gemm(nq, w[p + ".q.w"], q, M=B * Tar, N=D, K=D)
-                hip.attention(q, Kb, Vb, a, B=B, H=H, dh=dh, Tq=Tar, Tk=Tr, ldq=D, ldk=D, ldv=D, ldo=D, q_bstride=Tar * D,
-                              k_bstride=kv_bstride, v_bstride=kv_bstride, o_bstride=Tar * D, klens=klens)
-                hip.rms_match(a, cond, am, B * Tar, D)
-                hip.gemm(am, w[p + ".o.w"], cond, M=B * Tar, N=D, K=D, epilogue=hip.EPI_RES, R=cond, scale=w[p + ".gate_scale"])
+            kv_index = None if U in (1, B) else _i32([seen[id(r)] for r in refs], dev)
+            if U == 1:  # the voice's own dense [Tr, D] copies, made once (self._voice)
+                kvs = self._voice_entry(order[0])["kv"]
+            else:  # one [U, Tr, D] stack per layer, made once per set of voices
+                kvs = self._voice_stack(order, Tr)
+            txt_seq, txt_pool = torch.empty(B, S, D, device=dev), torch.empty(B, D, device=dev)
             cond_ar = torch.empty(B, Tar, D, device=dev)
-            hip.norm(cond, cond_ar, w["cond_norm.weight"], rows=B * Tar, C_=D, eps=RMS_EPS)
+            wsb = self.ws.get("cond.ws", (int(lib.sopro_cond_workspace_bytes(eng.h, B, S, Tar)) // 4 + 64,))
+            hip.cond_prepare(eng.h, wsb, ids, lens, min(lens_h) != S, mul, add, [k for k, _v in kvs], [v for _k, v in kvs],
+                             0 if (U == 1 and B > 1) else Tr * D, kv_index, klens, B, S, Tar, Tr, txt_seq, txt_pool, cond_ar)
         self.prep_stream.synchronize()
         return {"txt_seq": txt_seq, "text_lens": lens, "text_lens_host": lens_h, "txt_pool": txt_pool, "sv_ref": sv,
                 "cond_ar": cond_ar}

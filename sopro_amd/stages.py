@@ -85,6 +85,7 @@ class EngineHandle:
 
 def _sopro_tensors(m) -> Dict[str, torch.Tensor]:
     tensors = dict(m.w)
+    tensors["pe"] = m.pe  # position table of the conditioning family
     for i, s in enumerate(m.cfg.stage_order()):  # the C side names the stages by position
         tensors[f"nar.heads.{_POS[i]}.w"], tensors[f"nar.heads.{_POS[i]}.b"] = m.w[f"nar.heads.{s}.w"], m.w[f"nar.heads.{s}.b"]
     return tensors
@@ -102,6 +103,8 @@ def _cfg_of(m, codec, precision: str) -> hip.EngineCfg:
     rope_n = int(codec._rope_tables(1)[0].shape[0]) if codec is not None else 1024
     c = engine_cfg(scfg, mc, gates, mix, prev, codec.final_bias if codec is not None else 0.0, rope_n)
     c.precision = 1 if precision == "bf16" else 0
+    c.n_layers_text, c.ref_enc_layers, c.ref_xattn_layers = int(scfg.n_layers_text), int(scfg.ref_enc_layers), int(scfg.ref_xattn_layers)
+    c.ref_xattn_heads, c.sv_student_dim, c.enc_kernel = int(scfg.ref_xattn_heads), int(scfg.sv_student_dim), 7
     return c
 
 

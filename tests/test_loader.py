@@ -140,7 +140,8 @@ def test_export_for_non_python_hosts(tmp_path):
     names = {t["name"]: t for t in meta["tensors"]}
     for need in ("ar.blocks.0.glu.w", "ar.x_attns.1.q.wT", "ar.head.w", "cb_embed", "nar.blocks.5.ff2.w", "nar.heads.B.w", "nar.heads.E.b",
                  "nar.adapter.mlp.2.w", "codebooks", "rvq_proj.w", "tr.7.fc2.w", "sea.conv0.w", "sea.up3.w", "sea.res2.c1.w", "sea.final.w",
-                 "rope.cos", "upsample.w"):
+                 "rope.cos", "upsample.w", "pe", "text_enc.embed", "text_enc.layers.0.glu.w", "ref_enc_blocks.0.ff2.w", "ref_xattn.blocks.2.kv.w",
+                 "spk_film.mlp.0.w", "token2sv.proj.w", "cond_norm.weight"):
         assert need in names, need
     blob = np.fromfile(str(tmp_path / "packed.bin"), dtype=np.uint8)
     assert blob.size == meta["bytes"] and all(t["offset"] % 256 == 0 for t in meta["tensors"])
@@ -151,4 +152,5 @@ def test_export_for_non_python_hosts(tmp_path):
         want = (src[name] if src is not None else ps["nar.heads.C.w"]).numpy()
         assert np.array_equal(a, want), name
     c = meta["cfg"]
+    assert c["n_layers_text"] == cfg.n_layers_text and c["ref_xattn_layers"] == cfg.ref_xattn_layers and c["enc_kernel"] == 7
     assert c["stage_first_cb"] == [1, 4, 8, 16] and c["stage_n_cb"] == [3, 4, 8, 16] and c["ar_xattn"] == [0, 1, 0, 1, 0, 1] and c["mimi_ratios"] == [8, 6, 5, 4]
