@@ -142,6 +142,43 @@ class StageEngine(EngineHandle):
         return ws
 
     @torch.inference_mode()
+    def reference(self, ref_tokens_tq: torch.Tensor) -> Dict[str, object]:
+        """One voice from its codec tokens [T, Q] (sopro_ref_prepare): {"sv" [1, svd], "ref_seq" [T, D], "kv" [layers x [T, 2D]]}."""
+        cfg, D = self.tts.cfg, int(self.tts.cfg.d_model)
+        T, lib, st = int(ref_tokens_tq.shape[0]), self.lib, self.stream
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        tok = ref_tokens_tq.to(self.device).to(torch.int32).contiguous()
+        sv, ref_seq = torch.empty(1, int(cfg.sv_student_dim), device=self.device), torch.empty(T, D, device=self.device)
+        kv = [torch.empty(T, 2 * D, device=self.device) for _ in range(int(cfg.ref_xattn_layers))]
+        ws = self._workspace("ref", int(lib.sopro_ref_workspace_bytes(self.h, T)))
+        with torch.cuda.stream(st):
+            hip.ref_prepare(self.h, ws.view(torch.float32), tok, T, sv, ref_seq, kv)
+        st.synchronize()
+        return {"sv": sv, "ref_seq": ref_seq, "kv": kv}
+
+    @torch.inference_mode()
+    def conditioning(self, ids: torch.Tensor, voice: Dict[str, object], max_frames: int, style_strength: float = 1.0) -> Dict[str, torch.Tensor]:
+        """One utterance: text ids [S] + a voice of ``reference`` -> {"cond_ar" [1, Tar, D], "txt_seq" [1, S, D]} (sopro_film_coeffs +
+        sopro_cond_prepare)."""
+        D, lib, st = int(self.tts.cfg.d_model), self.lib, self.stream
+        S, Tar = int(ids.numel()), int(max_frames) + 1
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        idd = ids.to(self.device).to(torch.int32).reshape(1, S).contiguous()
+        lens = torch.tensor([S], dtype=torch.int32, device=self.device)
+        kvs = voice["kv"]
+        Tr = int(kvs[0].shape[0])
+        ks, vs = [kv[:, :D].contiguous() for kv in kvs], [kv[:, D:].contiguous() for kv in kvs]
+        mul, add = torch.empty(1, D, device=self.device), torch.empty(1, D, device=self.device)
+        txt_seq, txt_pool = torch.empty(1, S, D, device=self.device), torch.empty(1, D, device=self.device)
+        cond_ar = torch.empty(1, Tar, D, device=self.device)
+        ws = self._workspace("cond", int(lib.sopro_cond_workspace_bytes(self.h, 1, S, Tar)))
+        with torch.cuda.stream(st):
+            hip.film_coeffs(self.h, voice["sv"], float(style_strength), 1, torch.empty(5 * D, device=self.device), mul, add)
+            hip.cond_prepare(self.h, ws.view(torch.float32), idd, lens, False, mul, add, ks, vs, Tr * D, None, None, 1, S, Tar, Tr, txt_seq, txt_pool, cond_ar)
+        st.synchronize()
+        return {"cond_ar": cond_ar, "txt_seq": txt_seq}
+
+    @torch.inference_mode()
     def ar_generate(self, cond_ar: torch.Tensor, txt_seq: torch.Tensor, text_lens: Optional[torch.Tensor], *, top_p: float, temperature: float,
                     anti_loop: bool, min_gen_frames: int = 12, seed: int = 0, nonce: int = 0, steps: Optional[int] = None
                     ) -> Tuple[torch.Tensor, torch.Tensor]:

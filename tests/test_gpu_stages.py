@@ -1,6 +1,6 @@
-"""The stage-level C entry points (sopro_engine_*, sopro_ar_begin / _run_graph / _tokens, sopro_nar_refine,
-sopro_mimi_decode: include/sopro_hip.h), driven through ctypes WITHOUT the launch sequencing of sopro_amd/model.py and
-codec.py: a whole utterance from conditioning outputs to samples, against the reference's full-size fixture, the oracle and
+"""The stage-level C entry points (sopro_engine_*, sopro_ref_prepare, sopro_cond_prepare, sopro_ar_begin / _run_graph / _tokens,
+sopro_nar_refine, sopro_mimi_decode: include/sopro_hip.h), driven through ctypes WITHOUT sopro_amd/model.py and
+codec.py: a whole utterance from reference tokens + text ids to samples, against the reference's full-size fixture, the oracle and
 the Python host (which issues the same kernels in the same order: results must be bit-identical)."""
 import numpy as np
 import pytest
@@ -31,7 +31,13 @@ def test_whole_utterance_through_the_c_stages_matches_the_reference(eng, tts_noe
     maxf = int(g["max_frames"])
     want = _t(g["tokens"].astype(np.int64))
     ref = tts.prepare_reference(ref_tokens_tq=_t(g["ref_tq"]))
-    prep = tts.model.prepare_conditioning(_t(g["ids"]), ref, max_frames=maxf, style_strength=1.0)  # conditioning stays with the host
+    # reference preparation and conditioning through the library's sequences alone (tokens + text ids in) ...
+    voice = eng.reference(_t(g["ref_tq"]))
+    prep = eng.conditioning(_t(g["ids"]), voice, maxf, style_strength=1.0)
+    # ... which the Python host marshals to as well: identical bits
+    pprep = tts.model.prepare_conditioning(_t(g["ids"]), ref, max_frames=maxf, style_strength=1.0)
+    assert torch.equal(voice["sv"], ref.sv_ref) and torch.equal(voice["ref_seq"], ref.ref_seq[0])
+    assert torch.equal(prep["cond_ar"], pprep["cond_ar"]) and torch.equal(prep["txt_seq"], pprep["txt_seq"])
     hist, feos = eng.ar_generate(prep["cond_ar"], prep["txt_seq"], None, **GREEDY)
     assert int(feos[0]) == -1 and hist.shape == (1, maxf + 1)
     assert torch.equal(hist[0].cpu().long(), want[:, 0]), "codebook-0 tokens differ from the reference"
