@@ -302,6 +302,9 @@ def main() -> None:
     ap.add_argument("--input-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: a 1-GPU run on the inputs of rank R
     args = ap.parse_args()
     BATCH, FRAMES = int(args.batch), int(args.frames)
+    # passes of two jobs pay off up to ~256 frames; beyond that the decoder of a 64 x 400 pass outgrows what the generation phases
+    # hide (32 x 400: 17.5 k coalesced against 18.2 k, profiles/r03_experiments.md)
+    COALESCE = int(args.coalesce) if FRAMES <= 256 else 1
 
     if args.cpu_baseline_only:  # child process of the N=1 run: CPU only, bounded by the parent's timeout
         from sopro_amd.config import MimiDecoderConfig, SoproTTSConfig
@@ -394,7 +397,7 @@ def main() -> None:
             for _ in range(n):
                 check(tts.synthesize_batch(timings=timings, **job))
         else:
-            for out in pipe.run([job] * n, timings=timings, coalesce=args.coalesce):
+            for out in pipe.run([job] * n, timings=timings, coalesce=COALESCE):
                 check(out)
 
     def fence():
@@ -710,13 +713,13 @@ def main() -> None:
                                    "region, top_p=0.9 T=1.05 anti_loop (reference defaults), synthetic weights with EOS suppressed",
                        "batch_per_gpu": BATCH, "frames": FRAMES, "voices_per_batch": n_voices,
                        "parallelism": f"replicas x{world} (utterance sharding, no collective)",
-                       "lanes_per_gpu": args.lanes, "coalesce": (args.coalesce if args.lanes > 1 else 1),
+                       "lanes_per_gpu": args.lanes, "coalesce": (COALESCE if args.lanes > 1 else 1),
                        "pipelining": (f"{args.lanes} engines per GPU share the weights: up to {args.ar_parts} AR phases at a time on "
                                       f"{'one shared partition' if args.ar_shared else 'partitions'} of {args.ar_cus} CUs while conditioning, NAR and Mimi "
                                       f"decode of other batches run on the other {int(round(256 * share))} CUs (hipExtStreamCreateWithCUMask); NAR and Mimi "
                                       "launch sequences are recorded hipGraphs"
-                                      + (f"; {args.coalesce} consecutive batches are coalesced into one {args.coalesce * BATCH}-row pass (every utterance keeps its "
-                                         "own sampler stream: outputs are bit-identical to un-coalesced steps)" if args.coalesce > 1 else "")) if args.lanes > 1 else "none"},
+                                      + (f"; {COALESCE} consecutive batches are coalesced into one {COALESCE * BATCH}-row pass (every utterance keeps its "
+                                         "own sampler stream: outputs are bit-identical to un-coalesced steps)" if COALESCE > 1 else "")) if args.lanes > 1 else "none"},
             "dtype_detail": ("fp32 tensors and accumulation everywhere; conditioning + AR on v_mfma_f32_*_f32; NAR contractions with operands split into "
                              "three bf16 pieces (24 mantissa bits, 6 MFMA passes); Mimi decoder contractions with two pieces (16 bits, 3 passes)")
                             if args.precision == "f32" else
