@@ -720,8 +720,10 @@ def main() -> None:
                                       "launch sequences are recorded hipGraphs"
                                       + (f"; {COALESCE} consecutive batches are coalesced into one {COALESCE * BATCH}-row pass (every utterance keeps its "
                                          "own sampler stream: outputs are bit-identical to un-coalesced steps)" if COALESCE > 1 else "")) if args.lanes > 1 else "none"},
-            "dtype_detail": ("fp32 tensors and accumulation everywhere; conditioning + AR on v_mfma_f32_*_f32; NAR contractions with operands split into "
-                             "three bf16 pieces (24 mantissa bits, 6 MFMA passes); Mimi decoder contractions with two pieces (16 bits, 3 passes)")
+            "dtype_detail": ("fp32 tensors and accumulation everywhere; conditioning + AR on v_mfma_f32_*_f32 (the two encoders' contractions on three "
+                             "bf16 pieces / 6 MFMA passes, 24 mantissa bits); NAR contractions with operands split into two fp16 pieces (22 mantissa bits, "
+                             "3 MFMA passes, power-of-two operand scaling: as accurate as the six-pass bf16 form, profiles/r03_f16x3_probe.txt); Mimi decoder "
+                             "contractions with two bf16 pieces (16 bits, 3 passes)")
                             if args.precision == "f32" else
                             ("bf16 mode (SURVEY 8d config 2): NAR + Mimi contractions with both operands rounded to bf16 once, one MFMA pass, fp32 accumulators, "
                              "norms, softmax and residual streams; the AR frame streams bf16 weights with bf16 MFMA operands (fp32 accumulate, norms, ring buffers, residual); "
