@@ -367,7 +367,8 @@ int sopro_seanet_res_set_tiles(int tiles); /* developer probe / tests: 64-row ti
 int sopro_seanet_up128_f32(const float* x, int64_t x_seg_stride, const float* w, const float* bias, float* out,
                            int64_t out_seg_stride, int32_t B, int32_t T, int32_t passes, void* stream);
 int sopro_seanet_up_set_tiles(int tiles); /* developer probe / tests: 64-row tiles per workgroup, 0 = by size */
-int sopro_seanet_tail_set_tiles(int tiles); /* developer probe / tests: 126-sample tiles per workgroup, 0 = by size */
+int sopro_seanet_tail_set_tiles(int tiles); /* developer probe / tests: 126-sample tiles per workgroup of the four-wave kernel, 0 = by size
+                                             * (long inputs: the sixteen-wave kernel), < 0 = the sixteen-wave kernel at any size */
 
 /* ---- launch timing of the stage sequences (csrc/prof.hip) -------------------------------------
  * bench.py's roofline leg (the reference has no counterpart: its profiler is torch's).  While enabled, every heavy launch

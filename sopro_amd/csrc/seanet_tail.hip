@@ -18,6 +18,18 @@
 // accumulator layout) and the last layer's weights are requested in the tile's memory round.  2 workgroups per CU (55 KB LDS).
 #include "common.h"
 
+// Developer timeline builds (tools/micro/build_tail_dbg.sh, never the product library): shader-clock stamps of one tile group's phases
+#ifdef SOPRO_TAIL_DBG
+__device__ long long* g_tail_dbg = nullptr;
+extern "C" int sopro_tail_dbg_set(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tail_dbg), &p, sizeof(p)); }
+#define TAIL_STAMP(i) do { if (g_tail_dbg && blockIdx.x == 7 && blockIdx.y == 1 && threadIdx.x == 64 * 5 && it < 16) g_tail_dbg[it * 8 + (i)] = clock64(); } while (0)
+#else
+#define TAIL_STAMP(i) do { } while (0)
+#endif
+#ifdef TAIL_EXP_OFF  // (timeline builds: ELU replaced by the identity - wrong results, the time of what is left is the point)
+#define eluf_(v) (v)
+#endif
+
 namespace {
 
 constexpr int TO = 126;        // output samples per tile
@@ -211,11 +223,212 @@ __global__ __launch_bounds__(256, 2) void seanet_tail_kernel(const float* __rest
   }  // tiles of this workgroup
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 3: the same tail for long inputs as SIXTEEN AUTONOMOUS WAVES per CU.  Shader-clock stamps inside the kernel above (one
+// workgroup of four waves, two per CU; tools/tail_timeline.py) showed ~9 cycles per instruction for a wave that has a SIMD to
+// itself - its instruction streams are dependent chains (ELU, split, pack) - and a first sixteen-wave form with workgroup
+// barriers lost 30 % of its cycles in them.  Here the weight fragments live in LDS (written once per workgroup, shared by its
+// sixteen waves; <= 128 registers per lane, four waves per SIMD) and every wave owns whole tiles of 14 output samples: it
+// stages the 18 rows it needs itself (two rows of halo per convolution), so no phase of a tile waits for another wave - only
+// wavefront-scope fences between its own LDS writes and reads.  Products on v_mfma_f32_16x16x32_bf16, the same three passes
+// (lo*hi + hi*lo + hi*hi), the same operand rounding as the kernel above.
+constexpr int T3O = 14;            // output samples per wave tile
+constexpr int H3R = T3O + 4;       // staged h rows (samples s0-4 .. s0+13)
+constexpr int ES3 = H3R * EROW;    // 4896 B: split ELU(h); later ELU(h') as fp32 [16][HLD]
+constexpr int YS3 = 16 * YROW;     // 2304 B: split ELU(intermediate), rows = samples s0-2 .. s0+13
+constexpr int W1F = 2 * 6 * 2;     // first convolution: [column tile][k-step][hi | lo] fragment blocks of 64 lanes x 16 B
+constexpr int W2F = 4 * 2;         // second: [column tile][hi | lo]
+constexpr int TAIL3_LDS = (W1F + W2F) * 1024 + 16 * (ES3 + YS3);
+static_assert(16 * HLD * 4 <= ES3, "the fp32 ELU(h') tile must fit over the split h tile");
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void tail_wave_sync() {  // a wave's own LDS writes -> its other lanes' reads (see ar_driver.hip wave_lds_sync)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __restrict__ h, int64_t h_seg_stride, const float* __restrict__ w1,
+                                                                const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                const float* __restrict__ b2, const float* __restrict__ wf, float bf,
+                                                                float* __restrict__ wav, int64_t wav_seg_stride, int T, int trips) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+  uint4* w1s = reinterpret_cast<uint4*>(lds3);
+  uint4* w2s = w1s + W1F * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* es = lds3 + (W1F + W2F) * 1024 + wave * (ES3 + YS3);
+  unsigned char* ys = es + ES3;
+  const int b = blockIdx.y;
+  const int col = lane & 15, kq = lane >> 4;  // MFMA 16x16x32: operand row / column, k quarter (8 consecutive k); C: column, rows 4 kq + i
+  const float* hb = h + (int64_t)b * h_seg_stride;
+
+  // ---- weight fragments -> LDS, once per workgroup: waves 0-11 one (column tile, k-step) block pair of the first convolution
+  // each (B operand: n = 16 nt + col, k = 32 s + 8 kq .. + 7), waves 12-15 one column tile of the second (n = 16 nt + col, k = 8 kq ..)
+  {
+    uint4 hi, lo;
+    if (wave < 12) {
+      const int nt = wave / 6, s = wave % 6;
+      split8(w1 + (16 * nt + col) * 192 + s * 32 + kq * 8, hi, lo);
+      w1s[((nt * 6 + s) * 2 + 0) * 64 + lane] = hi;
+      w1s[((nt * 6 + s) * 2 + 1) * 64 + lane] = lo;
+    } else {
+      const int nt = wave - 12;
+      split8(w2 + (16 * nt + col) * 32 + kq * 8, hi, lo);
+      w2s[(nt * 2 + 0) * 64 + lane] = hi;
+      w2s[(nt * 2 + 1) * 64 + lane] = lo;
+    }
+  }
+  const float b1v[2] = {b1[col], b1[16 + col]};
+  const float b2v[4] = {b2[col], b2[16 + col], b2[32 + col], b2[48 + col]};
+  const float wl0 = wf[lane], wl1 = wf[64 + lane], wl2 = wf[128 + lane];  // last layer: tap j of this lane's channel
+
+  // tile request of this wave: local row r holds sample s0-4+r = padded row s0-2+r (two zero rows in front of the segment);
+  // rows outside the segment are redirected to padded row 0, a zero row (branch-free loads)
+  float4 v[5];
+  auto request = [&](int s0) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int idx = lane + q * 64;  // float4 index: 16 per row
+      const int r = idx >> 4, c4 = idx & 15;
+      const int p = s0 - 2 + r;
+      const int pc = (r < H3R && p >= 0 && p < T + 2) ? p : 0;
+      v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)pc * 64 + c4 * 4);
+    }
+  };
+  const int tile0 = (int)blockIdx.x * trips * 16 + wave;  // this wave's tiles: tile0, tile0 + 16, ...
+  request(tile0 * T3O);
+  __syncthreads();  // the weight fragments are in place (the only workgroup barrier)
+  for (int it = 0; it < trips; ++it) {
+    const int s0 = (tile0 + it * 16) * T3O;
+    if (s0 >= T) break;  // uniform over the wave
+    TAIL_STAMP(0);
+#ifdef SOPRO_TAIL_DBG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (timeline builds: the tile's arrival gets its own stamp)
+#endif
+    TAIL_STAMP(1);
+    // ---- ELU + split once per element
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int idx = lane + q * 64;
+      const int r = idx >> 4, c4 = idx & 15;
+      if (r < H3R) {
+        uint2 hi, lo;
+        split2_bf16(eluf_(v[q].x), eluf_(v[q].y), hi.x, lo.x);
+        split2_bf16(eluf_(v[q].z), eluf_(v[q].w), hi.y, lo.y);
+        *reinterpret_cast<uint2*>(es + r * EROW + c4 * 8) = hi;
+        *reinterpret_cast<uint2*>(es + r * EROW + 128 + c4 * 8) = lo;
+      }
+    }
+    tail_wave_sync();
+    TAIL_STAMP(2);
+    // the staging registers are free: the next tile's rows travel while this one computes
+    if (it + 1 < trips && s0 + 16 * T3O < T) request(s0 + 16 * T3O);
+    // skip operand of the residual block in the accumulator layout of the second convolution (row 4 kq + i of the intermediate
+    // = sample s0-2+row, columns 16 nt + col): an L2-resident re-read of rows the tile request brought in
+    float skip[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = s0 + 4 * kq + i;  // padded row of sample s0-2+row
+      const float* hp = hb + (int64_t)((p >= 2 && p < T + 2) ? p : 0) * 64 + col;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) skip[nt][i] = hp[16 * nt];
+    }
+    TAIL_STAMP(3);
+
+    // ---- conv k=3, 64 -> 32: intermediate row m (sample s0-2+m) reads tile rows m, m+1, m+2.
+    // K index = tap * 64 + channel; k-step s covers tap s / 2, channels 32 (s % 2) .. + 31
+    {
+      f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const unsigned char* a = es + col * EROW + kq * 16;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        const unsigned char* p = a + (s >> 1) * EROW + (s & 1) * 64;
+        const uint4 ah = *reinterpret_cast<const uint4*>(p), al = *reinterpret_cast<const uint4*>(p + 128);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const uint4 wh = w1s[((nt * 6 + s) * 2 + 0) * 64 + lane], wl = w1s[((nt * 6 + s) * 2 + 1) * 64 + lane];
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(al), frag(wh), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(ah), frag(wl), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(ah), frag(wh), acc[nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 4 * kq + i;
+          unsigned hi, lo;
+          split2_bf16(eluf_(acc[nt][i] + b1v[nt]), 0.f, hi, lo);
+          *reinterpret_cast<unsigned short*>(ys + m * YROW + (16 * nt + col) * 2) = (unsigned short)(hi & 0xffffu);
+          *reinterpret_cast<unsigned short*>(ys + m * YROW + 64 + (16 * nt + col) * 2) = (unsigned short)(lo & 0xffffu);
+        }
+    }
+    tail_wave_sync();  // (this wave is also done reading the split h tile: its memory becomes the ELU(h') tile below)
+    TAIL_STAMP(4);
+
+    // ---- conv k=1, 32 -> 64 on the intermediate, + skip operand, ELU(h') -> fp32 tile rows 0 .. 15 (row m = sample s0-2+m)
+    {
+      f32x4v acc2[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc2[nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+      const unsigned char* a = ys + col * YROW + kq * 16;
+      const uint4 ah = *reinterpret_cast<const uint4*>(a), al = *reinterpret_cast<const uint4*>(a + 64);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const uint4 wh = w2s[(nt * 2 + 0) * 64 + lane], wl = w2s[(nt * 2 + 1) * 64 + lane];
+        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(al), frag(wh), acc2[nt], 0, 0, 0);
+        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(ah), frag(wl), acc2[nt], 0, 0, 0);
+        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(ah), frag(wh), acc2[nt], 0, 0, 0);
+      }
+      float* hs = reinterpret_cast<float*>(es);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 4 * kq + i;
+        const bool real = (s0 - 2 + m) >= 0;  // samples before the utterance start are the zero padding of the last conv
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) hs[m * HLD + 16 * nt + col] = real ? eluf_(skip[nt][i] + acc2[nt][i] + b2v[nt]) : 0.f;
+      }
+    }
+    tail_wave_sync();
+    TAIL_STAMP(5);
+
+    // ---- last conv k=3, 64 -> 1 on the stored ELU(h'): lane = channel; 16 column reads (the whole tile: 4 KB of LDS traffic
+    // instead of 48 KB with one output per lane group), three FMAs per output, then a transpose-reduction over the 64 lanes:
+    // every exchange halves the values a lane still carries, after four of them lane l holds output l >> 2 summed over 16 lanes
+    {
+      const float* hs = reinterpret_cast<const float*>(es);
+      float x[16], p16[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = hs[r * HLD + lane];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) p16[i] = i < T3O ? fmaf(wl2, x[i + 2 < 16 ? i + 2 : 15], fmaf(wl1, x[i + 1 < 16 ? i + 1 : 15], wl0 * x[i])) : 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int n = 8 >> st, bit = 32 >> st;  // values kept per lane after this exchange; lane bit that picks the half
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+          const float keep = up ? p16[k + n] : p16[k], send = up ? p16[k] : p16[k + n];
+          p16[k] = keep + __shfl_xor(send, bit, 64);
+        }
+      }
+      float sum = p16[0];
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      const int i = lane >> 2;
+      if ((lane & 3) == 0 && i < T3O && s0 + i < T) wav[(int64_t)b * wav_seg_stride + s0 + i] = sum + bf;
+    }
+    tail_wave_sync();  // the last phase is done with the LDS tiles before the next trip's staging
+    TAIL_STAMP(6);
+    TAIL_STAMP(7);
+  }
+}
+
 }  // namespace
 
-static int g_tail_tiles = 0;  // developer probe / tests: tiles per workgroup, 0 = heuristic
+static int g_tail_tiles = 0;  // developer probe / tests: tiles per workgroup of the four-wave kernel, 0 = by size, < 0 = the sixteen-wave kernel
 extern "C" int sopro_seanet_tail_set_tiles(int tiles) {
-  g_tail_tiles = tiles > 0 ? tiles : 0;
+  g_tail_tiles = tiles;
   return 0;
 }
 
@@ -224,6 +437,17 @@ extern "C" int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const
                                       int32_t T, void* stream) {
   SOPRO_CHECK_ARG(h && w1 && b1 && w2 && b2 && wf && wav && B > 0 && T > 0, "bad pointers or sizes");
   SOPRO_CHECK_ARG(aligned16(h) && aligned16(w1) && aligned16(w2) && aligned16(wf) && (h_seg_stride & 3) == 0, "alignment");
+  // long inputs: sixteen autonomous waves per CU over LDS-resident weight fragments (a wave owns whole tiles of 14 samples)
+  const int64_t all16 = (int64_t)((T + T3O - 1) / T3O) * B;
+  if (g_tail_tiles < 0 || (g_tail_tiles == 0 && all16 >= 16 * 1024)) {
+    const int n16 = (int)(((T + T3O - 1) / T3O + 15) / 16);  // sixteen-tile rounds per utterance
+    int trips = all16 >= 64 * 4096 ? 32 : (all16 >= 16 * 4096 ? 8 : 2);  // rounds per workgroup (the fragments are made once per workgroup)
+    if (g_tail_tiles < -1) trips = -g_tail_tiles;                         // (developer probe)
+    SOPRO_SET_MAX_LDS_ONCE(seanet_tail16_kernel, TAIL3_LDS);
+    hipLaunchKernelGGL(seanet_tail16_kernel, dim3((n16 + trips - 1) / trips, B), dim3(1024), TAIL3_LDS, (hipStream_t)stream, h, h_seg_stride, w1, b1,
+                       w2, b2, wf, bf, wav, wav_seg_stride, T, trips);
+    SOPRO_LAUNCH_CHECK();
+  }
   const int ntile = (T + TO - 1) / TO;
   // several tiles per workgroup once there are enough of them to keep every CU supplied (>= 8 workgroups per CU after the grouping)
   const int tiles = g_tail_tiles > 0 ? g_tail_tiles : ((int64_t)ntile * B >= 16 * 2048 ? 16 : ((int64_t)ntile * B >= 8 * 1024 ? 8 : 1));

@@ -816,6 +816,36 @@ def test_seanet_tail_tiles_per_workgroup_is_the_same_function():
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("B,T", [(2, 300), (3, 1000), (1, 62), (2, 8000)])
+def test_seanet_tail_sixteen_wave_kernel(B, T):
+    """The long-input form of the tail (four tile groups of 62 samples per workgroup over LDS-resident weight fragments,
+    v_mfma_f32_16x16x32_bf16): against torch's convolutions and against the four-wave kernel (same operand rounding, another
+    accumulation order)."""
+    h = rnd(B, T, 64, seed=730)
+    w1, b1 = rnd(32, 64, 3, seed=731, scale=0.07), rnd(32, seed=732, scale=0.1)
+    w2, b2 = rnd(64, 32, 1, seed=733, scale=0.17), rnd(64, seed=734, scale=0.1)
+    wf, bf = rnd(1, 64, 3, seed=735, scale=0.07), 0.03
+    x = h.transpose(1, 2)
+    y = O.causal_conv1d(F.elu(x), w1, b1)
+    y = O.causal_conv1d(F.elu(y), w2, b2)
+    ref = O.causal_conv1d(F.elu(x + y), wf, torch.tensor([bf]))[:, 0]
+    hb = torch.zeros(B, 2 + T, 64)
+    hb[:, 2:] = h
+    args = [dev(t) for t in (hb, pack.pack_conv1d(w1), b1, pack.pack_conv1d(w2), b2, wf[0].t())]
+    lib, outs = hip.load(), {}
+    try:
+        for tiles in (-1, 1):
+            lib.sopro_seanet_tail_set_tiles(tiles)
+            wav = torch.full((B, T), float("nan"), device=DEV)
+            hip.seanet_tail(*args, bf, wav, B=B, T=T, h_seg_stride=(2 + T) * 64, wav_seg_stride=T)
+            torch.cuda.synchronize()
+            outs[tiles] = wav.cpu()
+    finally:
+        lib.sopro_seanet_tail_set_tiles(0)
+    close(outs[-1], ref, 1e-4, "sixteen-wave SEANet tail")
+    assert float((outs[-1] - outs[1]).abs().max()) < 2e-6 * float(ref.abs().max() + 1.0)
+
+
 def test_seanet_res128_fused_block_matches_the_layers():
     """MimiResnetBlock(dim 128) + the next layer's ELU in one weight-stationary kernel (HF:modeling_mimi.py:408-447):
     against torch's convolutions, for one and several tiles per workgroup (bit-identical), partial last tile, batch of 3."""

@@ -12,7 +12,7 @@ from sopro_amd import hip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 384000
 dev = "cuda:0"
-if len(sys.argv) > 3:  # tiles per workgroup (0 = the library's choice)
+if len(sys.argv) > 3:  # tiles per workgroup of the four-wave kernel (0 = the library's choice; -1 = the sixteen-wave kernel, -N = with N trips per workgroup)
     hip.load().sopro_seanet_tail_set_tiles(int(sys.argv[3]))
 g = torch.Generator(device=dev).manual_seed(0)
 h = torch.randn(B, 2 + T, 64, device=dev, generator=g)
