@@ -226,6 +226,8 @@ def load() -> C.CDLL:
     if v != ABI_VERSION:
         raise SoproHipError(f"{LIB_PATH} has ABI version {v}, the Python host expects {ABI_VERSION}: rebuild it")
     lib.sopro_gemm_set_group_m(int(os.environ.get("SOPRO_GEMM_GROUP_M", str(DEFAULT_GROUP_M))))
+    if os.environ.get("SOPRO_GEMM_TILE"):  # developer A/B: tile shape of every split contraction (1: 128x128, 2: 256x128, 4: 128x64, 5: 64x64)
+        lib.sopro_gemm_bf16_set_tile_override(int(os.environ["SOPRO_GEMM_TILE"]))
     _lib = lib
     return lib
 
