@@ -670,11 +670,17 @@ extern "C" int sopro_gemm_f16x3(const sopro_gemm_args* a, const void* packed_w, 
   const uint4* wp = reinterpret_cast<const uint4*>(packed_w);
   const int ksubs = (g.K + 31) / 32 * 2;
   if (ext.c_mode == 5) return launch_argmax<2, true>(g, wp, ksubs, ext, s);
-  switch (g_tile_override) {
+  static const int env_tile = getenv("SOPRO_F16X3_TILE") ? atoi(getenv("SOPRO_F16X3_TILE")) : 0;  // developer A/B of this family alone
+  switch (g_tile_override ? g_tile_override : env_tile) {
     case 1: return launch_cfg6<2, 2, 2, 2, 2, true>(g, wp, ksubs, ext, s);
     case 4: return launch_cfg6<2, 2, 2, 1, 2, true>(g, wp, ksubs, ext, s);
+    case 5: return g.epilogue == SOPRO_EPI_GLU ? launch_cfg6<2, 2, 2, 1, 2, true>(g, wp, ksubs, ext, s) : launch_cfg6<2, 2, 2, 1, 1, true>(g, wp, ksubs, ext, s);
     default: break;
   }
+  // many rows (64-utterance passes of the pipeline: 12800 rows): 128x128 tiles - NAR phase 5.8 -> 5.5-5.7 ms per step in the
+  // pipeline (profiles/r03_experiments.md); a few thousand rows and below: the small tiles (tools/gemm_x6_probe.py).  Results
+  // do not depend on the tile shape (every output element runs the same K loop)
+  if (g.M >= 8192 && env_tile == 0) return launch_cfg6<2, 2, 2, 2, 2, true>(g, wp, ksubs, ext, s);
   if (g.epilogue == SOPRO_EPI_GLU) return launch_cfg6<2, 2, 2, 1, 2, true>(g, wp, ksubs, ext, s);
   return launch_cfg6<2, 2, 2, 1, 1, true>(g, wp, ksubs, ext, s);
 }
