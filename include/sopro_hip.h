@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 33
+#define SOPRO_ABI_VERSION 34
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -558,6 +558,13 @@ int sopro_ar_tokens(sopro_engine* e, int32_t* hist, int32_t* first_eos, int32_t*
 int64_t sopro_nar_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T);
 int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_t cond_bstride, const int32_t* rvq1, const int32_t* lens,
                      int32_t B, int32_t T, int32_t* tokens, void* stream);
+
+/* ---- Mimi encode (reference audio -> codec tokens; src/sopro/codec/mimi.py:42-63 -> HF MimiModel.encode): SEANet encoder,
+ * encoder transformer, stride-2 downsample, split residual VQ, every contraction in exact fp32.  Family marker "enc.conv0.w"
+ * (+ the "etr.*" transformer tensors, "rope.cos" / "rope.sin").  wav [B, N] at the codec rate -> codes [B, ceil(N / 1920), Q]
+ * int32.  Launches only. */
+int64_t sopro_mimi_encode_workspace_bytes(const sopro_engine* e, int32_t B, int32_t N);
+int sopro_mimi_encode(sopro_engine* e, void* workspace, const float* wav, int32_t B, int32_t N, int32_t* codes, void* stream);
 
 /* ---- Mimi decode: tokens [B, T, Q] int32 -> wav [B, T * 1920] fp32 */
 int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T);

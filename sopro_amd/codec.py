@@ -152,76 +152,21 @@ class MimiCodec:
     @torch.inference_mode()
     def encode_waveform(self, wav: torch.Tensor) -> torch.Tensor:
         """[N] / [1, N] / [B, N] waveform(s) at the codec rate -> codes [T, Q] (or [B, T, Q]), T = ceil(N / 1920).
-        HF:modeling_mimi.py MimiModel._encode_frame: SEANet encoder -> transformer -> stride-2 downsample ->
-        split residual VQ.  Every contraction runs in ``sopro_gemm_f32`` (strided convs = overlapping-row windows)."""
-        mc, w, dev, ws = self.mc, self.w, self.device, self.ws
-        if "enc.conv0.w" not in w:
+        HF:modeling_mimi.py MimiModel._encode_frame: SEANet encoder -> transformer -> stride-2 downsample -> split residual VQ;
+        the launch sequence is ``sopro_mimi_encode`` (csrc/stages.hip), every contraction in exact fp32."""
+        if "enc.conv0.w" not in self.w:
             raise hip.SoproHipError("this Mimi checkpoint was loaded without its encoder-side tensors")
         squeeze = wav.dim() == 1
-        x = (wav.unsqueeze(0) if squeeze else wav.reshape(-1, wav.shape[-1])).to(dev, torch.float32).contiguous()
+        x = (wav.unsqueeze(0) if squeeze else wav.reshape(-1, wav.shape[-1])).to(self.device, torch.float32).contiguous()
         B, N = int(x.shape[0]), int(x.shape[1])
         if N == 0:
             raise ValueError("empty waveform")
-        HS, CD, V, Q = int(mc.hidden_size), int(mc.codebook_dim), int(mc.codebook_size), self.num_quantizers
-        ratios = [int(r) for r in reversed(mc.upsampling_ratios)]
-        k0, rk, lk = int(mc.kernel_size), int(mc.residual_kernel_size), int(mc.last_kernel_size)
-        s2 = int(mc.upsample_stride)
+        lib, Q = hip.load(), self.num_quantizers
+        T = -(-N // int(self.mc.frame_samples))
         with self.on_stream():
-            ch, L = int(mc.num_filters), N
-            pad = max(ratios[0], rk - 1)
-            Lo = -(-L // ratios[0])
-            Hc = torch.zeros(B, pad + Lo * ratios[0], ch, device=dev)  # per-call: lengths vary freely
-            # first conv 1 -> 64, k = 7, causal
-            hip.fir1(x, w["enc.conv0.w"], Hc, B=B, n_in=N, n_out=N, C_=ch, K=k0, stride=1, left=k0 - 1, bias=w["enc.conv0.b"],
-                     o_off=pad * ch, o_seg_stride=int(Hc.shape[1]) * ch)
-            for si, r in enumerate(ratios):
-                seg_stride = int(Hc.shape[1]) * ch
-                hid = ch // int(mc.compress)
-                # residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x))))
-                Y1 = torch.empty(B * L, hid, device=dev)
-                hip.gemm(Hc, w[f"enc.res{si}.c1.w"], Y1, M=B * L, N=hid, K=rk * ch, lda=ch, bias=w[f"enc.res{si}.c1.b"],
-                         prologue=hip.PRO_ELU, rows_per_seg=L, a_seg_stride=seg_stride, a_off=(pad - (rk - 1)) * ch)
-                hip.gemm(Y1, w[f"enc.res{si}.c2.w"], Hc, M=B * L, N=ch, K=hid, bias=w[f"enc.res{si}.c2.b"], prologue=hip.PRO_ELU,
-                         epilogue=hip.EPI_RES, R=Hc, rows_per_seg=L, c_off=pad * ch, r_off=pad * ch, c_seg_stride=seg_stride,
-                         r_seg_stride=seg_stride, ldc=ch, ldr=ch)
-                # ELU -> Conv1d(ch -> 2ch, k = 2r, stride r): frame j contracts rows j*r - r .. j*r + r - 1
-                Lo = -(-L // r)
-                last = si == len(ratios) - 1
-                if last:
-                    npad, ntail = lk - 1, 0
-                else:
-                    npad = max(ratios[si + 1], rk - 1)
-                    ntail = -(-Lo // ratios[si + 1]) * ratios[si + 1] - Lo
-                Hn = torch.zeros(B, npad + Lo + ntail, 2 * ch, device=dev)
-                hip.gemm(Hc, w[f"enc.down{si}.w"], Hn, M=B * Lo, N=2 * ch, K=2 * r * ch, lda=r * ch, bias=w[f"enc.down{si}.b"],
-                         prologue=hip.PRO_ELU, rows_per_seg=Lo, a_seg_stride=seg_stride, a_off=(pad - r) * ch, c_off=npad * 2 * ch,
-                         c_seg_stride=int(Hn.shape[1]) * 2 * ch, ldc=2 * ch)
-                Hc, ch, L, pad = Hn, 2 * ch, Lo, npad
-            # ELU -> last conv (k = 3) into the transformer stream, which carries the downsample conv's replicate pads
-            T25 = L
-            T = -(-T25 // s2)
-            pad_x, tail_x = s2, T * s2 - T25
-            xs_stride = (pad_x + T25 + tail_x) * HS
-            X = torch.empty(B, pad_x + T25 + tail_x, HS, device=dev)
-            hip.gemm(Hc, w["enc.final.w"], X, M=B * T25, N=HS, K=lk * ch, lda=ch, bias=w["enc.final.b"], prologue=hip.PRO_ELU,
-                     rows_per_seg=T25, a_seg_stride=int(Hc.shape[1]) * ch, c_off=pad_x * HS, c_seg_stride=xs_stride, ldc=HS)
-            self._transformer("etr", X, B, T25, pad_x, xs_stride)
-            # downsample: Conv1d(k = 2*s2, stride s2, no bias), replicate padding on both sides
-            X[:, :pad_x] = X[:, pad_x:pad_x + 1]
-            if tail_x:
-                X[:, pad_x + T25:] = X[:, pad_x + T25 - 1:pad_x + T25]
-            Dn = torch.empty(B * T, HS, device=dev)
-            hip.gemm(X, w["enc.ds.w"], Dn, M=B * T, N=HS, K=2 * s2 * HS, lda=s2 * HS, rows_per_seg=T, a_seg_stride=xs_stride)
-            # split residual VQ: semantic group (input_proj + ns layers), acoustic group (input_proj + the rest)
-            codes = torch.empty(B * T, Q, dtype=torch.int32, device=dev)
-            res = torch.empty(B * T, CD, device=dev)
-            scores = torch.empty(B * T, V, device=dev)
-            ns = int(mc.num_semantic_quantizers)
-            for grp, q0, q1 in (("sem", 0, ns), ("ac", ns, Q)):
-                hip.gemm(Dn, w[f"enc.inproj.{grp}.w"], res, M=B * T, N=CD, K=HS)
-                for q in range(q0, q1):
-                    hip.gemm(res, w["codebooks"][q * V:(q + 1) * V], scores, M=B * T, N=V, K=CD, bias=w["enc.cb_bias"][q * V:(q + 1) * V])
-                    hip.rvq_assign(scores, w["codebooks"], res, codes, rows=B * T, V=V, D=CD, ldc=Q, t_off=q * V * CD, c_off=q)
+            codes = torch.empty(B * T, Q, dtype=torch.int32, device=self.device)
+            wsb = torch.empty(int(lib.sopro_mimi_encode_workspace_bytes(self.eng.h, B, N)) // 4 + 64, device=self.device)  # per call: lengths vary freely
+            hip._check(lib.sopro_mimi_encode(self.eng.h, hip.ptr(wsb), hip.ptr(x), B, N, hip.ptr(codes, torch.int32), hip._stream()), "sopro_mimi_encode")
         self.stream.synchronize()
         out = codes.view(B, T, Q).long()
         return out[0] if squeeze else out
@@ -282,41 +227,6 @@ class MimiCodec:
             wav = out.clone()  # the caller owns its result
         self.stream.synchronize()
         return wav
-
-    def _transformer(self, pre: str, X: torch.Tensor, B: int, n: int, pad: int, xs_stride: int) -> None:
-        """Pre-norm causal sliding-window RoPE transformer over the residual stream ``X`` [B, pad + n (+ tail), HS], in place
-        (HF:modeling_mimi.py MimiTransformerModel).  The ENCODER side's ("etr"): the decoder side's runs inside
-        ``sopro_mimi_decode``."""
-        mc, w, ws = self.mc, self.w, self.ws
-        HS, H, dh, win = int(mc.hidden_size), int(mc.num_attention_heads), int(mc.head_dim), int(mc.sliding_window)
-        inter = int(mc.intermediate_size)
-        cos_t, sin_t = self._rope_tables(n)
-        y = ws.get("tr.y", (B * n, HS))
-        qkv = ws.get("tr.qkv", (B * n, 3 * HS))
-        ao = ws.get("tr.ao", (B * n, HS))
-        hd = ws.get("tr.hd", (B * n, inter))
-        seg = dict(rows_per_seg=n)
-        for li in range(int(mc.num_hidden_layers)):
-            p = f"{pre}.{li}"
-            self._ln_stream(X, y, w[p + ".ln1.w"], w[p + ".ln1.b"], B, n, pad, HS, xs_stride)
-            hip.gemm(y, w[p + ".qkv.w"], qkv, M=B * n, N=3 * HS, K=HS)
-            hip.rope(qkv, cos_t, sin_t, rows=B * n, rows_per_seg=n, pos0=0, H=H, dh=dh, ldx=3 * HS)
-            hip.rope(qkv, cos_t, sin_t, rows=B * n, rows_per_seg=n, pos0=0, H=H, dh=dh, ldx=3 * HS, x_off=HS)
-            hip.attention(qkv, qkv, qkv, ao, B=B, H=H, dh=dh, Tq=n, Tk=n, ldq=3 * HS, ldk=3 * HS, ldv=3 * HS, ldo=HS,
-                          q_bstride=n * 3 * HS, k_bstride=n * 3 * HS, v_bstride=n * 3 * HS, o_bstride=n * HS,
-                          causal=True, window=win, k_off=HS, v_off=2 * HS)
-            hip.gemm(ao, w[p + ".o.w"], X, M=B * n, N=HS, K=HS, epilogue=hip.EPI_RES, R=X, scale=w[p + ".ls1"],
-                     c_off=pad * HS, r_off=pad * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
-            self._ln_stream(X, y, w[p + ".ln2.w"], w[p + ".ln2.b"], B, n, pad, HS, xs_stride)
-            hip.gemm(y, w[p + ".fc1.w"], hd, M=B * n, N=inter, K=HS, epilogue=hip.EPI_GELU)
-            hip.gemm(hd, w[p + ".fc2.w"], X, M=B * n, N=HS, K=inter, epilogue=hip.EPI_RES, R=X,
-                     scale=w[p + ".ls2"], c_off=pad * HS, r_off=pad * HS, c_seg_stride=xs_stride, r_seg_stride=xs_stride, **seg)
-
-    def _ln_stream(self, X: torch.Tensor, y: torch.Tensor, wt: torch.Tensor, bs: torch.Tensor, B: int, N2: int, pad: int, HS: int,
-                   xs_stride: int) -> None:
-        """LayerNorm of the zero-padded residual stream into a dense [B*N2, HS] buffer."""
-        hip.norm(X, y, wt, rows=B * N2, C_=HS, eps=float(self.mc.norm_eps), kind=hip.NORM_LN, b=bs, rows_per_seg=N2,
-                 x_off=pad * HS, x_seg_stride=xs_stride)
 
 
 class MimiStreamDecoder:

@@ -66,7 +66,7 @@ struct sopro_engine {
   std::map<std::string, const float*> sk;  // AR-step weights in skinny fragment order
   std::vector<void*> owned;
   bool final = false;
-  bool has_ar = false, has_nar = false, has_mimi = false, has_cond = false;  // families whose tensors were given before sopro_engine_finalize
+  bool has_ar = false, has_nar = false, has_mimi = false, has_cond = false, has_enc = false;  // families whose tensors were given before sopro_engine_finalize
   int32_t *q_col = nullptr, *q_off = nullptr;  // conditioning: codebook columns 0..Q-1 and their table offsets q * V
   // NAR constants
   std::vector<int32_t*> nar_cols, nar_offs;
@@ -360,7 +360,8 @@ int sopro_engine_finalize(sopro_engine* e, void* stream) {
   e->has_nar = e->t.count("nar.pre.w") != 0;
   e->has_mimi = e->t.count("rvq_proj.w") != 0;
   e->has_cond = e->t.count("text_enc.embed") != 0;
-  if (!e->has_ar && !e->has_nar && !e->has_mimi && !e->has_cond) {
+  e->has_enc = e->t.count("enc.conv0.w") != 0;
+  if (!e->has_ar && !e->has_nar && !e->has_mimi && !e->has_cond && !e->has_enc) {
     // report the first tensor of the first stage by name (what a host that forgot sopro_engine_set_tensor wants to read)
     STG(need(e, "ar.blocks.0.glu.w", &t, 2));
   }
@@ -513,6 +514,23 @@ int sopro_engine_finalize(sopro_engine* e, void* stream) {
       std::vector<float> one((size_t)Q, 1.0f);
       STG(dev_upload(e, one, &e->ones));
     }
+  }
+  // ---- Mimi encoder (reference audio -> codes): every contraction in exact fp32 (the codes must equal the reference's)
+  if (e->has_enc) {
+    for (int si = 0; si < c.mimi_n_ratios; ++si) {
+      const std::string r = "enc.res" + std::to_string(si), d = "enc.down" + std::to_string(si);
+      for (const char* nm : {".c1.w", ".c2.w"}) STG(plain(e, r + nm));
+      STG(plain(e, d + ".w"));
+      for (const char* nm : {".c1.b", ".c2.b"}) STG(need(e, r + nm, &t));
+      STG(need(e, d + ".b", &t));
+    }
+    for (int l = 0; l < c.mimi_layers; ++l) {
+      const std::string p = "etr." + std::to_string(l);
+      for (const char* nm : {".qkv.w", ".o.w", ".fc1.w", ".fc2.w"}) STG(plain(e, p + nm));
+      for (const char* nm : {".ln1.w", ".ln1.b", ".ln2.w", ".ln2.b", ".ls1", ".ls2"}) STG(need(e, p + nm, &t));
+    }
+    for (const char* nm : {"enc.final.w", "enc.ds.w", "enc.inproj.sem.w", "enc.inproj.ac.w"}) STG(plain(e, nm));
+    for (const char* nm : {"enc.conv0.w", "enc.conv0.b", "enc.final.b", "enc.cb_bias", "codebooks", "rope.cos", "rope.sin"}) STG(need(e, nm, &t));
   }
   e->final = true;
   return 0;
@@ -961,48 +979,16 @@ int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T) 
   return (int64_t)mimi_carve(e, w, nullptr, B, T);
 }
 
-static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream,
-                            sopro_mimi_stream_state* sst) {
-  SOPRO_CHECK_ARG(e && e->final && e->has_mimi && workspace && tokens && wav && B > 0 && T > 0,
-                  "bad arguments (finalize the engine with the Mimi tensors first)");
-  hipStream_t s = (hipStream_t)stream;
+// Pre-norm causal sliding-window RoPE transformer over the zero-padded residual stream X [B, pad + n (+ tail), HS], in place
+// (HF:modeling_mimi.py MimiTransformerModel, 729-928): the decoder's ("tr", packed operands, optional streaming cache) and the
+// encoder's ("etr", fp32 operands).  y [B n, HS], qkv [B n, 3 HS], ao [B n, HS], hd [B n, inter] are scratch.
+static int transformer_stack(sopro_engine* e, hipStream_t s, const char* pre, float* X, int PADX, int64_t xs, float* y, float* qkv, float* ao,
+                             float* hd, const SplitK* sk, int B, int n, int past, sopro_mimi_stream_state* sst) {
   const sopro_engine_cfg& c = e->c;
-  const int Q = c.num_codebooks, HS = c.mimi_hidden, CD = c.mimi_codebook_dim, N2 = 2 * T, PADX = c.mimi_kernel - 1;
-  const int H = c.mimi_heads, dh = c.mimi_head_dim, ns = c.mimi_n_semantic;
-  const int past = sst ? sst->pos : 0;
-  SOPRO_CHECK_ARG(past + N2 <= c.mimi_rope_positions, "more positions than the RoPE tables hold");
-  SOPRO_CHECK_ARG(!sst || (B == 1 && sst->kv && sst->kv_len + N2 <= sst->cap_rows), "streaming state: one utterance, kv_len + 2T <= cap_rows");
-  SOPRO_CHECK_ARG(c.mimi_res_kernel == 3 && c.mimi_last_kernel == 3 && c.mimi_compress == 2, "the SEANet sequence is written for k = 3 residual / last convs, compress 2");
-  MimiWs w;
-  mimi_carve(e, w, workspace, B, T);
-  if (w.sk.ws) STG(sopro_fill2d_u32(w.sk.tickets, SPLITK_TICKETS, 1, SPLITK_TICKETS, 0u, s));
-  // the zero rows in front of every segment of a convolution input are never written by the kernels: clear just those
-  {
-    STG(sopro_fill2d_u32(w.X, (int64_t)(PADX + N2) * HS, B, PADX * HS, 0u, s));
-    size_t chz = (size_t)c.mimi_num_filters << c.mimi_n_ratios, rowz = (size_t)N2;
-    STG(sopro_fill2d_u32(w.e0, (int64_t)((1 + rowz) * chz), B, (int)chz, 0u, s));
-    for (int si = 0; si < c.mimi_n_ratios; ++si) {
-      const size_t co = chz / 2, orow = rowz * c.mimi_ratios[si];
-      STG(sopro_fill2d_u32(w.hraw[si], (int64_t)((2 + orow) * co), B, (int)(2 * co), 0u, s));
-      if (w.hact[si]) STG(sopro_fill2d_u32(w.hact[si], (int64_t)((2 + orow) * co), B, (int)(2 * co), 0u, s));
-      chz = co; rowz = orow;
-    }
-  }
-  // ---- RVQ decode + output projections (HF:modeling_mimi.py:1128-1137)
-  const int64_t cb_rows = e->t["codebooks"].shape[0];
-  STG(sopro_codebook_sum_f32(tokens, Q, e->sem_col, e->sem_off, e->ones, ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb, 2 * CD, 0,
-                             B * T, B * T, CD, s));
-  STG(sopro_codebook_sum_f32(tokens, Q, e->ac_col, e->ac_off, e->ones, Q - ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb + CD, 2 * CD,
-                             0, B * T, B * T, CD, s));
-  G pj; pj.sk = &w.sk; pj.M = B * T; pj.N = HS; pj.K = 2 * CD;
-  STG(gemm(s, w.emb, WT(e, "rvq_proj.w"), nullptr, w.q, pj));
-  // ---- upsample into the zero-padded transformer stream (HF:1208-1216)
-  const int64_t xs = (int64_t)(PADX + N2) * HS;
-  STG(sopro_upsample2_f32(w.q, F(e, "upsample.w"), w.X + (size_t)PADX * HS, xs, B, T, HS, s));
-  // ---- transformer: 8 pre-LN layers, RoPE, causal window (HF:729-928)
-  const int n = N2;
+  const int HS = c.mimi_hidden, H = c.mimi_heads, dh = c.mimi_head_dim;
+  struct { float *X, *y, *qkv, *ao, *hd; SplitK sk; } w{X, y, qkv, ao, hd, sk ? *sk : SplitK()};
   for (int l = 0; l < c.mimi_layers; ++l) {
-    const std::string p = "tr." + std::to_string(l);
+    const std::string p = std::string(pre) + "." + std::to_string(l);
     STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln1.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln1.b"), nullptr, nullptr, n, xs));
     G qg; qg.sk = &w.sk; qg.M = B * n; qg.N = 3 * HS; qg.K = HS;
     STG(gemm(s, w.y, WT(e, p + ".qkv.w"), nullptr, w.qkv, qg));
@@ -1047,6 +1033,49 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     f2.c_seg = xs; f2.r_seg = xs; f2.rows_per_seg = n;
     STG(gemm(s, w.hd, WT(e, p + ".fc2.w"), nullptr, w.X + (size_t)PADX * HS, f2));
   }
+  return 0;
+}
+
+static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream,
+                            sopro_mimi_stream_state* sst) {
+  SOPRO_CHECK_ARG(e && e->final && e->has_mimi && workspace && tokens && wav && B > 0 && T > 0,
+                  "bad arguments (finalize the engine with the Mimi tensors first)");
+  hipStream_t s = (hipStream_t)stream;
+  const sopro_engine_cfg& c = e->c;
+  const int Q = c.num_codebooks, HS = c.mimi_hidden, CD = c.mimi_codebook_dim, N2 = 2 * T, PADX = c.mimi_kernel - 1;
+  const int ns = c.mimi_n_semantic;
+  const int past = sst ? sst->pos : 0;
+  SOPRO_CHECK_ARG(past + N2 <= c.mimi_rope_positions, "more positions than the RoPE tables hold");
+  SOPRO_CHECK_ARG(!sst || (B == 1 && sst->kv && sst->kv_len + N2 <= sst->cap_rows), "streaming state: one utterance, kv_len + 2T <= cap_rows");
+  SOPRO_CHECK_ARG(c.mimi_res_kernel == 3 && c.mimi_last_kernel == 3 && c.mimi_compress == 2, "the SEANet sequence is written for k = 3 residual / last convs, compress 2");
+  MimiWs w;
+  mimi_carve(e, w, workspace, B, T);
+  if (w.sk.ws) STG(sopro_fill2d_u32(w.sk.tickets, SPLITK_TICKETS, 1, SPLITK_TICKETS, 0u, s));
+  // the zero rows in front of every segment of a convolution input are never written by the kernels: clear just those
+  {
+    STG(sopro_fill2d_u32(w.X, (int64_t)(PADX + N2) * HS, B, PADX * HS, 0u, s));
+    size_t chz = (size_t)c.mimi_num_filters << c.mimi_n_ratios, rowz = (size_t)N2;
+    STG(sopro_fill2d_u32(w.e0, (int64_t)((1 + rowz) * chz), B, (int)chz, 0u, s));
+    for (int si = 0; si < c.mimi_n_ratios; ++si) {
+      const size_t co = chz / 2, orow = rowz * c.mimi_ratios[si];
+      STG(sopro_fill2d_u32(w.hraw[si], (int64_t)((2 + orow) * co), B, (int)(2 * co), 0u, s));
+      if (w.hact[si]) STG(sopro_fill2d_u32(w.hact[si], (int64_t)((2 + orow) * co), B, (int)(2 * co), 0u, s));
+      chz = co; rowz = orow;
+    }
+  }
+  // ---- RVQ decode + output projections (HF:modeling_mimi.py:1128-1137)
+  const int64_t cb_rows = e->t["codebooks"].shape[0];
+  STG(sopro_codebook_sum_f32(tokens, Q, e->sem_col, e->sem_off, e->ones, ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb, 2 * CD, 0,
+                             B * T, B * T, CD, s));
+  STG(sopro_codebook_sum_f32(tokens, Q, e->ac_col, e->ac_off, e->ones, Q - ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb + CD, 2 * CD,
+                             0, B * T, B * T, CD, s));
+  G pj; pj.sk = &w.sk; pj.M = B * T; pj.N = HS; pj.K = 2 * CD;
+  STG(gemm(s, w.emb, WT(e, "rvq_proj.w"), nullptr, w.q, pj));
+  // ---- upsample into the zero-padded transformer stream (HF:1208-1216)
+  const int64_t xs = (int64_t)(PADX + N2) * HS;
+  STG(sopro_upsample2_f32(w.q, F(e, "upsample.w"), w.X + (size_t)PADX * HS, xs, B, T, HS, s));
+  // ---- transformer: 8 pre-LN layers, RoPE, causal window (HF:729-928)
+  STG(transformer_stack(e, s, "tr", w.X, PADX, xs, w.y, w.qkv, w.ao, w.hd, &w.sk, B, N2, past, sst));
   // ---- SEANet decoder (HF:931-961), activated-copy flow of sopro_amd.codec.MimiCodec._seanet_act
   int ch = c.mimi_num_filters << c.mimi_n_ratios, rows = N2, pad_in = 1;
   {  // first conv k = 7 -> ELU; one zero row in front = x[t-1] of the transposed conv
@@ -1097,6 +1126,111 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   }
   sopro_set_error("sopro_mimi_decode: the decoder has no last stage");
   return -2;
+}
+
+// ------------------------------------------------------------------------------------------------ Mimi encode
+// HF:modeling_mimi.py MimiModel._encode_frame: SEANet encoder (strided convs = overlapping-row windows of the padded level
+// buffers) -> transformer -> stride-2 downsample -> split residual VQ.  Exact-fp32 contractions throughout.
+struct EncPlan {
+  float* H[9]; int rows[9], pad[9], len[9], ch[9];  // level buffers [B][rows][ch]: pad zero rows, len rows in use, a zero tail
+  float *Y1, *X, *y, *qkv, *ao, *hd, *Dn, *res, *scores;
+  int T25, T, pad_x, tail_x;
+};
+static size_t enc_carve(const sopro_engine* e, EncPlan& p, void* ws, int B, int N) {
+  const sopro_engine_cfg& c = e->c;
+  const int nr = c.mimi_n_ratios, rk = c.mimi_res_kernel, lk = c.mimi_last_kernel, HS = c.mimi_hidden;
+  Carver cv(ws);
+  int ch = c.mimi_num_filters, L = N;
+  size_t y1max = 0;
+  auto ratio = [&](int si) { return c.mimi_ratios[nr - 1 - si]; };  // the encoder walks the decoder's ratios backwards
+  p.pad[0] = std::max(ratio(0), rk - 1);
+  p.len[0] = L; p.ch[0] = ch;
+  p.rows[0] = p.pad[0] + (L + ratio(0) - 1) / ratio(0) * ratio(0);
+  p.H[0] = cv.take<float>((size_t)B * p.rows[0] * ch);
+  for (int si = 0; si < nr; ++si) {
+    const int r = ratio(si), Lo = (L + r - 1) / r;
+    y1max = std::max(y1max, (size_t)B * L * (ch / c.mimi_compress));
+    const bool last = si == nr - 1;
+    const int npad = last ? lk - 1 : std::max(ratio(si + 1), rk - 1);
+    const int ntail = last ? 0 : (Lo + ratio(si + 1) - 1) / ratio(si + 1) * ratio(si + 1) - Lo;
+    p.pad[si + 1] = npad; p.len[si + 1] = Lo; p.ch[si + 1] = 2 * ch; p.rows[si + 1] = npad + Lo + ntail;
+    p.H[si + 1] = cv.take<float>((size_t)B * p.rows[si + 1] * 2 * ch);
+    ch *= 2; L = Lo;
+  }
+  p.Y1 = cv.take<float>(y1max);
+  p.T25 = L; p.T = (L + 1) / 2; p.pad_x = 2; p.tail_x = p.T * 2 - L;
+  const size_t xr = (size_t)p.pad_x + L + p.tail_x;
+  p.X = cv.take<float>((size_t)B * xr * HS);
+  p.y = cv.take<float>((size_t)B * L * HS); p.qkv = cv.take<float>((size_t)B * L * 3 * HS); p.ao = cv.take<float>((size_t)B * L * HS);
+  p.hd = cv.take<float>((size_t)B * L * c.mimi_inter);
+  p.Dn = cv.take<float>((size_t)B * p.T * HS); p.res = cv.take<float>((size_t)B * p.T * c.mimi_codebook_dim);
+  p.scores = cv.take<float>((size_t)B * p.T * c.codebook_size);
+  return cv.off;
+}
+
+int64_t sopro_mimi_encode_workspace_bytes(const sopro_engine* e, int32_t B, int32_t N) {
+  if (!e || B <= 0 || N <= 0) return 0;
+  EncPlan p;
+  return (int64_t)enc_carve(e, p, nullptr, B, N);
+}
+
+int sopro_mimi_encode(sopro_engine* e, void* workspace, const float* wav, int32_t B, int32_t N, int32_t* codes, void* stream) {
+  SOPRO_CHECK_ARG(e && e->final && e->has_enc && workspace && wav && codes && B > 0 && N > 0,
+                  "bad arguments (finalize the engine with the Mimi encoder tensors first)");
+  hipStream_t s = (hipStream_t)stream;
+  const sopro_engine_cfg& c = e->c;
+  const int nr = c.mimi_n_ratios, rk = c.mimi_res_kernel, lk = c.mimi_last_kernel, k0 = c.mimi_kernel, HS = c.mimi_hidden, CD = c.mimi_codebook_dim;
+  const int V = c.codebook_size, Q = c.num_codebooks, ns = c.mimi_n_semantic;
+  SOPRO_CHECK_ARG(c.mimi_compress == 2, "the encoder sequence is written for compress 2");
+  EncPlan p;
+  enc_carve(e, p, workspace, B, N);
+  SOPRO_CHECK_ARG(p.T25 <= c.mimi_rope_positions, "more positions than the RoPE tables hold");
+  for (int i = 0; i <= nr; ++i) STG(sopro_fill2d_u32(p.H[i], (int64_t)p.rows[i] * p.ch[i], B, p.rows[i] * p.ch[i], 0u, s));  // pads and tails read as zeros
+  // first conv 1 -> 64, k = 7, causal
+  STG(sopro_fir1_f32(wav, N, N, F(e, "enc.conv0.w"), F(e, "enc.conv0.b"), p.H[0] + (size_t)p.pad[0] * p.ch[0], p.ch[0], (int64_t)p.rows[0] * p.ch[0], B, N,
+                     p.ch[0], k0, 1, k0 - 1, s));
+  for (int si = 0; si < nr; ++si) {
+    const int r = c.mimi_ratios[nr - 1 - si], ch = p.ch[si], L = p.len[si], pad = p.pad[si], hid = ch / c.mimi_compress, Lo = p.len[si + 1];
+    const int64_t seg = (int64_t)p.rows[si] * ch;
+    const std::string rs = "enc.res" + std::to_string(si), dn = "enc.down" + std::to_string(si);
+    float* Hc = p.H[si];
+    // residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x))))
+    G c1; c1.M = B * L; c1.N = hid; c1.K = rk * ch; c1.lda = ch; c1.bias = F(e, rs + ".c1.b"); c1.pro = SOPRO_PRO_ELU; c1.rows_per_seg = L; c1.a_seg = seg;
+    STG(gemm(s, Hc + (size_t)(pad - (rk - 1)) * ch, WT(e, rs + ".c1.w"), nullptr, p.Y1, c1));
+    G c2; c2.M = B * L; c2.N = ch; c2.K = hid; c2.bias = F(e, rs + ".c2.b"); c2.pro = SOPRO_PRO_ELU; c2.epi = SOPRO_EPI_RES; c2.R = Hc + (size_t)pad * ch;
+    c2.rows_per_seg = L; c2.c_seg = seg; c2.r_seg = seg; c2.ldc = ch; c2.ldr = ch;
+    STG(gemm(s, p.Y1, WT(e, rs + ".c2.w"), nullptr, Hc + (size_t)pad * ch, c2));
+    // ELU -> Conv1d(ch -> 2 ch, k = 2 r, stride r): frame j contracts rows j r - r .. j r + r - 1
+    G d; d.M = B * Lo; d.N = 2 * ch; d.K = 2 * r * ch; d.lda = (int64_t)r * ch; d.bias = F(e, dn + ".b"); d.pro = SOPRO_PRO_ELU; d.rows_per_seg = Lo; d.a_seg = seg;
+    d.c_seg = (int64_t)p.rows[si + 1] * 2 * ch; d.ldc = 2 * ch;
+    STG(gemm(s, Hc + (size_t)(pad - r) * ch, WT(e, dn + ".w"), nullptr, p.H[si + 1] + (size_t)p.pad[si + 1] * 2 * ch, d));
+  }
+  // ELU -> last conv (k = 3) into the transformer stream, which carries the downsample conv's replicate pads
+  const int T25 = p.T25, T = p.T, chl = p.ch[nr];
+  const int64_t xs = (int64_t)(p.pad_x + T25 + p.tail_x) * HS;
+  G fc; fc.M = B * T25; fc.N = HS; fc.K = lk * chl; fc.lda = chl; fc.bias = F(e, "enc.final.b"); fc.pro = SOPRO_PRO_ELU; fc.rows_per_seg = T25;
+  fc.a_seg = (int64_t)p.rows[nr] * chl; fc.c_seg = xs; fc.ldc = HS;
+  STG(gemm(s, p.H[nr], WT(e, "enc.final.w"), nullptr, p.X + (size_t)p.pad_x * HS, fc));
+  STG(transformer_stack(e, s, "etr", p.X, p.pad_x, xs, p.y, p.qkv, p.ao, p.hd, nullptr, B, T25, 0, nullptr));
+  // downsample: Conv1d(k = 4, stride 2, no bias), replicate padding on both sides
+  for (int r = 0; r < p.pad_x; ++r) STG(sopro_copy2d_u32(p.X + (size_t)r * HS, xs, p.X + (size_t)p.pad_x * HS, xs, B, HS, s));
+  for (int r = 0; r < p.tail_x; ++r)
+    STG(sopro_copy2d_u32(p.X + (size_t)(p.pad_x + T25 + r) * HS, xs, p.X + (size_t)(p.pad_x + T25 - 1) * HS, xs, B, HS, s));
+  G ds; ds.M = B * T; ds.N = HS; ds.K = 4 * HS; ds.lda = 2 * HS; ds.rows_per_seg = T; ds.a_seg = xs;
+  STG(gemm(s, p.X, WT(e, "enc.ds.w"), nullptr, p.Dn, ds));
+  // split residual VQ: semantic group (input_proj + ns layers), acoustic group (input_proj + the rest)
+  for (int grp = 0; grp < 2; ++grp) {
+    G ip; ip.M = B * T; ip.N = CD; ip.K = HS;
+    STG(gemm(s, p.Dn, WT(e, grp == 0 ? "enc.inproj.sem.w" : "enc.inproj.ac.w"), nullptr, p.res, ip));
+    for (int q = grp == 0 ? 0 : ns; q < (grp == 0 ? ns : Q); ++q) {
+      const float* table = F(e, "codebooks") + (size_t)q * V * CD;
+      G sc; sc.M = B * T; sc.N = V; sc.K = CD; sc.bias = F(e, "enc.cb_bias") + (size_t)q * V;
+      Wt wq; wq.f32 = table;
+      STG(gemm(s, p.res, wq, nullptr, p.scores, sc));
+      STG(sopro_rvq_assign_f32(p.scores, V, V, table, p.res, CD, CD, codes + q, Q, B * T, s));
+    }
+  }
+  return 0;
 }
 
 int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream) {

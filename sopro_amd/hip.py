@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -196,6 +196,8 @@ SYMBOLS = {
     "sopro_film_coeffs": (C.c_int, [_p, _p, _f32, _i32, _p, _p, _p, _p]),
     "sopro_ref_workspace_bytes": (_i64, [_p, _i32]),
     "sopro_ref_prepare": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p]),
+    "sopro_mimi_encode_workspace_bytes": (_i64, [_p, _i32, _i32]),
+    "sopro_mimi_encode": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p]),
     "sopro_prof_enable": (C.c_int, [C.c_int]),
     "sopro_prof_collect": (C.c_int, [_p, _i32, _p]),
 }
