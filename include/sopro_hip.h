@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 34
+#define SOPRO_ABI_VERSION 35
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -351,12 +351,19 @@ int sopro_final_conv_f32(const float* h, int64_t h_seg_stride, const float* w, f
 int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
                           const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
                           int32_t T, void* stream);
+/* the same with the MFMA passes per product chosen: 3 (above) or 1 (the engine's bf16 mode: operands rounded to bf16 once; long
+ * inputs only - short ones run the three-pass kernel either way) */
+int sopro_seanet_tail_p_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
+                            const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
+                            int32_t T, int32_t passes, void* stream);
 /* Fused MimiResnetBlock at the 128-channel level of the SEANet decoder (HF:modeling_mimi.py:408-447, dim 128: k=3 conv
  * 128->64, k=1 conv 64->128, residual) followed by the ELU of the next layer: out = ELU(h + c2(ELU(c1(ELU(h))))).
  * h, out: [B][2 + T][128] (two zero rows in front of each segment; out's are not written), h != out.  w1 [64][3*128]
  * (tap-major K), w2 [128][64].  h is read once, out written once; both weight matrices stay in registers. */
 int sopro_seanet_res128_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2, const float* b2,
                             float* out, int64_t out_seg_stride, int32_t B, int32_t T, void* stream);
+int sopro_seanet_res128_p_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2, const float* b2,
+                              float* out, int64_t out_seg_stride, int32_t B, int32_t T, int32_t passes /* 3, or 1: bf16 mode */, void* stream);
 int sopro_seanet_res_set_tiles(int tiles); /* developer probe / tests: 64-row tiles per workgroup, 0 = by size */
 /* Last transposed convolution of the SEANet decoder, ConvTranspose1d(128 -> 64, k = 8, s = 4) (HF:modeling_mimi.py:931-961),
  * weight-stationary: out[b][t][0..255] = bias + W . [x[b][t] | x[b][t+1]], t < T, with x [B][>= 1 + T][128] the ACTIVATED input

@@ -37,6 +37,7 @@ __device__ __forceinline__ void rsplit8(const float* __restrict__ p, uint4& hi, 
   split2_bf16(b.z, b.w, hi.w, lo.w);
 }
 
+template <int PASSES>
 __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __restrict__ h, int64_t h_seg_stride,
                                                                const float* __restrict__ w1, const float* __restrict__ b1,
                                                                const float* __restrict__ w2, const float* __restrict__ b2,
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
         split2_bf16(eluf_(v[q].x), eluf_(v[q].y), hi.x, lo.x);
         split2_bf16(eluf_(v[q].z), eluf_(v[q].w), hi.y, lo.y);
         *reinterpret_cast<uint2*>(es + r * REROW + c4 * 8) = hi;
-        *reinterpret_cast<uint2*>(es + r * REROW + 2 * RC + c4 * 8) = lo;
+        if (PASSES == 3) *reinterpret_cast<uint2*>(es + r * REROW + 2 * RC + c4 * 8) = lo;
       }
     }
     __syncthreads();
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           ah[s][mt] = *reinterpret_cast<const uint4*>(fptr(s, mt));
-          al[s][mt] = *reinterpret_cast<const uint4*>(fptr(s, mt) + 2 * RC);
+          al[s][mt] = PASSES == 3 ? *reinterpret_cast<const uint4*>(fptr(s, mt) + 2 * RC) : ah[s][mt];
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -127,17 +128,19 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
         uint4 ch[2], cl[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) { ch[mt] = ah[s % DEPTH][mt]; cl[mt] = al[s % DEPTH][mt]; }
+        if (PASSES == 3) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(cl[mt]), rfrag(w1h[s]), acc[mt], 0, 0, 0);
+          for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(cl[mt]), rfrag(w1h[s]), acc[mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ch[mt]), rfrag(w1l[s]), acc[mt], 0, 0, 0);
+          for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ch[mt]), rfrag(w1l[s]), acc[mt], 0, 0, 0);
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ch[mt]), rfrag(w1h[s]), acc[mt], 0, 0, 0);
         if (s + DEPTH < 12) {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
             ah[s % DEPTH][mt] = *reinterpret_cast<const uint4*>(fptr(s + DEPTH, mt));
-            al[s % DEPTH][mt] = *reinterpret_cast<const uint4*>(fptr(s + DEPTH, mt) + 2 * RC);
+            al[s % DEPTH][mt] = PASSES == 3 ? *reinterpret_cast<const uint4*>(fptr(s + DEPTH, mt) + 2 * RC) : ah[s % DEPTH][mt];
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
         unsigned hi, lo;
         split2_bf16(eluf_(v), 0.f, hi, lo);
         *reinterpret_cast<unsigned short*>(ys + mr * RYROW + (nt1 * 32 + frow) * 2) = (unsigned short)(hi & 0xffffu);
-        *reinterpret_cast<unsigned short*>(ys + mr * RYROW + 2 * RH + (nt1 * 32 + frow) * 2) = (unsigned short)(lo & 0xffffu);
+        if (PASSES == 3) *reinterpret_cast<unsigned short*>(ys + mr * RYROW + 2 * RH + (nt1 * 32 + frow) * 2) = (unsigned short)(lo & 0xffffu);
       }
     }
     __syncthreads();
@@ -180,9 +183,12 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
       const unsigned char* a = ys + (mt * 32 + frow) * RYROW + fg * 16;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const uint4 ah = *reinterpret_cast<const uint4*>(a + s * 32), al = *reinterpret_cast<const uint4*>(a + 2 * RH + s * 32);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(al), rfrag(w2h[s]), acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w2l[s]), acc2, 0, 0, 0);
+        const uint4 ah = *reinterpret_cast<const uint4*>(a + s * 32);
+        if (PASSES == 3) {
+          const uint4 al = *reinterpret_cast<const uint4*>(a + 2 * RH + s * 32);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(al), rfrag(w2h[s]), acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w2l[s]), acc2, 0, 0, 0);
+        }
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w2h[s]), acc2, 0, 0, 0);
       }
 #pragma unroll
@@ -202,8 +208,9 @@ extern "C" int sopro_seanet_res_set_tiles(int tiles) {
   return 0;
 }
 
-extern "C" int sopro_seanet_res128_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
-                                        const float* b2, float* out, int64_t out_seg_stride, int32_t B, int32_t T, void* stream) {
+extern "C" int sopro_seanet_res128_p_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
+                                          const float* b2, float* out, int64_t out_seg_stride, int32_t B, int32_t T, int32_t passes, void* stream) {
+  SOPRO_CHECK_ARG(passes == 1 || passes == 3, "passes must be 3 (three-pass split-bf16) or 1 (bf16 mode)");
   SOPRO_CHECK_ARG(h && w1 && b1 && w2 && b2 && out && B > 0 && T > 0, "bad pointers or sizes");
   SOPRO_CHECK_ARG(h != out, "the block is not computed in place (a tile reads two rows of its left neighbour)");
   SOPRO_CHECK_ARG(aligned16(h) && aligned16(w1) && aligned16(w2) && aligned16(out) && (h_seg_stride & 3) == 0 && (out_seg_stride & 3) == 0,
@@ -214,7 +221,14 @@ extern "C" int sopro_seanet_res128_f32(const float* h, int64_t h_seg_stride, con
   const int64_t all = (int64_t)ntile * B;
   const int tiles = g_res_tiles > 0 ? g_res_tiles : (all >= 16 * 2048 ? 16 : (all >= 8 * 1024 ? 8 : (all >= 2048 ? 2 : 1)));
   dim3 grid((ntile + tiles - 1) / tiles, B);
-  hipLaunchKernelGGL(seanet_res128_kernel, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride,
-                     T, tiles);
+  if (passes == 3)
+    hipLaunchKernelGGL(seanet_res128_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride, T, tiles);
+  else  // the engine's bf16 mode: hi * hi only
+    hipLaunchKernelGGL(seanet_res128_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride, T, tiles);
   SOPRO_LAUNCH_CHECK();
+}
+
+extern "C" int sopro_seanet_res128_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
+                                        const float* b2, float* out, int64_t out_seg_stride, int32_t B, int32_t T, void* stream) {
+  return sopro_seanet_res128_p_f32(h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride, B, T, 3, stream);
 }

@@ -16,6 +16,8 @@
 // intermediate goes through LDS in the same split form, and ELU(h') is stored once (fp32, over the dead h tile) for the
 // last 64 -> 1 convolution, which reads every row three times.  The skip operand (an L2-resident re-read of h in the
 // accumulator layout) and the last layer's weights are requested in the tile's memory round.  2 workgroups per CU (55 KB LDS).
+#include <type_traits>
+
 #include "common.h"
 
 // Developer timeline builds (tools/micro/build_tail_dbg.sh, never the product library): shader-clock stamps of one tile group's phases
@@ -248,6 +250,7 @@ __device__ __forceinline__ void tail_wave_sync() {  // a wave's own LDS writes -
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int PASSES>
 __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __restrict__ h, int64_t h_seg_stride, const float* __restrict__ w1,
                                                                 const float* __restrict__ b1, const float* __restrict__ w2,
                                                                 const float* __restrict__ b2, const float* __restrict__ wf, float bf,
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
         split2_bf16(eluf_(v[q].x), eluf_(v[q].y), hi.x, lo.x);
         split2_bf16(eluf_(v[q].z), eluf_(v[q].w), hi.y, lo.y);
         *reinterpret_cast<uint2*>(es + r * EROW + c4 * 8) = hi;
-        *reinterpret_cast<uint2*>(es + r * EROW + 128 + c4 * 8) = lo;
+        if (PASSES == 3) *reinterpret_cast<uint2*>(es + r * EROW + 128 + c4 * 8) = lo;
       }
     }
     tail_wave_sync();
@@ -343,24 +346,34 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
 #pragma unroll
       for (int s = 0; s < 6; ++s) {
         const unsigned char* p = a + (s >> 1) * EROW + (s & 1) * 64;
-        const uint4 ah = *reinterpret_cast<const uint4*>(p), al = *reinterpret_cast<const uint4*>(p + 128);
+        const uint4 ah = *reinterpret_cast<const uint4*>(p);
+        uint4 al = ah;
+        if (PASSES == 3) al = *reinterpret_cast<const uint4*>(p + 128);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const uint4 wh = w1s[((nt * 6 + s) * 2 + 0) * 64 + lane], wl = w1s[((nt * 6 + s) * 2 + 1) * 64 + lane];
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(al), frag(wh), acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(ah), frag(wl), acc[nt], 0, 0, 0);
+          const uint4 wh = w1s[((nt * 6 + s) * 2 + 0) * 64 + lane];
+          if (PASSES == 3) {
+            const uint4 wl = w1s[((nt * 6 + s) * 2 + 1) * 64 + lane];
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(al), frag(wh), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(ah), frag(wl), acc[nt], 0, 0, 0);
+          }
           acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(ah), frag(wh), acc[nt], 0, 0, 0);
         }
       }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; i += 2) {  // two rows per conversion (the packed convert takes a pair)
           const int m = 4 * kq + i;
           unsigned hi, lo;
-          split2_bf16(eluf_(acc[nt][i] + b1v[nt]), 0.f, hi, lo);
-          *reinterpret_cast<unsigned short*>(ys + m * YROW + (16 * nt + col) * 2) = (unsigned short)(hi & 0xffffu);
-          *reinterpret_cast<unsigned short*>(ys + m * YROW + 64 + (16 * nt + col) * 2) = (unsigned short)(lo & 0xffffu);
+          split2_bf16(eluf_(acc[nt][i] + b1v[nt]), eluf_(acc[nt][i + 1] + b1v[nt]), hi, lo);
+          unsigned char* yp = ys + m * YROW + (16 * nt + col) * 2;
+          *reinterpret_cast<unsigned short*>(yp) = (unsigned short)(hi & 0xffffu);
+          *reinterpret_cast<unsigned short*>(yp + YROW) = (unsigned short)(hi >> 16);
+          if (PASSES == 3) {
+            *reinterpret_cast<unsigned short*>(yp + 64) = (unsigned short)(lo & 0xffffu);
+            *reinterpret_cast<unsigned short*>(yp + YROW + 64) = (unsigned short)(lo >> 16);
+          }
         }
     }
     tail_wave_sync();  // (this wave is also done reading the split h tile: its memory becomes the ELU(h') tile below)
@@ -372,12 +385,17 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc2[nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
       const unsigned char* a = ys + col * YROW + kq * 16;
-      const uint4 ah = *reinterpret_cast<const uint4*>(a), al = *reinterpret_cast<const uint4*>(a + 64);
+      const uint4 ah = *reinterpret_cast<const uint4*>(a);
+      uint4 al = ah;
+      if (PASSES == 3) al = *reinterpret_cast<const uint4*>(a + 64);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const uint4 wh = w2s[(nt * 2 + 0) * 64 + lane], wl = w2s[(nt * 2 + 1) * 64 + lane];
-        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(al), frag(wh), acc2[nt], 0, 0, 0);
-        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(ah), frag(wl), acc2[nt], 0, 0, 0);
+        const uint4 wh = w2s[(nt * 2 + 0) * 64 + lane];
+        if (PASSES == 3) {
+          const uint4 wl = w2s[(nt * 2 + 1) * 64 + lane];
+          acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(al), frag(wh), acc2[nt], 0, 0, 0);
+          acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(ah), frag(wl), acc2[nt], 0, 0, 0);
+        }
         acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(ah), frag(wh), acc2[nt], 0, 0, 0);
       }
       float* hs = reinterpret_cast<float*>(es);
@@ -401,17 +419,21 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) x[r] = hs[r * HLD + lane];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) p16[i] = i < T3O ? fmaf(wl2, x[i + 2 < 16 ? i + 2 : 15], fmaf(wl1, x[i + 1 < 16 ? i + 1 : 15], wl0 * x[i])) : 0.f;
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const int n = 8 >> st, bit = 32 >> st;  // values kept per lane after this exchange; lane bit that picks the half
+      for (int i = 0; i < T3O; ++i) p16[i] = fmaf(wl2, x[i + 2], fmaf(wl1, x[i + 1], wl0 * x[i]));
+      p16[14] = p16[15] = 0.f;
+      auto exchange = [&](auto n_, auto bit_) {  // n values kept per lane after this exchange; the lane bit that picks the half
+        constexpr int n = decltype(n_)::value, bit = decltype(bit_)::value;  // (compile-time: the value arrays must stay in registers)
         const bool up = (lane & bit) != 0;
 #pragma unroll
         for (int k = 0; k < n; ++k) {
           const float keep = up ? p16[k + n] : p16[k], send = up ? p16[k] : p16[k + n];
           p16[k] = keep + __shfl_xor(send, bit, 64);
         }
-      }
+      };
+      exchange(std::integral_constant<int, 8>(), std::integral_constant<int, 32>());
+      exchange(std::integral_constant<int, 4>(), std::integral_constant<int, 16>());
+      exchange(std::integral_constant<int, 2>(), std::integral_constant<int, 8>());
+      exchange(std::integral_constant<int, 1>(), std::integral_constant<int, 4>());
       float sum = p16[0];
       sum += __shfl_xor(sum, 1, 64);
       sum += __shfl_xor(sum, 2, 64);
@@ -432,9 +454,10 @@ extern "C" int sopro_seanet_tail_set_tiles(int tiles) {
   return 0;
 }
 
-extern "C" int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
-                                      const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
-                                      int32_t T, void* stream) {
+extern "C" int sopro_seanet_tail_p_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
+                                        const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
+                                        int32_t T, int32_t passes, void* stream) {
+  SOPRO_CHECK_ARG(passes == 1 || passes == 3, "passes must be 3 (three-pass split-bf16) or 1 (bf16 mode)");
   SOPRO_CHECK_ARG(h && w1 && b1 && w2 && b2 && wf && wav && B > 0 && T > 0, "bad pointers or sizes");
   SOPRO_CHECK_ARG(aligned16(h) && aligned16(w1) && aligned16(w2) && aligned16(wf) && (h_seg_stride & 3) == 0, "alignment");
   // long inputs: sixteen autonomous waves per CU over LDS-resident weight fragments (a wave owns whole tiles of 14 samples)
@@ -443,9 +466,14 @@ extern "C" int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const
     const int n16 = (int)(((T + T3O - 1) / T3O + 15) / 16);  // sixteen-tile rounds per utterance
     int trips = all16 >= 64 * 4096 ? 32 : (all16 >= 16 * 4096 ? 8 : 2);  // rounds per workgroup (the fragments are made once per workgroup)
     if (g_tail_tiles < -1) trips = -g_tail_tiles;                         // (developer probe)
-    SOPRO_SET_MAX_LDS_ONCE(seanet_tail16_kernel, TAIL3_LDS);
-    hipLaunchKernelGGL(seanet_tail16_kernel, dim3((n16 + trips - 1) / trips, B), dim3(1024), TAIL3_LDS, (hipStream_t)stream, h, h_seg_stride, w1, b1,
-                       w2, b2, wf, bf, wav, wav_seg_stride, T, trips);
+    SOPRO_SET_MAX_LDS_ONCE(seanet_tail16_kernel<3>, TAIL3_LDS);
+    SOPRO_SET_MAX_LDS_ONCE(seanet_tail16_kernel<1>, TAIL3_LDS);
+    if (passes == 3)
+      hipLaunchKernelGGL(seanet_tail16_kernel<3>, dim3((n16 + trips - 1) / trips, B), dim3(1024), TAIL3_LDS, (hipStream_t)stream, h, h_seg_stride, w1, b1,
+                         w2, b2, wf, bf, wav, wav_seg_stride, T, trips);
+    else  // the engine's bf16 mode: hi * hi only (short inputs below keep the three-pass four-wave kernel)
+      hipLaunchKernelGGL(seanet_tail16_kernel<1>, dim3((n16 + trips - 1) / trips, B), dim3(1024), TAIL3_LDS, (hipStream_t)stream, h, h_seg_stride, w1, b1,
+                         w2, b2, wf, bf, wav, wav_seg_stride, T, trips);
     SOPRO_LAUNCH_CHECK();
   }
   const int ntile = (T + TO - 1) / TO;
@@ -459,4 +487,10 @@ extern "C" int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const
     hipLaunchKernelGGL(seanet_tail_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, wf, bf, wav,
                        wav_seg_stride, T, 1);
   SOPRO_LAUNCH_CHECK();
+}
+
+extern "C" int sopro_seanet_tail_f32(const float* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
+                                      const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
+                                      int32_t T, void* stream) {
+  return sopro_seanet_tail_p_f32(h, h_seg_stride, w1, b1, w2, b2, wf, bf, wav, wav_seg_stride, B, T, 3, stream);
 }

@@ -1076,6 +1076,8 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   STG(sopro_upsample2_f32(w.q, F(e, "upsample.w"), w.X + (size_t)PADX * HS, xs, B, T, HS, s));
   // ---- transformer: 8 pre-LN layers, RoPE, causal window (HF:729-928)
   STG(transformer_stack(e, s, "tr", w.X, PADX, xs, w.y, w.qkv, w.ao, w.hd, &w.sk, B, N2, past, sst));
+  static const bool three = getenv("SOPRO_SEANET_PASSES3") != nullptr;  // developer A/B: the fused kernels' three-pass form in bf16 mode too
+  const int sea_passes = (c.precision == 1 && !three) ? 1 : 3;
   // ---- SEANet decoder (HF:931-961), activated-copy flow of sopro_amd.codec.MimiCodec._seanet_act
   int ch = c.mimi_num_filters << c.mimi_n_ratios, rows = N2, pad_in = 1;
   {  // first conv k = 7 -> ELU; one zero row in front = x[t-1] of the transposed conv
@@ -1102,15 +1104,15 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
       }
       // last residual block (k=3 conv 64->32, k=1 conv 32->64) + final k=3 conv 64->1 per output sample
       sopro_prof_scope prof("seanet_tail_kernel", 2.0 * B * orow * (3 * 64 * 32 + 32 * 64 + 3 * 64), s);
-      return sopro_seanet_tail_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"),
-                                   F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, orow, s);
+      return sopro_seanet_tail_p_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"),
+                                     F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, orow, sea_passes, s);
     }
     float* Hn = w.hact[si];
     if (co == 128 && hid == 64) {
       STG(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
       sopro_prof_scope prof("seanet_res128_kernel", 2.0 * B * orow * (3 * 128 * 64 + 64 * 128), s);
-      STG(sopro_seanet_res128_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
-                                  (int64_t)(2 + orow) * co, B, orow, s));
+      STG(sopro_seanet_res128_p_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
+                                    (int64_t)(2 + orow) * co, B, orow, sea_passes, s));
     } else {
       up.c_mode = 4; up.C2 = Hn + 2 * co; up.ldc2 = (int64_t)r * co; up.c2_seg = (int64_t)(2 + orow) * co;
       STG(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));

@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -169,6 +169,8 @@ SYMBOLS = {
     "sopro_upsample2_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_final_conv_f32": (C.c_int, [_p, _i64, _p, _f32, _p, _i64, _i32, _i32, _p]),
     "sopro_seanet_tail_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _f32, _p, _i64, _i32, _i32, _p]),
+    "sopro_seanet_res128_p_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "sopro_seanet_tail_p_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _f32, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_engine_create": (C.c_int, [C.POINTER(EngineCfg), C.POINTER(_p)]),
     "sopro_engine_set_tensor": (C.c_int, [_p, C.c_char_p, _p, C.POINTER(_i64), _i32]),
     "sopro_engine_finalize": (C.c_int, [_p, _p]),
