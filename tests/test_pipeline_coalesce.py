@@ -1,0 +1,52 @@
+"""Host logic of the pipeline's job coalescing (sopro_amd/pipeline.py `_coalesce`), no GPU: which consecutive jobs merge into one
+pass, and that every utterance keeps the sampler identity (nonce of its own job, index within it) it has when run alone."""
+import types
+
+from sopro_amd.pipeline import PipelinedSynthesizer
+
+
+class _Model:
+    def __init__(self):
+        self.n = 100
+
+    def next_nonce(self, seed=None):
+        if seed is not None:
+            return 7000 + int(seed)
+        self.n += 1
+        return self.n
+
+
+def _stub():
+    return types.SimpleNamespace(lanes=[types.SimpleNamespace(model=_Model())], _PER_UTT=PipelinedSynthesizer._PER_UTT)
+
+
+def _job(n, **kw):
+    j = dict(texts=[f"t{i}" for i in range(n)], refs=[object() for _ in range(n)], text_ids=[[i] for i in range(n)], max_frames=199, top_p=0.9,
+             temperature=1.05, anti_loop=True)
+    j.update(kw)
+    return j
+
+
+def test_consecutive_compatible_jobs_merge_in_groups_of_n():
+    jobs = [_job(3), _job(2), _job(4), _job(1), _job(2)]
+    passes = PipelinedSynthesizer._coalesce(_stub(), jobs, 2)
+    assert [g for g, _m, _s in passes] == [[0, 1], [2, 3], [4]]
+    g, merged, sizes = passes[0]
+    assert sizes == [3, 2] and len(merged["refs"]) == 5 and merged["texts"] == ["t0", "t1", "t2", "t0", "t1"]
+    assert merged["row_ids"] == [0, 1, 2, 0, 1]  # index within the utterance's own job
+    assert merged["nonces"][:3] == [merged["nonces"][0]] * 3 and merged["nonces"][3:] == [merged["nonces"][3]] * 2
+    assert merged["nonces"][0] != merged["nonces"][3]  # one nonce per job, as if each had run alone
+    assert "seed" not in merged and merged["max_frames"] == 199
+    assert passes[2][1] is jobs[4] and passes[2][2] is None  # a single job passes through untouched
+
+
+def test_jobs_with_other_sampling_parameters_do_not_merge():
+    jobs = [_job(2), _job(2, top_p=0.5), _job(2, top_p=0.5), _job(2, max_frames=99), _job(2)]
+    groups = [g for g, _m, _s in PipelinedSynthesizer._coalesce(_stub(), jobs, 4)]
+    assert groups == [[0], [1, 2], [3], [4]]
+
+
+def test_a_seeded_job_keeps_its_seed_nonce_inside_a_merged_pass():
+    jobs = [_job(2, seed=5), _job(3, seed=9)]
+    (g, merged, sizes), = PipelinedSynthesizer._coalesce(_stub(), jobs, 2)
+    assert g == [0, 1] and merged["nonces"] == [7005, 7005, 7009, 7009, 7009]
