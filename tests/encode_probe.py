@@ -1,5 +1,5 @@
 """Time the reference-audio path on the GPU (Mimi encode of a 12 s reference, the reference's default ref_seconds)
-and the CPU oracle beside it.  Usage: python tools/encode_probe.py [seconds]"""
+and the CPU oracle beside it.  Usage: python tests/encode_probe.py [seconds]   (a probe, not a test: it lives here because only tests/ may import oracle/)"""
 import json
 import os
 import sys
