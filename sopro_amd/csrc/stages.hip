@@ -992,8 +992,8 @@ static int transformer_stack(sopro_engine* e, hipStream_t s, const char* pre, fl
     STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln1.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln1.b"), nullptr, nullptr, n, xs));
     G qg; qg.sk = &w.sk; qg.M = B * n; qg.N = 3 * HS; qg.K = HS;
     STG(gemm(s, w.y, WT(e, p + ".qkv.w"), nullptr, w.qkv, qg));
-    STG(sopro_rope_f32(w.qkv, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, past, H, dh, s));
-    STG(sopro_rope_f32(w.qkv + HS, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, past, H, dh, s));
+    // queries and keys in one launch: their heads are 2 H consecutive blocks of dh columns
+    STG(sopro_rope_f32(w.qkv, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, past, 2 * H, dh, s));
     sopro_attn_args a;
     memset(&a, 0, sizeof(a));
     a.Q = w.qkv; a.ldq = 3 * HS; a.q_bstride = (int64_t)n * 3 * HS;
