@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 35
+#define SOPRO_ABI_VERSION 36
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -311,6 +311,11 @@ typedef struct sopro_attn_args {
                              * rows that share a voice share one copy of its keys (sopro_attention_f32 only) */
 } sopro_attn_args;
 int sopro_attention_f32(const sopro_attn_args* args, void* stream);
+/* Decoder-only form of the causal window attention with dh == 64 (HF:modeling_mimi.py:657-726, sliding window :882-888):
+ * Q, K, V and the softmax weights as two bf16 pieces, three bf16 MFMA passes per product (passes == 3: 16 mantissa bits,
+ * the precision of the decoder's contractions under its waveform tolerance) or one piece (passes == 1, bf16 mode).
+ * Any other shape runs sopro_attention_f32. */
+int sopro_attention_split_bf16(const sopro_attn_args* args, int32_t passes, void* stream);
 /* Tq == 1 form for the AR frame (cached text K/V, src/sopro/nn/text.py:85-132): one workgroup per
  * (batch row, head), all loads issued up front; dh in {64, 96}; no causal mask. */
 int sopro_attn_decode_f32(const sopro_attn_args* args, void* stream);

@@ -159,6 +159,7 @@ int launch_attn(const sopro_attn_args& a, hipStream_t s) {
 }  // namespace
 
 int sopro_attn_mfma(const sopro_attn_args& a, hipStream_t s);  // attention_mfma.hip
+int sopro_attn_mfma_split(const sopro_attn_args& a, int passes, hipStream_t s);
 
 extern "C" int sopro_attention_f32(const sopro_attn_args* p, void* stream) {
   SOPRO_CHECK_ARG(p != nullptr, "args is NULL");
@@ -181,6 +182,21 @@ extern "C" int sopro_attention_f32(const sopro_attn_args* p, void* stream) {
     case 192: return launch_attn<192>(a, s);
     default: sopro_set_error("sopro_attention_f32: unsupported head dim %d (64, 96, 192)", a.dh); return -2;
   }
+}
+
+// Waveform-path form of the codec decoder's causal window attention: Q, K, V, P as two bf16 pieces multiplied in three
+// v_mfma_f32_32x32x16_bf16 passes (passes == 3; 16 mantissa bits like the decoder's contractions) or as one piece
+// (passes == 1, bf16 mode).  Shapes it is not written for (dh != 64, no causal window, < 16 queries, unaligned rows) run
+// the exact kernel.  HF:modeling_mimi.py:657-726.
+extern "C" int sopro_attention_split_bf16(const sopro_attn_args* p, int32_t passes, void* stream) {
+  SOPRO_CHECK_ARG(p != nullptr, "args is NULL");
+  SOPRO_CHECK_ARG(passes == 1 || passes == 3, "passes must be 1 or 3");
+  const sopro_attn_args& a = *p;
+  const bool fits = a.Q && a.K && a.V && a.O && a.B > 0 && a.H > 0 && a.Tk > 0 && a.causal && a.window > 0 && a.dh == 64 && a.Tq >= 16 &&
+                    aligned16(a.Q) && aligned16(a.K) && aligned16(a.V) && aligned16(a.O) && ((a.ldq | a.ldk | a.ldv | a.ldo) & 3) == 0 &&
+                    ((a.q_bstride | a.k_bstride | a.v_bstride | a.o_bstride) & 3) == 0 && !getenv("SOPRO_ATTN_EXACT");
+  if (!fits) return sopro_attention_f32(p, stream);
+  return sopro_attn_mfma_split(a, passes, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -299,6 +315,21 @@ namespace {
 
 constexpr int XD = 384;
 
+// NT: the folded operands are read once per frame and not again for a whole frame time (hundreds of MB per pass): non-temporal
+// requests keep them from displacing what the throughput partition's kernels reuse in the XCDs' L2s (SOPRO_XATTN_NT=0: plain loads;
+// measured in the pipeline: AR phase 38.6 -> 36.9 ms per step, 21.1 -> 21.5 k audio-s/s, profiles/r03_experiments.md).
+typedef float xf32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld_stream4(const float* p) {
+  if constexpr (NT) {
+    const xf32x4 v = __builtin_nontemporal_load(reinterpret_cast<const xf32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *reinterpret_cast<const float4*>(p);
+  }
+}
+
+template <bool NT>
 __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args a) {
   __shared__ float xsum[XD];
   __shared__ float xn[XD];
@@ -325,12 +356,12 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
 #pragma unroll
     for (int f = 0; f < 12; ++f) {
       kreg[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kin) kreg[f] = *reinterpret_cast<const float4*>(Kb + (int64_t)(k0 + key) * XD + (f * 8 + part) * 4);
+      if (kin) kreg[f] = ld_stream4<NT>(Kb + (int64_t)(k0 + key) * XD + (f * 8 + part) * 4);
     }
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       vreg[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (vg < 4 && (k0 + vg * 16 + kk) < klen) vreg[kk] = *reinterpret_cast<const float4*>(Vb + (int64_t)(k0 + vg * 16 + kk) * XD + vd4 * 4);
+      if (vg < 4 && (k0 + vg * 16 + kk) < klen) vreg[kk] = ld_stream4<NT>(Vb + (int64_t)(k0 + vg * 16 + kk) * XD + vd4 * 4);
     }
     if (k0 == 0) {
       // ---- input stream (+ the producer's partial sums, fixed order), RMSNorm (src/sopro/nn/blocks.py:26-37)
@@ -427,6 +458,8 @@ extern "C" int sopro_xattn_step_f32(const sopro_xattn_args* p, void* stream) {
   SOPRO_CHECK_ARG(aligned16(a.X) && aligned16(a.Kp) && aligned16(a.Vp) && aligned16(a.Y) && (!a.norm_w || aligned16(a.norm_w)) && (a.ldx & 3) == 0 &&
                       (a.xp_stride & 3) == 0 && (a.y_part_stride & 3) == 0,
                   "16-byte alignment / strides % 4");
-  hipLaunchKernelGGL(xattn_step_kernel, dim3(a.H, a.B), dim3(512), 0, (hipStream_t)stream, a);
+  static const bool nt = !(getenv("SOPRO_XATTN_NT") != nullptr && getenv("SOPRO_XATTN_NT")[0] == '0');  // default on (r03: +1.7 %)
+  if (nt) hipLaunchKernelGGL(xattn_step_kernel<true>, dim3(a.H, a.B), dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(xattn_step_kernel<false>, dim3(a.H, a.B), dim3(512), 0, (hipStream_t)stream, a);
   SOPRO_LAUNCH_CHECK();
 }

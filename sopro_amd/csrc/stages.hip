@@ -232,7 +232,7 @@ struct G {  // one contraction: mirrors sopro_amd.hip.gemm's keyword arguments
 };
 
 // attention launch with its timing scope: 4 * dh flops per visible (query, key) pair
-int attend(const sopro_attn_args& a, hipStream_t s) {
+int attend(const sopro_attn_args& a, hipStream_t s, int split_passes = 0) {
   double pairs = (double)a.Tq * a.Tk;
   if (a.causal) {
     pairs = 0;
@@ -242,6 +242,7 @@ int attend(const sopro_attn_args& a, hipStream_t s) {
     }
   }
   sopro_prof_scope prof("attention_kernel", 4.0 * a.dh * pairs * a.B * a.H, s);
+  if (split_passes) return sopro_attention_split_bf16(&a, split_passes, s);
   return sopro_attention_f32(&a, s);
 }
 
@@ -983,7 +984,7 @@ int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T) 
 // (HF:modeling_mimi.py MimiTransformerModel, 729-928): the decoder's ("tr", packed operands, optional streaming cache) and the
 // encoder's ("etr", fp32 operands).  y [B n, HS], qkv [B n, 3 HS], ao [B n, HS], hd [B n, inter] are scratch.
 static int transformer_stack(sopro_engine* e, hipStream_t s, const char* pre, float* X, int PADX, int64_t xs, float* y, float* qkv, float* ao,
-                             float* hd, const SplitK* sk, int B, int n, int past, sopro_mimi_stream_state* sst) {
+                             float* hd, const SplitK* sk, int B, int n, int past, sopro_mimi_stream_state* sst, int attn_split = 0) {
   const sopro_engine_cfg& c = e->c;
   const int HS = c.mimi_hidden, H = c.mimi_heads, dh = c.mimi_head_dim;
   struct { float *X, *y, *qkv, *ao, *hd; SplitK sk; } w{X, y, qkv, ao, hd, sk ? *sk : SplitK()};
@@ -1016,12 +1017,12 @@ static int transformer_stack(sopro_engine* e, hipStream_t s, const char* pre, fl
       if (sst->evict && Tk > c.mimi_window - 1) {
         const int keep = c.mimi_window - 1;
         float* other = sst->kv + ((size_t)(l * 2 + (sst->half ^ 1)) * sst->cap_rows) * 2 * HS;
-        STG(attend(a, s));
+        STG(attend(a, s, attn_split));
         STG(sopro_copy2d_u32(other, 2 * HS, cache + (size_t)(Tk - keep) * 2 * HS, 2 * HS, keep, 2 * HS, s));
         goto attended;
       }
     }
-    STG(attend(a, s));
+    STG(attend(a, s, attn_split));
   attended:;
     G og; og.sk = &w.sk; og.M = B * n; og.N = HS; og.K = HS; og.epi = SOPRO_EPI_RES; og.R = w.X + (size_t)PADX * HS; og.scale = F(e, p + ".ls1");
     og.c_seg = xs; og.r_seg = xs; og.rows_per_seg = n;
@@ -1075,7 +1076,12 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   const int64_t xs = (int64_t)(PADX + N2) * HS;
   STG(sopro_upsample2_f32(w.q, F(e, "upsample.w"), w.X + (size_t)PADX * HS, xs, B, T, HS, s));
   // ---- transformer: 8 pre-LN layers, RoPE, causal window (HF:729-928)
-  STG(transformer_stack(e, s, "tr", w.X, PADX, xs, w.y, w.qkv, w.ao, w.hd, &w.sk, B, N2, past, sst));
+  // the decoder's attention on the waveform path's operand precision (two bf16 pieces, three passes; one in bf16 mode when
+  // SOPRO_ATTN_PASSES=1); SOPRO_ATTN_SPLIT=0 keeps the exact-fp32 kernel the encoder uses
+  static const bool attn_exact = getenv("SOPRO_ATTN_SPLIT") != nullptr && getenv("SOPRO_ATTN_SPLIT")[0] == '0';
+  static const bool attn_one = getenv("SOPRO_ATTN_PASSES") != nullptr && getenv("SOPRO_ATTN_PASSES")[0] == '1';
+  const int attn_split = attn_exact ? 0 : ((c.precision == 1 && attn_one) ? 1 : 3);
+  STG(transformer_stack(e, s, "tr", w.X, PADX, xs, w.y, w.qkv, w.ao, w.hd, &w.sk, B, N2, past, sst, attn_split));
   static const bool three = getenv("SOPRO_SEANET_PASSES3") != nullptr;  // developer A/B: the fused kernels' three-pass form in bf16 mode too
   const int sea_passes = (c.precision == 1 && !three) ? 1 : 3;
   // ---- SEANet decoder (HF:931-961), activated-copy flow of sopro_amd.codec.MimiCodec._seanet_act

@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -163,6 +163,7 @@ SYMBOLS = {
     "sopro_fir1_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "sopro_rvq_assign_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _i32, _p, _i64, _i32, _p]),
     "sopro_attention_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
+    "sopro_attention_split_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_int32, _p]),
     "sopro_attn_decode_f32": (C.c_int, [C.POINTER(AttnArgs), _p]),
     "sopro_xattn_step_f32": (C.c_int, [C.POINTER(XattnArgs), _p]),
     "sopro_rope_f32": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
@@ -646,7 +647,7 @@ def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor
               Tk: int, ldq: int, ldk: int, ldv: int, ldo: int, q_bstride: int, k_bstride: int, v_bstride: int,
               o_bstride: int, klens: Optional[torch.Tensor] = None, causal: bool = False, q_pos0: int = 0, k_pos0: int = 0,
               window: int = 0, scale: Optional[float] = None, q_off: int = 0, k_off: int = 0, v_off: int = 0,
-              o_off: int = 0, decode: bool = False, kv_index: Optional[torch.Tensor] = None) -> None:
+              o_off: int = 0, decode: bool = False, kv_index: Optional[torch.Tensor] = None, split_passes: int = 0) -> None:
     a = AttnArgs()
     a.kv_index = ptr(kv_index, torch.int32)
     a.Q, a.ldq, a.q_bstride = ptr(Q) + 4 * q_off, ldq, q_bstride
@@ -661,7 +662,10 @@ def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor
         _check(load().sopro_attn_decode_f32(C.byref(a), _stream()), "sopro_attn_decode_f32")
         return
     e0 = _prof.begin() if _prof is not None else None
-    _check(load().sopro_attention_f32(C.byref(a), _stream()), "sopro_attention_f32")
+    if split_passes:  # the codec decoder's waveform-path form (two bf16 pieces / three passes, or one)
+        _check(load().sopro_attention_split_bf16(C.byref(a), int(split_passes), _stream()), "sopro_attention_split_bf16")
+    else:
+        _check(load().sopro_attention_f32(C.byref(a), _stream()), "sopro_attention_f32")
     if e0 is not None:
         pairs = float(Tq) * Tk if not causal else float(sum(max(0, min(Tk - 1, q_pos0 + q - k_pos0) - max(0, q_pos0 + q - window + 1 - k_pos0) + 1) for q in range(Tq)))
         _prof.end("attention_kernel", 4.0 * dh * pairs * B * H, e0)

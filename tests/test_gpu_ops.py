@@ -744,6 +744,36 @@ def test_attention_causal_sliding_window_with_cache(N, win, past):
     close(out, ref, 2e-5, "causal window attention")
 
 
+@pytest.mark.parametrize("N,win,past,passes", [(400, 250, 0, 3), (100, 250, 0, 3), (16, 250, 300, 3), (300, 17, 5, 3), (33, 250, 0, 3), (95, 40, 1000, 3),
+                                               (400, 250, 0, 1), (7, 250, 40, 3)])
+def test_attention_window_split_bf16_form(N, win, past, passes):
+    """The decoder's waveform-path form of the window attention (two bf16 pieces / three MFMA passes, or one piece): same
+    masks and cache geometry as the exact kernel, error at the level of 16-bit (8-bit) operands.  < 16 queries: exact kernel."""
+    B, H, dh = (2 if past == 0 else 1), 8, 64
+    D = H * dh
+    Tk = N + min(past, win - 1)
+    q, kv = rnd(B, N, D, seed=75), rnd(B, Tk, 2 * D, seed=76)
+    pos = torch.arange(N) + past
+    kpos = torch.arange(past + N - Tk, past + N)
+    vis = (kpos[None, :] <= pos[:, None]) & (kpos[None, :] > pos[:, None] - win)
+    s = torch.matmul(O._heads(q.double(), H), O._heads(kv[..., :D].contiguous().double(), H).transpose(-1, -2)) / math.sqrt(dh)
+    s = s.masked_fill(~vis[None, None], float("-inf"))
+    ref = O._unheads(torch.matmul(torch.softmax(s, -1), O._heads(kv[..., D:].contiguous().double(), H))).float()
+    kvd = dev(kv)
+    kw = dict(B=B, H=H, dh=dh, Tq=N, Tk=Tk, ldq=D, ldk=2 * D, ldv=2 * D, ldo=D, q_bstride=N * D, k_bstride=Tk * 2 * D,
+              v_bstride=Tk * 2 * D, o_bstride=N * D, causal=True, window=win, q_pos0=past, k_pos0=past + N - Tk, v_off=D)
+    out, exact = torch.empty(B, N, D, device=DEV), torch.empty(B, N, D, device=DEV)
+    hip.attention(dev(q), kvd, kvd, out, split_passes=passes, **kw)
+    hip.attention(dev(q), kvd, kvd, exact, **kw)
+    close(exact, ref, 2e-5, "exact window attention")
+    scale = float(ref.abs().max())
+    err = float((out.cpu() - ref).abs().max()) / scale
+    assert torch.isfinite(out).all()
+    assert err < (3e-5 if passes == 3 else 2e-2), f"split window attention ({passes} passes): {err:.2e} of the largest output"
+    if N < 16:
+        assert torch.equal(out, exact)
+
+
 def test_rope_upsample_final_conv():
     H, dh, rows_per_seg, B = 8, 64, 21, 2
     x = rnd(B * rows_per_seg, 3 * H * dh, seed=80)
