@@ -193,7 +193,7 @@ def rocprof_family_table() -> dict:
     pat = {"gemm_f32_kernel": "gemm_f32_kernel", "gemm_bf16s_kernel<1,": "gemm_bf16x1_kernel", "gemm_bf16s_kernel<2,": "gemm_bf16x3_kernel",
            "gemm_bf16s_kernel<3,": "gemm_bf16x6_kernel",  # (<2, ..., true> = the fp16 pieces of the NAR path: told apart below)
            "attention_kernel": "attention_kernel", "attn_window_mfma_kernel": "attention_kernel", "attn_mfma_kernel": "attention_kernel",
-           "attn_decode_kernel": "attention_kernel", "seanet_tail_kernel": "seanet_tail_kernel", "seanet_tail16_kernel": "seanet_tail_kernel", "seanet_res128_kernel": "seanet_res128_kernel",
+           "attn_decode_kernel": "attention_kernel", "attn_mfma_split_kernel": "attention_split_kernel", "seanet_tail_kernel": "seanet_tail_kernel", "seanet_tail16_kernel": "seanet_tail_kernel", "seanet_res128_kernel": "seanet_res128_kernel",
            "seanet_up128_kernel": "seanet_up128_kernel"}
     out: dict = {}
     try:
@@ -541,8 +541,12 @@ def main() -> None:
                                                        PEAK_BF16_MFMA_TFLOPS, mimi_passes, "16-bit operands, waveform contract 1e-4 of peak")))
     if "attention_kernel" in fam and fam["attention_kernel"]["flops"] > 0:
         entries.append((fam["attention_kernel"]["ms"], mfma_entry(
-            "attention_kernel", "attention_kernel family (attn_mfma_kernel: codec transformer window attention + reference cross-attention; v_mfma_f32_32x32x2_f32)",
+            "attention_kernel", "attention_kernel family (attn_mfma_kernel: reference cross-attention of the conditioning, exact fp32; v_mfma_f32_32x32x2_f32)",
             PEAK_F32_MFMA_TFLOPS, 1, "")))
+    if "attention_split_kernel" in fam and fam["attention_split_kernel"]["flops"] > 0:
+        entries.append((fam["attention_split_kernel"]["ms"], mfma_entry(
+            "attention_split_kernel", "attn_mfma_split_kernel (codec decoder window attention, two bf16 pieces per operand; v_mfma_f32_32x32x16_bf16, 3 passes per product)",
+            PEAK_BF16_MFMA_TFLOPS, 3, "16-bit operands, waveform contract 1e-4 of peak")))
     if "ar_step_graph" in fam:
         f = fam["ar_step_graph"]
         inst_ms = f["ms"] / max(1, f["launches"])  # instrumented repeat (events around every replay; NAR / Mimi issued eagerly)

@@ -241,7 +241,7 @@ int attend(const sopro_attn_args& a, hipStream_t s, int split_passes = 0) {
       pairs += std::max(0, hi - lo + 1);
     }
   }
-  sopro_prof_scope prof("attention_kernel", 4.0 * a.dh * pairs * a.B * a.H, s);
+  sopro_prof_scope prof(split_passes ? "attention_split_kernel" : "attention_kernel", 4.0 * a.dh * pairs * a.B * a.H, s);
   if (split_passes) return sopro_attention_split_bf16(&a, split_passes, s);
   return sopro_attention_f32(&a, s);
 }

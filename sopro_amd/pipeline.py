@@ -29,7 +29,6 @@ class PipelinedSynthesizer:
         that ``ar_parts`` AR phases use at the same time (their short kernels interleave on the same CUs)."""
         self.device = tts.device
         self.unpartitioned = int(ar_cus) <= 0
-        self.prep_place = "bulk"
         if self.unpartitioned:
             self._init_unpartitioned(tts, int(lanes), max(1, int(ar_parts)), bulk_slots)
             return
@@ -38,9 +37,6 @@ class PipelinedSynthesizer:
                                "the schedulers re-point the engine's streams at CU partitions")
         total = hip.device_info(self.device.index or 0)["cus"]
         ar_parts = max(1, int(ar_parts))
-        # where a batch's conditioning runs: "bulk" = unlocked on the throughput partition beside other lanes' refinement /
-        # decode (default), "ar" = on the generation partition's CUs, "locked" = on the throughput partition inside its slot
-        self.prep_place = os.environ.get("SOPRO_PREP_PLACE", "bulk")
         n_ar = ar_cus if ar_shared else ar_cus * ar_parts
         if not (0 < n_ar < total):
             raise ValueError("the AR partitions must leave CUs for the bulk phase")
@@ -48,15 +44,10 @@ class PipelinedSynthesizer:
         self._saved = (tts.model.stream, tts.model.bulk_stream, tts.codec.stream, tts.model.prep_stream)
         self._streams = []
         bulk0 = n_ar
-        mk = mk_range = lambda lo, n: hip.cu_range_stream(lo, n, self.device)  # noqa: E731
-        if os.environ.get("SOPRO_PART_LAYOUT", "range") == "xcd" and ar_shared and ar_cus % 32 == 0 and total % 8 == 0:
-            # developer A/B: the generation partition as WHOLE XCDs (mask bit i = XCD i % 8, slot i // 8) so that its streams
-            # of folded operands and weights go through its own L2s only; the throughput partition owns the other XCDs' L2s
-            nx = ar_cus // (total // 8)
-
-            def mk(lo, n):  # noqa: E306
-                xs = range(0, nx) if lo == 0 and n == ar_cus else range(nx, 8)
-                return hip.cu_mask_stream([i for i in range(total) if i % 8 in xs], self.device)
+        # CU ranges, not arbitrary masks: mask bit i is slot i // 8 of XCD i % 8, workgroups are dealt to ALL eight XCDs whatever the
+        # mask says, and an XCD whose slots are all masked out runs the stream on all of its CUs (profiles/r03_mask_census.txt) -
+        # a partition can take fewer CUs of every XCD, never fewer XCDs.
+        mk = lambda lo, n: hip.cu_range_stream(lo, n, self.device)  # noqa: E731
         for i in range(int(lanes)):
             lane = tts if i == 0 else tts.clone_lane()
             # (one stream set per lane, not per partition: sharing the AR stream of a lock, one refinement / decode stream and
@@ -66,9 +57,6 @@ class PipelinedSynthesizer:
             lane.model.bulk_stream = mk(bulk0, total - bulk0)
             lane.model.prep_stream = lane.model.bulk_stream  # idle while this lane generates; GEMM-shaped preparation belongs there
             self._streams += [lane.model.stream, lane.model.bulk_stream]
-            if self.prep_place == "ar":  # developer A/B: conditioning on its own stream over the generation partition's CUs
-                lane.model.prep_stream = mk(0 if ar_shared else (i % ar_parts) * ar_cus, ar_cus)
-                self._streams.append(lane.model.prep_stream)
             lane.codec.stream = lane.model.bulk_stream
             lane.model._ar_cache.clear()  # recorded graphs belong to the stream they were captured on
             lane.model._nar_graphs.clear()
@@ -82,7 +70,7 @@ class PipelinedSynthesizer:
         # measured at 390-830 us per frame for both (tools/ar_concurrency_probe.py, "64-CU partition + whole chip"), while
         # two disjoint halves give the same 136 us per frame as two ordinary streams.
         share = max(32, (total // ar_parts) // 32 * 32)  # whole multiples of 32 CUs (see the partition-size note in DESIGN.md)
-        self._full = [mk_range((i % ar_parts) * share, share) for i in range(int(lanes))]
+        self._full = [mk((i % ar_parts) * share, share) for i in range(int(lanes))]
         self._streams += self._full
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
         self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))
@@ -232,8 +220,7 @@ class PipelinedSynthesizer:
                     tj = {} if timings is not None else None
                     t_job = time.perf_counter()
                     try:
-                        locks = (ar_lock, self.bulk_lock) + ((self.bulk_lock,) if self.prep_place == "locked" else ())
-                        results[i] = lane.synthesize_batch(phase_locks=locks, timings=tj, **jobs[i])
+                        results[i] = lane.synthesize_batch(phase_locks=(ar_lock, self.bulk_lock), timings=tj, **jobs[i])
                     except BaseException as e:  # noqa: BLE001
                         errors.append(e)
                         return

@@ -134,8 +134,7 @@ class SoproTTS:
         import time
 
         ids = list(text_ids) if text_ids is not None else [self.encode_text(t) for t in texts]
-        ar_lock, bulk_lock = tuple(phase_locks)[:2] if phase_locks is not None else (contextlib.nullcontext(), contextlib.nullcontext())
-        prep_lock = phase_locks[2] if phase_locks is not None and len(phase_locks) > 2 else contextlib.nullcontext()
+        ar_lock, bulk_lock = phase_locks if phase_locks is not None else (contextlib.nullcontext(), contextlib.nullcontext())
         ss = float(style_strength if style_strength is not None else self.cfg.style_strength)
         from .model import _PhaseTimer
 
@@ -143,7 +142,7 @@ class SoproTTS:
         # the phase's kernels are, and no phase ever waits on a stream another engine of a pipeline may be generating on.
         self.model.prep_stream.wait_stream(torch.cuda.current_stream(self.device))  # the caller's inputs
         # conditioning needs no generation slot: it overlaps with whatever the other engines are doing
-        with prep_lock, torch.cuda.stream(self.model.prep_stream):
+        with torch.cuda.stream(self.model.prep_stream):
             ev = _PhaseTimer(self.model.prep_stream, timings)
             prep = self.model.phase_cond(ids, refs, max_frames=max_frames, style_strength=ss)
             # the AR phase's own preparation (plan buffers, folded text operands) belongs here too: the generation slot then

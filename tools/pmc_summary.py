@@ -22,6 +22,8 @@ def fam(name: str) -> str:
         return "gemm_f16x3_kernel" if name.split(">(")[0].rstrip().endswith("true") else "gemm_bf16x3_kernel"
     if "gemm_bf16s_kernel<3" in name:
         return "gemm_bf16x6_kernel"
+    if "attn_mfma_split_kernel" in name:
+        return "attention_split_kernel"
     if "attn_window_mfma_kernel" in name or "attn_mfma_kernel" in name:
         return "attention_kernel"
     if "seanet_tail" in name:  # (the four-wave and the sixteen-wave kernel)
