@@ -458,7 +458,10 @@ extern "C" int sopro_xattn_step_f32(const sopro_xattn_args* p, void* stream) {
   SOPRO_CHECK_ARG(aligned16(a.X) && aligned16(a.Kp) && aligned16(a.Vp) && aligned16(a.Y) && (!a.norm_w || aligned16(a.norm_w)) && (a.ldx & 3) == 0 &&
                       (a.xp_stride & 3) == 0 && (a.y_part_stride & 3) == 0,
                   "16-byte alignment / strides % 4");
-  static const bool nt = !(getenv("SOPRO_XATTN_NT") != nullptr && getenv("SOPRO_XATTN_NT")[0] == '0');  // default on (r03: +1.7 %)
+  static const bool nt_on = !(getenv("SOPRO_XATTN_NT") != nullptr && getenv("SOPRO_XATTN_NT")[0] == '0');  // default on (r03: +1.7 %)
+  // only where the operands cannot stay cached from one frame to the next anyway (> 8 MB per layer: the eight L2s hold 32 MB
+  // for three layers); a single utterance's 0.8 MB per layer is L2-resident across frames and is asked for normally
+  const bool nt = nt_on && (int64_t)a.B * a.H * a.S_cap * XD * 8 > ((int64_t)8 << 20);
   if (nt) hipLaunchKernelGGL(xattn_step_kernel<true>, dim3(a.H, a.B), dim3(512), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(xattn_step_kernel<false>, dim3(a.H, a.B), dim3(512), 0, (hipStream_t)stream, a);
   SOPRO_LAUNCH_CHECK();

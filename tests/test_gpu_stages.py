@@ -155,7 +155,7 @@ def test_library_profiler_times_the_stage_launches(tts_noeos):
         hip.set_profiler(None)
     fam = p.summary()
     assert torch.equal(got, want)  # the timed (eager) sequence is the recorded one
-    for k in ("gemm_bf16x3_kernel", "gemm_f16x3_kernel", "attention_kernel", "seanet_tail_kernel", "seanet_res128_kernel", "seanet_up128_kernel"):
+    for k in ("gemm_bf16x3_kernel", "gemm_f16x3_kernel", "attention_split_kernel", "seanet_tail_kernel", "seanet_res128_kernel", "seanet_up128_kernel"):
         assert k in fam and fam[k]["launches"] > 0 and fam[k]["flops"] > 0 and fam[k]["ms_all"] > 0, (k, fam.get(k))
     assert fam["seanet_tail_kernel"]["launches"] == 1 and fam["seanet_tail_kernel"]["flops"] == 2.0 * 2 * 40 * 1920 * (3 * 64 * 32 + 32 * 64 + 3 * 64)
     assert hip.Profiler().summary() == {}  # collected records are gone
