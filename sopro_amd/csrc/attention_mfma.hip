@@ -165,12 +165,14 @@ __global__ __launch_bounds__(256) void attn_mfma_split_kernel(const sopro_attn_a
 
   const int qi = min(q0 + col, a.Tq - 1);
   const int qabs = a.q_pos0 + qi;
+  const float qscale = a.scale * 1.44269504088896340736f;
   uint4 qh[NJ], ql[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const float* qp = Qb + (int64_t)qi * a.ldq + 16 * j + 8 * half;
     const float4 x = *reinterpret_cast<const float4*>(qp), y = *reinterpret_cast<const float4*>(qp + 4);
-    const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+    // the softmax scale and log2(e) go into Q once: scores come out of the MFMAs in the exp2 domain
+    const float v[8] = {x.x * qscale, x.y * qscale, x.z * qscale, x.w * qscale, y.x * qscale, y.y * qscale, y.z * qscale, y.w * qscale};
     asplit8<PASSES>(v, qh[j], ql[j]);
   }
 
@@ -184,8 +186,10 @@ __global__ __launch_bounds__(256) void attn_mfma_split_kernel(const sopro_attn_a
   const int q_lo_abs = a.q_pos0 + q0, q_hi_abs = a.q_pos0 + min(q0 + 31, a.Tq - 1);
   const int k_first = max(q_lo_abs - a.window + 1 - a.k_pos0, 0);
   const int k_last = min(q_hi_abs - a.k_pos0, klen - 1);
+  const int64_t v_lane = (int64_t)(4 * half) * a.ldv + col;  // this lane's place inside a tile's value rows (loop-invariant)
   for (int k0 = (k_first / 32) * 32; k0 <= k_last; k0 += 32) {
     // ---- operands of this tile: the lane's key row (its 32 head dims) and its value column (16 key rows per 32-wide tile)
+    const bool inrange = k0 + 31 < klen;  // wave-uniform: no clamping, row addresses = uniform row base + the lane's place
     const int kr = min(k0 + col, klen - 1);  // clamped: rows past the end are masked below
     const float* kp = Kb + (int64_t)kr * a.ldk + 8 * half;
     float4 kraw[2 * NJ];
@@ -195,14 +199,23 @@ __global__ __launch_bounds__(256) void attn_mfma_split_kernel(const sopro_attn_a
       kraw[2 * j + 1] = *reinterpret_cast<const float4*>(kp + 16 * j + 4);
     }
     float vraw[NT][16];
+    if (inrange) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = min(k0 + (r & 3) + 8 * (r >> 2) + 4 * half, klen - 1);
-      const float* vp = Vb + (int64_t)key * a.ldv + col;
+      for (int r = 0; r < 16; ++r) {
+        const float* vrow = Vb + (int64_t)(k0 + (r & 3) + 8 * (r >> 2)) * a.ldv;  // uniform
 #pragma unroll
-      for (int t = 0; t < NT; ++t) vraw[t][r] = vp[32 * t];
+        for (int t = 0; t < NT; ++t) vraw[t][r] = vrow[v_lane + 32 * t];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = min(k0 + (r & 3) + 8 * (r >> 2) + 4 * half, klen - 1);
+        const float* vp = Vb + (int64_t)key * a.ldv + col;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) vraw[t][r] = vp[32 * t];
+      }
     }
-    // ---- S^T = K_tile . Q^T
+    // ---- S^T = K_tile . Q^T (already in the exp2 domain: Q carries scale * log2 e)
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -213,33 +226,56 @@ __global__ __launch_bounds__(256) void attn_mfma_split_kernel(const sopro_attn_a
       asplit8<PASSES>(v, kh, kl);
       st = mma_split<PASSES>(kh, kl, qh[j], ql[j], st);
     }
-    // ---- mask + online softmax for this lane's query (rows of st = keys k0 + (r&3) + 8(r>>2) + 4*half)
+    // ---- online softmax for this lane's query (rows of st = keys k0 + (r&3) + 8(r>>2) + 4*half).
+    // Most tiles lie wholly inside every query's window: no masks, no infinities (wave-uniform test).
+    const bool full = inrange && (a.k_pos0 + k0 + 31 <= q_lo_abs) && (a.k_pos0 + k0 > q_hi_abs - a.window);
     float mx = -INFINITY;
+    if (full) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int kabs = a.k_pos0 + key;
-      const bool ok = key < klen && kabs <= qabs && kabs > qabs - a.window;
-      st[r] = ok ? st[r] * a.scale : -INFINITY;
-      mx = fmaxf(mx, st[r]);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int kabs = a.k_pos0 + key;
+        const bool ok = key < klen && kabs <= qabs && kabs > qabs - a.window;
+        st[r] = ok ? st[r] : -INFINITY;
+        mx = fmaxf(mx, st[r]);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);
-    float ps = 0.f;
+    // Lazy reference: the running reference m_run only moves when some query's maximum outgrows it by more than 2^8 (or has
+    // none yet); until then the weights are taken against the old reference (at most 2^8, exact in fp32 and in the split) and
+    // the accumulators (AGPRs: a read, a multiply and a write each) are left alone.  O / l at the end is the same quotient.
+    const bool grow = mx > m_run + 8.f || m_run == -INFINITY;
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      // a query that has seen nothing yet keeps its (empty) state: m_new == -inf only before its first visible key
+      const float alpha = (m_new == -INFINITY || m_new == m_run) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = (st[r] == -INFINITY) ? 0.f : expf(st[r] - m_new);
-      st[r] = p;
-      ps += p;
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) o[t][r] *= alpha;
+    }
+    float ps = 0.f;
+    if (full) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = __builtin_amdgcn_exp2f(st[r] - m_run);
+        ps += st[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = (st[r] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[r] - m_run);
+        st[r] = p;
+        ps += p;
+      }
     }
     ps += __shfl_xor(ps, 32, 64);
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) o[t][r] *= alpha;
+    l_run += ps;
     // ---- O^T += V_tile^T . P   (step j: key rows of accumulator registers 8 j .. 8 j + 7)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
