@@ -194,7 +194,7 @@ extern "C" int sopro_attention_split_bf16(const sopro_attn_args* p, int32_t pass
   const sopro_attn_args& a = *p;
   const bool fits = a.Q && a.K && a.V && a.O && a.B > 0 && a.H > 0 && a.Tk > 0 && a.causal && a.window > 0 && a.dh == 64 && a.Tq >= 16 &&
                     aligned16(a.Q) && aligned16(a.K) && aligned16(a.V) && aligned16(a.O) && ((a.ldq | a.ldk | a.ldv | a.ldo) & 3) == 0 &&
-                    ((a.q_bstride | a.k_bstride | a.v_bstride | a.o_bstride) & 3) == 0 && !getenv("SOPRO_ATTN_EXACT");
+                    ((a.q_bstride | a.k_bstride | a.v_bstride | a.o_bstride) & 3) == 0;
   if (!fits) return sopro_attention_f32(p, stream);
   return sopro_attn_mfma_split(a, passes, reinterpret_cast<hipStream_t>(stream));
 }
