@@ -72,6 +72,11 @@ class PipelinedSynthesizer:
         share = max(32, (total // ar_parts) // 32 * 32)  # whole multiples of 32 CUs (see the partition-size note in DESIGN.md)
         self._full = [mk((i % ar_parts) * share, share) for i in range(int(lanes))]
         self._streams += self._full
+        # ... and a pipeline that is running dry has nothing left for the generation partition: once every job of a run is past
+        # its AR phase, the remaining refinement / decode phases take the whole chip (CU-masked streams over all CUs: an
+        # ordinary stream beside masked ones is the slow combination noted above).  SOPRO_DRAIN_WHOLE=0: stay on the partition.
+        self._whole = [mk(0, total) for _ in range(int(lanes))] if os.environ.get("SOPRO_DRAIN_WHOLE", "1") != "0" else None
+        self._streams += self._whole or []
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
         self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))
         self.ar_cus, self.ar_parts, self.bulk_cus = ar_cus, ar_parts, total - bulk0
@@ -98,6 +103,7 @@ class PipelinedSynthesizer:
             lane.codec._graphs.clear()
             self.lanes.append(lane)
         self._full = [lane.model.stream for lane in self.lanes]
+        self._whole = None
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
         self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))
         self.ar_cus, self.ar_parts, self.bulk_cus = 0, ar_parts, hip.device_info(self.device.index or 0)["cus"]
@@ -208,8 +214,29 @@ class PipelinedSynthesizer:
                 self.ar_locks[slot.part].release()
                 return False
 
+        class _BulkSlot:
+            def __init__(slot, lane, lane_idx):
+                slot.lane, slot.lane_idx = lane, lane_idx
+
+            def __enter__(slot):
+                self.bulk_lock.acquire()
+                slot.saved = None
+                with pick:
+                    dry = ar_finished[0] >= len(jobs)  # every job of this run is past its AR phase
+                if dry and self._whole is not None:
+                    slot.saved = (slot.lane.model.bulk_stream, slot.lane.codec.stream)
+                    slot.lane.model.bulk_stream = slot.lane.codec.stream = self._whole[slot.lane_idx]
+                    self.drain_jobs += 1
+
+            def __exit__(slot, *exc):
+                if slot.saved is not None:
+                    slot.lane.model.bulk_stream, slot.lane.codec.stream = slot.saved
+                self.bulk_lock.release()
+                return False
+
         def worker(lane, ar_lock, lane_idx):
             # the worker's current stream is the lane's own (never the NULL stream, which would serialise the lanes)
+            bulk_slot = _BulkSlot(lane, lane_idx)
             with torch.cuda.stream(lane.model.stream):
                 while True:
                     with pick:
@@ -220,7 +247,7 @@ class PipelinedSynthesizer:
                     tj = {} if timings is not None else None
                     t_job = time.perf_counter()
                     try:
-                        results[i] = lane.synthesize_batch(phase_locks=(ar_lock, self.bulk_lock), timings=tj, **jobs[i])
+                        results[i] = lane.synthesize_batch(phase_locks=(ar_lock, bulk_slot), timings=tj, **jobs[i])
                     except BaseException as e:  # noqa: BLE001
                         errors.append(e)
                         return
@@ -239,6 +266,7 @@ class PipelinedSynthesizer:
 
         self.trace = []  # (job, lane, start s, end s, per-phase seconds) of the last timed run: who was slow, and when
         self.fill_jobs = []  # jobs whose AR phase ran on a pipeline-fill stream (at most one per partition lock and run)
+        self.drain_jobs = 0  # refinement / decode phases of this run that had the whole chip (the pipeline was running dry)
         t_run = time.perf_counter()
 
         swi = sys.getswitchinterval()
