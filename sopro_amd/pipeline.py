@@ -75,8 +75,12 @@ class PipelinedSynthesizer:
         # ... and a pipeline that is running dry has nothing left for the generation partition: once every job of a run is past
         # its AR phase, the remaining refinement / decode phases take the whole chip (CU-masked streams over all CUs: an
         # ordinary stream beside masked ones is the slow combination noted above).  SOPRO_DRAIN_WHOLE=0: stay on the partition.
-        self._whole = [mk(0, total) for _ in range(int(lanes))] if os.environ.get("SOPRO_DRAIN_WHOLE", "1") != "0" else None
-        self._streams += self._whole or []
+        self._whole = None
+        if os.environ.get("SOPRO_DRAIN_WHOLE", "1") != "0":
+            # (one stream for all lanes while the throughput slot is exclusive: its phases are serial anyway)
+            own = [mk(0, total) for _ in range(int(lanes) if bulk_slots > 1 else 1)]
+            self._whole = [own[i % len(own)] for i in range(int(lanes))]
+            self._streams += own
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
         self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))
         self.ar_cus, self.ar_parts, self.bulk_cus = ar_cus, ar_parts, total - bulk0
