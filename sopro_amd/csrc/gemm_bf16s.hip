@@ -247,19 +247,43 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   lstore(0, raA, pvA);
   __syncthreads();
   if (dbg && tid == 0) dbg[1] = clock64();
-  for (int it = 0; it < nkt; it += 2) {
-    const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl), k3 = min(kt0 + it + 3, ktl);
-    if (!(ABL & 2)) { if (DEEP) gload(k2, raA, pvA); else gload(k1, raA, pvA); }
-    if (!(ABL & 4)) bload(k1, rb1);
-    compute(0, (ABL & 4) ? rb0 : rb0);
-    if (!(ABL & 2)) { if (DEEP) lstore(1, raB, pvB, it + 1 < nkt); else lstore(1, raA, pvA, it + 1 < nkt); }
-    if (!(ABL & 8)) __syncthreads();
-    if (it + 1 >= nkt) break;
-    if (!(ABL & 2)) { if (DEEP) gload(k3, raB, pvB); else gload(k2, raA, pvA); }
-    if (!(ABL & 4)) bload(k2, rb0);
-    compute((ABL & 2) ? 0 : 1, (ABL & 4) ? rb0 : rb1);
-    if (!(ABL & 2)) lstore(0, raA, pvA, it + 2 < nkt);
-    if (!(ABL & 8)) __syncthreads();
+  if constexpr ((ABL & 64) == 0) {
+    // The two-step body is ONE basic block: the odd last step is peeled off instead of leaving through a break in the middle
+    // (which let the optimiser sink the second step's W requests out of the first step and cost a vmcnt(0) at the loop header).
+    // +2-3 % on the large decoder shapes, bit-identical (tools/gemm_ab_probe.py; SOPRO_ABLATE=64 builds the old form, +32 pins
+    // every step's requests ahead of its MFMAs with sched_barrier, which measured 0-9 % SLOWER).
+    int it = 0;
+    for (; it + 1 < nkt; it += 2) {
+      const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl), k3 = min(kt0 + it + 3, ktl);
+      gload(k2, raA, pvA);
+      bload(k1, rb1);
+      if constexpr ((ABL & 32) != 0) __builtin_amdgcn_sched_barrier(0);
+      compute(0, rb0);
+      lstore(1, raB, pvB, true);
+      __syncthreads();
+      gload(k3, raB, pvB);
+      bload(k2, rb0);
+      if constexpr ((ABL & 32) != 0) __builtin_amdgcn_sched_barrier(0);
+      compute(1, rb1);
+      lstore(0, raA, pvA, it + 2 < nkt);
+      __syncthreads();
+    }
+    if (it < nkt) compute(0, rb0);
+  } else {
+    for (int it = 0; it < nkt; it += 2) {
+      const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl), k3 = min(kt0 + it + 3, ktl);
+      if (!(ABL & 2)) { if (DEEP) gload(k2, raA, pvA); else gload(k1, raA, pvA); }
+      if (!(ABL & 4)) bload(k1, rb1);
+      compute(0, (ABL & 4) ? rb0 : rb0);
+      if (!(ABL & 2)) { if (DEEP) lstore(1, raB, pvB, it + 1 < nkt); else lstore(1, raA, pvA, it + 1 < nkt); }
+      if (!(ABL & 8)) __syncthreads();
+      if (it + 1 >= nkt) break;
+      if (!(ABL & 2)) { if (DEEP) gload(k3, raB, pvB); else gload(k2, raA, pvA); }
+      if (!(ABL & 4)) bload(k2, rb0);
+      compute((ABL & 2) ? 0 : 1, (ABL & 4) ? rb0 : rb1);
+      if (!(ABL & 2)) lstore(0, raA, pvA, it + 2 < nkt);
+      if (!(ABL & 8)) __syncthreads();
+    }
   }
   if (dbg && tid == 0) dbg[2] = clock64();
   if constexpr (SK) {

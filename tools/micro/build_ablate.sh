@@ -7,5 +7,5 @@ make -s
 for n in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DSOPRO_ABLATE=$n -c gemm_bf16s.hip -o /tmp/gemm_bf16s_abl$n.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/micro/libsopro_abl$n.so /tmp/gemm_bf16s_abl$n.o \
-    capi.o gemm_f32.o skinny_f32.o elementwise.o attention.o attention_mfma.o ar_driver.o seanet_tail.o
+    $(ls *.o | grep -v '^gemm_bf16s.o$')
 done
