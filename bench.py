@@ -556,9 +556,18 @@ def main() -> None:
         ach = bytes_step / (per_launch_ms * 1e-3) / 1e9
         per_frame = ark.get("launches_per_frame") or {"skinny_kernel": 19, "xattn_step_kernel": 3, "ar_sample_kernel": 1}
         tr = round(sum(pmc.get(k, {}).get("traffic_bytes_per_launch", 0) * n for k, n in per_frame.items())) if pmc else None
+        # the PMC pass has its own row count per frame (profiles/rNN_pmc_summary.json "ar_rows_per_frame"; the r03 file was a
+        # 32-row --lanes 1 run): traffic is compared with the algorithmic bytes of THAT frame, not of this run's coalesced one
+        pmc_rows = int(pmc_d.get("ar_rows_per_frame", 32)) if pmc else None
+        pmc_prec = pmc_d.get("precision", "f32") if pmc else None
+        tr_alg = ar_step_bytes(pmc_rows, TEXT_LEN, 2 if pmc_prec == "bf16" else 4) if pmc else None
         e = {"kernel": f"AR frame (hipGraph of {sum(per_frame.values())} launches: " + ", ".join(f"{k} x{n}" for k, n in per_frame.items()) + ")",
              "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5),
-             "traffic": tr or None, "traffic_ratio": round(tr / bytes_step, 3) if tr else None, "launches": ar_frames or f["launches"],
+             "traffic": tr or None, "traffic_ratio": round(tr / tr_alg, 3) if tr else None,
+             "traffic_rows_per_launch": pmc_rows if tr else None, "traffic_algorithmic_bytes": tr_alg if tr else None,
+             "traffic_note": (f"PMC pass of a {pmc_rows}-row {pmc_prec} frame (kernels serialised by the counter collection): traffic and traffic_ratio "
+                              f"describe that frame; achieved / avg_launch_us describe this run's {rows_launch}-row frames") if tr else None,
+             "launches": ar_frames or f["launches"],
              "avg_launch_us": round(per_launch_ms * 1e3, 2), "ms_per_step": round((ar_ms / args.steps) if ar_frames else f["ms"] / max(1, nprof), 3),
              "avg_launch_us_instrumented_repeat": round(inst_ms * 1e3, 2),
              "algorithmic_bytes_per_launch": bytes_step, "rows_per_launch": rows_launch, "cu_share": ar_share,
@@ -697,6 +706,15 @@ def main() -> None:
                                capture_output=True, text=True, timeout=180, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
             both = json.loads(r.stdout.strip().splitlines()[-1])
             cpu, parity = both["cpu_baseline"], both["parity"]
+            rr = latest_profile("cpu_reference_ratio.json")  # oracle vs THE REFERENCE on one host (build container: tools/cpu_reference_ratio.py)
+            if cpu and rr.get("oracle_over_reference"):
+                cpu["reference_ratio"] = {"oracle_over_reference": rr["oracle_over_reference"], "reference_audio_s_per_s": rr.get("reference_audio_s_per_s"),
+                                          "oracle_audio_s_per_s": rr.get("oracle_audio_s_per_s"), "host": rr.get("host"),
+                                          "note": "kind = 'port': /root/reference is not on the GPU box; on the build container the port runs this much "
+                                                  "faster than the reference itself on the same utterances, so the reference on THIS host would be about "
+                                                  "value / oracle_over_reference",
+                                          "estimated_reference_value_here": round(cpu["value"] / rr["oracle_over_reference"], 3),
+                                          **profile_stamp(os.path.join(ROOT, rr["source"]))}
         except Exception as e:  # noqa: BLE001  (a missing baseline must not void the GPU measurement)
             log(f"cpu baseline failed: {e!r}")
             cpu = None

@@ -550,7 +550,8 @@ int sopro_film_coeffs(sopro_engine* e, const float* sv, float style, int32_t n, 
 /* Reference preparation of one voice from its codec tokens (src/sopro/model.py:151-170): Token2SV (src/sopro/nn/speaker.py:37-61)
  * -> sv [sv_student_dim]; reference sequence encoder (model.py:133-149) -> ref_seq [T, D]; K | V rows of every reference
  * cross-attention block (src/sopro/nn/ref.py:120-128) -> kv[i] [T, 2 D] (host array of ref_xattn_layers device pointers).
- * tokens [T, Q] int32.  Launches only. */
+ * tokens [T, Q] int32.  ref_seq == NULL and kv == NULL: the speaker vector alone (SoproTTS.encode_speaker,
+ * src/sopro/model.py:457-475 -> token2sv).  Launches only. */
 int64_t sopro_ref_workspace_bytes(const sopro_engine* e, int32_t T);
 int sopro_ref_prepare(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t T, float* sv, float* ref_seq, float* const* kv, void* stream);
 

@@ -670,8 +670,8 @@ int64_t sopro_ref_workspace_bytes(const sopro_engine* e, int32_t T) {
 }
 
 int sopro_ref_prepare(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t T, float* sv, float* ref_seq, float* const* kv, void* stream) {
-  SOPRO_CHECK_ARG(e && e->final && e->has_cond && workspace && tokens && sv && ref_seq && kv && T > 0,
-                  "bad arguments (finalize the engine with the conditioning tensors first)");
+  SOPRO_CHECK_ARG(e && e->final && e->has_cond && workspace && tokens && sv && T > 0 && ((ref_seq && kv) || (!ref_seq && !kv)),
+                  "bad arguments (finalize the engine with the conditioning tensors first; ref_seq and kv are given or omitted together)");
   hipStream_t s = (hipStream_t)stream;
   const sopro_engine_cfg& c = e->c;
   const int D = c.d_model, Q = c.num_codebooks, SD = (int)e->t["token2sv.emb"].shape[1], svd = c.sv_student_dim;
@@ -694,6 +694,7 @@ int sopro_ref_prepare(sopro_engine* e, void* workspace, const int32_t* tokens, i
   Wt wp; wp.f32 = F(e, "token2sv.proj.w");
   STG(gemm(s, w.st, wp, nullptr, w.ev, gp));
   STG(sopro_l2norm_f32(w.ev, sv, 1, svd, 1e-6f, s));
+  if (!ref_seq) return 0;  // speaker vector only: SoproTTS.encode_speaker (src/sopro/model.py:457-475)
   // ---- reference sequence encoder (model.py:133-149)
   float *xa = w.xa, *xb = w.xb;
   STG(sopro_codebook_sum_f32(tokens, Q, e->q_col, e->q_off, F(e, "ref_cw"), Q, F(e, "cb_embed"), e->t["cb_embed"].shape[0], nullptr, 0.f, 1.f, xa, D, 0,

@@ -776,6 +776,9 @@ def film_coeffs(engine, sv: torch.Tensor, style: float, n: int, scratch: torch.T
 
 def ref_prepare(engine, ws: torch.Tensor, tokens: torch.Tensor, T: int, sv: torch.Tensor, ref_seq: torch.Tensor, kvs) -> None:
     """sopro_ref_prepare: Token2SV, reference encoder and the K | V rows of the reference cross-attention blocks of one voice."""
+    if ref_seq is None:  # speaker vector only (SoproTTS.encode_speaker)
+        _check(load().sopro_ref_prepare(engine, ptr(ws), ptr(tokens, torch.int32), T, ptr(sv), None, None, _stream()), "sopro_ref_prepare")
+        return
     ka = (C.c_void_p * len(kvs))(*[ptr(t) for t in kvs])
     _check(load().sopro_ref_prepare(engine, ptr(ws), ptr(tokens, torch.int32), T, ptr(sv), ptr(ref_seq), ka, _stream()), "sopro_ref_prepare")
 
@@ -865,6 +868,7 @@ class GraphCache:
     def clear(self) -> None:
         self.graphs.clear()
         self.seen.clear()
+        reap_parked_graphs()  # the handles were only parked by Graph.__del__: destroy them now if no recording is open
 
 
 # A recording is thread-local (hipStreamCaptureModeThreadLocal), but the runtime still refused a pinned-host allocation made
@@ -874,11 +878,33 @@ class GraphCache:
 _capture_lock = threading.RLock()
 
 
+def reap_parked_graphs() -> bool:
+    """Destroy the parked graph handles NOW if no recording is open in any thread (a warmed-up server may never record again,
+    and the handles keep their workspaces' launch descriptors alive: ADVICE r3).  Non-blocking: returns False, leaving them for
+    the next capture_begin, when another thread holds the recording lock."""
+    if not _dead_graphs:
+        return True
+    if not _capture_lock.acquire(blocking=False):
+        return False
+    try:
+        if getattr(_capture_depth, "n", 0) == 0:  # (the lock is re-entrant: not inside THIS thread's own recording either)
+            reap_graphs()
+            return True
+        return False
+    finally:
+        _capture_lock.release()
+
+
+_capture_depth = threading.local()
+
+
 def capture_begin() -> None:
     _capture_lock.acquire()
     try:
-        reap_graphs()
+        if getattr(_capture_depth, "n", 0) == 0:
+            reap_graphs()
         _check(load().sopro_capture_begin(_stream()), "sopro_capture_begin")
+        _capture_depth.n = getattr(_capture_depth, "n", 0) + 1
     except BaseException:
         _capture_lock.release()
         raise
@@ -889,6 +915,7 @@ def capture_end() -> Graph:
     try:
         _check(load().sopro_capture_end(_stream(), C.byref(out)), "sopro_capture_end")
     finally:
+        _capture_depth.n = max(0, getattr(_capture_depth, "n", 0) - 1)
         _capture_lock.release()
     return Graph(out.value)
 

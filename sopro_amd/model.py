@@ -253,6 +253,24 @@ class SoproTTSModel:
         self.stream.synchronize()
         return PreparedReference(ref_tokens_btq=tok64.unsqueeze(0), sv_ref=sv, ref_seq=ref_seq, ref_kv_caches=caches)
 
+    @torch.inference_mode()
+    def token2sv(self, ref_btq: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Speaker vector of one voice's codec tokens, [1, T, Q] -> [1, sv_student_dim] (reference: the ``token2sv`` module,
+        src/sopro/nn/speaker.py:37-61, as ``SoproTTS.encode_speaker`` calls it, src/sopro/model.py:457-475).  The launch
+        sequence is the Token2SV part of ``sopro_ref_prepare`` (csrc/stages.hip)."""
+        if ref_btq.dim() != 3 or ref_btq.shape[0] != 1 or ref_btq.shape[2] != self.Q:
+            raise ValueError(f"ref_btq must be [1, T, {self.Q}], got {tuple(ref_btq.shape)}")
+        T = int(ref_btq.shape[1])
+        if lengths is not None and int(lengths.reshape(-1)[0]) != T:
+            raise ValueError("lengths must equal the token count (one unpadded voice)")
+        with self.on_stream():
+            tok = ref_btq[0].to(self.device).to(torch.int32).contiguous()
+            sv = torch.empty(1, int(self.cfg.sv_student_dim), device=self.device)
+            wsb = self._ref_ws.get("ref.ws", (int(hip.load().sopro_ref_workspace_bytes(self.eng.h, T)) // 4 + 64,))
+            hip.ref_prepare(self.eng.h, wsb, tok, T, sv, None, None)
+        self.stream.synchronize()
+        return sv
+
     # ------------------------------------------------------------------ per-utterance conditioning
     @torch.inference_mode()
     def prepare_conditioning(self, text_ids_1d: torch.Tensor, ref: PreparedReference, *, max_frames: int,

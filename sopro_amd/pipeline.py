@@ -133,6 +133,10 @@ class PipelinedSynthesizer:
         lane0.model.stream, lane0.model.bulk_stream, lane0.codec.stream, lane0.model.prep_stream = self._saved
         self.lanes = []
         torch.cuda.synchronize(self.device)
+        import gc
+
+        gc.collect()  # Graph.__del__ of the dropped plans parks the handles ...
+        hip.reap_parked_graphs()  # ... and the device is idle, no recording is open: destroy them before their streams go
         for st in self._streams:
             hip.destroy_stream(st)
         self._streams = []
@@ -143,11 +147,16 @@ class PipelinedSynthesizer:
         """Groups of up to ``n`` CONSECUTIVE jobs with equal sampling parameters become one pass over their concatenated
         utterances (the AR frame chain costs nearly the same for 64 rows as for 32: profiles/r03_experiments.md).  Every
         utterance keeps the sampler stream it has in its own job - that job's nonce and its index within the job (``nonces`` /
-        ``row_ids`` of synthesize_batch) - so results are bit-identical to running the jobs one by one."""
+        ``row_ids`` of synthesize_batch) - so results are bit-identical to running the jobs one by one FOR SEEDED JOBS; a job
+        without a ``seed`` takes the next nonce of the process-wide run counter here, in job order, which is not the order the
+        passes later execute in (a seedless job is "a new take" either way)."""
         groups: List[List[int]] = []
         for i, j in enumerate(jobs):
+            head = jobs[groups[-1][0]] if groups else None
             same = bool(groups) and len(groups[-1]) < n and all(
-                jobs[groups[-1][0]].get(k) == j.get(k) for k in (set(j) | set(jobs[groups[-1][0]])) - set(self._PER_UTT) - {"seed"})
+                head.get(k) == j.get(k) for k in (set(j) | set(head)) - set(self._PER_UTT) - {"seed"})
+            # ... and the same per-utterance lists present (one job with `texts`, its neighbour with `text_ids` do not merge)
+            same = same and all((head.get(k) is None) == (j.get(k) is None) for k in self._PER_UTT)
             if same:
                 groups[-1].append(i)
             else:

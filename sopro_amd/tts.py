@@ -75,6 +75,16 @@ class SoproTTS:
         return torch.tensor(ids, dtype=torch.long)
 
     @torch.inference_mode()
+    def encode_speaker(self, *, ref_audio_path: Optional[str] = None, ref_tokens_tq: Optional[torch.Tensor] = None,
+                       ref_seconds: Optional[float] = None) -> torch.Tensor:
+        """reference: src/sopro/model.py:457-475 -> the voice's speaker vector [sv_student_dim] (Token2SV over the cropped
+        reference tokens; the same vector ``prepare_reference`` stores as ``sv_ref``)."""
+        ref = self.encode_reference(ref_audio_path=ref_audio_path, ref_tokens_tq=ref_tokens_tq, ref_seconds=ref_seconds)
+        ref_btq = ref.unsqueeze(0)
+        lengths = torch.tensor([int(ref_btq.size(1))], dtype=torch.long)
+        return self.model.token2sv(ref_btq, lengths=lengths).squeeze(0).detach()
+
+    @torch.inference_mode()
     def encode_reference(self, *, ref_audio_path: Optional[str] = None, ref_tokens_tq: Optional[torch.Tensor] = None,
                          ref_seconds: Optional[float] = None) -> torch.Tensor:
         """reference: src/sopro/model.py:477-514 (token path only; audio -> tokens needs the Mimi encoder)."""

@@ -103,3 +103,34 @@ def tts_noeos(cfg, sopro_np_noeos, mimi_np):
     """Engine with the EOS-suppressed checkpoint (gpu tests at the BASELINE shapes)."""
     from sopro_amd import SoproTTS
     return SoproTTS.from_weights(cfg, sopro_np_noeos, mimi_np, FakeTok(), device="cuda:0")
+
+
+def oracle_request(ids_1d, ref_tq, w, mw, cfg, mc, **kw):
+    """One request through the CPU oracle (oracle/sopro_oracle.py: generate_tokens + decode_full) -> (tokens [T, Q], wav
+    [1, 1, N]).  The serving / admission tests take their expected results from here, not from the engine's own lone runs."""
+    from oracle import sopro_oracle as O
+    kw.setdefault("style_strength", float(cfg.style_strength))
+    oref = O.prepare_reference(ref_tq, w, cfg)
+    toks = O.generate_tokens(ids_1d, oref, w, cfg, **kw)
+    wav = O.decode_full(toks, mw, mc) if toks.shape[0] > 0 else torch.zeros(1, 1, 0)
+    return toks, wav, oref
+
+
+def assert_request_matches_oracle(got_wav, got_toks, want_toks, want_wav, oref, ids_1d, w, mw, cfg, mc, what="", **kw):
+    """Codebook 0 exact; refined codebooks exact or - on these random inputs - every deviating decision an audited near-tie of
+    the oracle (teacher-forced logit gap < 1e-4); waveform within 1e-4 of the peak of the oracle's decode of the same tokens."""
+    from oracle import sopro_oracle as O
+    if got_toks is not None:
+        g, wt = got_toks.cpu().long(), want_toks.cpu().long()
+        assert tuple(g.shape) == tuple(wt.shape), (what, tuple(g.shape), tuple(wt.shape))
+        assert torch.equal(g[:, 0], wt[:, 0]), f"{what}: codebook-0 tokens differ from the oracle's"
+        if not torch.equal(g, wt):
+            kw.setdefault("style_strength", float(cfg.style_strength))
+            prep = O.prepare_conditioning(ids_1d, oref, w, cfg, max_frames=kw["max_frames"], style_strength=kw["style_strength"])
+            n_off, gap = O.nar_audit(prep["cond_ar"][:, : g.shape[0]], g.unsqueeze(0), w, cfg)
+            assert gap < 1e-4, f"{what}: {n_off} refined tokens off the oracle's arg-max, worst gap {gap:.3e}"
+            want_wav = O.decode_full(g, mw, mc)
+    assert tuple(got_wav.shape) == tuple(want_wav.shape), (what, tuple(got_wav.shape), tuple(want_wav.shape))
+    if want_wav.numel():
+        err = float((got_wav.detach().float().cpu() - want_wav).abs().max())
+        assert err <= 1e-4 * float(want_wav.abs().max()), (what, err)

@@ -9,6 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import golden
 from oracle import sopro_oracle as O
 from sopro_amd import hip, pack
 
@@ -23,6 +24,10 @@ def rnd(*shape, seed=0, scale=1.0):
 
 def dev(t):
     return t.to(DEV).contiguous()
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
 
 
 def close(a, b, atol, what=""):
@@ -161,6 +166,31 @@ def test_gemm_bf16x3_epilogues_prologue_and_row_windows():
     hip.gemm(dev(buf), hip.pack_w_bf16x3(dev(wp)), out, M=B * T, N=s_ * co, K=2 * ci, lda=ci, bias=dev(bp), rows_per_seg=T,
              a_seg_stride=(1 + T) * ci, c_off=2 * co, c_seg_stride=(2 + T * s_) * co, ldc=s_ * co)
     close(out[:, 2:], ref, 2e-4, "conv transpose stride 5")
+
+
+@pytest.mark.parametrize("K", [32, 96, 160, 16])
+def test_gemm_split_odd_k_steps_many_workgroups_per_cu(K):
+    """An odd number of 32-wide K-steps ends on the peeled last step, whose A-fragment reads (LDS buffer 0) must be complete in
+    EVERY wave before the epilogue overwrites that memory with the transposed accumulators (the barrier was
+    missing; the model's own shapes all have an even K / 32).  Many small tiles per CU and repeated launches give the waves
+    of a workgroup every chance to drift apart; every piece count / tile shape the engine issues."""
+    M, N = 8192, 512
+    A, W, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13)
+    ref = A.double() @ W.double().t() + b.double()
+    aw = A.double().abs() @ W.double().abs().t() + b.double().abs()
+    Ad, bd = dev(A), dev(b)
+    for name, Wp, rel in (("bf16x3", hip.pack_w_bf16x3(dev(W)), 2.0 ** -15), ("bf16x6", hip.pack_w_bf16x6(dev(W)), 2.0 ** -21),
+                          ("f16x3", hip.pack_w_f16x3(dev(W)), 2.0 ** -19)):
+        outs = []
+        for rep in range(6):
+            C = torch.full((M, N), float("nan"), device=DEV)
+            hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd)
+            outs.append(C)
+        torch.cuda.synchronize()
+        err = (outs[0].cpu().double() - ref).abs()
+        assert bool((err <= aw * rel + 1e-6).all()), f"{name} K={K}: worst {float((err / (aw * rel + 1e-6)).max()):.2f} of the bound"
+        for C in outs[1:]:
+            assert torch.equal(C, outs[0]), f"{name} K={K}: repeated launches differ (a race in the kernel)"
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 96), (129, 64, 64), (70, 33, 192), (257, 2048, 256), (640, 384, 1536),
@@ -1115,6 +1145,44 @@ def test_sampler_whole_distribution_matches_reference(top_p, temp, top_k, scale)
     worst = ((freq - p).abs() - tol).max()
     assert float(worst) <= 0.0, (float(worst), int(((freq - p).abs() - tol).argmax()))
     assert int((p > 0).sum()) >= 2
+
+
+def test_sampler_matches_reference_draws_with_history():
+    """ar_sample_kernel against 20 000 seeded draws of THE REFERENCE's sample_token per case (tests/golden/sampler.npz, made by
+    tests/golden/make_golden_sampler.py from /root/reference/src/sopro/sampling.py:24-93): every case has a 60-token history
+    (repetition penalty over the set of the last 50), so the whole temperature -> penalty -> softmax -> top-k -> top-p order
+    is compared.  Two-sample test per token (5 sigma of the difference of two empirical frequencies + 0.003), nothing outside
+    the reference's drawn set beyond what 20 000 draws can miss."""
+    g = golden("sampler")
+    n_ref = int(g["n_draws"])
+    B, V1, steps = 256, 2049, 48
+    for ci, (top_p, temp, top_k, _scale) in enumerate(g["cases"].tolist()):
+        logits, hist = _t(g[f"logits{ci}"]).float(), g[f"hist{ci}"].tolist()
+        ref_freq = _t(g[f"counts{ci}"]).double() / n_ref
+        rig = _SamplerRig(B, Tar=steps + 1)
+        rig.set_params(top_p, temp, False, rep=1.1, top_k=int(top_k))
+        rig.nonce.copy_(torch.arange(B, dtype=torch.int32) * 104729 + 17 + ci)
+        hip.ar_init(rig.st)
+        window = torch.full((64,), -1, dtype=torch.int32)
+        for j in range(min(64, len(hist))):
+            window[j] = hist[-1 - j]  # slot j = the token sampled j + 1 frames ago
+        rec0 = dev(window[None].repeat(B, 1))
+        lg = dev(logits[None].repeat(B, 1))
+        for _ in range(steps):
+            rig.recent.copy_(rec0)  # the same history for every draw (the kernel appends its token)
+            hip.ar_sample(rig.st, lg, V1)
+        torch.cuda.synchronize()
+        got = rig.hist[:, :steps].cpu().reshape(-1).long()
+        n = got.numel()
+        freq = torch.bincount(got, minlength=V1).double() / n
+        sp, si, forced = O.sampling_distribution(logits, hist, top_p, temp, top_k=int(top_k), repetition_penalty=1.1)
+        p = torch.zeros(V1, dtype=torch.float64)
+        p[si] = sp.double()
+        assert float(freq[p == 0].sum()) == 0.0, (ci, "a token outside the kept set was drawn")
+        pool = (freq * n + ref_freq * n_ref) / (n + n_ref)
+        tol = 5.0 * torch.sqrt(pool * (1 - pool) * (1.0 / n + 1.0 / n_ref)) + 0.003
+        worst = ((freq - ref_freq).abs() - tol).max()
+        assert float(worst) <= 0.0, (ci, float(worst), int(((freq - ref_freq).abs() - tol).argmax()))
 
 
 def test_sampler_nonce_changes_the_take_and_pins_it():

@@ -40,6 +40,21 @@ def test_prepare_reference_matches_reference(ref_prep):
     assert _err(ref.ref_kv_caches[2]["v"], _t(g["ref_v2"])) < 5e-5
 
 
+def test_encode_speaker_matches_reference(tts):
+    """SoproTTS.encode_speaker against the reference facade's own method (src/sopro/model.py:457-475;
+    tests/golden/make_golden_speaker.py) under its three crop policies, and the error behaviour of encode_reference."""
+    g = golden("speaker")
+    ref_tq = _t(g["ref_tq"])
+    for name, secs in (("default", None), ("sec4", 4.0), ("nocrop", 0.0)):
+        sv = tts.encode_speaker(ref_tokens_tq=ref_tq, ref_seconds=secs)
+        assert tuple(sv.shape) == (192,) and sv.device.type == "cuda"
+        assert _err(sv, _t(g["sv_" + name])) < 5e-6, name
+    # the vector prepare_reference stores for the same voice
+    assert _err(tts.prepare_reference(ref_tokens_tq=ref_tq).sv_ref.squeeze(0), _t(g["sv_default"])) < 5e-6
+    with pytest.raises(RuntimeError):
+        tts.encode_speaker()
+
+
 def test_prepare_conditioning_matches_reference(ref_prep):
     g, _, prep = ref_prep
     assert _err(prep["txt_seq"], _t(g["txt_seq"])) < 5e-5

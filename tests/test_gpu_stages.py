@@ -43,11 +43,7 @@ def test_whole_utterance_through_the_c_stages_matches_the_reference(eng, tts_noe
     assert torch.equal(hist[0].cpu().long(), want[:, 0]), "codebook-0 tokens differ from the reference"
     toks = eng.nar_refine(prep["cond_ar"], hist)
     assert toks.shape == (1, maxf + 1, 32) and torch.equal(toks[0, :, 0].cpu().long(), want[:, 0])
-    if not torch.equal(toks[0].cpu().long(), want):  # only audited near-ties may differ
-        oref = O.prepare_reference(_t(g["ref_tq"]), w_noeos, cfg)
-        oprep = O.prepare_conditioning(_t(g["ids"]), oref, w_noeos, cfg, max_frames=maxf, style_strength=1.0)
-        n_off, gap = O.nar_audit(oprep["cond_ar"][:, : maxf + 1], toks.cpu().long(), w_noeos, cfg)
-        assert gap < 1e-4, (n_off, gap)
+    assert torch.equal(toks[0].cpu().long(), want), "refined tokens differ from the reference's fixture (strict: no audit)"
     wav = eng.mimi_decode(_t(g["tokens"].astype(np.int64)).unsqueeze(0).to(eng.device))
     assert tuple(wav.shape) == (1, (maxf + 1) * 1920)
     assert float((wav[0].cpu() - _t(g["wav"])).abs().max()) < 1e-4 * float(np.abs(g["wav"]).max())

@@ -121,6 +121,52 @@ def test_repeated_tail_and_sampling_distribution():
     assert torch.allclose(sp.sort(descending=True).values, p.sort(descending=True).values, atol=1e-6)
 
 
+def test_sampling_distribution_matches_reference_draws():
+    """The oracle's sampling distribution against 20 000 seeded draws of THE REFERENCE's sample_token per case
+    (tests/golden/make_golden_sampler.py; src/sopro/sampling.py:24-93 with top_k 50 / repetition penalty 1.1 of
+    src/sopro/model.py:289-290): nothing outside the oracle's kept set was ever drawn, every kept token was drawn at its
+    probability (5 sigma + 0.002), and the overall chi-square is in range.  Pins the temperature -> penalty -> softmax ->
+    top-k -> renormalise -> top-p (shift by one) -> renormalise order."""
+    g = golden("sampler")
+    n = int(g["n_draws"])
+    for ci, (top_p, temp, top_k, _scale) in enumerate(g["cases"].tolist()):
+        logits, hist = _t(g[f"logits{ci}"]), g[f"hist{ci}"].tolist()
+        counts = _t(g[f"counts{ci}"]).double()
+        sp, si, forced = O.sampling_distribution(logits, hist, top_p, temp, top_k=int(top_k), repetition_penalty=1.1)
+        assert forced is None
+        p = torch.zeros(logits.numel(), dtype=torch.float64)
+        p[si] = sp.double()
+        assert float(counts[p == 0].sum()) == 0.0, (ci, "the reference drew a token outside the oracle's kept set")
+        assert int((p > 0).sum()) == int((counts > 0).sum()), (ci, int((p > 0).sum()), int((counts > 0).sum()))
+        freq = counts / n
+        tol = 5.0 * torch.sqrt(p * (1 - p) / n) + 0.002
+        assert float(((freq - p).abs() - tol).max()) <= 0.0, (ci, int(((freq - p).abs() - tol).argmax()))
+        k = p > 0
+        chi2 = float((((counts[k] - n * p[k]) ** 2) / (n * p[k])).sum())
+        dof = int(k.sum()) - 1
+        assert chi2 < dof + 6.0 * (2.0 * dof) ** 0.5 + 10.0, (ci, chi2, dof)
+        # a different order of the steps is told apart by these fixtures: the penalty applied AFTER the softmax / top-k would
+        # keep another set or other weights
+        sp2, si2, _ = O.sampling_distribution(logits, [], top_p, temp, top_k=int(top_k), repetition_penalty=1.1)
+        p2 = torch.zeros_like(p)
+        p2[si2] = sp2.double()
+        assert float((p2 - p).abs().max()) > 0.01, ci
+
+
+def test_token2sv_matches_reference_encode_speaker(cfg, w):
+    """SoproTTS.encode_speaker of the reference (src/sopro/model.py:457-475; fixture: tests/golden/make_golden_speaker.py)
+    under its three crop policies (center crop: src/sopro/sampling.py:8-13)."""
+    g = golden("speaker")
+    ref_tq = _t(g["ref_tq"])
+    for name, win in (("default", 150), ("sec4", 50), ("nocrop", None)):
+        r = ref_tq
+        if win is not None and r.shape[0] > win:
+            s0 = (r.shape[0] - win) // 2
+            r = r[s0: s0 + win]
+        sv = O.token2sv(r.unsqueeze(0), w, int(cfg.codebook_size))
+        assert float((sv.squeeze(0) - _t(g["sv_" + name])).abs().max()) < 2e-6, name
+
+
 def test_mimi_encode(mc):
     """Oracle encoder (SEANet -> transformer -> downsample -> RVQ) against HF MimiModel.encode on the stored waveform."""
     from sopro_amd.weights import synth_mimi_weights

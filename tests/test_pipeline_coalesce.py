@@ -50,3 +50,16 @@ def test_a_seeded_job_keeps_its_seed_nonce_inside_a_merged_pass():
     jobs = [_job(2, seed=5), _job(3, seed=9)]
     (g, merged, sizes), = PipelinedSynthesizer._coalesce(_stub(), jobs, 2)
     assert g == [0, 1] and merged["nonces"] == [7005, 7005, 7009, 7009, 7009]
+
+
+def test_jobs_with_different_per_utterance_keys_do_not_merge():
+    """one job passing `texts`, its neighbour only `text_ids` (or omitting a list) must not end up in one pass whose
+    merged lists have different lengths."""
+    a, b, c = _job(2), _job(2), _job(2)
+    b["texts"] = None
+    del c["text_ids"]
+    groups = [g for g, _m, _s in PipelinedSynthesizer._coalesce(_stub(), [a, b, b, c, c, a], 3)]
+    assert groups == [[0], [1, 2], [3, 4], [5]]
+    for g, merged, sizes in PipelinedSynthesizer._coalesce(_stub(), [b, b, c, c], 2):
+        n = sum(sizes)
+        assert all(len(merged[k]) == n for k in PipelinedSynthesizer._PER_UTT if merged.get(k) is not None)

@@ -1,3 +1,5 @@
+// DEVELOPER COPY of sopro_amd/csrc/gemm_bf16s.hip as of round 3 WITH the ablation switches (SOPRO_ABLATE bits); built only by
+// tools/micro/build_ablate.sh, never part of libsopro_hip.so.  The product kernel no longer carries the switches.
 // fp32 contraction at bf16 matrix-core rate: every operand is split into NPL bf16 pieces (x = p0 + p1 [+ p2], each the
 // round-to-nearest bf16 of what the previous pieces left) and the product is accumulated in fp32 with
 // v_mfma_f32_32x32x16_bf16 over the piece pairs that matter:
@@ -13,15 +15,20 @@
 // 16-lane group hit 16 distinct 16-byte slots.  W is split ONCE on the device by sopro_pack_w_bf16 into MFMA fragment
 // order [n/32][k/16][piece][lane][8 bf16]; each wave streams its B fragments straight from L2 into registers with fully
 // coalesced dwordx4 loads (1 KB per instruction, every byte used once), so W never touches LDS.
-#include "common.h"
-#include "gemm_epilogue.h"
+#include "../../sopro_amd/csrc/common.h"
+#include "../../sopro_amd/csrc/gemm_epilogue.h"
 
 namespace {
 
 constexpr int BK = 32;
 
-// (The ablation builds that priced this loop's parts - no MFMAs / no A path / no W loads / no barriers - live in the developer
-// copy tools/micro/gemm_bf16s_ablate.hip, built by tools/micro/build_ablate.sh; the product kernel carries no switches.)
+// Developer ablation builds (tools/micro/build_ablate.sh, never the product library): bit 0 drops the MFMAs (fragment reads are
+// kept alive by a cheap fold), bit 1 the A path after the first tile (no global loads, no split, no LDS stores), bit 2 the W
+// loads after the first step, bit 3 the per-step barriers.  Results are meaningless; the time of what is left is the point.
+#ifndef SOPRO_ABLATE
+#define SOPRO_ABLATE 0
+#endif
+constexpr int ABL = SOPRO_ABLATE;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -213,7 +220,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            if constexpr (F16)
+            if constexpr (ABL & 1)
+              acc[i][j][q & 15] += __uint_as_float((af[i][PA[q]].x ^ rb[j][s][PB[q]].y) & 0x3fffffffu);
+            else if constexpr (F16)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag16(af[i][PA[q]]), as_frag16(rb[j][s][PB[q]]), acc[i][j], 0, 0, 0);
             else
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af[i][PA[q]]), as_frag(rb[j][s][PB[q]]), acc[i][j], 0, 0, 0);
@@ -240,30 +249,42 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   lstore(0, raA, pvA);
   __syncthreads();
   if (dbg && tid == 0) dbg[1] = clock64();
-  {
+  if constexpr ((ABL & 64) == 0) {
     // The two-step body is ONE basic block: the odd last step is peeled off instead of leaving through a break in the middle
     // (which let the optimiser sink the second step's W requests out of the first step and cost a vmcnt(0) at the loop header).
-    // +2-3 % on the large decoder shapes, bit-identical (tools/gemm_ab_probe.py; pinning every step's requests ahead of its
-    // MFMAs with sched_barrier measured 0-9 % SLOWER).
+    // +2-3 % on the large decoder shapes, bit-identical (tools/gemm_ab_probe.py; SOPRO_ABLATE=64 builds the old form, +32 pins
+    // every step's requests ahead of its MFMAs with sched_barrier, which measured 0-9 % SLOWER).
     int it = 0;
     for (; it + 1 < nkt; it += 2) {
       const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl), k3 = min(kt0 + it + 3, ktl);
       gload(k2, raA, pvA);
       bload(k1, rb1);
+      if constexpr ((ABL & 32) != 0) __builtin_amdgcn_sched_barrier(0);
       compute(0, rb0);
       lstore(1, raB, pvB, true);
       __syncthreads();
       gload(k3, raB, pvB);
       bload(k2, rb0);
+      if constexpr ((ABL & 32) != 0) __builtin_amdgcn_sched_barrier(0);
       compute(1, rb1);
       lstore(0, raA, pvA, it + 2 < nkt);
       __syncthreads();
     }
-    if (it < nkt) {  // (workgroup-uniform)
-      compute(0, rb0);
-      // the epilogue's tile (and the split-K flag word) alias A buffer 0: every wave must be done reading its fragments
-      // before any wave writes there (odd step counts - K = 32, 96, ... - raced without this barrier)
-      __syncthreads();
+    if (it < nkt) compute(0, rb0);
+  } else {
+    for (int it = 0; it < nkt; it += 2) {
+      const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl), k3 = min(kt0 + it + 3, ktl);
+      if (!(ABL & 2)) { if (DEEP) gload(k2, raA, pvA); else gload(k1, raA, pvA); }
+      if (!(ABL & 4)) bload(k1, rb1);
+      compute(0, (ABL & 4) ? rb0 : rb0);
+      if (!(ABL & 2)) { if (DEEP) lstore(1, raB, pvB, it + 1 < nkt); else lstore(1, raA, pvA, it + 1 < nkt); }
+      if (!(ABL & 8)) __syncthreads();
+      if (it + 1 >= nkt) break;
+      if (!(ABL & 2)) { if (DEEP) gload(k3, raB, pvB); else gload(k2, raA, pvA); }
+      if (!(ABL & 4)) bload(k2, rb0);
+      compute((ABL & 2) ? 0 : 1, (ABL & 4) ? rb0 : rb1);
+      if (!(ABL & 2)) lstore(0, raA, pvA, it + 2 < nkt);
+      if (!(ABL & 8)) __syncthreads();
     }
   }
   if (dbg && tid == 0) dbg[2] = clock64();

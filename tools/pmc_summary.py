@@ -74,13 +74,17 @@ def agg(path):
     return d
 
 
+import os
+
 f, w = agg(sys.argv[1]), agg(sys.argv[2])
 out = {}
 for k in f:
     n = f[k][0]
     out[k] = {"launches": n, "fetch_kib_raw": round(f[k][1]), "write_kib": round(w.get(k, [0, 0])[1]),
               "traffic_bytes_per_launch": round((2 * f[k][1] + w.get(k, [0, 0])[1]) * 1024 / max(1, n))}
-json.dump({"command": "python bench.py --lanes 1 --steps 1 --warmup 2 --profile-steps 0 --no-cpu-baseline --ttfa-runs 0 (3 passes of the step)",
+# PMC_ROWS / PMC_PRECISION / PMC_COMMAND: set by tools/collect_evidence.sh to what the profiled command ran (rows of an AR frame)
+json.dump({"command": os.environ.get("PMC_COMMAND", "python bench.py --lanes 1 --steps 1 --warmup 2 --profile-steps 0 --no-cpu-baseline --ttfa-runs 0 (3 passes of the step)"),
+           "ar_rows_per_frame": int(os.environ.get("PMC_ROWS", "32")), "precision": os.environ.get("PMC_PRECISION", "f32"),
            "correction": "read side doubled (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16 B/lane reads)", "families": out},
           open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
