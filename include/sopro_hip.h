@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 36
+#define SOPRO_ABI_VERSION 37
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -40,6 +40,11 @@ int sopro_abi_version(void);
  * every CU for the short kernels of an AR frame generated at the same time on another stream - the alternative to carving
  * the chip up with CU masks (sopro_stream_create_cu_range).  0 = off.  Recorded graphs keep the value they were recorded with. */
 int sopro_set_lds_floor(int bytes);
+/* How this process's host threads wait for the current device (hipSetDeviceFlags): 0 = spin (runtime default), 1 = block on the
+ * completion interrupt.  A scheduler with several launch threads per device (the lanes of sopro_amd/pipeline.py: each waits for
+ * its AR poll / phase end most of the time) sets 1, which frees a core per waiting thread; a single latency-critical caller
+ * (stream(), batch 1) keeps 0.  No reference counterpart. */
+int sopro_set_host_wait(int blocking);
 /* device facts: out[0]=CU count, out[1]=LDS bytes per block, out[2]=clock kHz, out[3]=gfx arch number */
 int sopro_device_info(int device, int* out4);
 
@@ -203,6 +208,8 @@ typedef struct sopro_skinny_args {
   int32_t w_layout;       /* 0: W is [N, ldw] row-major; 1: W was laid out by sopro_pack_skinny_w (ldw unused);
                            * 2: bf16 weights from sopro_pack_skinny_w_bf16 (the engine's bf16 mode: activations are rounded to
                            *    bf16 as MFMA operands, v_mfma_f32_16x16x32_bf16 with fp32 accumulation) */
+  int32_t ring_format;    /* EPI_GLU_DW: 0 = `ring` holds fp32; 1 (with w_layout 2, the engine's bf16 mode) = `ring` points at bf16 elements
+                           * [L, ring_bcap, D]: h is rounded once when it is written, the older taps are widened when they are read */
   int32_t mt, nt;         /* workgroup shape: mt 16-row groups of the batch x nt column tiles (0 or 1 = one; 2 = two).  1 x 1 has
                            * the most workgroups and the shortest latency; 2 x 2 reads the weights once per 32 rows and halves the
                            * activation re-reads (throughput form for a small CU partition).  Results are bit-identical. */
@@ -223,6 +230,12 @@ int sopro_pack_skinny_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, 
  * instead of hipMemset* / hipMemcpy* so that a recorded sequence holds kernel nodes only. */
 int sopro_fill2d_u32(void* p, int64_t pitch, int32_t rows, int32_t width, uint32_t value, void* stream);
 int sopro_copy2d_u32(void* dst, int64_t dpitch, const void* src, int64_t spitch, int32_t rows, int32_t width, void* stream);
+/* fp32 <-> bf16 images of a tensor of n elements (n % 4 == 0; round to nearest even).  The engine's bf16 mode keeps the state the AR
+ * frame streams every frame (folded text operands, ring buffers) and the SEANet decoder's activations as bf16 in memory; these
+ * make / read such images outside the hot kernels (operand preparation, tests).  No reference counterpart (the reference has
+ * no dtype argument anywhere: src/sopro/model.py:419-451). */
+int sopro_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int sopro_cvt_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
 enum { SOPRO_NORM_RMS = 0, SOPRO_NORM_LN = 1 };
 /* out[r, :] = (norm(x[r, :]) * w (+ b)) * mul[seg(r), :] + add[seg(r), :]   (mul/add optional, one
  * row per segment of rows_per_seg rows).  RMS: src/sopro/nn/blocks.py:26-37 (eps inside rsqrt);
@@ -332,6 +345,8 @@ typedef struct sopro_xattn_args {
   float* Y; int64_t y_part_stride;
   float eps, gate, scale;
   int32_t np, B, H, D, S_cap;
+  int32_t kv_format;      /* 0: Kp / Vp hold fp32; 1 (the engine's bf16 mode): they point at bf16 elements, same [B, H, S_cap, D] layout -
+                           * half the bytes of the block's dominant stream; scores, softmax and the weighted sum stay fp32 */
 } sopro_xattn_args;
 int sopro_xattn_step_f32(const sopro_xattn_args* args, void* stream);
 
@@ -450,8 +465,9 @@ typedef struct sopro_ar_block {
   const void* glu_w; const float* glu_b; const float* dw_w; const float* dw_b;
   const void* ff1_w; const float* ff1_b;
   const void* ff2_w; const float* ff2_b;
-  float* ring;             /* [(ksize-1)*dil + 1, B, D] */
-  const float* kp;         /* xattn != 0: folded text operands [B, H, S_cap, D] (src/sopro/nn/text.py:75-83 x q_proj / out_proj) */
+  float* ring;             /* [(ksize-1)*dil + 1, B, D]; bf16 elements when the frame's store_format is 1 */
+  const float* kp;         /* xattn != 0: folded text operands [B, H, S_cap, D] (src/sopro/nn/text.py:75-83 x q_proj / out_proj);
+                            * bf16 elements when the frame's store_format is 1 */
   const float* vp;
   int32_t dil, xattn;
   float gate;              /* tanh(gate) of the cross-attention block (text.py:131) */
@@ -470,7 +486,8 @@ typedef struct sopro_ar_frame {
   int32_t n_layers, B, D, S_cap, V1, H, ksize, w_layout;
   int32_t tile_glu, tile_ff1, tile_ff2, tile_head;
   float eps;
-  int32_t pad_;
+  int32_t store_format;    /* 0: ring buffers and folded text operands in fp32; 1 (bf16 mode, needs w_layout 2): both in bf16 - the
+                            * frame's state streams at half the bytes; accumulation, norms, softmax, residual stream stay fp32 */
   sopro_ar_state st;
 } sopro_ar_frame;
 int sopro_ar_issue_frame(const sopro_ar_frame* frame, void* stream);

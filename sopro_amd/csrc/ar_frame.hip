@@ -18,6 +18,7 @@ extern "C" int sopro_ar_issue_frame(const sopro_ar_frame* fp, void* stream) {
                   "1..16 blocks, d_model 384, 4 heads");
   SOPRO_CHECK_ARG(f.x0 && f.xa && f.xb && f.part && f.u && f.xp && f.logits && f.head_w && f.head_b && f.st.step, "NULL buffer");
   SOPRO_CHECK_ARG(f.w_layout == 1 || f.w_layout == 2, "w_layout: 1 (sopro_pack_skinny_w) or 2 (sopro_pack_skinny_w_bf16)");
+  SOPRO_CHECK_ARG(f.store_format == 0 || (f.store_format == 1 && f.w_layout == 2), "store_format: 0 (fp32 state), or 1 (bf16 rings / folded operands) in bf16 mode");
   SOPRO_CHECK_ARG(f.st.x_cur == f.x0, "the sampler must write the next frame's input where block 0 reads (st.x_cur == x0)");
   hipStream_t s = (hipStream_t)stream;
   const int B = f.B, D = f.D, H = f.H, KSL = 4 * D / 384;  // FF2 K slices
@@ -40,6 +41,7 @@ extern "C" int sopro_ar_issue_frame(const sopro_ar_frame* fp, void* stream) {
     a.Xp = pend; a.xp_stride = BD; a.np = pend ? 3 : 0;
     a.eps = f.eps; a.B = B; a.N = 2 * D; a.K = D; a.epilogue = SOPRO_EPI_GLU_DW;
     a.ring_len = (f.ksize - 1) * b.dil + 1; a.ring_bcap = B; a.dil = b.dil; a.ksize = f.ksize; a.rms_norm = 1;
+    a.ring_format = f.store_format;
     a.mt = f.tile_glu >> 4; a.nt = f.tile_glu & 15;
     FRM(sopro_skinny_f32(&a, s));
     // RMSNorm -> Linear -> GELU (blocks.py:158-160)
@@ -65,7 +67,7 @@ extern "C" int sopro_ar_issue_frame(const sopro_ar_frame* fp, void* stream) {
       x.X = base; x.ldx = D; x.Xp = pend; x.xp_stride = BD; x.np = 3;
       x.Kp = b.kp; x.Vp = b.vp; x.klens = f.klens; x.Y = f.xp; x.y_part_stride = BD;
       x.eps = f.eps; x.gate = b.gate; x.scale = 1.0f / sqrtf((float)(D / H));
-      x.B = B; x.H = H; x.D = D; x.S_cap = f.S_cap;
+      x.B = B; x.H = H; x.D = D; x.S_cap = f.S_cap; x.kv_format = f.store_format;
       FRM(sopro_xattn_step_f32(&x, s));
       base = f.xp; pend = f.xp + BD;
     }

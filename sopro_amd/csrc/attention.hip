@@ -329,7 +329,32 @@ __device__ __forceinline__ float4 ld_stream4(const float* p) {
   }
 }
 
+// HB (the engine's bf16 mode, round 4): K' / V' are stored as bf16 (half the bytes of the block's dominant stream: 98 KB instead
+// of 196 KB per (row, head) at S = 64); scores and the weighted sum are accumulated in fp32 as before.
 template <bool NT>
+__device__ __forceinline__ uint4 ld_stream_u4(const void* p) {
+  typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
+  if constexpr (NT) {
+    const xu32x4 v = __builtin_nontemporal_load(reinterpret_cast<const xu32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  } else {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ uint2 ld_stream_u2(const void* p) {
+  typedef unsigned xu32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (NT) {
+    const xu32x2 v = __builtin_nontemporal_load(reinterpret_cast<const xu32x2*>(p));
+    return make_uint2(v.x, v.y);
+  } else {
+    return *reinterpret_cast<const uint2*>(p);
+  }
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }          // element 0 of a packed pair
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }  // element 1
+
+template <bool NT, bool HB>
 __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args a) {
   __shared__ float xsum[XD];
   __shared__ float xn[XD];
@@ -340,28 +365,41 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, b = blockIdx.y;
   const int klen = a.klens ? min(a.klens[b], a.S_cap) : a.S_cap;
-  const float* Kb = a.Kp + ((int64_t)(b * a.H + h) * a.S_cap) * XD;
-  const float* Vb = a.Vp + ((int64_t)(b * a.H + h) * a.S_cap) * XD;
-  const int key = tid >> 3, part = tid & 7;   // score mapping: 8 lanes share a key; float4 f*8+part of its row each, so that one
+  constexpr int ES = HB ? 2 : 4;  // bytes per stored element
+  const char* Kb = reinterpret_cast<const char*>(a.Kp) + ((int64_t)(b * a.H + h) * a.S_cap) * XD * ES;
+  const char* Vb = reinterpret_cast<const char*>(a.Vp) + ((int64_t)(b * a.H + h) * a.S_cap) * XD * ES;
+  const int key = tid >> 3, part = tid & 7;   // score mapping: 8 lanes share a key; 16-byte piece f*8+part of its row each, so that one
                                               // load instruction covers whole 128-byte lines (8 per wave instead of 64)
-  const int vd4 = tid % 96, vg = tid / 96;    // P.V' mapping: float4 column, 16-key group (vg < 4)
+  const int vd4 = tid % 96, vg = tid / 96;    // P.V' mapping: 4-column group, 16-key group (vg < 4)
+  constexpr int KF = HB ? 6 : 12;             // 16-byte pieces per lane of a K' row (768 / 1536 bytes over 8 lanes)
 
   float m_run = -INFINITY, l_run = 0.f;
   float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int k0 = 0; k0 < klen; k0 += 64) {
     // ---- every operand of this 64-key tile is requested up front
-    float4 kreg[12], vreg[16];
+    uint4 kreg[KF];
+    uint4 vreg[HB ? 8 : 16];  // HB: 16 keys x 4 bf16 (8 bytes) = two keys per register
     const bool kin = (k0 + key) < klen;
 #pragma unroll
-    for (int f = 0; f < 12; ++f) {
-      kreg[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kin) kreg[f] = ld_stream4<NT>(Kb + (int64_t)(k0 + key) * XD + (f * 8 + part) * 4);
+    for (int f = 0; f < KF; ++f) {
+      kreg[f] = make_uint4(0u, 0u, 0u, 0u);
+      if (kin) kreg[f] = ld_stream_u4<NT>(Kb + ((int64_t)(k0 + key) * XD) * ES + (f * 8 + part) * 16);
     }
+    if constexpr (HB) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      vreg[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (vg < 4 && (k0 + vg * 16 + kk) < klen) vreg[kk] = ld_stream4<NT>(Vb + (int64_t)(k0 + vg * 16 + kk) * XD + vd4 * 4);
+      for (int kk = 0; kk < 16; kk += 2) {
+        uint2 v0 = make_uint2(0u, 0u), v1 = make_uint2(0u, 0u);
+        if (vg < 4 && (k0 + vg * 16 + kk) < klen) v0 = ld_stream_u2<NT>(Vb + ((int64_t)(k0 + vg * 16 + kk) * XD + vd4 * 4) * 2);
+        if (vg < 4 && (k0 + vg * 16 + kk + 1) < klen) v1 = ld_stream_u2<NT>(Vb + ((int64_t)(k0 + vg * 16 + kk + 1) * XD + vd4 * 4) * 2);
+        vreg[kk >> 1] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        vreg[kk] = make_uint4(0u, 0u, 0u, 0u);
+        if (vg < 4 && (k0 + vg * 16 + kk) < klen) vreg[kk] = ld_stream_u4<NT>(Vb + ((int64_t)(k0 + vg * 16 + kk) * XD + vd4 * 4) * 4);
+      }
     }
     if (k0 == 0) {
       // ---- input stream (+ the producer's partial sums, fixed order), RMSNorm (src/sopro/nn/blocks.py:26-37)
@@ -394,10 +432,19 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
     }
     // ---- scores of this tile
     float s = 0.f;
+    if constexpr (HB) {
 #pragma unroll
-    for (int f = 0; f < 12; ++f) {
-      const float4 q4 = *reinterpret_cast<const float4*>(xn + (f * 8 + part) * 4);
-      s += q4.x * kreg[f].x + q4.y * kreg[f].y + q4.z * kreg[f].z + q4.w * kreg[f].w;
+      for (int f = 0; f < KF; ++f) {  // piece f*8+part of the row = elements 8 * (f*8+part) .. + 7
+        const float4 q0 = *reinterpret_cast<const float4*>(xn + (f * 8 + part) * 8), q1 = *reinterpret_cast<const float4*>(xn + (f * 8 + part) * 8 + 4);
+        s += q0.x * bf_lo(kreg[f].x) + q0.y * bf_hi(kreg[f].x) + q0.z * bf_lo(kreg[f].y) + q0.w * bf_hi(kreg[f].y);
+        s += q1.x * bf_lo(kreg[f].z) + q1.y * bf_hi(kreg[f].z) + q1.z * bf_lo(kreg[f].w) + q1.w * bf_hi(kreg[f].w);
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < KF; ++f) {
+        const float4 q4 = *reinterpret_cast<const float4*>(xn + (f * 8 + part) * 4);
+        s += q4.x * __uint_as_float(kreg[f].x) + q4.y * __uint_as_float(kreg[f].y) + q4.z * __uint_as_float(kreg[f].z) + q4.w * __uint_as_float(kreg[f].w);
+      }
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
@@ -419,10 +466,21 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
     m_run = m_new;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (vg < 4) {
+      if constexpr (HB) {
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const float p = ps[vg * 16 + kk];
-        acc.x += p * vreg[kk].x; acc.y += p * vreg[kk].y; acc.z += p * vreg[kk].z; acc.w += p * vreg[kk].w;
+        for (int kk = 0; kk < 16; kk += 2) {
+          const float p0 = ps[vg * 16 + kk], p1 = ps[vg * 16 + kk + 1];
+          const uint4 v = vreg[kk >> 1];
+          acc.x += p0 * bf_lo(v.x); acc.y += p0 * bf_hi(v.x); acc.z += p0 * bf_lo(v.y); acc.w += p0 * bf_hi(v.y);
+          acc.x += p1 * bf_lo(v.z); acc.y += p1 * bf_hi(v.z); acc.z += p1 * bf_lo(v.w); acc.w += p1 * bf_hi(v.w);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const float p = ps[vg * 16 + kk];
+          acc.x += p * __uint_as_float(vreg[kk].x); acc.y += p * __uint_as_float(vreg[kk].y);
+          acc.z += p * __uint_as_float(vreg[kk].z); acc.w += p * __uint_as_float(vreg[kk].w);
+        }
       }
     }
     o4.x = o4.x * alpha + acc.x; o4.y = o4.y * alpha + acc.y; o4.z = o4.z * alpha + acc.z; o4.w = o4.w * alpha + acc.w;
@@ -461,8 +519,17 @@ extern "C" int sopro_xattn_step_f32(const sopro_xattn_args* p, void* stream) {
   static const bool nt_on = !(getenv("SOPRO_XATTN_NT") != nullptr && getenv("SOPRO_XATTN_NT")[0] == '0');  // default on (r03: +1.7 %)
   // only where the operands cannot stay cached from one frame to the next anyway (> 8 MB per layer: the eight L2s hold 32 MB
   // for three layers); a single utterance's 0.8 MB per layer is L2-resident across frames and is asked for normally
-  const bool nt = nt_on && (int64_t)a.B * a.H * a.S_cap * XD * 8 > ((int64_t)8 << 20);
-  if (nt) hipLaunchKernelGGL(xattn_step_kernel<true>, dim3(a.H, a.B), dim3(512), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(xattn_step_kernel<false>, dim3(a.H, a.B), dim3(512), 0, (hipStream_t)stream, a);
+  SOPRO_CHECK_ARG(a.kv_format == 0 || a.kv_format == 1, "kv_format: 0 (fp32 Kp / Vp) or 1 (bf16)");
+  const bool hb = a.kv_format == 1;
+  const bool nt = nt_on && (int64_t)a.B * a.H * a.S_cap * XD * (hb ? 4 : 8) > ((int64_t)8 << 20);
+  const dim3 grid(a.H, a.B), blk(512);
+  hipStream_t st = (hipStream_t)stream;
+  if (hb) {
+    if (nt) hipLaunchKernelGGL((xattn_step_kernel<true, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((xattn_step_kernel<false, true>), grid, blk, 0, st, a);
+  } else {
+    if (nt) hipLaunchKernelGGL((xattn_step_kernel<true, false>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((xattn_step_kernel<false, false>), grid, blk, 0, st, a);
+  }
   SOPRO_LAUNCH_CHECK();
 }

@@ -28,6 +28,14 @@ int sopro_set_lds_floor(int bytes) {
   return 0;
 }
 
+int sopro_set_host_wait(int blocking) {
+  // hipSetDeviceFlags on the CURRENT device: how host threads of this process wait in hipStreamSynchronize / hipEventSynchronize /
+  // synchronous copies from now on.  0 = spin (the runtime's default: lowest wake-up latency, one busy core per waiting thread);
+  // 1 = block on the completion signal's interrupt.
+  SOPRO_HIP(hipSetDeviceFlags(blocking ? hipDeviceScheduleBlockingSync : hipDeviceScheduleSpin));
+  return 0;
+}
+
 int sopro_device_info(int device, int* out4) {
   SOPRO_CHECK_ARG(out4 != nullptr, "out4 is NULL");
   hipDeviceProp_t p;

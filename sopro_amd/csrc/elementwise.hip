@@ -438,6 +438,24 @@ __global__ __launch_bounds__(256) void copy2d_kernel(unsigned* __restrict__ d, i
   d[(i / width) * dpitch + (i % width)] = s[(i / width) * spitch + (i % width)];
 }
 
+// fp32 <-> bf16 images of a tensor (round to nearest even), 4 elements per thread
+__global__ __launch_bounds__(256) void cvt_f32_bf16_kernel(const float* __restrict__ src, uint2* __restrict__ dst, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(src)[i];
+  unsigned a, b, lo;
+  split2_bf16(v.x, v.y, a, lo);
+  split2_bf16(v.z, v.w, b, lo);
+  dst[i] = make_uint2(a, b);
+}
+__global__ __launch_bounds__(256) void cvt_bf16_f32_kernel(const uint2* __restrict__ src, float* __restrict__ dst, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const uint2 v = src[i];
+  reinterpret_cast<float4*>(dst)[i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                                                  __uint_as_float(v.y & 0xffff0000u));
+}
+
 }  // namespace
 
 extern "C" {
@@ -595,6 +613,18 @@ int sopro_copy2d_u32(void* dst, int64_t dpitch, const void* src, int64_t spitch,
   SOPRO_CHECK_ARG(dst && src && rows > 0 && width > 0 && dpitch >= width && spitch >= width, "bad pointers or sizes");
   hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)rows * width, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<unsigned*>(dst), dpitch,
                      reinterpret_cast<const unsigned*>(src), spitch, rows, width);
+  SOPRO_LAUNCH_CHECK();
+}
+
+int sopro_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  SOPRO_CHECK_ARG(src && dst && n > 0 && (n & 3) == 0 && aligned16(src) && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0, "n % 4 == 0, 16 / 8-byte aligned");
+  hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(nblk(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, reinterpret_cast<uint2*>(dst), n / 4);
+  SOPRO_LAUNCH_CHECK();
+}
+
+int sopro_cvt_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
+  SOPRO_CHECK_ARG(src && dst && n > 0 && (n & 3) == 0 && aligned16(dst) && (reinterpret_cast<uintptr_t>(src) & 7u) == 0, "n % 4 == 0, 16 / 8-byte aligned");
+  hipLaunchKernelGGL(cvt_bf16_f32_kernel, dim3(nblk(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint2*>(src), dst, n / 4);
   SOPRO_LAUNCH_CHECK();
 }
 

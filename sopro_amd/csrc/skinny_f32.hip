@@ -49,7 +49,10 @@ __device__ __forceinline__ unsigned cvt2_bf16(float x, float y) {
 // the activation re-reads of a 32-row batch, which is what bounds two frames sharing a 64-CU partition (a CU ingests
 // ~17-23 B/clk however many workgroups ask: profiles/r03_experiments.md).  Same arithmetic per output element in every form
 // (same K order inside a wave, same cross-wave order), so the forms are bit-identical to each other.
-template <bool GLU, int NP, bool NORM, bool WB, int MT, int NT>
+// RB (bf16 mode, round 4; GLU tail only): the ring buffer holds bf16 (h is rounded once when it is written; the 12 older taps
+// are read as bf16 and widened) - half the bytes of the frame's second-largest activation stream.  The newest tap, the tap
+// weights and the accumulation stay fp32.
+template <bool GLU, int NP, bool NORM, bool WB, int MT, int NT, bool RB = false>
 __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) {
   __shared__ float xs[16 * MT * XLD];          // raw (combined) input slice
   __shared__ float red[MT * NT * 4 * 4 * 64];
@@ -204,7 +207,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) tapv[mt][nt][j] = a.ring[((int64_t)slot * a.ring_bcap + b_cl[mt]) * D + n_ld[nt]];
+          for (int nt = 0; nt < NT; ++nt) {
+            const int64_t ri = ((int64_t)slot * a.ring_bcap + b_cl[mt]) * D + n_ld[nt];
+            if constexpr (RB) tapv[mt][nt][j] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(a.ring)[ri] << 16);
+            else tapv[mt][nt][j] = a.ring[ri];
+          }
         slot += (unsigned)a.dil;
         if (slot >= L) slot -= L;
       }
@@ -286,7 +293,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
         y = fmaf(tapw[nt][MAXTAPS - 1], h, y);                                            // not pick mul + add in one shape
         y += e_dwb[nt];
         if (ok) {
-          a.ring[((int64_t)slot_now * a.ring_bcap + b_row[mt]) * D + n_col[nt]] = h;
+          if constexpr (RB) reinterpret_cast<unsigned short*>(a.ring)[((int64_t)slot_now * a.ring_bcap + b_row[mt]) * D + n_col[nt]] = (unsigned short)(cvt2_bf16(h, 0.f) & 0xffffu);
+          else a.ring[((int64_t)slot_now * a.ring_bcap + b_row[mt]) * D + n_col[nt]] = h;
           a.Y[(int64_t)b_row[mt] * a.ldy + n_col[nt]] = xs[(mt * 16 + g * 4 + wave) * XLD + n_col[nt]] + y;
         }
       }
@@ -353,6 +361,12 @@ __global__ __launch_bounds__(256) void pack_skinny_bf16_kernel(const float* __re
 
 template <bool GLU, int NP, bool NORM, int MT, int NT>
 int launch_t(const sopro_skinny_args& a, dim3 grid, hipStream_t s) {
+  if constexpr (GLU) {
+    if (a.w_layout == 2 && a.ring_format == 1) {
+      hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM, true, MT, NT, true>), grid, dim3(256), 0, s, a);
+      SOPRO_LAUNCH_CHECK();
+    }
+  }
   if (a.w_layout == 2)
     hipLaunchKernelGGL((skinny_kernel<GLU, NP, NORM, true, MT, NT>), grid, dim3(256), 0, s, a);
   else
@@ -418,6 +432,7 @@ extern "C" int sopro_skinny_f32(const sopro_skinny_args* p, void* stream) {
                     "EPI_GLU_DW needs N == 2*K == 768, ring, dw_w, dw_b, step");
     SOPRO_CHECK_ARG(a.ksize >= 1 && a.ksize <= MAXTAPS && a.dil >= 1 && a.ring_len == (a.ksize - 1) * a.dil + 1, "ring_len must be (ksize-1)*dil+1, ksize <= 13");
     SOPRO_CHECK_ARG(a.ring_bcap >= a.B && a.rms_norm, "ring_bcap < B, or rms_norm not set (the GLU tail always follows an RMSNorm)");
+    SOPRO_CHECK_ARG(a.ring_format == 0 || (a.ring_format == 1 && a.w_layout == 2), "ring_format: 0 (fp32), or 1 (bf16 ring) with the bf16 weights of w_layout 2");
   }
   const int nslices = a.K / KS;
   const int gy = (a.ksplit && nslices > 1) ? nslices : 1;

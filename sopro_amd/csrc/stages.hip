@@ -47,6 +47,7 @@ struct ArPlan {
   int B = 0, S = 0, S_cap = 0, Tar = 0;
   void* ws = nullptr;
   float *cond, *x[4], *part, *u, *logits, *kp[16], *vp[16], *xp, *params, *rings[16], *nkv, *kvd;
+  float *fold_k = nullptr, *fold_v = nullptr;  // bf16 mode: fp32 scratch the text operands are folded into before they are rounded to bf16
   int32_t *klens, *hist, *ctr, *first_eos, *stop_t, *recent;
   uint32_t* nonce;
   uint32_t* key;
@@ -737,6 +738,11 @@ static size_t ar_carve(const sopro_engine* e, ArPlan& p, void* ws, int B, int S,
   for (int i = 0; i < c.n_layers_ar; ++i) p.rings[i] = cv.take<float>((size_t)((c.ar_kernel - 1) * c.ar_dilations[i] + 1) * B * D);
   p.nkv = cv.take<float>((size_t)B * S * D);
   p.kvd = cv.take<float>((size_t)B * S * 2 * D);
+  p.fold_k = p.fold_v = nullptr;
+  if (c.precision == 1) {  // bf16 mode: kp / vp / rings hold bf16 elements (the first half of their fp32-sized buffers)
+    p.fold_k = cv.take<float>((size_t)B * H * S_cap * D);
+    p.fold_v = cv.take<float>((size_t)B * H * S_cap * D);
+  }
   p.klens = cv.take<int32_t>(B);
   p.hist = cv.take<int32_t>((size_t)B * Tar);
   p.ctr = cv.take<int32_t>(8);
@@ -773,6 +779,7 @@ static int ar_issue_step(sopro_engine* e, hipStream_t s) {
   f.x0 = p.x[0]; f.xa = p.x[1]; f.xb = p.x[2]; f.part = p.part; f.u = p.u; f.xp = p.xp; f.logits = p.logits; f.klens = p.klens;
   f.n_layers = c.n_layers_ar; f.B = p.B; f.D = c.d_model; f.S_cap = p.S_cap; f.V1 = c.codebook_size + 1; f.H = 4; f.ksize = c.ar_kernel;
   f.w_layout = c.precision == 1 ? 2 : 1;
+  f.store_format = c.precision == 1 ? 1 : 0;  // bf16 mode: ring buffers and folded text operands as bf16 in memory
   f.tile_glu = e->ar_tiles[0]; f.tile_ff1 = e->ar_tiles[1]; f.tile_ff2 = e->ar_tiles[2]; f.tile_head = e->ar_tiles[3];
   f.eps = RMS_EPS;
   f.st = p.st;
@@ -800,8 +807,14 @@ int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* con
   for (int i = 0; i < c.n_layers_ar; ++i) {
     if (!c.ar_xattn[i]) continue;
     const std::string pa = "ar.x_attns." + std::to_string(i);
-    STG(sopro_ar_fold_text(txt_seq, F(e, pa + ".nkv.weight"), F(e, pa + ".kv.w"), F(e, pa + ".q.wT"), F(e, pa + ".o.w"), p.nkv, p.kvd, p.kp[i],
-                           p.vp[i], B, S, p.S_cap, D, H, RMS_EPS, s));
+    float* kdst = c.precision == 1 ? p.fold_k : p.kp[i];
+    float* vdst = c.precision == 1 ? p.fold_v : p.vp[i];
+    STG(sopro_ar_fold_text(txt_seq, F(e, pa + ".nkv.weight"), F(e, pa + ".kv.w"), F(e, pa + ".q.wT"), F(e, pa + ".o.w"), p.nkv, p.kvd, kdst,
+                           vdst, B, S, p.S_cap, D, H, RMS_EPS, s));
+    if (c.precision == 1) {  // rounded once; the frame streams half the bytes (sopro_ar_frame.store_format)
+      STG(sopro_cvt_f32_bf16(kdst, p.kp[i], (int64_t)B * H * p.S_cap * D, s));
+      STG(sopro_cvt_f32_bf16(vdst, p.vp[i], (int64_t)B * H * p.S_cap * D, s));
+    }
   }
   for (int i = 0; i < c.n_layers_ar; ++i)
     SOPRO_HIP(hipMemsetAsync(p.rings[i], 0, (size_t)((c.ar_kernel - 1) * c.ar_dilations[i] + 1) * B * D * 4, s));

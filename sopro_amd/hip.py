@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -47,7 +47,7 @@ class SkinnyArgs(C.Structure):
                 ("Xp", _p), ("xp_stride", _i64), ("y_part_stride", _i64), ("dbg", _p), ("eps", _f32),
                 ("B", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32),
                 ("ring_len", _i32), ("ring_bcap", _i32), ("dil", _i32), ("ksize", _i32),
-                ("np", _i32), ("ksplit", _i32), ("rms_norm", _i32), ("w_layout", _i32), ("mt", _i32), ("nt", _i32)]
+                ("np", _i32), ("ksplit", _i32), ("rms_norm", _i32), ("w_layout", _i32), ("ring_format", _i32), ("mt", _i32), ("nt", _i32)]
 
 
 class AttnArgs(C.Structure):
@@ -60,7 +60,7 @@ class AttnArgs(C.Structure):
 class XattnArgs(C.Structure):
     _fields_ = [("X", _p), ("ldx", _i64), ("Xp", _p), ("xp_stride", _i64), ("norm_w", _p), ("Kp", _p), ("Vp", _p), ("klens", _p),
                 ("Y", _p), ("y_part_stride", _i64), ("eps", _f32), ("gate", _f32), ("scale", _f32),
-                ("np", _i32), ("B", _i32), ("H", _i32), ("D", _i32), ("S_cap", _i32)]
+                ("np", _i32), ("B", _i32), ("H", _i32), ("D", _i32), ("S_cap", _i32), ("kv_format", _i32)]
 
 
 class ArState(C.Structure):
@@ -84,7 +84,7 @@ class ArFrame(C.Structure):
     _fields_ = [("blk", ArBlock * AR_MAX_LAYERS), ("head_w", _p), ("head_b", _p), ("x0", _p), ("xa", _p), ("xb", _p), ("part", _p),
                 ("u", _p), ("xp", _p), ("logits", _p), ("klens", _p),
                 ("n_layers", _i32), ("B", _i32), ("D", _i32), ("S_cap", _i32), ("V1", _i32), ("H", _i32), ("ksize", _i32), ("w_layout", _i32),
-                ("tile_glu", _i32), ("tile_ff1", _i32), ("tile_ff2", _i32), ("tile_head", _i32), ("eps", _f32), ("pad_", _i32),
+                ("tile_glu", _i32), ("tile_ff1", _i32), ("tile_ff2", _i32), ("tile_head", _i32), ("eps", _f32), ("store_format", _i32),
                 ("st", ArState)]
 
 
@@ -117,6 +117,7 @@ SYMBOLS = {
     "sopro_host_free": (C.c_int, [_p]),
     "sopro_copy_to_host_async": (C.c_int, [_p, _p, _i64, _p]),
     "sopro_set_lds_floor": (C.c_int, [C.c_int]),
+    "sopro_set_host_wait": (C.c_int, [C.c_int]),
     "sopro_device_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "sopro_capture_begin": (C.c_int, [_p]),
     "sopro_capture_end": (C.c_int, [_p, C.POINTER(_p)]),
@@ -201,6 +202,8 @@ SYMBOLS = {
     "sopro_ref_prepare": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p]),
     "sopro_mimi_encode_workspace_bytes": (_i64, [_p, _i32, _i32]),
     "sopro_mimi_encode": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p]),
+    "sopro_cvt_f32_bf16": (C.c_int, [_p, _p, _i64, _p]),
+    "sopro_cvt_bf16_f32": (C.c_int, [_p, _p, _i64, _p]),
     "sopro_prof_enable": (C.c_int, [C.c_int]),
     "sopro_prof_collect": (C.c_int, [_p, _i32, _p]),
 }
@@ -548,7 +551,9 @@ def skinny(X: torch.Tensor, W, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: 
     n_out = N // 2 if epilogue == EPI_GLU_DW else N
     a.Y, a.ldy = ptr(Y), (n_out if ldy is None else ldy)
     a.R, a.ldr, a.scale = ptr(R), (n_out if ldr is None else ldr), ptr(scale)
-    a.ring, a.dw_w, a.dw_b, a.step = ptr(ring), ptr(dw_w), ptr(dw_b), ptr(step, torch.int32)
+    ring_bf16 = ring is not None and ring.dtype == torch.bfloat16
+    a.ring, a.dw_w, a.dw_b, a.step = ptr(ring, torch.bfloat16 if ring_bf16 else torch.float32), ptr(dw_w), ptr(dw_b), ptr(step, torch.int32)
+    a.ring_format = 1 if ring_bf16 else 0
     a.Xp, a.xp_stride, a.y_part_stride, a.dbg = ptr(Xp), xp_stride, y_part_stride, ptr(dbg, torch.int64)
     a.eps = eps
     a.B, a.N, a.K, a.epilogue = B, N, K, epilogue
@@ -676,7 +681,9 @@ def xattn_step(X: torch.Tensor, Y: torch.Tensor, norm_w: Optional[torch.Tensor],
                xp_stride: int = 0, y_part_stride: int = 0) -> None:
     a = XattnArgs()
     a.X, a.ldx, a.Xp, a.xp_stride, a.np = ptr(X), D, ptr(Xp), xp_stride, np_
-    a.norm_w, a.Kp, a.Vp, a.klens = ptr(norm_w), ptr(Kp), ptr(Vp), ptr(klens, torch.int32)
+    kv16 = Kp.dtype == torch.bfloat16
+    a.norm_w, a.Kp, a.Vp, a.klens = ptr(norm_w), ptr(Kp, Kp.dtype), ptr(Vp, Kp.dtype), ptr(klens, torch.int32)
+    a.kv_format = 1 if kv16 else 0
     a.Y, a.y_part_stride = ptr(Y), y_part_stride
     a.eps, a.gate, a.scale = eps, gate, scale
     a.B, a.H, a.D, a.S_cap = B, H, D, S_cap
@@ -748,6 +755,23 @@ def ar_fold_text(txt: torch.Tensor, nkv_weight: torch.Tensor, kv_w: torch.Tensor
     """Folded text operands of one AR cross-attention layer (sopro_ar_fold_text); ``out_off``: float offset into kp / vp."""
     _check(load().sopro_ar_fold_text(ptr(txt), ptr(nkv_weight), ptr(kv_w), ptr(q_wT), ptr(o_w), ptr(nkv), ptr(kvd), ptr(kp) + 4 * out_off,
                                      ptr(vp) + 4 * out_off, B, S, S_cap, D, H, eps, _stream()), "sopro_ar_fold_text")
+
+
+def cvt_f32_bf16(src: torch.Tensor, dst: torch.Tensor, n: Optional[int] = None, dst_off: int = 0) -> None:
+    """fp32 -> bf16 image (sopro_cvt_f32_bf16); ``dst_off``: element offset into ``dst``."""
+    n = int(src.numel() if n is None else n)
+    _check(load().sopro_cvt_f32_bf16(ptr(src), ptr(dst, torch.bfloat16) + 2 * dst_off, n, _stream()), "sopro_cvt_f32_bf16")
+
+
+def cvt_bf16_f32(src: torch.Tensor, dst: torch.Tensor, n: Optional[int] = None) -> None:
+    n = int(src.numel() if n is None else n)
+    _check(load().sopro_cvt_bf16_f32(ptr(src, torch.bfloat16), ptr(dst), n, _stream()), "sopro_cvt_bf16_f32")
+
+
+def set_host_wait(blocking: bool, device=None) -> None:
+    """How host threads wait for ``device`` from now on (sopro_set_host_wait): spin (default) or block on the interrupt."""
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        _check(load().sopro_set_host_wait(1 if blocking else 0), "sopro_set_host_wait")
 
 
 def ar_tile_code(spec: str) -> int:

@@ -596,13 +596,18 @@ class _ARPlan:
         self.q = z(B, D)
         self.att = z(B, D)
         self.logits = z(B, V1)
-        # folded cross-attention operands per layer: K' = K_h Wq_h, V' = V_h Wo_h^T, [B, H, S_cap, D]
-        self.kp = {i: z(B, 4, S_cap, D) for i in cfg.ar_xattn_layers}
-        self.vp = {i: z(B, 4, S_cap, D) for i in cfg.ar_xattn_layers}
+        # folded cross-attention operands per layer: K' = K_h Wq_h, V' = V_h Wo_h^T, [B, H, S_cap, D].  bf16 mode keeps what the
+        # frame streams EVERY frame - these operands and the ring buffers - as bf16 in memory (store_format 1 of sopro_ar_frame):
+        # half the bytes of the frame's two largest state streams; they are folded in fp32 (one scratch pair) and rounded once.
+        self.bf16_state = m.precision == "bf16" and os.environ.get("SOPRO_BF16_STATE", "1") != "0"
+        sdt = torch.bfloat16 if self.bf16_state else torch.float32
+        self.kp = {i: z(B, 4, S_cap, D, dt=sdt) for i in cfg.ar_xattn_layers}
+        self.vp = {i: z(B, 4, S_cap, D, dt=sdt) for i in cfg.ar_xattn_layers}
+        self.fold32 = (z(B, 4, S_cap, D), z(B, 4, S_cap, D)) if self.bf16_state else None
         self.xp = z(4, B, D)  # per-head partial outputs of the cross-attention block
         self.klens = z(B, dt=torch.int32)
         k = int(cfg.ar_kernel)
-        self.rings = [z((k - 1) * int(d) + 1, B, D) for d in cfg.ar_dilations]
+        self.rings = [z((k - 1) * int(d) + 1, B, D, dt=sdt) for d in cfg.ar_dilations]
         self.hist = z(B, self.max_steps, dt=torch.int32)
         self.ctr = z(8, dt=torch.int32)  # step, -, n_stopped
         self.row_step = z(B, dt=torch.int32)  # per-row copy of the frame index (the sampler's own time base: no ticket)
@@ -652,9 +657,10 @@ class _ARPlan:
             p, b = f"ar.blocks.{i}", f.blk[i]
             b.glu_w, b.glu_b, b.dw_w, b.dw_b = wp(p + ".glu.w"), hip.ptr(w[p + ".glu.b"]), hip.ptr(w[p + ".dw.w"]), hip.ptr(w[p + ".dw.b"])
             b.ff1_w, b.ff1_b, b.ff2_w, b.ff2_b = wp(p + ".ff1.w"), hip.ptr(w[p + ".ff1.b"]), wp(p + ".ff2.w"), hip.ptr(w[p + ".ff2.b"])
-            b.ring, b.dil = hip.ptr(self.rings[i]), int(dil)
+            sdt = torch.bfloat16 if self.bf16_state else torch.float32
+            b.ring, b.dil = hip.ptr(self.rings[i], sdt), int(dil)
             if i in self.kp:
-                b.xattn, b.gate, b.kp, b.vp = 1, float(m.gates[i]), hip.ptr(self.kp[i]), hip.ptr(self.vp[i])
+                b.xattn, b.gate, b.kp, b.vp = 1, float(m.gates[i]), hip.ptr(self.kp[i], sdt), hip.ptr(self.vp[i], sdt)
         f.head_w, f.head_b = wp("ar.head.w"), hip.ptr(w["ar.head.b"])
         X0, XA, XB, _XC = self.x
         f.x0, f.xa, f.xb = hip.ptr(X0), hip.ptr(XA), hip.ptr(XB)
@@ -662,6 +668,7 @@ class _ARPlan:
         f.klens = hip.ptr(self.klens, torch.int32)
         f.n_layers, f.B, f.D, f.S_cap, f.V1, f.H, f.ksize = len(cfg.ar_dilations), self.B, D, self.S_cap, m.V + 1, 4, int(cfg.ar_kernel)
         f.w_layout = 2 if bf16 else 1
+        f.store_format = 1 if self.bf16_state else 0
         wide = m.ar_tiles_wide if self.B > 32 else None
         f.tile_glu, f.tile_ff1, f.tile_ff2, f.tile_head = (hip.ar_tile_code(wide or m.ar_tiles[k]) for k in ("glu", "ff1", "ff2", "head"))
         f.eps = RMS_EPS
@@ -672,6 +679,23 @@ class _ARPlan:
         """Enqueue one frame on the current stream (this is what the graph records)."""
         hip.ar_issue_frame(self.frame())
         self.nlaunch = 3 * len(self.m.cfg.ar_dilations) + len(self.kp) + 2
+
+    def fold_text(self, layer: int, ts: torch.Tensor, nkv: torch.Tensor, kvd: torch.Tensor, *, B: int, S: int, row0: int = 0) -> None:
+        """Folded text operands of cross-attention layer ``layer`` for ``B`` utterances starting at plan row ``row0``
+        (sopro_ar_fold_text; src/sopro/nn/text.py:75-83 with q_proj / out_proj folded in); in bf16 mode they are folded in fp32
+        into the plan's scratch pair and rounded once into the bf16 operands the frame reads."""
+        m, w, D = self.m, self.m.w, self.m.D
+        pa = f"ar.x_attns.{layer}"
+        blk = 4 * self.S_cap * D  # elements per row block
+        if not self.bf16_state:
+            hip.ar_fold_text(ts, w[pa + ".nkv.weight"], w[pa + ".kv.w"], w[pa + ".q.wT"], w[pa + ".o.w"], nkv, kvd, self.kp[layer], self.vp[layer],
+                             B=B, S=S, S_cap=self.S_cap, D=D, H=4, eps=RMS_EPS, out_off=row0 * blk)
+            return
+        k32, v32 = self.fold32
+        hip.ar_fold_text(ts, w[pa + ".nkv.weight"], w[pa + ".kv.w"], w[pa + ".q.wT"], w[pa + ".o.w"], nkv, kvd, k32, v32,
+                         B=B, S=S, S_cap=self.S_cap, D=D, H=4, eps=RMS_EPS, out_off=0)
+        hip.cvt_f32_bf16(k32, self.kp[layer], n=B * blk, dst_off=row0 * blk)
+        hip.cvt_f32_bf16(v32, self.vp[layer], n=B * blk, dst_off=row0 * blk)
 
     def load_row(self, row: int, cond_row: torch.Tensor, txt_row: torch.Tensor) -> None:
         """Slot mode: install one utterance in row ``row`` (launches only, on the current stream): its conditioning rows
@@ -686,9 +710,7 @@ class _ARPlan:
         kvd = m.ws.get("ar.row.kvd", (S, 2 * D))
         ts = txt_row.contiguous()
         for i in cfg.ar_xattn_layers:
-            pa = f"ar.x_attns.{i}"
-            hip.ar_fold_text(ts, w[pa + ".nkv.weight"], w[pa + ".kv.w"], w[pa + ".q.wT"], w[pa + ".o.w"], nkv, kvd, self.kp[i], self.vp[i],
-                             B=1, S=S, S_cap=self.S_cap, D=D, H=4, eps=RMS_EPS, out_off=row * 4 * self.S_cap * D)
+            self.fold_text(i, ts, nkv, kvd, B=1, S=S, row0=row)
         for r in self.rings:
             r[:, row].zero_()
 
@@ -772,9 +794,7 @@ class _ARRun:
             kvd = m.ws.get("ar.kvd", (B * S, 2 * D))
             ts = txt_seq.to(dev).float().contiguous().view(B * S, D)
             for i in cfg.ar_xattn_layers:
-                pa = f"ar.x_attns.{i}"
-                hip.ar_fold_text(ts, w[pa + ".nkv.weight"], w[pa + ".kv.w"], w[pa + ".q.wT"], w[pa + ".o.w"], nkv, kvd, plan.kp[i], plan.vp[i],
-                                 B=B, S=S, S_cap=S_cap, D=D, H=4, eps=RMS_EPS)
+                plan.fold_text(i, ts, nkv, kvd, B=B, S=S)
             for r in plan.rings:
                 r.zero_()
             plan.hist.zero_()

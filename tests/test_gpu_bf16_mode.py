@@ -135,6 +135,84 @@ def test_skinny_bf16_weights_match_the_rounded_product(B, w):
     close(ring[0], h, 5e-5, "ring row of this frame")
 
 
+@pytest.mark.parametrize("S,np_", [(19, 0), (64, 3), (130, 3)])
+def test_xattn_step_bf16_operands_match_the_rounded_operands(S, np_, w):
+    """Round 4: the folded text operands K' / V' of the AR frame stored as bf16 (sopro_xattn_args.kv_format 1) - against the
+    fp32-operand kernel on the bf16-ROUNDED operands (the same arithmetic on the same values: round-off class) and against
+    TextXAttnBlock on the unrounded ones (src/sopro/nn/text.py:85-132; a bf16-class deviation)."""
+    B, H, D = 5, 4, 384
+    dh = D // H
+    p = "ar.x_attns.3"
+    S_cap = ((S + 63) // 64) * 64
+    parts = [rnd(B, D, seed=800 + i) for i in range(np_ + 1)]
+    x = sum(parts)
+    ctx = rnd(B, S, D, seed=810)
+    klens = [S, 1, max(1, S // 2), S, max(1, S - 3)]
+    keep = torch.arange(S)[None, :] < torch.tensor(klens)[:, None]
+    k, v = O.xattn_kv(ctx, w, p, H)
+    ref = O.text_xattn(x[:, None], k, v, keep, w, p)[:, 0]
+    Wq, Wo = w[p + ".q_proj.weight"], w[p + ".out_proj.weight"]
+    Kp, Vp = torch.zeros(B, H, S_cap, D), torch.zeros(B, H, S_cap, D)
+    for h in range(H):
+        Kp[:, h, :S] = (k[:, h] @ Wq[h * dh:(h + 1) * dh]) * w[p + ".nq.weight"]
+        Vp[:, h, :S] = v[:, h] @ Wo[:, h * dh:(h + 1) * dh].t()
+    Pd = dev(torch.stack(parts))
+    kl = dev(torch.tensor(klens, dtype=torch.int32))
+    kw = dict(B=B, H=H, D=D, S_cap=S_cap, gate=float(torch.tanh(w[p + ".gate"])), scale=dh ** -0.5, eps=1e-6, Xp=Pd[1:] if np_ else None, np_=np_,
+              xp_stride=B * D, y_part_stride=B * D)
+    K16, V16 = torch.empty(B, H, S_cap, D, dtype=torch.bfloat16, device=DEV), torch.empty(B, H, S_cap, D, dtype=torch.bfloat16, device=DEV)
+    hip.cvt_f32_bf16(dev(Kp), K16)
+    hip.cvt_f32_bf16(dev(Vp), V16)
+    torch.cuda.synchronize()
+    assert torch.equal(K16.cpu(), Kp.to(torch.bfloat16)) and torch.equal(V16.cpu(), Vp.to(torch.bfloat16)), "sopro_cvt_f32_bf16 is not round-to-nearest-even"
+    back = torch.empty(B, H, S_cap, D, device=DEV)
+    hip.cvt_bf16_f32(K16, back)
+    assert torch.equal(back.cpu(), bf(Kp))
+    Y16 = torch.full((H, B, D), float("nan"), device=DEV)
+    hip.xattn_step(Pd[0], Y16, None, K16, V16, kl, **kw)
+    Y32 = torch.full((H, B, D), float("nan"), device=DEV)
+    hip.xattn_step(Pd[0], Y32, None, dev(bf(Kp)), dev(bf(Vp)), kl, **kw)
+    close(Y16.sum(0), Y32.sum(0), 2e-5, "bf16-stored operands vs the same values in fp32")
+    close(Y16.sum(0), ref, 3e-2, "bf16 operands vs the unrounded block")
+    assert float((Y16.sum(0).cpu() - ref).abs().max()) > 1e-6  # (the operands really were rounded)
+
+
+@pytest.mark.parametrize("B,dil", [(5, 2), (32, 4)])
+def test_skinny_glu_bf16_ring_buffer_over_frames(B, dil, w):
+    """Round 4: the AR frame's ring buffers stored as bf16 (sopro_skinny_args.ring_format 1, bf16 mode only): h is rounded once
+    when it is written and the twelve older taps are widened when they are read - over 30 frames against a torch model of
+    exactly that (bf16 weights / operands as in w_layout 2, the newest tap in fp32, older taps bf16(h))."""
+    D, k = 384, 13
+    p = "ar.blocks.2"
+    L = (k - 1) * dil + 1
+    ring = torch.zeros(L, B, D, dtype=torch.bfloat16, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    gwf = (w[p + ".glu.pro.weight"] * w[p + ".norm.weight"][None, :]).contiguous()
+    gw, gb = hip.pack_skinny_w(dev(gwf), glu=True, bf16=True), dev(w[p + ".glu.pro.bias"])
+    dww, dwb = dev(pack.pack_dw(w[p + ".dw.dw.weight"])), dev(w[p + ".dw.dw.bias"])
+    wt = w[p + ".dw.dw.weight"].squeeze(1)  # [D, k], oldest tap first
+    Y = torch.empty(B, D, device=DEV)
+    hist = torch.zeros(B, L, D)  # bf16-rounded h of earlier frames, oldest first
+    for t in range(30):
+        x = rnd(B, D, seed=100 + t)
+        rs = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-6)
+        pre = ((bf(x).double() @ bf(gwf).double().t()) * rs).float() + w[p + ".glu.pro.bias"]
+        h = pre[:, :D] * torch.sigmoid(pre[:, D:])
+        hist = torch.cat([hist[:, 1:], h.unsqueeze(1)], dim=1)
+        taps = hist[:, torch.arange(0, k * dil, dil)].clone()  # [B, k, D]; the newest (last) is this frame's fp32 h
+        y = (taps.transpose(1, 2) * wt).sum(-1) + w[p + ".dw.dw.bias"]
+        hist[:, -1] = bf(h)  # what later frames read back
+        step.fill_(t)
+        hip.skinny(dev(x), gw, Y, B=B, N=2 * D, K=D, rms_norm=True, eps=1e-6, bias=gb, epilogue=hip.EPI_GLU_DW, ring=ring,
+                   dw_w=dww, dw_b=dwb, step=step, ring_len=L, ring_bcap=B, dil=dil, ksize=k)
+        close(Y, x + y, 5e-3, f"glu + bf16 ring, frame {t}")  # (h itself carries the bf16 operands' round-off: a torch-vs-MFMA order effect at the rounding boundaries)
+    torch.cuda.synchronize()
+    assert ring.dtype == torch.bfloat16 and float(ring.float().abs().max()) > 0
+    with pytest.raises(hip.SoproHipError):  # a bf16 ring needs the bf16 weights of the mode
+        hip.skinny(dev(x), hip.pack_skinny_w(dev(gwf), glu=True), Y, B=B, N=2 * D, K=D, rms_norm=True, eps=1e-6, bias=gb, epilogue=hip.EPI_GLU_DW,
+                   ring=ring, dw_w=dww, dw_b=dwb, step=step, ring_len=L, ring_bcap=B, dil=dil, ksize=k)
+
+
 @pytest.fixture(scope="module")
 def tts_bf16(cfg, sopro_np_noeos, mimi_np):
     from sopro_amd import SoproTTS
