@@ -333,6 +333,14 @@ def main() -> None:
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
+    from sopro_amd import hip
+
+    # Host wait mode: a process-level decision, taken before the first stream exists (hip.set_host_wait).  The lanes' threads wait
+    # most of the time (AR stop polls, phase ends): blocking waits instead of the runtime's spin free a core per lane - what 8
+    # ranks on one host need.  SOPRO_BLOCKING_WAIT=0 keeps the spin wait (lowest wake-up latency for the TTFA leg).
+    blocking_wait = (args.lanes > 1 or world > 1) and os.environ.get("SOPRO_BLOCKING_WAIT", "1") != "0"
+    if blocking_wait:
+        hip.set_host_wait(True, dev_index)
     import torch.distributed as dist
 
     # One rank per GPU means 1 + lanes host threads per rank, all latency-sensitive (they keep the AR launch queues fed).  With
@@ -759,6 +767,7 @@ def main() -> None:
             "host_threads": {"per_rank": 1 + (args.lanes if args.lanes > 1 else 0), "torch_intra_op": torch.get_num_threads(),
                              "pinned_cores_rank0": (len(pinned) if pinned else None)},
             "host_cpu_note": "CPU time of all threads of this rank's process over the timed region / steps (launch threads of the lanes included)",
+            "host_wait": "blocking (hipDeviceScheduleBlockingSync, set at process start)" if blocking_wait else "spin (runtime default)",
             "legs": legs, "roofline_dropped": dropped,
             "unpinned": ["sinc_resample of the reference-audio front end (SURVEY 8f rank 1, outside this line's timed path): pinned by derivation "
                          "only - torchaudio is not in the image to generate a fixture from"],

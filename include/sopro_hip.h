@@ -120,9 +120,13 @@ int sopro_gemm_set_tile_override(int cfg);
  * producer writes ELU(x) in that form (c_mode 1), optionally next to the raw fp32 tensor (c_mode 2), and the consumer
  * (a_format 1) stages it with plain 16-byte copies: no activation or split work is left in its main loop. */
 typedef struct sopro_gemm_split_ext {
-  int32_t a_format; /* 0: A is fp32 rows; 1: split form (prologue must be NONE) */
+  int32_t a_format; /* 0: A is fp32 rows; 1: split form (prologue must be NONE); 2 (sopro_gemm_bf16x1 only, round 4): A points at
+                     * bf16 rows, lda / a_seg_stride count bf16 elements (multiples of 4) - the bf16 mode's activation flow */
   int32_t c_mode;   /* 0: fp32 to C; 1: ELU + split form to C; 2: fp32 to C and ELU + split form to C2;
-                     * 3: ELU(C) as fp32 to C; 4: fp32 to C and ELU(C) as fp32 to C2 */
+                     * 3: ELU(C) as fp32 to C; 4: fp32 to C and ELU(C) as fp32 to C2; 5: arg-max partials (see sopro_argmax_partials_i32);
+                     * sopro_gemm_bf16x1 only, epilogue NONE or RES: 6: C as bf16 rows; 7: ELU(C) as bf16 rows to C; 8: C as bf16 rows to C
+                     * AND ELU(C) as bf16 rows to C2 - C / C2 / R (the skip operand of EPI_RES) then point at bf16 elements and
+                     * ldc / ldc2 / ldr and the segment strides count bf16 elements (multiples of 4, 8-byte aligned rows) */
   float* C2; int64_t ldc2; int64_t c2_seg_stride; /* c_mode 2 / 4; strides in 4-byte units like ldc / c_seg_stride */
   /* Split-K for problems with too few output tiles to fill the chip (a few rows: streaming chunks, batch 1): `ksplit`
    * workgroups share a tile, each stores its raw accumulators into `ws`, the last to take the tile's ticket adds them in
@@ -393,6 +397,18 @@ int sopro_seanet_res_set_tiles(int tiles); /* developer probe / tests: 64-row ti
  * for bit; the weights are split once per workgroup and stay in registers. */
 int sopro_seanet_up128_f32(const float* x, int64_t x_seg_stride, const float* w, const float* bias, float* out,
                            int64_t out_seg_stride, int32_t B, int32_t T, int32_t passes, void* stream);
+/* The bf16 mode's activation flow (round 4): the three fused SEANet kernels on bf16 ROWS in memory - half the bytes of the decoder's
+ * largest tensors - with one MFMA pass on the rounded operands and fp32 accumulation / bias / ELU / skip additions.  Pointers are
+ * to bf16 elements and the segment strides count bf16 elements; layouts as in the fp32 forms above.
+ *   sopro_seanet_res128_bf16: h raw [B][2 + T][128] -> out = ELU(h + c2(ELU(c1(ELU(h))))) [B][2 + T][128]
+ *   sopro_seanet_up128_bf16 : x activated [B][>= 1 + T][128] -> out rows of 256 (4 samples x 64 channels), raw
+ *   sopro_seanet_tail_bf16  : h raw [B][2 + T][64] -> wav fp32 [B][T]  (the sixteen-wave kernel at any size) */
+int sopro_seanet_res128_bf16(const void* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2, const float* b2,
+                             void* out, int64_t out_seg_stride, int32_t B, int32_t T, void* stream);
+int sopro_seanet_up128_bf16(const void* x, int64_t x_seg_stride, const float* w, const float* bias, void* out, int64_t out_seg_stride,
+                            int32_t B, int32_t T, void* stream);
+int sopro_seanet_tail_bf16(const void* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2, const float* b2,
+                           const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B, int32_t T, void* stream);
 int sopro_seanet_up_set_tiles(int tiles); /* developer probe / tests: 64-row tiles per workgroup, 0 = by size */
 int sopro_seanet_tail_set_tiles(int tiles); /* developer probe / tests: 126-sample tiles per workgroup of the four-wave kernel, 0 = by size
                                              * (long inputs: the sixteen-wave kernel), < 0 = the sixteen-wave kernel at any size */

@@ -63,7 +63,9 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned (&pc)[NPL]
 // (NPL == 2 only: each 32-channel group = [32 hi | 32 lo] bf16, written by a producer's OUT = 1 / 2 epilogue): pure
 // 16-byte copies; 3 = fp32 rows + pro_vec[k] (PRO_ADDVEC); 4 = fp32 rows whose RMSNorm is fused: the row's sum of squares is
 // accumulated while it is staged and rsqrt(mean + eps) scales the accumulator in the epilogue (the norm's weight vector is
-// folded into W by the host; needs K % 32 == 0 and no split-K: every workgroup sees its rows' whole K).
+// folded into W by the host; needs K % 32 == 0 and no split-K: every workgroup sees its rows' whole K); 5 (round 4, NPL == 1 only:
+// the bf16 mode's activation flow) = A is bf16 rows in memory (lda / a_seg_stride count bf16 elements): a K-step of a row is 64
+// bytes, staged by pure 8-byte copies - half the operand bytes of the loop that bounds the one-pass kernel, no conversion work.
 template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT, bool SK, bool F16 = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gemm_args g, const uint4* __restrict__ Wp,
                                                                  int ksubs, const sopro_gemm_split_ext ext) {
@@ -99,13 +101,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   // Branch-free operand addressing: rows >= M and column tiles >= N are clamped onto valid ones (their accumulators
   // are never stored) and the K tail re-reads the row's last in-range piece (W is zero-padded there), so the main loop
   // is one basic block and the compiler can count its outstanding loads instead of draining them.
-  const float* ap[A_F4];
+  static_assert(AMODE != 5 || NPL == 1, "bf16 rows are a one-pass (bf16 mode) operand form");
+  constexpr int AES = AMODE == 5 ? 2 : 4;  // bytes per stored A element
+  const char* ap[A_F4];
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
     const int m = min(m0 + lrow + i * RSTEP, g.M - 1);
     const int seg = m / rps;
     const int r = m - seg * rps;
-    ap[i] = g.A + (int64_t)seg * g.a_seg_stride + (int64_t)r * g.lda;
+    ap[i] = reinterpret_cast<const char*>(g.A) + ((int64_t)seg * g.a_seg_stride + (int64_t)r * g.lda) * AES;
   }
   const int ntiles = (g.N + 31) >> 5;
   const uint4* bp[TN];
@@ -131,8 +135,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
 
   auto gload = [&](int kt, float4 (&ra)[A_F4], float4& pv) {  // split-form A has the fp32 addresses: a K-step is the same 128 bytes of the row
     const int k = min(kt * BK + lc4 * 4, klast);
+    if constexpr (AMODE == 5) {  // four bf16 = 8 bytes per thread and row, carried in .x / .y (bit patterns)
 #pragma unroll
-    for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i] + k);
+      for (int i = 0; i < A_F4; ++i) {
+        const uint2 v = *reinterpret_cast<const uint2*>(ap[i] + (int64_t)k * 2);
+        ra[i].x = __uint_as_float(v.x);
+        ra[i].y = __uint_as_float(v.y);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i] + (int64_t)k * 4);
+    }
     if (AMODE == 3) pv = *reinterpret_cast<const float4*>(g.pro_vec + k);
   };
   auto bload = [&](int kt, uint4 (&rb)[TN][2][NPL]) {
@@ -144,7 +157,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
         for (int p = 0; p < NPL; ++p) rb[j][s][p] = bp[j][((int64_t)(kt * 2 + s) * NPL + p) * 64];
   };
   auto lstore = [&](int buf, float4 (&ra)[A_F4], const float4& pv, bool fresh = true) {  // fresh: not the clamped re-stage of the last step (RMSNorm sums count once)
-    if constexpr (AMODE == 2) {  // pieces 0-3 of the 128-byte group are the hi halves, 4-7 the lo halves: the LDS row layout
+    if constexpr (AMODE == 5) {  // the row piece is already what the MFMA reads: 8-byte copy into the piece-0 plane
+      unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 8;
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) *reinterpret_cast<uint2*>(a + i * RSTEP * AROW) = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
+    } else if constexpr (AMODE == 2) {  // pieces 0-3 of the 128-byte group are the hi halves, 4-7 the lo halves: the LDS row layout
       unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 16;
 #pragma unroll
       for (int i = 0; i < A_F4; ++i)  // member-wise: whole-struct copies keep the array in scratch memory (no promotion to registers)
@@ -404,6 +421,7 @@ int launch_one(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro
 
 inline int amode_of(const sopro_gemm_args& g, const sopro_gemm_split_ext& ext) {
   if (ext.a_format == 1) return 2;
+  if (ext.a_format == 2) return 5;
   if (ext.rms_norm) return 4;
   return g.prologue == SOPRO_PRO_ELU ? 1 : (g.prologue == SOPRO_PRO_ADDVEC ? 3 : 0);
 }
@@ -424,6 +442,17 @@ int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 4);
     SOPRO_CASE(SOPRO_EPI_RES, 0, 3);
     default: break;
+  }
+  if constexpr (NPL == 1) {  // bf16 mode with bf16 activations in memory (round 4): the SEANet decoder's flow
+    switch (key) {
+      SOPRO_CASE(SOPRO_EPI_NONE, 0, 7);  // first conv: fp32 transformer stream in, ELU as bf16 rows out
+      SOPRO_CASE(SOPRO_EPI_NONE, 5, 8);  // transposed convs: bf16 in, raw + activated bf16 copies out
+      SOPRO_CASE(SOPRO_EPI_NONE, 5, 7);  // residual block k = 3 conv
+      SOPRO_CASE(SOPRO_EPI_RES, 5, 7);   // residual block k = 1 conv + bf16 skip operand
+      SOPRO_CASE(SOPRO_EPI_NONE, 5, 6);  // transposed conv in front of the fused 128-channel block: raw bf16 out
+      SOPRO_CASE(SOPRO_EPI_NONE, 5, 0);  // (bf16 in, fp32 out: tests, mixed flows)
+      default: break;
+    }
   }
   if constexpr (NPL == 2) {
     switch (key) {
@@ -582,13 +611,26 @@ extern "C" int sopro_gemm_bf16x1(const sopro_gemm_args* a, const void* packed_w,
   memset(&ext, 0, sizeof(ext));
   if (x) ext = *x;
   if (ext.group_m == 0) ext.group_m = g_group_m;
-  SOPRO_CHECK_ARG(ext.a_format == 0 && (ext.c_mode == 0 || ext.c_mode == 3 || ext.c_mode == 4 || ext.c_mode == 5),
-                  "bf16x1 reads fp32 rows and writes fp32 rows (c_mode 0, 3, 4) or arg-max partials (5)");
+  SOPRO_CHECK_ARG((ext.a_format == 0 || ext.a_format == 2) && (ext.c_mode == 0 || (ext.c_mode >= 3 && ext.c_mode <= 8)),
+                  "bf16x1 reads fp32 rows (a_format 0) or bf16 rows (2) and writes fp32 rows (c_mode 0, 3, 4), arg-max partials (5) or bf16 rows (6, 7, 8)");
+  if (ext.a_format == 2 || ext.c_mode >= 6) {
+    SOPRO_CHECK_ARG(!ext.rms_norm && g.prologue == SOPRO_PRO_NONE && (g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_RES),
+                    "bf16 rows: no prologue / fused norm, epilogue NONE or RES (the activation is applied by the producer: c_mode 7 / 8)");
+    SOPRO_CHECK_ARG(ext.a_format != 2 || ((g.lda & 3) == 0 && (g.a_seg_stride & 3) == 0), "bf16 A rows: lda, a_seg_stride multiples of 4 elements");
+    SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_RES || ext.c_mode >= 6, "EPI_RES with bf16 A writes bf16 rows (its skip operand R is bf16 then)");
+  }
   SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f && ext.c_mode == 0),
                   "fused RMSNorm needs K % 32 == 0, no split-K, no prologue, eps > 0 and a plain output");
   if (int rc = check_common(g, ext, packed_w)) return rc;
   if (ext.c_mode == 5) return launch_argmax<1>(g, reinterpret_cast<const uint4*>(packed_w), (g.K + 31) / 32 * 2, ext, reinterpret_cast<hipStream_t>(stream));
-  if (ext.c_mode != 0) {
+  if (ext.c_mode >= 6) {  // bf16 rows: C (and C2 for c_mode 8; R for EPI_RES) point at bf16 elements, strides count elements
+    SOPRO_CHECK_ARG((g.N & 3) == 0 && g.C && (reinterpret_cast<uintptr_t>(g.C) & 7u) == 0 && (g.ldc & 3) == 0 && (g.c_seg_stride & 3) == 0 && g.ldc >= g.N,
+                    "bf16 output rows must be 8-byte aligned (N, ld, seg stride multiples of 4)");
+    SOPRO_CHECK_ARG(ext.c_mode != 8 || (ext.C2 && (reinterpret_cast<uintptr_t>(ext.C2) & 7u) == 0 && (ext.ldc2 & 3) == 0 && (ext.c2_seg_stride & 3) == 0 && ext.ldc2 >= g.N),
+                    "c_mode 8: C2 (the activated bf16 copy) must be given, 8-byte aligned rows");
+    SOPRO_CHECK_ARG(g.epilogue != SOPRO_EPI_RES || ((reinterpret_cast<uintptr_t>(g.R) & 7u) == 0 && (g.ldr & 3) == 0 && (g.r_seg_stride & 3) == 0),
+                    "bf16 skip operand rows must be 8-byte aligned");
+  } else if (ext.c_mode != 0) {
     const bool second = ext.c_mode == 4;
     float* d = second ? ext.C2 : g.C;
     const int64_t ldd = second ? ext.ldc2 : g.ldc, dseg = second ? ext.c2_seg_stride : g.c_seg_stride;

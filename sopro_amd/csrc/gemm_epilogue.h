@@ -12,6 +12,9 @@
 // OUT: 5 = no C at all: per tile row the maximum of the tile's columns and its column index go to ext.C2 as (float value,
 // int32 index) pairs, [M][ext.ldc2 = column tiles] - the arg-max of a wide projection (the 31 NAR heads: 2048 logits each,
 // src/sopro/model.py:338-345) without ever writing the logits; sopro_argmax_partials_i32 finishes the reduction.
+// OUT: 6 / 7 / 8 (round 4, the bf16 mode's activation flow; EPI NONE or RES): bf16 rows - 6 = C as bf16 to g.C; 7 = ELU(C) as bf16
+// to g.C; 8 = C as bf16 to g.C AND ELU(C) as bf16 to ext.C2.  g.C / ext.C2 / g.R (the skip operand of EPI_RES) point at bf16
+// elements and their strides count elements; host guarantees N % 4 == 0 and 8-byte aligned rows.
 // rs (optional, LDS): one scale per tile row applied to the accumulator before the bias: the RMSNorm of the operand row
 // when its weight vector has been folded into W (out = rs * (x W'^T) + b).
 template <int WM, int WN, int TM, int TN, int EPI, int OUT = 0>
@@ -66,6 +69,64 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
       float* pp = ext->C2 + ((int64_t)(m0 + row) * ext->ldc2 + n0 / BN) * 2;
       pp[0] = best;
       pp[1] = __int_as_float(bi);
+    }
+    return;
+  }
+  if constexpr (OUT >= 6) {
+    constexpr bool hres = EPI == SOPRO_EPI_RES;
+    static_assert(EPI == SOPRO_EPI_NONE || EPI == SOPRO_EPI_RES, "bf16 rows take EPI_NONE or EPI_RES");
+    constexpr int HTPR = BN / 4, HRPP = NT / HTPR, HNPASS = BM / HRPP;
+    const int prow = tid / HTPR, pc4 = tid % HTPR;
+    const int ocol = n0 + pc4 * 4;
+    const bool col_ok = ocol < g.N;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (hres && g.scale && col_ok) sc4 = make_float4(g.scale[ocol], g.scale[ocol + 1], g.scale[ocol + 2], g.scale[ocol + 3]);
+    int m = m0 + prow;
+    int seg = m / rps, rr = m - seg * rps;
+    char* const rawb = reinterpret_cast<char*>(g.C);
+    char* const actb = OUT == 8 ? reinterpret_cast<char*>(ext->C2) : rawb;
+    const int64_t ldact = OUT == 8 ? ext->ldc2 : g.ldc, segact = OUT == 8 ? ext->c2_seg_stride : g.c_seg_stride;
+    const char* const rb = reinterpret_cast<const char*>(g.R);
+    auto at = [&](int64_t sg, int64_t r, int64_t ld, int64_t sstride) { return (sg * sstride + r * ld + ocol) * 2; };
+    const float* csrc = Cs + prow * CLD + pc4 * 4;
+    constexpr int HB = HNPASS < 8 ? HNPASS : 8;
+#pragma unroll 1
+    for (int p0 = 0; p0 < HNPASS; p0 += HB) {
+      int64_t oraw[HB], oact[HB];
+      bool okq[HB];
+      uint2 rv[HB];
+#pragma unroll
+      for (int q = 0; q < HB; ++q) {
+        okq[q] = col_ok && m < g.M;
+        oraw[q] = at(seg, rr, g.ldc, g.c_seg_stride);
+        oact[q] = at(seg, rr, ldact, segact);
+        rv[q] = make_uint2(0u, 0u);
+        if (hres && okq[q]) rv[q] = *reinterpret_cast<const uint2*>(rb + at(seg, rr, g.ldr, g.r_seg_stride));
+        m += HRPP; rr += HRPP;
+        while (rr >= rps) { rr -= rps; ++seg; }
+      }
+#pragma unroll
+      for (int q = 0; q < HB; ++q) {
+        if (!okq[q]) continue;
+        float4 v = *reinterpret_cast<const float4*>(csrc + (p0 + q) * HRPP * CLD);
+        if (hres) {
+          v.x = __uint_as_float(rv[q].x << 16) + sc4.x * v.x; v.y = __uint_as_float(rv[q].x & 0xffff0000u) + sc4.y * v.y;
+          v.z = __uint_as_float(rv[q].y << 16) + sc4.z * v.z; v.w = __uint_as_float(rv[q].y & 0xffff0000u) + sc4.w * v.w;
+        }
+        unsigned lo_;
+        if (OUT != 7) {
+          uint2 h;
+          split2_bf16(v.x, v.y, h.x, lo_);
+          split2_bf16(v.z, v.w, h.y, lo_);
+          *reinterpret_cast<uint2*>(rawb + oraw[q]) = h;
+        }
+        if (OUT != 6) {
+          uint2 h;
+          split2_bf16(eluf_(v.x), eluf_(v.y), h.x, lo_);
+          split2_bf16(eluf_(v.z), eluf_(v.w), h.y, lo_);
+          *reinterpret_cast<uint2*>(actb + oact[q]) = h;
+        }
+      }
     }
     return;
   }

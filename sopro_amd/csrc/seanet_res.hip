@@ -200,6 +200,149 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
   }
 }
 
+// HB (round 4: the bf16 mode's activation flow): h and out are bf16 rows (256 bytes per row) - the 1.57 GB level is read and written
+// at half the bytes; one MFMA pass on the rounded operands.  ELU is applied to the widened values and the result is rounded again
+// while the tile is staged (LDS row = 128 bf16 + 16 B pad = 272 B); the skip operand is the raw bf16 h widened to fp32; the sum is
+// accumulated in fp32 and rounded once when it is stored (two neighbouring columns per lane: 4-byte stores).
+constexpr int REROW_H = RC * 2 + 16;   // 272
+constexpr int RYROW_H = RH * 2 + 16;   // 144
+__device__ __forceinline__ unsigned relu2_bf16(unsigned pk) {  // two packed bf16 -> ELU in fp32 -> two packed bf16
+  unsigned o, lo_;
+  split2_bf16(eluf_(__uint_as_float(pk << 16)), eluf_(__uint_as_float(pk & 0xffff0000u)), o, lo_);
+  return o;
+}
+__global__ __launch_bounds__(256, 2) void seanet_res128_hb_kernel(const unsigned short* __restrict__ h, int64_t h_seg_stride,
+                                                                  const float* __restrict__ w1, const float* __restrict__ b1,
+                                                                  const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                  unsigned short* __restrict__ out, int64_t out_seg_stride, int T, int tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char es[RHR * REROW_H];   // bf16 ELU(h)
+  __shared__ __attribute__((aligned(16))) unsigned char ys[RTO * RYROW_H];   // bf16 ELU(intermediate)
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];            // K-half exchange of the first convolution
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int frow = lane & 31, fg = lane >> 5;
+  const int nt1 = wave & 1, kh = wave >> 1;
+  const unsigned short* hb = h + (int64_t)b * h_seg_stride;   // 2 zero rows, then T rows of RC bf16
+  unsigned short* ob = out + (int64_t)b * out_seg_stride;
+
+  uint4 w1h[12];
+#pragma unroll
+  for (int s = 0; s < 12; ++s) { uint4 lo; rsplit8(w1 + (int64_t)(nt1 * 32 + frow) * (3 * RC) + (kh * 12 + s) * 16 + fg * 8, w1h[s], lo); }
+  uint4 w2h[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { uint4 lo; rsplit8(w2 + (int64_t)(wave * 32 + frow) * RH + s * 16 + fg * 8, w2h[s], lo); }
+  const float b1v = b1[nt1 * 32 + frow];
+  const float b2v = b2[wave * 32 + frow];
+
+  uint4 v[5];  // 66 rows x 16 pieces of 16 bytes = 1056 pieces over 256 threads
+  auto request = [&](int s0) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int idx = tid + q * 256;
+      const int r = idx >> 4, c8 = idx & 15;
+      const int p = s0 + r;
+      const int pc = (r < RHR && p < T + 2) ? p : 0;
+      v[q] = *reinterpret_cast<const uint4*>(hb + (int64_t)pc * RC + c8 * 8);
+    }
+  };
+
+  for (int it = 0; it < tiles; ++it) {
+    const int s0 = ((int)blockIdx.x * tiles + it) * RTO;
+    if (s0 >= T) break;
+    request(s0);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int idx = tid + q * 256;
+      const int r = idx >> 4, c8 = idx & 15;
+      if (r < RHR) *reinterpret_cast<uint4*>(es + r * REROW_H + c8 * 16) = make_uint4(relu2_bf16(v[q].x), relu2_bf16(v[q].y), relu2_bf16(v[q].z), relu2_bf16(v[q].w));
+    }
+    __syncthreads();
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    }
+    {
+      constexpr int DEPTH = 2;
+      const unsigned char* a = es + frow * REROW_H + fg * 16;
+      auto fptr = [&](int s, int mt) { const int sg = kh * 12 + s; return a + mt * 32 * REROW_H + (sg >> 3) * REROW_H + (sg & 7) * 32; };
+      uint4 ah[DEPTH][2];
+#pragma unroll
+      for (int s = 0; s < DEPTH; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ah[s][mt] = *reinterpret_cast<const uint4*>(fptr(s, mt));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 12; ++s) {
+        uint4 ch[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ch[mt] = ah[s % DEPTH][mt];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ch[mt]), rfrag(w1h[s]), acc[mt], 0, 0, 0);
+        if (s + DEPTH < 12) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) ah[s % DEPTH][mt] = *reinterpret_cast<const uint4*>(fptr(s + DEPTH, mt));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = kh ? acc[0][r] : acc[1][r];
+    __syncthreads();
+    {
+      const int mt = kh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float mine = kh ? acc[1][r] : acc[0][r];
+        const float other = red[((wave ^ 2) * 16 + r) * 64 + lane];
+        const float v1 = (kh ? other + mine : mine + other) + b1v;   // K half 0 first, whichever wave adds
+        const int mr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+        unsigned hi, lo;
+        split2_bf16(eluf_(v1), 0.f, hi, lo);
+        *reinterpret_cast<unsigned short*>(ys + mr * RYROW_H + (nt1 * 32 + frow) * 2) = (unsigned short)(hi & 0xffffu);
+      }
+    }
+    __syncthreads();
+
+    // ---- conv k=1, 64 -> 128 (wave w: output columns 32w ..) + skip, ELU, store (column pairs: see seanet_up128_hb_kernel)
+    const bool odd = (lane & 1) != 0;
+    const int colp = wave * 32 + (frow & ~1);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      // skip operand: this lane's (row, column pair) of the raw tile, an L2-resident 4-byte re-read per output pair
+      unsigned skip[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg + (odd ? 1 : 0);
+        skip[r >> 1] = *reinterpret_cast<const unsigned*>(hb + (int64_t)((s0 + m < T) ? s0 + m + 2 : 0) * RC + colp);  // past the end: zero row 0
+      }
+      f32x16 acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+      const unsigned char* a = ys + (mt * 32 + frow) * RYROW_H + fg * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const uint4 ah = *reinterpret_cast<const uint4*>(a + s * 32);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w2h[s]), acc2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float mine0 = acc2[r] + b2v, mine1 = acc2[r + 1] + b2v;
+        // (the neighbour column's bias travels with its value: mine* already hold it)
+        const float got = __shfl_xor(odd ? mine0 : mine1, 1, 64);
+        const float c0 = odd ? got : mine0, c1 = odd ? mine1 : got;
+        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg + (odd ? 1 : 0);
+        const unsigned sk = skip[r >> 1];
+        unsigned pk, lo_;
+        split2_bf16(eluf_(__uint_as_float(sk << 16) + c0), eluf_(__uint_as_float(sk & 0xffff0000u) + c1), pk, lo_);
+        if (s0 + m < T) *reinterpret_cast<unsigned*>(ob + (int64_t)(s0 + m + 2) * RC + colp) = pk;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int g_res_tiles = 0;  // developer probe / tests: tiles per workgroup, 0 = heuristic
@@ -225,6 +368,23 @@ extern "C" int sopro_seanet_res128_p_f32(const float* h, int64_t h_seg_stride, c
     hipLaunchKernelGGL(seanet_res128_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride, T, tiles);
   else  // the engine's bf16 mode: hi * hi only
     hipLaunchKernelGGL(seanet_res128_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride, T, tiles);
+  SOPRO_LAUNCH_CHECK();
+}
+
+// bf16 rows in (raw h), bf16 rows out (the activated result): the bf16 mode's activation flow, one pass.  Strides count bf16 elements.
+extern "C" int sopro_seanet_res128_bf16(const void* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
+                                         const float* b2, void* out, int64_t out_seg_stride, int32_t B, int32_t T, void* stream) {
+  SOPRO_CHECK_ARG(h && w1 && b1 && w2 && b2 && out && B > 0 && T > 0, "bad pointers or sizes");
+  SOPRO_CHECK_ARG(h != out, "the block is not computed in place (a tile reads two rows of its left neighbour)");
+  SOPRO_CHECK_ARG(aligned16(h) && aligned16(w1) && aligned16(w2) && (reinterpret_cast<uintptr_t>(out) & 3u) == 0 && (h_seg_stride & 7) == 0 && (out_seg_stride & 1) == 0,
+                  "alignment (h rows in 16-byte pieces, out in 4-byte pairs)");
+  SOPRO_CHECK_ARG(h_seg_stride >= (int64_t)(T + 2) * RC && out_seg_stride >= (int64_t)(T + 2) * RC, "segments hold 2 + T rows of 128 bf16");
+  const int ntile = (T + RTO - 1) / RTO;
+  const int64_t all = (int64_t)ntile * B;
+  const int tiles = g_res_tiles > 0 ? g_res_tiles : (all >= 16 * 2048 ? 16 : (all >= 8 * 1024 ? 8 : (all >= 2048 ? 2 : 1)));
+  dim3 grid((ntile + tiles - 1) / tiles, B);
+  hipLaunchKernelGGL(seanet_res128_hb_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned short*>(h), h_seg_stride, w1, b1, w2, b2,
+                     reinterpret_cast<unsigned short*>(out), out_seg_stride, T, tiles);
   SOPRO_LAUNCH_CHECK();
 }
 

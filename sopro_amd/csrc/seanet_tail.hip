@@ -250,7 +250,10 @@ __device__ __forceinline__ void tail_wave_sync() {  // a wave's own LDS writes -
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int PASSES>
+// HB (round 4: the bf16 mode's activation flow; PASSES == 1): h is bf16 rows (128 bytes per sample row: the 3.1 GB level is read at
+// half the bytes); the tile request is three 16-byte pieces per lane, ELU is applied to the widened values and the result is
+// rounded again while it is staged; the skip operand is the raw bf16 h widened to fp32.  Strides count bf16 elements then.
+template <int PASSES, bool HB = false>
 __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __restrict__ h, int64_t h_seg_stride, const float* __restrict__ w1,
                                                                 const float* __restrict__ b1, const float* __restrict__ w2,
                                                                 const float* __restrict__ b2, const float* __restrict__ wf, float bf,
@@ -263,7 +266,9 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
   unsigned char* ys = es + ES3;
   const int b = blockIdx.y;
   const int col = lane & 15, kq = lane >> 4;  // MFMA 16x16x32: operand row / column, k quarter (8 consecutive k); C: column, rows 4 kq + i
-  const float* hb = h + (int64_t)b * h_seg_stride;
+  static_assert(!HB || PASSES == 1, "bf16 rows are a one-pass (bf16 mode) input form");
+  const float* hb = HB ? nullptr : h + (int64_t)b * h_seg_stride;
+  const unsigned short* hb16 = HB ? reinterpret_cast<const unsigned short*>(h) + (int64_t)b * h_seg_stride : nullptr;
 
   // ---- weight fragments -> LDS, once per workgroup: waves 0-11 one (column tile, k-step) block pair of the first convolution
   // each (B operand: n = 16 nt + col, k = 32 s + 8 kq .. + 7), waves 12-15 one column tile of the second (n = 16 nt + col, k = 8 kq ..)
@@ -287,15 +292,27 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
 
   // tile request of this wave: local row r holds sample s0-4+r = padded row s0-2+r (two zero rows in front of the segment);
   // rows outside the segment are redirected to padded row 0, a zero row (branch-free loads)
-  float4 v[5];
+  float4 v[5];  // HB: three 16-byte pieces (8 bf16 each) per lane, carried as bit patterns
   auto request = [&](int s0) {
+    if constexpr (HB) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int idx = lane + q * 64;  // float4 index: 16 per row
-      const int r = idx >> 4, c4 = idx & 15;
-      const int p = s0 - 2 + r;
-      const int pc = (r < H3R && p >= 0 && p < T + 2) ? p : 0;
-      v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)pc * 64 + c4 * 4);
+      for (int q = 0; q < 3; ++q) {
+        const int idx = lane + q * 64;  // 16-byte piece index: 8 per row
+        const int r = idx >> 3, c8 = idx & 7;
+        const int p = s0 - 2 + r;
+        const int pc = (r < H3R && p >= 0 && p < T + 2) ? p : 0;
+        const uint4 u = *reinterpret_cast<const uint4*>(hb16 + (int64_t)pc * 64 + c8 * 8);
+        v[q] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int idx = lane + q * 64;  // float4 index: 16 per row
+        const int r = idx >> 4, c4 = idx & 15;
+        const int p = s0 - 2 + r;
+        const int pc = (r < H3R && p >= 0 && p < T + 2) ? p : 0;
+        v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)pc * 64 + c4 * 4);
+      }
     }
   };
   const int tile0 = (int)blockIdx.x * trips * 16 + wave;  // this wave's tiles: tile0, tile0 + 16, ...
@@ -310,16 +327,31 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
 #endif
     TAIL_STAMP(1);
     // ---- ELU + split once per element
+    if constexpr (HB) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int idx = lane + q * 64;
-      const int r = idx >> 4, c4 = idx & 15;
-      if (r < H3R) {
-        uint2 hi, lo;
-        split2_bf16(eluf_(v[q].x), eluf_(v[q].y), hi.x, lo.x);
-        split2_bf16(eluf_(v[q].z), eluf_(v[q].w), hi.y, lo.y);
-        *reinterpret_cast<uint2*>(es + r * EROW + c4 * 8) = hi;
-        if (PASSES == 3) *reinterpret_cast<uint2*>(es + r * EROW + 128 + c4 * 8) = lo;
+      for (int q = 0; q < 3; ++q) {
+        const int idx = lane + q * 64;
+        const int r = idx >> 3, c8 = idx & 7;
+        if (r < H3R) {
+          const unsigned u[4] = {__float_as_uint(v[q].x), __float_as_uint(v[q].y), __float_as_uint(v[q].z), __float_as_uint(v[q].w)};
+          unsigned o[4], lo_;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2_bf16(eluf_(__uint_as_float(u[e] << 16)), eluf_(__uint_as_float(u[e] & 0xffff0000u)), o[e], lo_);
+          *reinterpret_cast<uint4*>(es + r * EROW + c8 * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int idx = lane + q * 64;
+        const int r = idx >> 4, c4 = idx & 15;
+        if (r < H3R) {
+          uint2 hi, lo;
+          split2_bf16(eluf_(v[q].x), eluf_(v[q].y), hi.x, lo.x);
+          split2_bf16(eluf_(v[q].z), eluf_(v[q].w), hi.y, lo.y);
+          *reinterpret_cast<uint2*>(es + r * EROW + c4 * 8) = hi;
+          if (PASSES == 3) *reinterpret_cast<uint2*>(es + r * EROW + 128 + c4 * 8) = lo;
+        }
       }
     }
     tail_wave_sync();
@@ -332,9 +364,12 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int p = s0 + 4 * kq + i;  // padded row of sample s0-2+row
-      const float* hp = hb + (int64_t)((p >= 2 && p < T + 2) ? p : 0) * 64 + col;
+      const int64_t off = (int64_t)((p >= 2 && p < T + 2) ? p : 0) * 64 + col;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) skip[nt][i] = hp[16 * nt];
+      for (int nt = 0; nt < 4; ++nt) {
+        if constexpr (HB) skip[nt][i] = __uint_as_float((unsigned)hb16[off + 16 * nt] << 16);
+        else skip[nt][i] = hb[off + 16 * nt];
+      }
     }
     TAIL_STAMP(3);
 
@@ -486,6 +521,24 @@ extern "C" int sopro_seanet_tail_p_f32(const float* h, int64_t h_seg_stride, con
   else
     hipLaunchKernelGGL(seanet_tail_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, wf, bf, wav,
                        wav_seg_stride, T, 1);
+  SOPRO_LAUNCH_CHECK();
+}
+
+// The tail on bf16 rows (the bf16 mode's activation flow; one pass): h [B][2 + T][64] bf16 (two zero rows in front of each segment),
+// h_seg_stride in bf16 elements; the sixteen-wave kernel at any size.
+extern "C" int sopro_seanet_tail_bf16(const void* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
+                                       int32_t T, void* stream) {
+  SOPRO_CHECK_ARG(h && w1 && b1 && w2 && b2 && wf && wav && B > 0 && T > 0, "bad pointers or sizes");
+  SOPRO_CHECK_ARG(aligned16(h) && aligned16(w1) && aligned16(w2) && aligned16(wf) && (h_seg_stride & 7) == 0, "alignment (h rows in 16-byte pieces)");
+  const int64_t all16 = (int64_t)((T + T3O - 1) / T3O) * B;
+  const int n16 = (int)(((T + T3O - 1) / T3O + 15) / 16);
+  int trips = all16 >= 64 * 4096 ? 32 : (all16 >= 16 * 4096 ? 8 : (all16 >= 1024 ? 2 : 1));
+  if (g_tail_tiles < -1) trips = -g_tail_tiles;
+  auto kern = seanet_tail16_kernel<1, true>;
+  SOPRO_SET_MAX_LDS_ONCE(kern, TAIL3_LDS);
+  hipLaunchKernelGGL(kern, dim3((n16 + trips - 1) / trips, B), dim3(1024), TAIL3_LDS, (hipStream_t)stream, reinterpret_cast<const float*>(h), h_seg_stride, w1, b1,
+                     w2, b2, wf, bf, wav, wav_seg_stride, T, trips);
   SOPRO_LAUNCH_CHECK();
 }
 

@@ -226,6 +226,7 @@ struct G {  // one contraction: mirrors sopro_amd.hip.gemm's keyword arguments
   int epi = SOPRO_EPI_NONE, pro = SOPRO_PRO_NONE, rows_per_seg = -1;
   int64_t a_seg = 0, c_seg = 0, r_seg = 0;
   int c_mode = 0;
+  int a_fmt = 0;  // sopro_gemm_split_ext.a_format (2: bf16 rows - the bf16 mode's SEANet flow)
   float* C2 = nullptr;
   int64_t ldc2 = -1, c2_seg = 0;
   float rms_eps = 0.f;
@@ -275,6 +276,7 @@ int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override
     sopro_gemm_split_ext x;
     memset(&x, 0, sizeof(x));
     x.c_mode = o.c_mode;
+    x.a_format = o.a_fmt;
     x.C2 = o.C2;
     x.ldc2 = o.ldc2 < 0 ? n_out : o.ldc2;
     x.c2_seg_stride = o.c2_seg;
@@ -962,8 +964,17 @@ struct MimiWs {
   float *emb, *q, *X, *y, *qkv, *ao, *hd, *e0, *hraw[8], *hact[8], *y1[8];
   SplitK sk;
 };
+// bf16 mode (round 4): the SEANet decoder's activations - everything from the first convolution's output on - live in memory as
+// bf16 rows (SOPRO_MIMI_BF16=0: fp32 rows with operands rounded in flight, the round-3 form); the transformer stream stays fp32.
+static bool mimi_half(const sopro_engine* e) {
+  static const bool off = getenv("SOPRO_MIMI_BF16") != nullptr && getenv("SOPRO_MIMI_BF16")[0] == '0';
+  return e->c.precision == 1 && !off;
+}
+
 static size_t mimi_carve(const sopro_engine* e, MimiWs& w, void* ws, int B, int T) {
   const sopro_engine_cfg& c = e->c;
+  const bool half = mimi_half(e);
+  auto act = [&](Carver& cv_, size_t n) { return half ? reinterpret_cast<float*>(cv_.take<uint16_t>(n)) : cv_.take<float>(n); };
   const size_t HS = c.mimi_hidden, CD = c.mimi_codebook_dim, N2 = 2 * (size_t)T, PADX = c.mimi_kernel - 1;
   Carver cv(ws);
   w.tok = cv.take<int32_t>((size_t)B * T * c.num_codebooks);
@@ -977,12 +988,12 @@ static size_t mimi_carve(const sopro_engine* e, MimiWs& w, void* ws, int B, int 
   w.ao = cv.take<float>((size_t)B * N2 * HS);
   w.hd = cv.take<float>((size_t)B * N2 * c.mimi_inter);
   size_t ch = (size_t)c.mimi_num_filters << c.mimi_n_ratios, rows = N2;
-  w.e0 = cv.take<float>((size_t)B * (1 + rows) * ch);
+  w.e0 = act(cv, (size_t)B * (1 + rows) * ch);
   for (int si = 0; si < c.mimi_n_ratios; ++si) {
     const size_t co = ch / 2, orow = rows * c.mimi_ratios[si];
-    w.hraw[si] = cv.take<float>((size_t)B * (2 + orow) * co);
-    w.hact[si] = si + 1 < c.mimi_n_ratios ? cv.take<float>((size_t)B * (2 + orow) * co) : nullptr;
-    w.y1[si] = si + 1 < c.mimi_n_ratios ? cv.take<float>((size_t)B * orow * (co / c.mimi_compress)) : nullptr;
+    w.hraw[si] = act(cv, (size_t)B * (2 + orow) * co);
+    w.hact[si] = si + 1 < c.mimi_n_ratios ? act(cv, (size_t)B * (2 + orow) * co) : nullptr;
+    w.y1[si] = si + 1 < c.mimi_n_ratios ? act(cv, (size_t)B * orow * (co / c.mimi_compress)) : nullptr;
     ch = co; rows = orow;
   }
   return cv.off;
@@ -1070,11 +1081,12 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   {
     STG(sopro_fill2d_u32(w.X, (int64_t)(PADX + N2) * HS, B, PADX * HS, 0u, s));
     size_t chz = (size_t)c.mimi_num_filters << c.mimi_n_ratios, rowz = (size_t)N2;
-    STG(sopro_fill2d_u32(w.e0, (int64_t)((1 + rowz) * chz), B, (int)chz, 0u, s));
+    const int wd = mimi_half(e) ? 2 : 1;  // activation elements per 32-bit word
+    STG(sopro_fill2d_u32(w.e0, (int64_t)((1 + rowz) * chz / wd), B, (int)(chz / wd), 0u, s));
     for (int si = 0; si < c.mimi_n_ratios; ++si) {
       const size_t co = chz / 2, orow = rowz * c.mimi_ratios[si];
-      STG(sopro_fill2d_u32(w.hraw[si], (int64_t)((2 + orow) * co), B, (int)(2 * co), 0u, s));
-      if (w.hact[si]) STG(sopro_fill2d_u32(w.hact[si], (int64_t)((2 + orow) * co), B, (int)(2 * co), 0u, s));
+      STG(sopro_fill2d_u32(w.hraw[si], (int64_t)((2 + orow) * co / wd), B, (int)(2 * co / wd), 0u, s));
+      if (w.hact[si]) STG(sopro_fill2d_u32(w.hact[si], (int64_t)((2 + orow) * co / wd), B, (int)(2 * co / wd), 0u, s));
       chz = co; rowz = orow;
     }
   }
@@ -1100,6 +1112,61 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   const int sea_passes = (c.precision == 1 && !three) ? 1 : 3;
   // ---- SEANet decoder (HF:931-961), activated-copy flow of sopro_amd.codec.MimiCodec._seanet_act
   int ch = c.mimi_num_filters << c.mimi_n_ratios, rows = N2, pad_in = 1;
+  if (mimi_half(e)) {
+    // bf16 mode: the same flow with every activation of the decoder as bf16 rows in memory (strides below count bf16 elements):
+    // the first convolution reads the fp32 transformer stream and writes ELU(.) as bf16; every later contraction reads bf16
+    // rows (a_format 2: staged by plain copies) and writes bf16 rows (c_mode 6 raw / 7 activated / 8 both); the fused
+    // kernels of the two 24 kHz-side levels have bf16-row forms.  Accumulation, bias, ELU and the skip additions are fp32.
+    auto HP = [](float* p, size_t n) { return reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(p) + n); };
+    {
+      G g; g.sk = &w.sk; g.M = B * rows; g.N = ch; g.K = c.mimi_kernel * HS; g.lda = HS; g.bias = F(e, "sea.conv0.b"); g.rows_per_seg = rows; g.a_seg = xs;
+      g.c_seg = (int64_t)(1 + rows) * ch; g.ldc = ch; g.c_mode = 7;
+      STG(gemm(s, w.X, WT(e, "sea.conv0.w"), nullptr, HP(w.e0, ch), g));
+    }
+    float* He16 = w.e0;
+    for (int si = 0; si < c.mimi_n_ratios; ++si) {
+      const int r = c.mimi_ratios[si], co = ch / 2, orow = rows * r, hid = co / c.mimi_compress;
+      const bool last = si == c.mimi_n_ratios - 1;
+      const std::string u = "sea.up" + std::to_string(si), rs = "sea.res" + std::to_string(si);
+      float* Ho = w.hraw[si];
+      G up; up.sk = &w.sk; up.M = B * rows; up.N = r * co; up.K = 2 * ch; up.lda = ch; up.bias = F(e, u + ".b"); up.rows_per_seg = rows; up.a_fmt = 2;
+      up.a_seg = (int64_t)(pad_in + rows) * ch; up.c_seg = (int64_t)(2 + orow) * co; up.ldc = (int64_t)r * co;
+      float* A = HP(He16, (size_t)(pad_in - 1) * ch);
+      if (last) {
+        SOPRO_CHECK_ARG(co == 64 && hid == 32, "the fused tail is written for a 64-channel last stage");
+        if (ch == 128 && r == 4) {
+          sopro_prof_scope prof("seanet_up128_kernel", 2.0 * B * rows * 256 * 256, s);
+          STG(sopro_seanet_up128_bf16(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), HP(Ho, 2 * co), up.c_seg, B, rows, s));
+        } else {
+          up.c_mode = 6;
+          STG(gemm(s, A, WT(e, u + ".w"), nullptr, HP(Ho, 2 * co), up));
+        }
+        sopro_prof_scope prof("seanet_tail_kernel", 2.0 * B * orow * (3 * 64 * 32 + 32 * 64 + 3 * 64), s);
+        return sopro_seanet_tail_bf16(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"),
+                                      F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, orow, s);
+      }
+      float* Hn = w.hact[si];
+      if (co == 128 && hid == 64) {
+        up.c_mode = 6;
+        STG(gemm(s, A, WT(e, u + ".w"), nullptr, HP(Ho, 2 * co), up));
+        sopro_prof_scope prof("seanet_res128_kernel", 2.0 * B * orow * (3 * 128 * 64 + 64 * 128), s);
+        STG(sopro_seanet_res128_bf16(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
+                                     (int64_t)(2 + orow) * co, B, orow, s));
+      } else {
+        up.c_mode = 8; up.C2 = HP(Hn, 2 * co); up.ldc2 = (int64_t)r * co; up.c2_seg = (int64_t)(2 + orow) * co;
+        STG(gemm(s, A, WT(e, u + ".w"), nullptr, HP(Ho, 2 * co), up));
+        G c1; c1.sk = &w.sk; c1.M = B * orow; c1.N = hid; c1.K = 3 * co; c1.lda = co; c1.bias = F(e, rs + ".c1.b"); c1.rows_per_seg = orow; c1.a_fmt = 2;
+        c1.a_seg = (int64_t)(2 + orow) * co; c1.c_mode = 7;
+        STG(gemm(s, Hn, WT(e, rs + ".c1.w"), nullptr, w.y1[si], c1));
+        G c2; c2.sk = &w.sk; c2.M = B * orow; c2.N = co; c2.K = hid; c2.bias = F(e, rs + ".c2.b"); c2.epi = SOPRO_EPI_RES; c2.R = HP(Ho, 2 * co); c2.rows_per_seg = orow;
+        c2.a_fmt = 2; c2.c_seg = (int64_t)(2 + orow) * co; c2.r_seg = (int64_t)(2 + orow) * co; c2.ldc = co; c2.ldr = co; c2.c_mode = 7;
+        STG(gemm(s, w.y1[si], WT(e, rs + ".c2.w"), nullptr, HP(Hn, 2 * co), c2));
+      }
+      He16 = Hn; ch = co; rows = orow; pad_in = 2;
+    }
+    sopro_set_error("sopro_mimi_decode: the decoder has no last stage");
+    return -2;
+  }
   {  // first conv k = 7 -> ELU; one zero row in front = x[t-1] of the transposed conv
     G g; g.sk = &w.sk; g.M = B * rows; g.N = ch; g.K = c.mimi_kernel * HS; g.lda = HS; g.bias = F(e, "sea.conv0.b"); g.rows_per_seg = rows; g.a_seg = xs;
     g.c_seg = (int64_t)(1 + rows) * ch; g.ldc = ch; g.c_mode = 3;

@@ -141,6 +141,9 @@ SYMBOLS = {
     "sopro_gemm_set_group_m": (C.c_int, [C.c_int]),
     "sopro_seanet_tail_set_tiles": (C.c_int, [C.c_int]),
     "sopro_seanet_res_set_tiles": (C.c_int, [C.c_int]),
+    "sopro_seanet_res128_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "sopro_seanet_up128_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "sopro_seanet_tail_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _f32, _p, _i64, _i32, _i32, _p]),
     "sopro_seanet_up_set_tiles": (C.c_int, [C.c_int]),
     "sopro_seanet_up128_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_seanet_res128_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
@@ -348,7 +351,10 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     ELU(C) in split form (to C, or to C2 next to the fp32 C): see sopro_gemm_split_ext in include/sopro_hip.h."""
     n_out = N // 2 if epilogue == EPI_GLU else N
     g = GemmArgs()
-    g.A = ptr(A) + 4 * a_off
+    a16 = A.dtype == torch.bfloat16  # bf16 rows (a_format 2 of sopro_gemm_bf16x1): offsets / strides count bf16 elements
+    c16 = c_mode in (6, 7, 8)        # bf16 rows out: Cout / C2 / R are bf16 tensors
+    cdt = torch.bfloat16 if c16 else torch.float32
+    g.A = ptr(A, A.dtype if a16 else torch.float32) + (2 if a16 else 4) * a_off
     g.lda = K if lda is None else lda
     g.a_seg_stride = a_seg_stride
     packed = isinstance(W, PackedW)
@@ -357,10 +363,10 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     g.W = None if packed else ptr(W)
     g.ldw = K if ldw is None else ldw
     g.bias = ptr(bias)
-    g.C = (ptr(Cout) + 4 * c_off) if Cout is not None else None  # None only with c_mode 5 (arg-max partials to C2)
+    g.C = (ptr(Cout, cdt) + (2 if c16 else 4) * c_off) if Cout is not None else None  # None only with c_mode 5 (arg-max partials to C2)
     g.ldc = n_out if ldc is None else ldc
     g.c_seg_stride = c_seg_stride
-    g.R = (ptr(R) + 4 * r_off) if R is not None else None
+    g.R = (ptr(R, cdt) + (2 if c16 else 4) * r_off) if R is not None else None
     g.ldr = (n_out if ldr is None else ldr)
     g.r_seg_stride = r_seg_stride
     g.scale = ptr(scale)
@@ -381,6 +387,8 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
         if ks > 1:
             ws, tk = _splitk_buffers()
             x.ksplit, x.n_tickets, x.ws, x.ws_bytes, x.tickets = ks, int(tk.numel()), ptr(ws), int(ws.numel()) * 4, ptr(tk, torch.int32)
+    if (a16 or c16) and not (packed and W.pieces == 1 and not W.f16):
+        raise SoproHipError("bf16 rows (a_format 2, c_mode 6 / 7 / 8) belong to the one-pass (pieces = 1) path")
     if packed and W.f16:  # two fp16 pieces, three passes: the forms of the six-pass path
         if a_split or c_mode not in (0, 5):
             raise SoproHipError("split-form operands belong to the bf16 three-pass (pieces = 2) path")
@@ -392,7 +400,8 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
         if a_split or c_mode in (1, 2):
             raise SoproHipError("split-form operands belong to the three-pass (pieces = 2) path")
         x.c_mode = c_mode
-        x.C2 = (ptr(C2) + 4 * c2_off) if C2 is not None else None
+        x.a_format = 2 if a16 else 0
+        x.C2 = (ptr(C2, cdt) + (2 if c16 else 4) * c2_off) if C2 is not None else None
         x.ldc2, x.c2_seg_stride = (n_out if ldc2 is None else ldc2), c2_seg_stride
         _check(load().sopro_gemm_bf16x1(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_bf16x1")
     elif packed and W.pieces == 3:
@@ -402,6 +411,8 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
             x.c_mode, x.C2, x.ldc2 = 5, ptr(C2) + 4 * c2_off, (-(-N // 64) if ldc2 is None else ldc2)
         _check(load().sopro_gemm_bf16x6(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_bf16x6")
     elif packed:
+        if a16 or c16:
+            raise SoproHipError("bf16 rows (a_format 2, c_mode 6 / 7 / 8) belong to the one-pass (pieces = 1) path")
         x.a_format, x.c_mode = int(bool(a_split)), c_mode
         x.C2 = (ptr(C2) + 4 * c2_off) if C2 is not None else None
         x.ldc2, x.c2_seg_stride = (n_out if ldc2 is None else ldc2), c2_seg_stride
@@ -727,6 +738,27 @@ def seanet_up128(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torc
                                          passes, _stream()), "sopro_seanet_up128_f32")
 
 
+def seanet_res128_bf16(h: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, out: torch.Tensor, *, B: int,
+                       T: int, h_seg_stride: int, out_seg_stride: int) -> None:
+    """sopro_seanet_res128_bf16: the fused 128-channel residual block on bf16 rows (strides in bf16 elements)."""
+    _check(load().sopro_seanet_res128_bf16(ptr(h, torch.bfloat16), h_seg_stride, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(out, torch.bfloat16),
+                                           out_seg_stride, B, T, _stream()), "sopro_seanet_res128_bf16")
+
+
+def seanet_up128_bf16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, *, B: int, T: int, x_seg_stride: int,
+                      out_seg_stride: int, x_off: int = 0, out_off: int = 0) -> None:
+    """sopro_seanet_up128_bf16: the last transposed convolution on bf16 rows (offsets / strides in bf16 elements)."""
+    _check(load().sopro_seanet_up128_bf16(ptr(x, torch.bfloat16) + 2 * x_off, x_seg_stride, ptr(w), ptr(bias), ptr(out, torch.bfloat16) + 2 * out_off,
+                                          out_seg_stride, B, T, _stream()), "sopro_seanet_up128_bf16")
+
+
+def seanet_tail_bf16(h: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, wf: torch.Tensor,
+                     bf: float, wav: torch.Tensor, *, B: int, T: int, h_seg_stride: int, wav_seg_stride: int) -> None:
+    """sopro_seanet_tail_bf16: the fused 24 kHz tail on bf16 rows (h_seg_stride in bf16 elements)."""
+    _check(load().sopro_seanet_tail_bf16(ptr(h, torch.bfloat16), h_seg_stride, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(wf), bf, ptr(wav),
+                                         wav_seg_stride, B, T, _stream()), "sopro_seanet_tail_bf16")
+
+
 def set_lds_floor(nbytes: int) -> None:
     """Minimum dynamic-LDS request of the split-bf16 GEMM launches (> 80 KiB: one workgroup per CU); see sopro_set_lds_floor."""
     _check(load().sopro_set_lds_floor(int(nbytes)), "sopro_set_lds_floor")
@@ -769,7 +801,12 @@ def cvt_bf16_f32(src: torch.Tensor, dst: torch.Tensor, n: Optional[int] = None) 
 
 
 def set_host_wait(blocking: bool, device=None) -> None:
-    """How host threads wait for ``device`` from now on (sopro_set_host_wait): spin (default) or block on the interrupt."""
+    """How host threads wait for ``device`` (sopro_set_host_wait -> hipSetDeviceFlags): spin (the runtime's default: one busy core
+    per waiting thread) or block on the completion interrupt.  Call it ONCE, AT PROCESS START, before any stream of the device
+    exists (before the engine is built): the runtime creates a queue's completion signals for the wait mode in force when the
+    queue is made, and a blocking wait on a signal made for spinning never wakes up - measured: hipHostFree hung in a
+    process that switched modes after its streams existed (profiles/r04_experiments.md).  A process that runs lanes of a
+    pipeline / a serving loop wants True (r04: 0.083 -> 0.040 CPU-s per 24 ms step at unchanged throughput)."""
     with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
         _check(load().sopro_set_host_wait(1 if blocking else 0), "sopro_set_host_wait")
 

@@ -85,13 +85,10 @@ class PipelinedSynthesizer:
         self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))
         self.ar_cus, self.ar_parts, self.bulk_cus = ar_cus, ar_parts, total - bulk0
         tts.model._driver = self
-        # The lane threads spend most of their time WAITING (AR stop polls one chunk behind the launches, the end of a refinement /
-        # decode phase): with the runtime's default spin wait that is one busy core per lane (r03: 3.6 cores per rank for 4 lanes,
-        # which 8 ranks on one host cannot afford).  Blocking waits free the cores; the polls are a chunk behind the GPU, so the
-        # wake-up latency is off the critical path.  SOPRO_BLOCKING_WAIT=0 keeps the spin wait.
-        self._blocking = os.environ.get("SOPRO_BLOCKING_WAIT", "1") != "0"
-        if self._blocking:
-            hip.set_host_wait(True, self.device)
+        # (The lane threads spend most of their time WAITING - AR stop polls one chunk behind the launches, the end of a refinement /
+        # decode phase.  With the runtime's default spin wait that is one busy core per lane: r03 measured 3.6 cores per rank.  The
+        # remedy is hip.set_host_wait(True) - and it is a PROCESS-level decision that has to be taken before the first stream of
+        # the device exists: see its docstring; bench.py and a serving process take it at start-up.)
 
     def _init_unpartitioned(self, tts, lanes: int, ar_parts: int, bulk_slots: int) -> None:
         """``ar_cus <= 0``: no CU masks.  Every stream may use the whole chip; the long contraction kernels of the throughput
@@ -134,8 +131,6 @@ class PipelinedSynthesizer:
             lane.codec._graphs.clear()
             lane.model.ws.clear()
             lane.codec.ws.clear()
-        if getattr(self, "_blocking", False):
-            hip.set_host_wait(False, self.device)  # single callers (stream(), batch 1) are latency-critical: back to the spin wait
         lane0 = self.lanes[0]
         lane0.model._driver = None
         lane0.model.ar_tiles_wide = None

@@ -50,6 +50,9 @@ def test_eight_ranks_on_the_shared_gpu():
         assert one["parity"]["rank_output_sha16"] == [hashes[r]], r
     cpu = eight["host_cpu_s_per_step_by_rank"]
     assert len(cpu) == 8 and all(0.0 < c for c in cpu)
-    assert max(cpu) < 4.0 * eight["ms_per_step"] * 1e-3 + 0.05  # CPU seconds per step of any rank stay of the order of the step's wall time
+    # CPU seconds per step of any rank stay BELOW the step's wall time: the ranks wait for the device by blocking on its interrupt
+    # (hip.set_host_wait at process start; with the runtime's spin wait every waiting thread is a busy core - r03: 3.6x the wall time)
+    assert eight["host_wait"].startswith("blocking")
+    assert max(cpu) < 1.0 * eight["ms_per_step"] * 1e-3 + 0.02
     assert abs(eight["value"] * eight["ms_per_step"] - 8 * 4 * 24 * 0.08 * 1e3) < 1e-3 * eight["value"] * eight["ms_per_step"]
     assert eight["host_threads"]["torch_intra_op"] == 1

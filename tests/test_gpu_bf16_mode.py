@@ -213,6 +213,212 @@ def test_skinny_glu_bf16_ring_buffer_over_frames(B, dil, w):
                    ring=ring, dw_w=dww, dw_b=dwb, step=step, ring_len=L, ring_bcap=B, dil=dil, ksize=k)
 
 
+# ----------------------------------------------------------------------- round 4: bf16 ROWS in memory (the decoder's activation flow)
+def b16(t):
+    return t.to(torch.bfloat16)
+
+
+def test_gemm_bf16x1_bf16_rows_in_and_out():
+    """sopro_gemm_bf16x1 with a_format 2 (A = bf16 rows, staged by plain copies) and c_mode 6 / 7 / 8 (bf16 rows out, raw /
+    activated / both), EPI_RES with a bf16 skip operand, row windows (the SEANet addressing), fp32 rows in -> bf16 rows out
+    (the first convolution), a ragged M / odd tile counts, and split-K on a few rows (streaming chunks).  Reference: torch on
+    the bf16 values in fp32, rounded to bf16 where the kernel rounds."""
+    M, N, K = 333, 192, 256
+    A, W, b, R = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43), rnd(M, N, seed=44)
+    Wp = hip.pack_w_bf16x1(dev(W))
+    A16, R16 = dev(b16(A)), dev(b16(R))
+    ref = bf(A) @ bf(W).t() + b  # fp32 accumulation of exact products
+    # bf16 in, fp32 out: the same numbers as the fp32-row kernel gives for the rounded values
+    C = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(A16, Wp, C, M=M, N=N, K=K, bias=dev(b))
+    C0 = torch.empty(M, N, device=DEV)
+    hip.gemm(dev(bf(A)), Wp, C0, M=M, N=N, K=K, bias=dev(b))
+    assert torch.equal(C, C0), "bf16 rows must give what the fp32 rows of the same values give (same MFMA operands, same order)"
+    close(C, ref, 5e-5, "bf16 A, fp32 C")
+
+    def near_bf16(got16, want32, what):  # equal up to one rounding step at a boundary
+        g, w_ = got16.float().cpu(), want32.float()
+        tol = w_.abs() * 2.0 ** -7 + 1e-30
+        bad = (g - bf(w_)).abs() > tol
+        assert not bool(bad.any()), f"{what}: {int(bad.sum())} elements off by more than one bf16 step"
+        assert float((g != bf(w_)).float().mean()) < 0.01, f"{what}: too many elements differ from the rounded reference"
+
+    C6 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(A16, Wp, C6, M=M, N=N, K=K, bias=dev(b), c_mode=6)
+    near_bf16(C6, ref, "c_mode 6 (raw bf16)")
+    C7 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(A16, Wp, C7, M=M, N=N, K=K, bias=dev(b), c_mode=7)
+    near_bf16(C7, F.elu(ref), "c_mode 7 (activated bf16)")
+    C8, C8a = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV), torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(A16, Wp, C8, M=M, N=N, K=K, bias=dev(b), c_mode=8, C2=C8a)
+    assert torch.equal(C8, C6) and torch.equal(C8a, C7)
+    # residual form: skip operand in bf16, sum in fp32, ELU, rounded once
+    Cr = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(A16, Wp, Cr, M=M, N=N, K=K, bias=dev(b), epilogue=hip.EPI_RES, R=R16, c_mode=7)
+    near_bf16(Cr, F.elu(bf(R) + ref), "EPI_RES + c_mode 7")
+    # fp32 rows in (the transformer stream), activated bf16 rows out: the first convolution of the decoder
+    Cf = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev(A), Wp, Cf, M=M, N=N, K=K, bias=dev(b), c_mode=7)
+    near_bf16(Cf, F.elu(ref), "fp32 A, c_mode 7")
+    # causal conv through overlapping bf16 row windows with padded segments on both sides
+    B, T, ci, co, k = 2, 150, 64, 96, 3
+    x, w3, b3 = rnd(B, T, ci, seed=51), rnd(co, ci, k, seed=52, scale=(ci * k) ** -0.5), rnd(co, seed=53)
+    refc = F.conv1d(F.pad(bf(x).transpose(1, 2), (k - 1, 0)), bf(w3), b3).transpose(1, 2)
+    buf = torch.zeros(B, k - 1 + T + 3, ci)
+    buf[:, k - 1:k - 1 + T] = x
+    wrow = w3.permute(0, 2, 1).reshape(co, k * ci).contiguous()
+    out = torch.full((B, 2 + T + 1, co), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev(b16(buf)), hip.pack_w_bf16x1(dev(wrow)), out, M=B * T, N=co, K=k * ci, lda=ci, bias=dev(b3), rows_per_seg=T, a_seg_stride=(k - 1 + T + 3) * ci,
+             c_off=2 * co, c_seg_stride=(2 + T + 1) * co, ldc=co, c_mode=6)
+    near_bf16(out[:, 2:2 + T], refc, "bf16 row-window conv")
+    assert bool(torch.isnan(out[:, :2].float()).all()) and bool(torch.isnan(out[:, 2 + T:].float()).all())  # nothing outside its rows
+    # a few rows with a long K: the split-K path (streaming chunks of the decoder)
+    M2, N2, K2 = 12, 512, 2048
+    A2, W2, b2 = rnd(M2, K2, seed=61), rnd(N2, K2, seed=62, scale=K2 ** -0.5), rnd(N2, seed=63)
+    C2o, C2a = torch.full((M2, N2), float("nan"), dtype=torch.bfloat16, device=DEV), torch.full((M2, N2), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev(b16(A2)), hip.pack_w_bf16x1(dev(W2)), C2o, M=M2, N=N2, K=K2, bias=dev(b2), c_mode=8, C2=C2a)
+    r2 = bf(A2) @ bf(W2).t() + b2
+    near_bf16(C2o, r2, "split-K raw")
+    near_bf16(C2a, F.elu(r2), "split-K activated")
+    with pytest.raises(hip.SoproHipError):  # bf16 rows take no activation prologue
+        hip.gemm(A16, Wp, C6, M=M, N=N, K=K, prologue=hip.PRO_ELU, c_mode=6)
+    with pytest.raises(hip.SoproHipError):  # ... and belong to the one-pass path
+        hip.gemm(A16, hip.pack_w_bf16x3(dev(W)), C, M=M, N=N, K=K)
+
+
+def _tail_ref(h16, w1, b1, w2, b2, wf, bf_):
+    """torch model of the bf16-row tail: h bf16 -> ELU -> bf16 -> conv -> +b -> ELU -> bf16 -> conv -> + skip(h) + b -> ELU (fp32) -> last conv."""
+    x = h16.float().transpose(1, 2)
+    y = O.causal_conv1d(bf(F.elu(x)), bf(w1), b1)
+    y = O.causal_conv1d(bf(F.elu(y)), bf(w2), b2)
+    return O.causal_conv1d(F.elu(x + y), wf, torch.tensor([bf_]))[:, 0]
+
+
+@pytest.mark.parametrize("B,T", [(2, 300), (1, 13), (3, 4100)])
+def test_seanet_tail_on_bf16_rows(B, T):
+    h = rnd(B, T, 64, seed=730)
+    w1, b1 = rnd(32, 64, 3, seed=731, scale=0.07), rnd(32, seed=732, scale=0.1)
+    w2, b2 = rnd(64, 32, 1, seed=733, scale=0.17), rnd(64, seed=734, scale=0.1)
+    wf, bf_ = rnd(1, 64, 3, seed=735, scale=0.07), 0.03
+    hb = torch.zeros(B, 2 + T, 64, dtype=torch.bfloat16)
+    hb[:, 2:] = b16(h)
+    ref = _tail_ref(hb[:, 2:], w1, b1, w2, b2, wf, bf_)
+    wav = torch.full((B, T), float("nan"), device=DEV)
+    hip.seanet_tail_bf16(dev(hb), dev(pack.pack_conv1d(w1)), dev(b1), dev(pack.pack_conv1d(w2)), dev(b2), dev(wf[0].t()), bf_, wav,
+                         B=B, T=T, h_seg_stride=(2 + T) * 64, wav_seg_stride=T)
+    # (the intermediate's bf16 rounding can fall on the other side of a boundary than torch's: 2^-8 of one of 32 operands)
+    close(wav, ref, 3e-3 * float(ref.abs().max() + 1.0), "tail on bf16 rows")
+    # and it is a bf16-class approximation of the fp32 layers
+    x = h.transpose(1, 2)
+    y = O.causal_conv1d(F.elu(O.causal_conv1d(F.elu(x), w1, b1)), w2, b2)
+    full = O.causal_conv1d(F.elu(x + y), wf, torch.tensor([bf_]))[:, 0]
+    close(wav, full, 3e-2 * float(full.abs().max() + 1.0), "tail on bf16 rows vs fp32 layers")
+
+
+def test_seanet_res128_on_bf16_rows():
+    B, T = 3, 333
+    h = rnd(B, T, 128, seed=720)
+    w1, b1 = rnd(64, 128, 3, seed=721, scale=0.05), rnd(64, seed=722, scale=0.1)
+    w2, b2 = rnd(128, 64, 1, seed=723, scale=0.12), rnd(128, seed=724, scale=0.1)
+    hb = torch.zeros(B, 2 + T + 5, 128, dtype=torch.bfloat16)
+    hb[:, 2:2 + T] = b16(h)
+    x = hb[:, 2:2 + T].float().transpose(1, 2)
+    y = O.causal_conv1d(bf(F.elu(x)), bf(w1), b1)
+    y = O.causal_conv1d(bf(F.elu(y)), bf(w2), b2)
+    ref = F.elu(x + y).transpose(1, 2)
+    args = [dev(hb)] + [dev(t) for t in (pack.pack_conv1d(w1), b1, pack.pack_conv1d(w2), b2)]
+    lib, outs = hip.load(), []
+    try:
+        for tiles in (0, 1, 4):
+            lib.sopro_seanet_res_set_tiles(tiles)
+            out = torch.full((B, 2 + T + 5, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+            out[:, :2] = 0.0
+            hip.seanet_res128_bf16(*args, out, B=B, T=T, h_seg_stride=(2 + T + 5) * 128, out_seg_stride=(2 + T + 5) * 128)
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        lib.sopro_seanet_res_set_tiles(0)
+    got = outs[0][:, 2:2 + T].float()
+    assert float((got - ref).abs().max()) <= 2.0 ** -6 * float(ref.abs().max()) + 1e-3  # a bf16 step of the result + the intermediate's boundary cases
+    assert float((got - ref).abs().mean()) < 2.0 ** -9 * float(ref.abs().mean() + 1e-3) * 4
+    assert bool(torch.isnan(outs[0][:, 2 + T:].float()).all()) and float(outs[0][:, :2].float().abs().max()) == 0.0
+    for o in outs[1:]:
+        assert torch.equal(o[:, 2:2 + T], outs[0][:, 2:2 + T])
+
+
+def test_seanet_up128_on_bf16_rows_equals_the_tile_kernel():
+    """The weight-stationary transposed convolution on bf16 rows: bit for bit what sopro_gemm_bf16x1 (a_format 2, c_mode 6) gives
+    on the same operands, for any number of tiles per workgroup; and torch's conv_transpose1d on the rounded operands."""
+    B, T, ci, co, r = 3, 333, 128, 64, 4
+    x = rnd(B, T, ci, seed=760)
+    wt, bt = rnd(ci, co, 2 * r, seed=761, scale=0.06), rnd(co, seed=762, scale=0.1)
+    W, bias = pack.pack_convtr1d(wt, bt, r)
+    xs, os_ = (1 + T + 7) * ci, (2 + T * r + 6) * co
+    xb = torch.zeros(B, 1 + T + 7, ci, dtype=torch.bfloat16)
+    xb[:, 1:1 + T] = b16(x)
+    ref = F.conv_transpose1d(xb[:, 1:1 + T].float().transpose(1, 2), bf(wt), bt, stride=r)[..., :T * r].transpose(1, 2)
+    xd, Wd, bd = dev(xb), dev(W), dev(bias)
+    lib, outs = hip.load(), []
+    try:
+        for tiles in (0, 1, 2, 5):
+            lib.sopro_seanet_up_set_tiles(tiles)
+            out = torch.full((B, 2 + T * r + 6, co), float("nan"), dtype=torch.bfloat16, device=DEV)
+            hip.seanet_up128_bf16(xd, Wd, bd, out, B=B, T=T, x_seg_stride=xs, out_seg_stride=os_, out_off=2 * co)
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        lib.sopro_seanet_up_set_tiles(0)
+    got = outs[0][:, 2:2 + T * r]
+    assert float((got.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-4
+    assert bool(torch.isnan(outs[0][:, :2].float()).all()) and bool(torch.isnan(outs[0][:, 2 + T * r:].float()).all())
+    for o in outs[1:]:
+        assert torch.equal(o[:, 2:2 + T * r], got)
+    out2 = torch.full((B, 2 + T * r + 6, co), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(xd, hip.pack_w_bf16x1(Wd), out2, M=B * T, N=r * co, K=2 * ci, lda=ci, bias=bd, rows_per_seg=T, a_seg_stride=xs, c_off=2 * co, c_seg_stride=os_,
+             ldc=r * co, c_mode=6)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.cpu()[:, 2:2 + T * r], got)
+
+
+def test_mimi_decode_bf16_rows_against_the_fp32_rows_form(cfg, mimi_np, mc):
+    """The whole decoder in bf16 mode with bf16 activations in memory against the same mode with fp32 activations (SOPRO_MIMI_BF16=0,
+    the round-3 form: operands rounded in flight) and against the fp32 engine: the new storage must cost little on top of what the
+    mode's one-pass products already cost.  Batch and streaming chunk shapes."""
+    import os
+    import subprocess
+    import sys
+
+    g = golden("full200")
+    from sopro_amd.codec import MimiCodec
+    from sopro_amd.config import MimiDecoderConfig
+
+    codes = torch.from_numpy(g["tokens"].astype(np.int64))[:60]
+    c16 = MimiCodec(mimi_np, MimiDecoderConfig(num_quantizers=32), DEV, precision="bf16")
+    c32 = MimiCodec(mimi_np, MimiDecoderConfig(num_quantizers=32), DEV, precision="f32")
+    w16 = c16.decode_full(codes).float().cpu().reshape(-1)
+    w32 = c32.decode_full(codes).float().cpu().reshape(-1)
+    wb = c16.decode_batch(torch.stack([codes, codes.flip(0), codes]))
+    # (few-row launches take split-K by row count: another summation order in front of the roundings, so a batch row is the lone
+    # run's waveform up to the mode's own rounding noise - measured 7e-3 of peak - not bit for bit)
+    assert float((wb[0].cpu() - w16).abs().max()) <= 2e-2 * float(w32.abs().max())
+    snr = 10.0 * float(torch.log10((w32 ** 2).mean() / ((w16 - w32) ** 2).mean()))
+    # the fp32-rows form of the same mode, in a child process (the switch is read once per process)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+            "from conftest import golden, SEED\nfrom sopro_amd.codec import MimiCodec\nfrom sopro_amd.config import MimiDecoderConfig\n"
+            "from sopro_amd.weights import synth_mimi_weights\nmc = MimiDecoderConfig(num_quantizers=32)\n"
+            "c = MimiCodec(synth_mimi_weights(MimiDecoderConfig(), SEED), mc, 'cuda:0', precision='bf16')\n"
+            "codes = torch.from_numpy(golden('full200')['tokens'].astype(np.int64))[:60]\n"
+            "np.save(sys.argv[1], c.decode_full(codes).float().cpu().numpy())\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                   os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import tempfile
+    path = os.path.join(tempfile.mkdtemp(), "w.npy")
+    subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, SOPRO_MIMI_BF16="0"), timeout=600)
+    wf32rows = torch.from_numpy(np.load(path)).reshape(-1)
+    snr_old = 10.0 * float(torch.log10((w32 ** 2).mean() / ((wf32rows - w32) ** 2).mean()))
+    print(f"\nbf16 mode decoder vs fp32 engine (60 frames): bf16 rows in memory SNR {snr:.1f} dB; fp32 rows (round-3 form) {snr_old:.1f} dB")
+    assert snr > 38.0 and snr > snr_old - 3.0
+
+
 @pytest.fixture(scope="module")
 def tts_bf16(cfg, sopro_np_noeos, mimi_np):
     from sopro_amd import SoproTTS
