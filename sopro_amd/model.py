@@ -450,7 +450,8 @@ class SoproTTSModel:
 
     # ------------------------------------------------------------------ NAR refinement
     @torch.inference_mode()
-    def nar_refine(self, cond_seq: torch.Tensor, tokens_A_1xT: torch.Tensor, lens: Optional[Sequence[int]] = None) -> torch.Tensor:
+    def nar_refine(self, cond_seq: torch.Tensor, tokens_A_1xT: torch.Tensor, lens: Optional[Sequence[int]] = None, *, sync: bool = True,
+                   raw: bool = False) -> torch.Tensor:
         """Codebooks 1..Q-1 from codebook 0: [B, T, D], [B, T] -> [B, T, Q] int64
         (reference: src/sopro/model.py:307-347 and src/sopro/nn/nar.py:89-116; B = 1 there).  The launch sequence is
         ``sopro_nar_refine`` (csrc/stages.hip); this method stages the inputs and records / replays it per (B, T) shape."""
@@ -482,8 +483,10 @@ class SoproTTSModel:
                 self._nar_graphs.run((B, T), issue)
             else:
                 issue()
-            out = toks.view(B, T, Q).long()
-        self.bulk_stream.synchronize()
+            # ``raw`` (a scheduler that decodes on the same stream right away): the engine's own int32 buffer, no widening copy
+            out = toks.view(B, T, Q) if raw else toks.view(B, T, Q).long()
+        if sync:  # (``sync=False``: the caller stays on the bulk stream - e.g. decodes there - and synchronises once, later)
+            self.bulk_stream.synchronize()
         return out
 
     # ------------------------------------------------------------------ text + reference -> tokens
@@ -539,7 +542,7 @@ class SoproTTSModel:
             ev.mark("ar")
         return {"cond_ar": prep["cond_ar"], "hist": hist, "lens": lens, "B": len(ids_list)}
 
-    def phase_nar(self, state, full: bool = False):
+    def phase_nar(self, state, full: bool = False, sync: bool = True, raw: bool = False):
         """Throughput-bound half: NAR refinement of the generated codebook-0 tokens -> one [T_b, Q] matrix per utterance, or with
         ``full`` the whole padded [B, Tn, Q] batch (rows hold valid but meaningless codes past their own length)."""
         lens, hist, B = state["lens"], state["hist"], state["B"]
@@ -551,7 +554,7 @@ class SoproTTSModel:
         # a few frames of padding keep the set of batch shapes (scratch + recorded graphs per shape) small
         Tm = min(-(-Tm // 8) * 8, int(hist.shape[1]), int(state["cond_ar"].shape[1]))
         rvq1 = hist[:, :Tm].clamp(max=self.V - 1)  # rows past their own length are ignored below
-        toks = self.nar_refine(state["cond_ar"][:, :Tm, :], rvq1, lens=[max(1, n) for n in lens])
+        toks = self.nar_refine(state["cond_ar"][:, :Tm, :], rvq1, lens=[max(1, n) for n in lens], sync=sync, raw=raw)
         if full:
             return toks
         return [toks[b, : lens[b]] for b in range(B)]

@@ -173,7 +173,17 @@ class SoproTTS:
             t0 = time.perf_counter()
             if timings is not None:
                 timings["_bulk_t0"] = t0
-            full = self.model.phase_nar(state, full=True)  # [B, Tn, Q]
+            # refinement and decoding are queued back to back on the one stream (no host round trip between them: the partition
+            # does not idle while the host wakes up and issues the decoder); with phase timings on, the host syncs in between
+            same = self.codec.stream is self.model.bulk_stream or self.codec.stream.cuda_stream == self.model.bulk_stream.cuda_stream
+            fused = same
+            evs = None
+            if fused and timings is not None:  # phase times from device events (a host sync between the phases is what fusing removes)
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                evs[0].record(self.model.bulk_stream)
+            full = self.model.phase_nar(state, full=True, sync=not fused, raw=fused)  # [B, Tn, Q]
+            if evs is not None:
+                evs[1].record(self.model.bulk_stream)
             t1 = time.perf_counter()
             lens = [int(n) for n in state["lens"]]
             B, Tn = int(full.shape[0]), int(full.shape[1])
@@ -184,8 +194,14 @@ class SoproTTS:
             codes = full
             wav = self.codec.decode_batch(codes)  # causal decoder: padding frames never reach earlier samples
             if timings is not None:
-                timings["nar"] = timings.get("nar", 0.0) + (t1 - t0)
-                timings["mimi"] = timings.get("mimi", 0.0) + (time.perf_counter() - t1)
+                if evs is not None:
+                    evs[2].record(self.model.bulk_stream)
+                    evs[2].synchronize()
+                    timings["nar"] = timings.get("nar", 0.0) + evs[0].elapsed_time(evs[1]) * 1e-3
+                    timings["mimi"] = timings.get("mimi", 0.0) + evs[1].elapsed_time(evs[2]) * 1e-3
+                else:
+                    timings["nar"] = timings.get("nar", 0.0) + (t1 - t0)
+                    timings["mimi"] = timings.get("mimi", 0.0) + (time.perf_counter() - t1)
                 timings["_bulk_t1"] = time.perf_counter()
         hop = int(self.codec.mc.frame_samples)
         return [wav[b, : lens[b] * hop].reshape(1, 1, -1) for b in range(B)]
