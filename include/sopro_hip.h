@@ -212,6 +212,13 @@ typedef struct sopro_skinny_args {
   int32_t w_layout;       /* 0: W is [N, ldw] row-major; 1: W was laid out by sopro_pack_skinny_w (ldw unused);
                            * 2: bf16 weights from sopro_pack_skinny_w_bf16 (the engine's bf16 mode: activations are rounded to
                            *    bf16 as MFMA operands, v_mfma_f32_16x16x32_bf16 with fp32 accumulation) */
+  /* AUX column tiles (round 4, plain form only; all zero = none): `aux_tiles` (even) more 16-column tiles behind the main ones run the
+   * same input rows against a second operand set (weights in the layout of w_layout, [16 * aux_tiles, K]) and write to aux_Y - the
+   * query projection of the following text cross-attention block rides on the feed-forward launches (see sopro_ar_frame.k_unfold).
+   * aux_flags: bit 0 = no RMSNorm row scale, bit 1 = epilogue NONE (else the launch's epilogue with aux_bias / aux_R). */
+  const float* aux_W; const float* aux_bias; const float* aux_R; float* aux_Y;
+  int64_t aux_ldy, aux_ldr, aux_y_part_stride;
+  int32_t aux_tiles, aux_flags;
   int32_t ring_format;    /* EPI_GLU_DW: 0 = `ring` holds fp32; 1 (with w_layout 2, the engine's bf16 mode) = `ring` points at bf16 elements
                            * [L, ring_bcap, D]: h is rounded once when it is written, the older taps are widened when they are read */
   int32_t mt, nt;         /* workgroup shape: mt 16-row groups of the batch x nt column tiles (0 or 1 = one; 2 = two).  1 x 1 has
@@ -349,6 +356,11 @@ typedef struct sopro_xattn_args {
   float* Y; int64_t y_part_stride;
   float eps, gate, scale;
   int32_t np, B, H, D, S_cap;
+  /* Unfolded keys (round 4): k_unfolded = 1: Kp points at K [B, S_cap, D] (the k projection, head h in columns (D / H) h ..; 4x fewer
+   * bytes than the folded K') and Qp at nqp (1..4) partial sums [B, D] (qp_stride elements apart) of the RAW query Wq' x (RMSNorm_nq's
+   * weight folded into Wq'), which the kernel adds in order and scales by the row scale of x; norm_w must be NULL.  Vp stays folded. */
+  const float* Qp; int64_t qp_stride;
+  int32_t nqp, k_unfolded;
   int32_t kv_format;      /* 0: Kp / Vp hold fp32; 1 (the engine's bf16 mode): they point at bf16 elements, same [B, H, S_cap, D] layout -
                            * half the bytes of the block's dominant stream; scores, softmax and the weighted sum stay fp32 */
 } sopro_xattn_args;
@@ -488,6 +500,10 @@ typedef struct sopro_ar_block {
   int32_t dil, xattn;
   float gate;              /* tanh(gate) of the cross-attention block (text.py:131) */
   int32_t pad_;
+  /* Unfolded keys (sopro_ar_frame.k_unfold, blocks with xattn != 0): kp then holds K [B, S_cap, D] and the block's feed-forward launches
+   * emit the query on aux tiles - qa_w = Wq' [D, D] (q_proj x RMSNorm_nq's weight) rides on FF1, qu_w = Wq' W2 [D, 4 D] (folded in
+   * float64 by the host) and q_b = Wq' b2 [D] on FF2's K-slices; all three in the fragment order / element type of the frame's w_layout. */
+  const void* qa_w; const void* qu_w; const float* q_b;
 } sopro_ar_block;
 typedef struct sopro_ar_frame {
   sopro_ar_block blk[SOPRO_AR_MAX_LAYERS];
@@ -497,11 +513,15 @@ typedef struct sopro_ar_frame {
   float* part;             /* [4, B, D] K-slice partial sums of FF2 */
   float* u;                /* [B, 4D] */
   float* xp;               /* [H, B, D] per-head outputs of a cross-attention block */
+  float* qa;               /* k_unfold: [B, D] the `Wq' out` part of the raw query (FF1's aux tiles) */
+  float* qpart;            /* k_unfold: [4, B, D] K-slice partials of the raw query (FF2's aux tiles; slice 0 carries qa + q_b) */
   float* logits;           /* [B, V1] */
   const int32_t* klens;    /* [B] text lengths */
   int32_t n_layers, B, D, S_cap, V1, H, ksize, w_layout;
   int32_t tile_glu, tile_ff1, tile_ff2, tile_head;
   float eps;
+  int32_t k_unfold;        /* 1: the text cross-attention blocks read UNFOLDED keys (sopro_xattn_args.k_unfolded) and their query rides on the
+                            * feed-forward launches in front of them (sopro_skinny_args aux tiles): 4x fewer key bytes per frame, no extra launch */
   int32_t store_format;    /* 0: ring buffers and folded text operands in fp32; 1 (bf16 mode, needs w_layout 2): both in bf16 - the
                             * frame's state streams at half the bytes; accumulation, norms, softmax, residual stream stay fp32 */
   sopro_ar_state st;
@@ -561,6 +581,10 @@ int sopro_engine_finalize(sopro_engine* e, void* stream);
  * The one place this preparation is written down: sopro_ar_begin and the Python host (batched and slot admission) call it. */
 int sopro_ar_fold_text(const float* txt, const float* nkv_weight, const float* kv_w, const float* q_wT, const float* o_w, float* nkv, float* kvd,
                        float* kp, float* vp, int32_t B, int32_t S, int32_t S_cap, int32_t D, int32_t H, float eps, void* stream);
+/* The same for a frame with UNFOLDED keys (sopro_ar_frame.k_unfold): kq [B, S_cap, D] = k_proj(RMSNorm_nkv(txt)) as it is (head h in columns
+ * (D / H) h ..), vp [B, H, S_cap, D] folded as above; no q_wT (the query projection rides on the frame's feed-forward launches). */
+int sopro_ar_fold_text_uk(const float* txt, const float* nkv_weight, const float* kv_w, const float* o_w, float* nkv, float* kvd, float* kq, float* vp,
+                          int32_t B, int32_t S, int32_t S_cap, int32_t D, int32_t H, float eps, void* stream);
 int sopro_engine_destroy(sopro_engine* e);
 /* workgroup shapes of the AR-step stage kinds, (mt << 4) | nt each (see sopro_skinny_args; 0 = 1 x 1).  Drops a recorded frame graph. */
 int sopro_engine_set_ar_tiles(sopro_engine* e, int32_t glu, int32_t ff1, int32_t ff2, int32_t head);

@@ -23,6 +23,7 @@ extern "C" int sopro_ar_issue_frame(const sopro_ar_frame* fp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int B = f.B, D = f.D, H = f.H, KSL = 4 * D / 384;  // FF2 K slices
   const int64_t BD = (int64_t)B * D;
+  SOPRO_CHECK_ARG(f.k_unfold == 0 || (f.k_unfold == 1 && f.qa && f.qpart), "k_unfold needs the qa / qpart buffers");
   // Residual stream = a base buffer plus (optionally) three pending partial buffers that the next kernel adds while it stages
   // its input: the K-slices of a feed-forward output (slice 0 carries bias + residual) or the per-head outputs of a
   // cross-attention block (head 0 carries the residual).
@@ -49,6 +50,11 @@ extern "C" int sopro_ar_issue_frame(const sopro_ar_frame* fp, void* stream) {
     a.X = out; a.ldx = D; a.W = (const float*)b.ff1_w; a.ldw = D; a.w_layout = f.w_layout; a.bias = b.ff1_b;
     a.Y = f.u; a.ldy = 4 * D; a.ldr = 4 * D; a.eps = f.eps; a.B = B; a.N = 4 * D; a.K = D; a.epilogue = SOPRO_EPI_GELU; a.rms_norm = 1;
     a.mt = f.tile_ff1 >> 4; a.nt = f.tile_ff1 & 15;
+    const bool uk = b.xattn && f.k_unfold;
+    if (uk) {  // the `Wq' out` part of the following cross-attention block's raw query: D more columns on the rows FF1 stages anyway
+      SOPRO_CHECK_ARG(b.qa_w && b.qu_w && b.q_b, "k_unfold: block without its query operands");
+      a.aux_tiles = D / 16; a.aux_W = (const float*)b.qa_w; a.aux_Y = f.qa; a.aux_ldy = D; a.aux_flags = 3;  // no row scale, no GELU, no bias
+    }
     FRM(sopro_skinny_f32(&a, s));
     // Linear 4D -> D + residual as K-slices on 4x the workgroups (blocks.py:161-162)
     memset(&a, 0, sizeof(a));
@@ -56,6 +62,10 @@ extern "C" int sopro_ar_issue_frame(const sopro_ar_frame* fp, void* stream) {
     a.Y = f.part; a.ldy = D; a.R = out; a.ldr = D; a.eps = f.eps; a.B = B; a.N = D; a.K = 4 * D; a.epilogue = SOPRO_EPI_RES;
     a.ksplit = 1; a.y_part_stride = BD;
     a.mt = f.tile_ff2 >> 4; a.nt = f.tile_ff2 & 15;
+    if (uk) {  // ... and its `(Wq' W2) u + Wq' b2` part as K-slices, slice 0 carrying qa: q_raw = Wq' (out + b2 + W2 u) = Wq' x
+      a.aux_tiles = D / 16; a.aux_W = (const float*)b.qu_w; a.aux_bias = b.q_b; a.aux_R = f.qa; a.aux_ldr = D; a.aux_Y = f.qpart; a.aux_ldy = D;
+      a.aux_y_part_stride = BD;
+    }
     FRM(sopro_skinny_f32(&a, s));
     SOPRO_CHECK_ARG(KSL == 4, "the partial-sum hand-over is written for four K slices");
     base = f.part; pend = f.part + BD;
@@ -68,6 +78,7 @@ extern "C" int sopro_ar_issue_frame(const sopro_ar_frame* fp, void* stream) {
       x.Kp = b.kp; x.Vp = b.vp; x.klens = f.klens; x.Y = f.xp; x.y_part_stride = BD;
       x.eps = f.eps; x.gate = b.gate; x.scale = 1.0f / sqrtf((float)(D / H));
       x.B = B; x.H = H; x.D = D; x.S_cap = f.S_cap; x.kv_format = f.store_format;
+      if (uk) { x.k_unfolded = 1; x.Qp = f.qpart; x.qp_stride = BD; x.nqp = KSL; }
       FRM(sopro_xattn_step_f32(&x, s));
       base = f.xp; pend = f.xp + BD;
     }

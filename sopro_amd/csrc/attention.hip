@@ -354,7 +354,11 @@ __device__ __forceinline__ uint2 ld_stream_u2(const void* p) {
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }          // element 0 of a packed pair
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }  // element 1
 
-template <bool NT, bool HB>
+// UK (round 4): UNFOLDED keys.  Kp then points at K [B, S_cap, D] (the k projection itself, head h in columns 96 h ..: 4x fewer
+// bytes than the folded K'_h [S_cap, D] per head) and the query comes from the feed-forward launches in front of this block
+// (sopro_skinny_args aux tiles): Qp = the K-slice partials of q_raw = Wq' x, summed here in slice order and scaled by the
+// RMSNorm row scale of x.  V' stays folded (its output projection has no launch to ride on).
+template <bool NT, bool HB, bool UK>
 __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args a) {
   __shared__ float xsum[XD];
   __shared__ float xn[XD];
@@ -366,12 +370,15 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
   const int h = blockIdx.x, b = blockIdx.y;
   const int klen = a.klens ? min(a.klens[b], a.S_cap) : a.S_cap;
   constexpr int ES = HB ? 2 : 4;  // bytes per stored element
-  const char* Kb = reinterpret_cast<const char*>(a.Kp) + ((int64_t)(b * a.H + h) * a.S_cap) * XD * ES;
+  constexpr int XDH = 96;  // head width of the unfolded keys (D / H)
+  const char* Kb = UK ? reinterpret_cast<const char*>(a.Kp) + (((int64_t)b * a.S_cap) * XD + h * XDH) * ES
+                      : reinterpret_cast<const char*>(a.Kp) + ((int64_t)(b * a.H + h) * a.S_cap) * XD * ES;
   const char* Vb = reinterpret_cast<const char*>(a.Vp) + ((int64_t)(b * a.H + h) * a.S_cap) * XD * ES;
   const int key = tid >> 3, part = tid & 7;   // score mapping: 8 lanes share a key; 16-byte piece f*8+part of its row each, so that one
                                               // load instruction covers whole 128-byte lines (8 per wave instead of 64)
   const int vd4 = tid % 96, vg = tid / 96;    // P.V' mapping: 4-column group, 16-key group (vg < 4)
-  constexpr int KF = HB ? 6 : 12;             // 16-byte pieces per lane of a K' row (768 / 1536 bytes over 8 lanes)
+  constexpr int KF = UK ? 3 : (HB ? 6 : 12);  // pieces per lane of a key row: 16-byte pieces of a K' row (768 / 1536 bytes over 8 lanes);
+                                              // UK: 3 pieces of 4 elements (16 bytes fp32 / 8 bytes bf16) of the head's 96
 
   float m_run = -INFINITY, l_run = 0.f;
   float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -384,7 +391,11 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
 #pragma unroll
     for (int f = 0; f < KF; ++f) {
       kreg[f] = make_uint4(0u, 0u, 0u, 0u);
-      if (kin) kreg[f] = ld_stream_u4<NT>(Kb + ((int64_t)(k0 + key) * XD) * ES + (f * 8 + part) * 16);
+      if constexpr (UK && HB) {
+        if (kin) { const uint2 u = ld_stream_u2<NT>(Kb + ((int64_t)(k0 + key) * XD) * ES + (f * 8 + part) * 8); kreg[f].x = u.x; kreg[f].y = u.y; }
+      } else {
+        if (kin) kreg[f] = ld_stream_u4<NT>(Kb + ((int64_t)(k0 + key) * XD) * ES + (f * 8 + part) * 16);
+      }
     }
     if constexpr (HB) {
 #pragma unroll
@@ -426,13 +437,34 @@ __global__ __launch_bounds__(512) void xattn_step_kernel(const sopro_xattn_args 
         if (a.norm_w) nw = *reinterpret_cast<const float4*>(a.norm_w + tid * 4);
         float4 y;
         y.x = (xv.x * rstd) * nw.x; y.y = (xv.y * rstd) * nw.y; y.z = (xv.z * rstd) * nw.z; y.w = (xv.w * rstd) * nw.w;
-        *reinterpret_cast<float4*>(xn + tid * 4) = y;
+        if constexpr (!UK) *reinterpret_cast<float4*>(xn + tid * 4) = y;
+      }
+      if constexpr (UK) {  // this head's query: the slices of q_raw in slice order, times the row scale  (xn[0 .. 95])
+        if (tid < XDH / 4) {
+          const float* qp = a.Qp + (int64_t)b * XD + h * XDH + tid * 4;
+          float4 q = *reinterpret_cast<const float4*>(qp);
+#pragma unroll
+          for (int s = 1; s < 4; ++s)
+            if (s < a.nqp) {
+              const float4 t = *reinterpret_cast<const float4*>(qp + (int64_t)s * a.qp_stride);
+              q.x += t.x; q.y += t.y; q.z += t.z; q.w += t.w;
+            }
+          q.x *= rstd; q.y *= rstd; q.z *= rstd; q.w *= rstd;
+          *reinterpret_cast<float4*>(xn + tid * 4) = q;
+        }
       }
       __syncthreads();
     }
     // ---- scores of this tile
     float s = 0.f;
-    if constexpr (HB) {
+    if constexpr (UK) {
+#pragma unroll
+      for (int f = 0; f < KF; ++f) {  // elements 4 * (f*8+part) .. + 3 of the head's 96
+        const float4 q4 = *reinterpret_cast<const float4*>(xn + (f * 8 + part) * 4);
+        if constexpr (HB) s += q4.x * bf_lo(kreg[f].x) + q4.y * bf_hi(kreg[f].x) + q4.z * bf_lo(kreg[f].y) + q4.w * bf_hi(kreg[f].y);
+        else s += q4.x * __uint_as_float(kreg[f].x) + q4.y * __uint_as_float(kreg[f].y) + q4.z * __uint_as_float(kreg[f].z) + q4.w * __uint_as_float(kreg[f].w);
+      }
+    } else if constexpr (HB) {
 #pragma unroll
       for (int f = 0; f < KF; ++f) {  // piece f*8+part of the row = elements 8 * (f*8+part) .. + 7
         const float4 q0 = *reinterpret_cast<const float4*>(xn + (f * 8 + part) * 8), q1 = *reinterpret_cast<const float4*>(xn + (f * 8 + part) * 8 + 4);
@@ -520,16 +552,20 @@ extern "C" int sopro_xattn_step_f32(const sopro_xattn_args* p, void* stream) {
   // only where the operands cannot stay cached from one frame to the next anyway (> 8 MB per layer: the eight L2s hold 32 MB
   // for three layers); a single utterance's 0.8 MB per layer is L2-resident across frames and is asked for normally
   SOPRO_CHECK_ARG(a.kv_format == 0 || a.kv_format == 1, "kv_format: 0 (fp32 Kp / Vp) or 1 (bf16)");
-  const bool hb = a.kv_format == 1;
+  SOPRO_CHECK_ARG(a.k_unfolded == 0 || (a.k_unfolded == 1 && a.H * 96 == XD && a.Qp && aligned16(a.Qp) && a.nqp >= 1 && a.nqp <= 4 && (a.qp_stride & 3) == 0 && !a.norm_w),
+                  "k_unfolded: Kp = K [B, S_cap, D] with 96-wide heads, Qp = 1..4 K-slice partials of the raw query (norm weight folded into it)");
+  const bool hb = a.kv_format == 1, uk = a.k_unfolded == 1;
   const bool nt = nt_on && (int64_t)a.B * a.H * a.S_cap * XD * (hb ? 4 : 8) > ((int64_t)8 << 20);
   const dim3 grid(a.H, a.B), blk(512);
   hipStream_t st = (hipStream_t)stream;
-  if (hb) {
-    if (nt) hipLaunchKernelGGL((xattn_step_kernel<true, true>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((xattn_step_kernel<false, true>), grid, blk, 0, st, a);
+#define SOPRO_XL(NTv, HBv, UKv) hipLaunchKernelGGL((xattn_step_kernel<NTv, HBv, UKv>), grid, blk, 0, st, a)
+  if (uk) {
+    if (hb) { if (nt) SOPRO_XL(true, true, true); else SOPRO_XL(false, true, true); }
+    else { if (nt) SOPRO_XL(true, false, true); else SOPRO_XL(false, false, true); }
   } else {
-    if (nt) hipLaunchKernelGGL((xattn_step_kernel<true, false>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((xattn_step_kernel<false, false>), grid, blk, 0, st, a);
+    if (hb) { if (nt) SOPRO_XL(true, true, false); else SOPRO_XL(false, true, false); }
+    else { if (nt) SOPRO_XL(true, false, false); else SOPRO_XL(false, false, false); }
   }
+#undef SOPRO_XL
   SOPRO_LAUNCH_CHECK();
 }

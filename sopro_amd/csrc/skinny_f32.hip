@@ -59,11 +59,26 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
   __shared__ float rstd_s[16 * MT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int tile0 = blockIdx.x * NT;
+  // AUX column tiles (round 4; plain form only): the workgroups behind the main ones run the SAME input rows against a second
+  // weight / bias / residual / output set - the query projection of the following cross-attention block, emitted by the
+  // feed-forward launches that already stage its operands (q = Wq' x is linear in x = out + b2 + W2 u: the `Wq' out` columns ride
+  // on FF1, the `(Wq' W2) u` columns on FF2's K-slices) - so the cached keys stay UNFOLDED ([S, 96] per head instead of the
+  // folded [S, 384]) without an extra launch.  aux_flags bit 0: no RMSNorm row scale; bit 1: epilogue NONE.
+  const int main_x = (int)gridDim.x - a.aux_tiles / NT;
+  const bool aux = !GLU && a.aux_tiles > 0 && (int)blockIdx.x >= main_x;
+  const float* const W_ = aux ? a.aux_W : a.W;
+  const float* const bias_ = aux ? a.aux_bias : a.bias;
+  const float* const R_ = aux ? a.aux_R : a.R;
+  float* const Y_ = aux ? a.aux_Y : a.Y;
+  const int N_ = aux ? a.aux_tiles * 16 : a.N;
+  const int64_t ldy_ = aux ? a.aux_ldy : a.ldy, ldr_ = aux ? a.aux_ldr : a.ldr, yps_ = aux ? a.aux_y_part_stride : a.y_part_stride;
+  const bool norm_ = NORM && !(aux && (a.aux_flags & 1));
+  const int epi_ = (aux && (a.aux_flags & 2)) ? SOPRO_EPI_NONE : a.epilogue;
+  const int tile0 = (aux ? (int)blockIdx.x - main_x : (int)blockIdx.x) * NT;
   const int bbase = blockIdx.z * 16 * MT;
   const int nslices = a.K / KS;
   const bool partial_out = gridDim.y > 1;
-  const int D = a.N / 2;  // GLU tail only
+  const int D = a.N / 2;  // GLU tail only (no aux tiles there: N_ == a.N)
   long long* dbg = a.dbg ? a.dbg + ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 : nullptr;
   if (dbg && tid == 0) dbg[0] = clock64();
 
@@ -73,8 +88,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
 
   // Columns owned by this lane.  Plain: 16 output columns per tile.  GLU tail: 8 channels per tile, lanes 0-7 carry the
   // value rows and lanes 8-15 the gate rows of the same channels (one B operand, paired by a shuffle).
-  const int ncols = GLU ? D : a.N;
-  const int ntiles = GLU ? (D + 7) / 8 : (a.N + 15) / 16;
+  const int ncols = GLU ? D : N_;
+  const int ntiles = GLU ? (D + 7) / 8 : (N_ + 15) / 16;
   int n_col[NT], n_ld[NT], w_row[NT];
   bool col_ok[NT];
 #pragma unroll
@@ -85,8 +100,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
     n_ld[nt] = min(n_col[nt], ncols - 1);  // clamped: loads stay in bounds, results are discarded
     w_row[nt] = GLU ? ((i < 8) ? n_ld[nt] : D + n_ld[nt]) : n_ld[nt];
   }
-  const bool res_here = a.epilogue == SOPRO_EPI_RES && (!partial_out || blockIdx.y == 0);
-  const bool bias_here = !partial_out || (blockIdx.y == 0 && a.epilogue == SOPRO_EPI_RES);
+  const bool res_here = epi_ == SOPRO_EPI_RES && (!partial_out || blockIdx.y == 0);
+  const bool bias_here = !partial_out || (blockIdx.y == 0 && epi_ == SOPRO_EPI_RES);
 
   // ---- epilogue operands: wave w finishes accumulator row r == w, i.e. batch row bbase + mt*16 + (lane>>4)*4 + w, column lane&15
   int b_row[MT], b_cl[MT];
@@ -99,11 +114,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
   float tapw[NT][MAXTAPS];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    e_bias[nt] = (a.bias && bias_here) ? a.bias[w_row[nt]] : 0.f;
+    e_bias[nt] = (bias_ && bias_here) ? bias_[w_row[nt]] : 0.f;
     e_scale[nt] = a.scale ? a.scale[n_ld[nt]] : 1.f;
     e_dwb[nt] = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) e_res[mt][nt] = res_here ? a.R[(int64_t)b_cl[mt] * a.ldr + n_ld[nt]] : 0.f;
+    for (int mt = 0; mt < MT; ++mt) e_res[mt][nt] = res_here ? R_[(int64_t)b_cl[mt] * ldr_ + n_ld[nt]] : 0.f;
     if (GLU) {
       e_dwb[nt] = a.dw_b[n_ld[nt]];
 #pragma unroll
@@ -123,8 +138,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int tile_ld = min(tile0 + nt, ntiles - 1);
-    wbase[nt] = packed ? a.W + ((int64_t)tile_ld * kchunks * 2) * 256 + lane * 4 : a.W + (int64_t)w_row[nt] * a.ldw + g * 8;
-    wbase16[nt] = reinterpret_cast<const uint4*>(a.W) + (int64_t)tile_ld * kchunks * 64 + lane;  // WB: [tile][chunk][lane] x 16 B
+    wbase[nt] = packed ? W_ + ((int64_t)tile_ld * kchunks * 2) * 256 + lane * 4 : W_ + (int64_t)w_row[nt] * a.ldw + g * 8;
+    wbase16[nt] = reinterpret_cast<const uint4*>(W_) + (int64_t)tile_ld * kchunks * 64 + lane;  // WB: [tile][chunk][lane] x 16 B
   }
   const int64_t w_chunk = packed ? 512 : 32, w_half = packed ? 256 : 4;
   f32x4 acc[MT][NT];
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
       for (int r = 0; r < 4; ++r) red[(((mt * NT + nt) * 4 + wave) * 4 + r) * 64 + lane] = acc[mt][nt][r];
   __syncthreads();
   if (dbg && tid == 0) dbg[4] = clock64();
-  const int epi = a.epilogue;
+  const int epi = epi_;
   const unsigned L = (unsigned)a.ring_len;
   const unsigned slot_now = slot0 == 0 ? L - 1 : slot0 - 1;  // t mod L (GLU only)
 #pragma unroll
@@ -272,17 +287,17 @@ __global__ __launch_bounds__(256) void skinny_kernel(const sopro_skinny_args a) 
     for (int nt = 0; nt < NT; ++nt) {
       const float* rp = red + ((mt * NT + nt) * 16 + wave) * 64 + lane;
       float v = ((rp[0 * 256] + rp[1 * 256]) + rp[2 * 256]) + rp[3 * 256];
-      if (NORM) v *= rstd_s[mt * 16 + g * 4 + wave];  // RMSNorm row scale (its weight is folded into W)
+      if (NORM && norm_) v *= rstd_s[mt * 16 + g * 4 + wave];  // RMSNorm row scale (its weight is folded into W)
       const bool ok = col_ok[nt] && b_row[mt] < a.B;
       if (!GLU) {
-        float* yp = partial_out ? a.Y + (int64_t)blockIdx.y * a.y_part_stride : a.Y;
+        float* yp = partial_out ? Y_ + (int64_t)blockIdx.y * yps_ : Y_;
         float y = v + e_bias[nt];
         if (!partial_out) {
           if (epi == SOPRO_EPI_GELU) y = gelu_erf(y);
           else if (epi == SOPRO_EPI_TANH) y = tanhf(y);
         }
         if (res_here) y = fmaf(e_scale[nt], y, e_res[mt][nt]);  // (explicit: every workgroup shape must round alike)
-        if (ok) yp[(int64_t)b_row[mt] * a.ldy + n_col[nt]] = y;
+        if (ok) yp[(int64_t)b_row[mt] * ldy_ + n_col[nt]] = y;
       } else {
         const float pre = v + e_bias[nt];                // lanes 0-7: value, lanes 8-15: gate pre-activation
         const float gate = __shfl_xor(pre, 8, 64);
@@ -377,7 +392,7 @@ int launch_t(const sopro_skinny_args& a, dim3 grid, hipStream_t s) {
 template <bool GLU, int NP, bool NORM>
 int launch(const sopro_skinny_args& a, int ntiles, int gy, hipStream_t s) {
   const int mt = a.mt == 2 ? 2 : 1, nt = a.nt == 2 ? 2 : 1;
-  dim3 grid((ntiles + nt - 1) / nt, gy, (a.B + 16 * mt - 1) / (16 * mt));
+  dim3 grid((ntiles + nt - 1) / nt + a.aux_tiles / nt, gy, (a.B + 16 * mt - 1) / (16 * mt));
   if (mt == 2 && nt == 2) return launch_t<GLU, NP, NORM, 2, 2>(a, grid, s);
   if (mt == 2) return launch_t<GLU, NP, NORM, 2, 1>(a, grid, s);
   if (nt == 2) return launch_t<GLU, NP, NORM, 1, 2>(a, grid, s);
@@ -439,6 +454,11 @@ extern "C" int sopro_skinny_f32(const sopro_skinny_args* p, void* stream) {
   SOPRO_CHECK_ARG(gy == 1 || a.epilogue == SOPRO_EPI_NONE || a.epilogue == SOPRO_EPI_RES,
                   "K-split output takes EPI_NONE or EPI_RES (slice 0 then carries bias + residual; the consumer sums the slices)");
   SOPRO_CHECK_ARG(a.mt >= 0 && a.mt <= 2 && a.nt >= 0 && a.nt <= 2, "mt / nt must be 0 (= 1), 1 or 2");
+  if (a.aux_tiles != 0) {
+    SOPRO_CHECK_ARG(a.aux_tiles > 0 && (a.aux_tiles & 1) == 0 && !dw && a.w_layout != 0 && (a.N & 31) == 0,
+                    "aux tiles: an even count, plain form, fragment-ordered weights, N a multiple of 32 (whole main tiles)");
+    SOPRO_CHECK_ARG(a.aux_W && a.aux_Y && aligned16(a.aux_W) && ((a.aux_flags & 2) || a.epilogue != SOPRO_EPI_RES || a.aux_R), "aux tiles: aux_W, aux_Y (and aux_R for EPI_RES)");
+  }
   const int ntiles = dw ? (a.N / 2 + 7) / 8 : (a.N + 15) / 16;
   const bool np3 = a.np == 3, nrm = a.rms_norm != 0;
   if (dw) return np3 ? launch<true, 3, true>(a, ntiles, gy, s) : launch<true, 0, true>(a, ntiles, gy, s);

@@ -563,6 +563,31 @@ int sopro_ar_fold_text(const float* txt, const float* nkv_weight, const float* k
   return 0;
 }
 
+// The same for UNFOLDED keys (sopro_ar_frame.k_unfold): kq [B, S_cap, D] = the k projection itself (head h in columns (D / H) h ..),
+// vp [B, H, S_cap, D] folded as above.  The query projection then rides on the frame's feed-forward launches.
+int sopro_ar_fold_text_uk(const float* txt, const float* nkv_weight, const float* kv_w, const float* o_w, float* nkv, float* kvd, float* kq, float* vp,
+                          int32_t B, int32_t S, int32_t S_cap, int32_t D, int32_t H, float eps, void* stream) {
+  SOPRO_CHECK_ARG(txt && nkv_weight && kv_w && o_w && nkv && kvd && kq && vp, "NULL pointer");
+  SOPRO_CHECK_ARG(B > 0 && S > 0 && S_cap >= S && D > 0 && H > 0 && D % H == 0, "bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const int dh = D / H;
+  STG(norm(s, txt, nkv, nkv_weight, B * S, D, eps));
+  G o; o.M = B * S; o.N = 2 * D; o.K = D;
+  Wt kv; kv.f32 = kv_w;
+  STG(gemm(s, nkv, kv, nullptr, kvd, o));
+  if (S == S_cap) {
+    STG(sopro_copy2d_u32(kq, D, kvd, 2 * D, B * S, D, s));
+  } else {
+    for (int b = 0; b < B; ++b) STG(sopro_copy2d_u32(kq + (size_t)b * S_cap * D, D, kvd + (size_t)b * S * 2 * D, 2 * D, S, D, s));
+  }
+  for (int h = 0; h < H; ++h) {
+    G f; f.M = B * S; f.N = D; f.K = dh; f.lda = 2 * D; f.rows_per_seg = S; f.ldc = D; f.c_seg = (int64_t)H * S_cap * D; f.ldw = D;
+    Wt none;
+    STG(gemm(s, kvd + D + h * dh, none, o_w + h * dh, vp + (size_t)h * S_cap * D, f));
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ conditioning stage
 static int ssm_block_bufs(sopro_engine* e, hipStream_t s, float* h, float* x1, float* u, const SplitK* sk, const float* x, float* out,
                           const std::string& p, int B, int T, int ksize, int dil, const int32_t* lens);  // (with the NAR stage below)

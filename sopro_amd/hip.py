@@ -47,7 +47,9 @@ class SkinnyArgs(C.Structure):
                 ("Xp", _p), ("xp_stride", _i64), ("y_part_stride", _i64), ("dbg", _p), ("eps", _f32),
                 ("B", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32),
                 ("ring_len", _i32), ("ring_bcap", _i32), ("dil", _i32), ("ksize", _i32),
-                ("np", _i32), ("ksplit", _i32), ("rms_norm", _i32), ("w_layout", _i32), ("ring_format", _i32), ("mt", _i32), ("nt", _i32)]
+                ("np", _i32), ("ksplit", _i32), ("rms_norm", _i32), ("w_layout", _i32),
+                ("aux_W", _p), ("aux_bias", _p), ("aux_R", _p), ("aux_Y", _p), ("aux_ldy", _i64), ("aux_ldr", _i64), ("aux_y_part_stride", _i64),
+                ("aux_tiles", _i32), ("aux_flags", _i32), ("ring_format", _i32), ("mt", _i32), ("nt", _i32)]
 
 
 class AttnArgs(C.Structure):
@@ -60,7 +62,8 @@ class AttnArgs(C.Structure):
 class XattnArgs(C.Structure):
     _fields_ = [("X", _p), ("ldx", _i64), ("Xp", _p), ("xp_stride", _i64), ("norm_w", _p), ("Kp", _p), ("Vp", _p), ("klens", _p),
                 ("Y", _p), ("y_part_stride", _i64), ("eps", _f32), ("gate", _f32), ("scale", _f32),
-                ("np", _i32), ("B", _i32), ("H", _i32), ("D", _i32), ("S_cap", _i32), ("kv_format", _i32)]
+                ("np", _i32), ("B", _i32), ("H", _i32), ("D", _i32), ("S_cap", _i32),
+                ("Qp", _p), ("qp_stride", _i64), ("nqp", _i32), ("k_unfolded", _i32), ("kv_format", _i32)]
 
 
 class ArState(C.Structure):
@@ -76,15 +79,16 @@ AR_MAX_LAYERS = 16
 class ArBlock(C.Structure):
     """sopro_ar_block"""
     _fields_ = [("glu_w", _p), ("glu_b", _p), ("dw_w", _p), ("dw_b", _p), ("ff1_w", _p), ("ff1_b", _p), ("ff2_w", _p), ("ff2_b", _p),
-                ("ring", _p), ("kp", _p), ("vp", _p), ("dil", _i32), ("xattn", _i32), ("gate", _f32), ("pad_", _i32)]
+                ("ring", _p), ("kp", _p), ("vp", _p), ("dil", _i32), ("xattn", _i32), ("gate", _f32), ("pad_", _i32),
+                ("qa_w", _p), ("qu_w", _p), ("q_b", _p)]
 
 
 class ArFrame(C.Structure):
     """sopro_ar_frame: the buffers of one autoregressive frame (the launch sequence itself is sopro_ar_issue_frame)."""
     _fields_ = [("blk", ArBlock * AR_MAX_LAYERS), ("head_w", _p), ("head_b", _p), ("x0", _p), ("xa", _p), ("xb", _p), ("part", _p),
-                ("u", _p), ("xp", _p), ("logits", _p), ("klens", _p),
+                ("u", _p), ("xp", _p), ("qa", _p), ("qpart", _p), ("logits", _p), ("klens", _p),
                 ("n_layers", _i32), ("B", _i32), ("D", _i32), ("S_cap", _i32), ("V1", _i32), ("H", _i32), ("ksize", _i32), ("w_layout", _i32),
-                ("tile_glu", _i32), ("tile_ff1", _i32), ("tile_ff2", _i32), ("tile_head", _i32), ("eps", _f32), ("store_format", _i32),
+                ("tile_glu", _i32), ("tile_ff1", _i32), ("tile_ff2", _i32), ("tile_head", _i32), ("eps", _f32), ("k_unfold", _i32), ("store_format", _i32),
                 ("st", ArState)]
 
 
@@ -197,6 +201,7 @@ SYMBOLS = {
     "sopro_ar_admit": (C.c_int, [C.POINTER(ArState), _i32, _p]),
     "sopro_ar_issue_frame": (C.c_int, [C.POINTER(ArFrame), _p]),
     "sopro_ar_fold_text": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p]),
+    "sopro_ar_fold_text_uk": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p]),
     "sopro_engine_set_ar_tiles": (C.c_int, [_p, _i32, _i32, _i32, _i32]),
     "sopro_cond_workspace_bytes": (_i64, [_p, _i32, _i32, _i32]),
     "sopro_cond_prepare": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
@@ -547,7 +552,9 @@ def skinny(X: torch.Tensor, W, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: 
            scale: Optional[torch.Tensor] = None, ring: Optional[torch.Tensor] = None, dw_w: Optional[torch.Tensor] = None,
            dw_b: Optional[torch.Tensor] = None, step: Optional[torch.Tensor] = None, ring_len: int = 0, ring_bcap: int = 0,
            dil: int = 1, ksize: int = 1, Xp: Optional[torch.Tensor] = None, np_: int = 0, xp_stride: int = 0,
-           ksplit: bool = False, y_part_stride: int = 0, dbg: Optional[torch.Tensor] = None, mt: int = 1, nt: int = 1) -> None:
+           ksplit: bool = False, y_part_stride: int = 0, dbg: Optional[torch.Tensor] = None, mt: int = 1, nt: int = 1,
+           aux_W=None, aux_Y: Optional[torch.Tensor] = None, aux_bias: Optional[torch.Tensor] = None, aux_R: Optional[torch.Tensor] = None,
+           aux_flags: int = 0, aux_y_part_stride: int = 0) -> None:
     """AR-step contraction.  With rms_norm the RMSNorm weight must already be folded into W (W * w_norm[None, :]).
     ``mt`` x ``nt``: 16-row groups x column tiles per workgroup (1 or 2 each; results are bit-identical)."""
     a = SkinnyArgs()
@@ -571,6 +578,13 @@ def skinny(X: torch.Tensor, W, Y: torch.Tensor, *, B: int, N: int, K: int, ldx: 
     a.ring_len, a.ring_bcap, a.dil, a.ksize = ring_len, ring_bcap, dil, ksize
     a.np, a.ksplit, a.rms_norm = np_, int(ksplit), int(rms_norm)
     a.mt, a.nt = int(mt), int(nt)
+    if aux_W is not None:  # aux column tiles (sopro_skinny_args.aux_*): a second operand set on the same input rows
+        if not isinstance(aux_W, SkinnyW) or aux_W.K != K or aux_W.glu or aux_W.bf16 != (a.w_layout == 2):
+            raise SoproHipError("aux_W must be a packed (non-GLU) weight of the same K and element type as W")
+        a.aux_W = ptr(aux_W.data, torch.int32) if aux_W.bf16 else ptr(aux_W.data)
+        a.aux_tiles, a.aux_flags = (aux_W.N + 15) // 16, int(aux_flags)
+        a.aux_Y, a.aux_ldy, a.aux_bias, a.aux_R, a.aux_ldr = ptr(aux_Y), aux_W.N, ptr(aux_bias), ptr(aux_R), aux_W.N
+        a.aux_y_part_stride = aux_y_part_stride
     _check(load().sopro_skinny_f32(C.byref(a), _stream()), "sopro_skinny_f32")
 
 
@@ -689,8 +703,11 @@ def attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, O: torch.Tensor
 
 def xattn_step(X: torch.Tensor, Y: torch.Tensor, norm_w: Optional[torch.Tensor], Kp: torch.Tensor, Vp: torch.Tensor, klens: Optional[torch.Tensor], *,
                B: int, H: int, D: int, S_cap: int, gate: float, scale: float, eps: float, Xp: Optional[torch.Tensor] = None, np_: int = 0,
-               xp_stride: int = 0, y_part_stride: int = 0) -> None:
+               xp_stride: int = 0, y_part_stride: int = 0, Qp: Optional[torch.Tensor] = None, nqp: int = 0, qp_stride: int = 0) -> None:
+    """``Qp`` given: unfolded keys - Kp is K [B, S_cap, D] and Qp the nqp partial sums of the raw query (sopro_xattn_args.k_unfolded)."""
     a = XattnArgs()
+    if Qp is not None:
+        a.Qp, a.nqp, a.qp_stride, a.k_unfolded = ptr(Qp), int(nqp), int(qp_stride), 1
     a.X, a.ldx, a.Xp, a.xp_stride, a.np = ptr(X), D, ptr(Xp), xp_stride, np_
     kv16 = Kp.dtype == torch.bfloat16
     a.norm_w, a.Kp, a.Vp, a.klens = ptr(norm_w), ptr(Kp, Kp.dtype), ptr(Vp, Kp.dtype), ptr(klens, torch.int32)
@@ -787,6 +804,13 @@ def ar_fold_text(txt: torch.Tensor, nkv_weight: torch.Tensor, kv_w: torch.Tensor
     """Folded text operands of one AR cross-attention layer (sopro_ar_fold_text); ``out_off``: float offset into kp / vp."""
     _check(load().sopro_ar_fold_text(ptr(txt), ptr(nkv_weight), ptr(kv_w), ptr(q_wT), ptr(o_w), ptr(nkv), ptr(kvd), ptr(kp) + 4 * out_off,
                                      ptr(vp) + 4 * out_off, B, S, S_cap, D, H, eps, _stream()), "sopro_ar_fold_text")
+
+
+def ar_fold_text_uk(txt: torch.Tensor, nkv_weight: torch.Tensor, kv_w: torch.Tensor, o_w: torch.Tensor, nkv: torch.Tensor, kvd: torch.Tensor,
+                    kq: torch.Tensor, vp: torch.Tensor, *, B: int, S: int, S_cap: int, D: int, H: int, eps: float, k_off: int = 0, v_off: int = 0) -> None:
+    """Text operands of one AR cross-attention layer with UNFOLDED keys (sopro_ar_fold_text_uk); offsets in floats into kq / vp."""
+    _check(load().sopro_ar_fold_text_uk(ptr(txt), ptr(nkv_weight), ptr(kv_w), ptr(o_w), ptr(nkv), ptr(kvd), ptr(kq) + 4 * k_off, ptr(vp) + 4 * v_off,
+                                        B, S, S_cap, D, H, eps, _stream()), "sopro_ar_fold_text_uk")
 
 
 def cvt_f32_bf16(src: torch.Tensor, dst: torch.Tensor, n: Optional[int] = None, dst_off: int = 0) -> None:

@@ -111,7 +111,8 @@ class SoproTTSModel:
         self.wk: Dict[str, hip.SkinnyW] = {}
         with torch.cuda.device(self.device):
             for k, v in self.w.items():
-                if (k.startswith("ar.blocks.") and k.endswith((".glu.w", ".ff1.w", ".ff2.w"))) or k == "ar.head.w":
+                if (k.startswith("ar.blocks.") and k.endswith((".glu.w", ".ff1.w", ".ff2.w"))) or k == "ar.head.w" or \
+                        (k.startswith("ar.x_attns.") and k.endswith((".qa.w", ".qu.w"))):
                     # bf16 mode: the frame's weight stream in bf16 (fp32 accumulate, fp32 norms / ring / residual)
                     self.wk[k] = hip.pack_skinny_w(v, glu=k.endswith(".glu.w"), bf16=(precision == "bf16"))
             torch.cuda.synchronize(self.device)
@@ -604,9 +605,17 @@ class _ARPlan:
         # half the bytes of the frame's two largest state streams; they are folded in fp32 (one scratch pair) and rounded once.
         self.bf16_state = m.precision == "bf16" and os.environ.get("SOPRO_BF16_STATE", "1") != "0"
         sdt = torch.bfloat16 if self.bf16_state else torch.float32
-        self.kp = {i: z(B, 4, S_cap, D, dt=sdt) for i in cfg.ar_xattn_layers}
+        # Unfolded keys (round 4, sopro_ar_frame.k_unfold): kp holds K [B, S_cap, D] instead of the folded K' [B, 4, S_cap, D] - a quarter
+        # of the key bytes the frame streams - and the query rides on the feed-forward launches (pack.py "qa.w" / "qu.w" / "q.b").
+        # Slot plans (continuous batching) keep the folded form: their per-row admission copies are written for it.
+        self.k_unfold = (not slots) and os.environ.get("SOPRO_AR_KUNFOLD", "1") != "0"
+        if self.k_unfold:
+            self.kp = {i: z(B, S_cap, D, dt=sdt) for i in cfg.ar_xattn_layers}
+            self.qa, self.qpart = z(B, D), z(4 * D // 384, B, D)
+        else:
+            self.kp = {i: z(B, 4, S_cap, D, dt=sdt) for i in cfg.ar_xattn_layers}
         self.vp = {i: z(B, 4, S_cap, D, dt=sdt) for i in cfg.ar_xattn_layers}
-        self.fold32 = (z(B, 4, S_cap, D), z(B, 4, S_cap, D)) if self.bf16_state else None
+        self.fold32 = (z(B, 4, S_cap, D), z(B, 4, S_cap, D)) if self.bf16_state else None  # (unfolded keys use the first quarter of [0])
         self.xp = z(4, B, D)  # per-head partial outputs of the cross-attention block
         self.klens = z(B, dt=torch.int32)
         k = int(cfg.ar_kernel)
@@ -664,6 +673,9 @@ class _ARPlan:
             b.ring, b.dil = hip.ptr(self.rings[i], sdt), int(dil)
             if i in self.kp:
                 b.xattn, b.gate, b.kp, b.vp = 1, float(m.gates[i]), hip.ptr(self.kp[i], sdt), hip.ptr(self.vp[i], sdt)
+                if self.k_unfold:
+                    pa = f"ar.x_attns.{i}"
+                    b.qa_w, b.qu_w, b.q_b = wp(pa + ".qa.w"), wp(pa + ".qu.w"), hip.ptr(w[pa + ".q.b"])
         f.head_w, f.head_b = wp("ar.head.w"), hip.ptr(w["ar.head.b"])
         X0, XA, XB, _XC = self.x
         f.x0, f.xa, f.xb = hip.ptr(X0), hip.ptr(XA), hip.ptr(XB)
@@ -672,6 +684,8 @@ class _ARPlan:
         f.n_layers, f.B, f.D, f.S_cap, f.V1, f.H, f.ksize = len(cfg.ar_dilations), self.B, D, self.S_cap, m.V + 1, 4, int(cfg.ar_kernel)
         f.w_layout = 2 if bf16 else 1
         f.store_format = 1 if self.bf16_state else 0
+        if self.k_unfold:
+            f.k_unfold, f.qa, f.qpart = 1, hip.ptr(self.qa), hip.ptr(self.qpart)
         wide = m.ar_tiles_wide if self.B > 32 else None
         f.tile_glu, f.tile_ff1, f.tile_ff2, f.tile_head = (hip.ar_tile_code(wide or m.ar_tiles[k]) for k in ("glu", "ff1", "ff2", "head"))
         f.eps = RMS_EPS
@@ -690,6 +704,18 @@ class _ARPlan:
         m, w, D = self.m, self.m.w, self.m.D
         pa = f"ar.x_attns.{layer}"
         blk = 4 * self.S_cap * D  # elements per row block
+        if self.k_unfold:
+            kblk = self.S_cap * D
+            if not self.bf16_state:
+                hip.ar_fold_text_uk(ts, w[pa + ".nkv.weight"], w[pa + ".kv.w"], w[pa + ".o.w"], nkv, kvd, self.kp[layer], self.vp[layer],
+                                    B=B, S=S, S_cap=self.S_cap, D=D, H=4, eps=RMS_EPS, k_off=row0 * kblk, v_off=row0 * blk)
+                return
+            k32, v32 = self.fold32
+            hip.ar_fold_text_uk(ts, w[pa + ".nkv.weight"], w[pa + ".kv.w"], w[pa + ".o.w"], nkv, kvd, k32, v32,
+                                B=B, S=S, S_cap=self.S_cap, D=D, H=4, eps=RMS_EPS)
+            hip.cvt_f32_bf16(k32, self.kp[layer], n=B * kblk, dst_off=row0 * kblk)
+            hip.cvt_f32_bf16(v32, self.vp[layer], n=B * blk, dst_off=row0 * blk)
+            return
         if not self.bf16_state:
             hip.ar_fold_text(ts, w[pa + ".nkv.weight"], w[pa + ".kv.w"], w[pa + ".q.wT"], w[pa + ".o.w"], nkv, kvd, self.kp[layer], self.vp[layer],
                              B=B, S=S, S_cap=self.S_cap, D=D, H=4, eps=RMS_EPS, out_off=row0 * blk)

@@ -120,6 +120,13 @@ def pack_sopro(weights: Dict[str, "np.ndarray"], cfg: SoproTTSConfig) -> Dict[st
         p = f"ar.x_attns.{i}"
         _xattn(out, w, p, 1.0, heads=4)  # 4 heads: reference src/sopro/nn/generator.py:36
         out[p + ".q.wT"] = (out[p + ".q.wT"] * w[p + ".nq.weight"][None, :, None]).contiguous()  # fold RMSNorm_nq's weight
+        # Unfolded keys (sopro_ar_frame.k_unfold): the query q_raw = Wq' x with Wq' = q_proj * RMSNorm_nq's weight is linear in the
+        # residual stream x = out + b2 + W2 u of block i, so it is emitted by that block's feed-forward launches:
+        #   qa.w = Wq' (on the rows FF1 stages), qu.w = Wq' W2 and q.b = Wq' b2 (on FF2's K-slices); products in float64
+        wq = (w[p + ".q_proj.weight"].double() * w[p + ".nq.weight"].double()[None, :])
+        out[p + ".qa.w"] = wq.float().contiguous()
+        out[p + ".qu.w"] = (wq @ w[f"ar.blocks.{i}.ff.3.weight"].double()).float().contiguous()
+        out[p + ".q.b"] = (wq @ w[f"ar.blocks.{i}.ff.3.bias"].double()).float().contiguous()
     out["ar.norm.weight"] = w["ar.norm.weight"]
     out["ar.head.w"] = (w["ar.head.weight"] * w["ar.norm.weight"][None, :]).contiguous()
     out["ar.head.b"] = w["ar.head.bias"]

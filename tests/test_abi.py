@@ -34,14 +34,14 @@ def test_struct_layouts_match_the_header(tmp_path):
     checks = {
         "sopro_gemm_split_ext": (hip.SplitExt, ["a_format", "c_mode", "C2", "ldc2", "c2_seg_stride", "rms_norm", "rms_eps", "ksplit", "n_tickets", "ws", "ws_bytes", "tickets", "group_m"]),
         "sopro_gemm_args": (hip.GemmArgs, ["A", "W", "C", "R", "scale", "pro_vec", "dbg", "M", "rows_per_seg", "epilogue"]),
-        "sopro_skinny_args": (hip.SkinnyArgs, ["X", "W", "Y", "scale", "ring", "step", "Xp", "y_part_stride", "dbg", "eps", "B", "epilogue", "ring_len", "ksize", "np", "ksplit", "rms_norm", "w_layout", "ring_format", "mt", "nt"]),
+        "sopro_skinny_args": (hip.SkinnyArgs, ["X", "W", "Y", "scale", "ring", "step", "Xp", "y_part_stride", "dbg", "eps", "B", "epilogue", "ring_len", "ksize", "np", "ksplit", "rms_norm", "w_layout", "aux_W", "aux_Y", "aux_ldr", "aux_y_part_stride", "aux_tiles", "aux_flags", "ring_format", "mt", "nt"]),
         "sopro_attn_args": (hip.AttnArgs, ["Q", "K", "V", "O", "klens", "B", "Tk", "causal", "window", "scale", "kv_index"]),
-        "sopro_xattn_args": (hip.XattnArgs, ["X", "Xp", "norm_w", "Kp", "klens", "Y", "eps", "scale", "np", "S_cap", "kv_format"]),
+        "sopro_xattn_args": (hip.XattnArgs, ["X", "Xp", "norm_w", "Kp", "klens", "Y", "eps", "scale", "np", "S_cap", "Qp", "qp_stride", "nqp", "k_unfolded", "kv_format"]),
         "sopro_engine_cfg": (hip.EngineCfg, ["d_model", "bos_row", "ar_dilations", "ar_gate", "nar_dilations", "stage_n_cb", "nar_mix", "nar_prev_cb_weights",
                                              "mimi_hidden", "mimi_ratios", "mimi_compress", "mimi_rope_positions", "mimi_norm_eps", "mimi_final_bias", "precision",
                                              "n_layers_text", "ref_xattn_heads", "sv_student_dim", "enc_kernel"]),
-        "sopro_ar_block": (hip.ArBlock, ["glu_w", "dw_b", "ff2_b", "ring", "kp", "vp", "dil", "xattn", "gate"]),
-        "sopro_ar_frame": (hip.ArFrame, ["blk", "head_w", "x0", "part", "xp", "logits", "klens", "n_layers", "S_cap", "w_layout", "tile_glu", "tile_head", "eps", "store_format", "st"]),
+        "sopro_ar_block": (hip.ArBlock, ["glu_w", "dw_b", "ff2_b", "ring", "kp", "vp", "dil", "xattn", "gate", "qa_w", "qu_w", "q_b"]),
+        "sopro_ar_frame": (hip.ArFrame, ["blk", "head_w", "x0", "part", "xp", "qa", "qpart", "logits", "klens", "n_layers", "S_cap", "w_layout", "tile_glu", "tile_head", "eps", "k_unfold", "store_format", "st"]),
         "sopro_prof_row": (hip.ProfRow, ["family", "launches", "gpu_bound", "flops", "flops_bound", "ms_all", "ms_bound"]),
         "sopro_mimi_stream_state": (hip.MimiStreamState, ["kv", "cap_rows", "kv_len", "pos", "evict", "half"]),
         "sopro_ar_state": (hip.ArState, ["x_cur", "emb", "hist", "recent", "params", "seed", "B", "bos_row", "start", "row_max", "row_params", "nonce", "dbg"]),

@@ -601,6 +601,86 @@ def test_xattn_step_folded_block_matches_text_xattn(S, np_, w):
     close(Y.sum(0), ref, 5e-5, "folded cross-attention block")
 
 
+@pytest.mark.parametrize("B,mt,nt", [(32, 1, 1), (64, 1, 2), (21, 2, 2)])
+def test_skinny_aux_tiles_equal_separate_launches(B, mt, nt):
+    """Round 4: aux column tiles (sopro_skinny_args.aux_*) - a second operand set on the rows a launch stages anyway - are the same
+    function as a launch of their own, bit for bit, and leave the main tiles' results untouched: the FF1 form (main: RMSNorm ->
+    projection -> GELU; aux: raw rows, no norm / bias / activation) and the FF2 form (K = 1536 as four K-slices with bias +
+    residual in slice 0, for both operand sets)."""
+    D = 384
+    X, nw = rnd(B, D, seed=40), 1 + 0.1 * rnd(D, seed=41)
+    W1, b1 = (rnd(4 * D, D, seed=42, scale=D ** -0.5) * nw[None, :]).contiguous(), rnd(4 * D, seed=43)
+    Wa = rnd(D, D, seed=44, scale=D ** -0.5)
+    kw = dict(mt=mt, nt=nt)
+    W1p, Wap = hip.pack_skinny_w(dev(W1)), hip.pack_skinny_w(dev(Wa))
+    Xd = dev(X)
+    Y0, Ya0 = torch.full((B, 4 * D), float("nan"), device=DEV), torch.full((B, D), float("nan"), device=DEV)
+    hip.skinny(Xd, W1p, Y0, B=B, N=4 * D, K=D, rms_norm=True, eps=1e-6, bias=dev(b1), epilogue=hip.EPI_GELU, **kw)
+    hip.skinny(Xd, Wap, Ya0, B=B, N=D, K=D, **kw)
+    Y1, Ya1 = torch.full((B, 4 * D), float("nan"), device=DEV), torch.full((B, D), float("nan"), device=DEV)
+    hip.skinny(Xd, W1p, Y1, B=B, N=4 * D, K=D, rms_norm=True, eps=1e-6, bias=dev(b1), epilogue=hip.EPI_GELU, aux_W=Wap, aux_Y=Ya1, aux_flags=3, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(Y1, Y0) and torch.equal(Ya1, Ya0)
+    close(Ya1, X @ Wa.t(), 5e-5, "aux projection of the raw rows")
+    # FF2 form
+    U, W2, b2, R = rnd(B, 4 * D, seed=45), rnd(D, 4 * D, seed=46, scale=(4 * D) ** -0.5), rnd(D, seed=47), rnd(B, D, seed=48)
+    Wu, bu, Ru = rnd(D, 4 * D, seed=49, scale=(4 * D) ** -0.5), rnd(D, seed=50), rnd(B, D, seed=51)
+    W2p, Wup, Ud = hip.pack_skinny_w(dev(W2)), hip.pack_skinny_w(dev(Wu)), dev(U)
+    P0, Q0 = torch.full((4, B, D), float("nan"), device=DEV), torch.full((4, B, D), float("nan"), device=DEV)
+    hip.skinny(Ud, W2p, P0, B=B, N=D, K=4 * D, bias=dev(b2), epilogue=hip.EPI_RES, R=dev(R), ksplit=True, y_part_stride=B * D, **kw)
+    hip.skinny(Ud, Wup, Q0, B=B, N=D, K=4 * D, bias=dev(bu), epilogue=hip.EPI_RES, R=dev(Ru), ksplit=True, y_part_stride=B * D, **kw)
+    P1, Q1 = torch.full((4, B, D), float("nan"), device=DEV), torch.full((4, B, D), float("nan"), device=DEV)
+    hip.skinny(Ud, W2p, P1, B=B, N=D, K=4 * D, bias=dev(b2), epilogue=hip.EPI_RES, R=dev(R), ksplit=True, y_part_stride=B * D,
+               aux_W=Wup, aux_Y=Q1, aux_bias=dev(bu), aux_R=dev(Ru), aux_y_part_stride=B * D, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(P1, P0) and torch.equal(Q1, Q0)
+    close(Q1.sum(0), Ru + bu + U @ Wu.t(), 1e-4, "aux K-slices")
+
+
+@pytest.mark.parametrize("S,np_", [(19, 0), (64, 3), (130, 3)])
+def test_xattn_step_unfolded_keys_match_text_xattn(S, np_, w):
+    """Round 4 (sopro_xattn_args.k_unfolded): the cross-attention block on UNFOLDED keys K [B, S_cap, D] with the raw query handed
+    in as K-slice partials == TextXAttnBlock.forward with cached K/V (src/sopro/nn/text.py:85-132), and == the folded-key kernel
+    to round-off (same softmax, same folded V')."""
+    B, H, D = 5, 4, 384
+    dh = D // H
+    p = "ar.x_attns.3"
+    S_cap = ((S + 63) // 64) * 64
+    parts = [rnd(B, D, seed=800 + i) for i in range(np_ + 1)]
+    x = sum(parts)
+    ctx = rnd(B, S, D, seed=810)
+    klens = [S, 1, max(1, S // 2), S, max(1, S - 3)]
+    keep = torch.arange(S)[None, :] < torch.tensor(klens)[:, None]
+    k, v = O.xattn_kv(ctx, w, p, H)
+    ref = O.text_xattn(x[:, None], k, v, keep, w, p)[:, 0]
+    Wq, Wo = w[p + ".q_proj.weight"], w[p + ".out_proj.weight"]
+    Kp, Vp, Ku = torch.zeros(B, H, S_cap, D), torch.zeros(B, H, S_cap, D), torch.zeros(B, S_cap, D)
+    for h in range(H):
+        Kp[:, h, :S] = (k[:, h] @ Wq[h * dh:(h + 1) * dh]) * w[p + ".nq.weight"]
+        Vp[:, h, :S] = v[:, h] @ Wo[:, h * dh:(h + 1) * dh].t()
+        Ku[:, :S, h * dh:(h + 1) * dh] = k[:, h]
+    q_raw = (x.double() @ (Wq.double() * w[p + ".nq.weight"].double()[None, :]).t()).float()  # Wq' x (the frame gets it from FF1 / FF2 aux tiles)
+    g = torch.Generator().manual_seed(3)
+    cuts = torch.rand(3, B, D, generator=g)
+    qparts = torch.stack([q_raw * cuts[0], q_raw * (1 - cuts[0]) * cuts[1], q_raw * (1 - cuts[0]) * (1 - cuts[1]) * cuts[2],
+                          q_raw * (1 - cuts[0]) * (1 - cuts[1]) * (1 - cuts[2])])
+    Pd = dev(torch.stack(parts))
+    kl = dev(torch.tensor(klens, dtype=torch.int32))
+    kw = dict(B=B, H=H, D=D, S_cap=S_cap, gate=float(torch.tanh(w[p + ".gate"])), scale=dh ** -0.5, eps=1e-6, Xp=Pd[1:] if np_ else None, np_=np_,
+              xp_stride=B * D, y_part_stride=B * D)
+    Yf, Yu = torch.full((H, B, D), float("nan"), device=DEV), torch.full((H, B, D), float("nan"), device=DEV)
+    hip.xattn_step(Pd[0], Yf, None, dev(Kp), dev(Vp), kl, **kw)
+    hip.xattn_step(Pd[0], Yu, None, dev(Ku), dev(Vp), kl, Qp=dev(qparts), nqp=4, qp_stride=B * D, **kw)
+    close(Yu.sum(0), ref, 5e-5, "unfolded keys vs TextXAttnBlock")
+    close(Yu.sum(0), Yf.sum(0), 2e-5, "unfolded vs folded keys")
+    # bf16 mode: the same with bf16 K / V'
+    K16, V16 = dev(Ku).to(torch.bfloat16), dev(Vp).to(torch.bfloat16)
+    Y16, Y32 = torch.full((H, B, D), float("nan"), device=DEV), torch.full((H, B, D), float("nan"), device=DEV)
+    hip.xattn_step(Pd[0], Y16, None, K16, V16, kl, Qp=dev(qparts), nqp=4, qp_stride=B * D, **kw)
+    hip.xattn_step(Pd[0], Y32, None, K16.float(), V16.float(), kl, Qp=dev(qparts), nqp=4, qp_stride=B * D, **kw)
+    close(Y16.sum(0), Y32.sum(0), 2e-5, "bf16-stored unfolded keys vs the same values in fp32")
+
+
 @pytest.mark.parametrize("S", [5, 64, 130])
 def test_attention_decode_single_query(S):
     B, H, dh = 5, 4, 96

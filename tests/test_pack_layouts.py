@@ -79,3 +79,35 @@ def test_pack_covers_reference_checkpoint_names(cfg, mc, sopro_np, mimi_np):
     assert pm["sea.conv0.w"].shape == (1024, 7 * 512)
     assert pm["sea.up0.w"].shape == (8 * 512, 2 * 1024) and pm["sea.up3.w"].shape == (4 * 64, 2 * 128)
     assert pm["sea.res3.c1.w"].shape == (32, 3 * 64) and pm["sea.final.w"].shape == (3, 64)
+
+
+def test_unfolded_key_query_operands_reproduce_the_folded_scores():
+    """Round 4 (sopro_ar_frame.k_unfold): the query of a text cross-attention block emitted by the feed-forward launches in front of
+    it - q_raw = qa.w @ out + q.b + qu.w @ u with the operands pack_sopro folds in float64 - must be Wq' x for x = out + b2 + W2 u,
+    and <q_raw_h, K_h[k]> must be the folded score <x * w_nq, K'_h[k]> (reference: src/sopro/nn/text.py:85-132, blocks.py:158-162)."""
+    import numpy as np
+    from sopro_amd.config import SoproTTSConfig
+    from sopro_amd.pack import pack_sopro
+    from sopro_amd.weights import synth_sopro_weights
+
+    cfg = SoproTTSConfig()
+    wn = synth_sopro_weights(cfg, 512, 3)
+    p = pack_sopro(wn, cfg)
+    g = torch.Generator().manual_seed(5)
+    D, H = 384, 4
+    dh = D // H
+    for i in cfg.ar_xattn_layers:
+        pa = f"ar.x_attns.{i}"
+        out, u = torch.randn(7, D, generator=g).double(), torch.randn(7, 4 * D, generator=g).double()
+        W2, b2 = torch.from_numpy(wn[f"ar.blocks.{i}.ff.3.weight"]).double(), torch.from_numpy(wn[f"ar.blocks.{i}.ff.3.bias"]).double()
+        x = out + b2 + u @ W2.t()
+        wq = torch.from_numpy(wn[pa + ".q_proj.weight"]).double() * torch.from_numpy(wn[pa + ".nq.weight"]).double()[None, :]
+        q_ref = x @ wq.t()
+        q_new = out @ p[pa + ".qa.w"].double().t() + p[pa + ".q.b"].double() + u @ p[pa + ".qu.w"].double().t()
+        assert float((q_new - q_ref).abs().max()) < 1e-5 * float(q_ref.abs().max())
+        K = torch.randn(7, 11, D, generator=g).double()  # unfolded keys, head h in columns 96 h ..
+        for h in range(H):
+            Kp = K[:, :, h * dh:(h + 1) * dh] @ p[pa + ".q.wT"][h].double().t()  # folded K'_h = K_h Wq_h (norm weight folded): [7, 11, D]
+            s_folded = torch.einsum("bd,bkd->bk", x, Kp)
+            s_unfolded = torch.einsum("bd,bkd->bk", q_ref[:, h * dh:(h + 1) * dh], K[:, :, h * dh:(h + 1) * dh])
+            assert float((s_folded - s_unfolded).abs().max()) < 1e-5 * float(s_folded.abs().max())
