@@ -608,7 +608,10 @@ class _ARPlan:
         # Unfolded keys (round 4, sopro_ar_frame.k_unfold): kp holds K [B, S_cap, D] instead of the folded K' [B, 4, S_cap, D] - a quarter
         # of the key bytes the frame streams - and the query rides on the feed-forward launches (pack.py "qa.w" / "qu.w" / "q.b").
         # Slot plans (continuous batching) keep the folded form: their per-row admission copies are written for it.
-        self.k_unfold = (not slots) and os.environ.get("SOPRO_AR_KUNFOLD", "1") != "0"
+        # Measured (profiles/r04_experiments.md): fp32 frame 380 -> 357 us per 64 rows in the pipeline, tokens exact on every fixture;
+        # with bf16 operands the keys are small already and the extra feed-forward columns cost what they save (24.3 -> 25.4 ms per
+        # step of AR phases) - the bf16 mode keeps the folded form.
+        self.k_unfold = (not slots) and os.environ.get("SOPRO_AR_KUNFOLD", "1" if m.precision == "f32" else "0") != "0"
         if self.k_unfold:
             self.kp = {i: z(B, S_cap, D, dt=sdt) for i in cfg.ar_xattn_layers}
             self.qa, self.qpart = z(B, D), z(4 * D // 384, B, D)

@@ -472,4 +472,10 @@ def test_bf16_mode_quality_against_the_fp32_reference(tts_bf16, cfg, mc, w_noeos
     print(f"\nbf16 mode vs fp32 reference (full200): cond_ar max err {cond_err:.2e}; AR teacher-forced: next-token agreement {ar_agree:.4f}, "
           f"max |dlogit| {worst_lg:.3f}; refined-token agreement {agree:.4f} ({n_off} of {T * 31} off the fp32 arg-max, worst fp32 logit "
           f"gap {gap:.3f}); waveform max err {werr:.3e} of peak, SNR {snr:.1f} dB")
-    assert agree > 0.80 and werr < 0.05 and snr > 30.0 and ar_agree > 0.85 and worst_lg < 0.5
+    # The mode's stated gate: teacher-forced AR next-token agreement >= 98.5 % (measured 99.0 %: 198 of 200
+    # frames), AR logits within 3e-2 of the fp32 oracle's (measured 0.023; SURVEY 8c estimated 2e-2 before the bf16 weight stream
+    # existed), waveform SNR >= 40 dB against the fp32 reference on its own tokens (measured 41.8 dB with bf16 rows in memory,
+    # 42.6 dB with fp32 rows).  Refined tokens are reported, with a floor: one early flip changes the later stages' inputs, so
+    # equality with the reference's 6200 tokens (0.84) says less than the fp32 logit gap at the flips (worst 0.012).
+    assert ar_agree >= 0.985 and worst_lg <= 3e-2 and snr >= 40.0 and werr < 0.02
+    assert agree > 0.80 and gap < 0.05
