@@ -22,7 +22,16 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int ROWS = 32, D = 384, F = 1536, NWG = 192, ALD = 388;  // ALD: LDS row stride (floats), 16-byte rows, conflict-free b128 reads
+// Round 4 (the no-go above was measured at 32 rows, where a hand-off moves 24-96 KB; at batch <= 4 it is <= 6 KB):
+//   -DPROTO_ROWS=16  one 16-row group (96 workgroups per stage), -DPROTO_BR=<1|4|16> real rows of the group (the others are padding:
+//   neither loaded nor stored, in the launched AND the resident form) - the frame of stream() / a batch-1 synthesize().
+#ifndef PROTO_ROWS
+#define PROTO_ROWS 32
+#endif
+#ifndef PROTO_BR
+#define PROTO_BR 16
+#endif
+constexpr int ROWS = PROTO_ROWS, BR = PROTO_BR, D = 384, F = 1536, NWG = 96 * (ROWS / 16), ALD = 388;  // ALD: LDS row stride (floats), 16-byte rows, conflict-free b128 reads
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Params {
@@ -129,7 +138,8 @@ __device__ __forceinline__ void stage_a(const Params& p, int w, int parity, cons
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         const float* src = P + (size_t)(2 * h + j) * ROWS * D + (size_t)(tid + q * 256) * 4;
-        v[j][q] = MODE == 1 ? ld_sc1(src) : ld_plain(src);
+        v[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((tid + q * 256) * 4 / D < BR) v[j][q] = MODE == 1 ? ld_sc1(src) : ld_plain(src);  // (padding rows are not moved)
       }
     if (MODE == 1) { wait6(v[0], true); wait6(v[1], false); }
 #pragma unroll
@@ -151,7 +161,7 @@ __device__ __forceinline__ void stage_a(const Params& p, int w, int parity, cons
   int row, col;
   const float s = reduce_tile(red, c, tid, row, col);
   float* dst = p.U + (size_t)(16 * ra + row) * F + 16 * ca + col;
-  if (MODE == 1) st_sc1(dst, gelu(s + b1v)); else *dst = gelu(s + b1v);
+  if (row < BR) { if (MODE == 1) st_sc1(dst, gelu(s + b1v)); else *dst = gelu(s + b1v); }
 }
 
 template <int MODE>
@@ -162,7 +172,8 @@ __device__ __forceinline__ void stage_b(const Params& p, int w, int parity_out, 
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
     const int e = (tid + q * 256) * 4, r = e / D, k = e % D;
-    uv[q] = MODE == 1 ? ld_sc1(U + (size_t)r * F + k) : ld_plain(U + (size_t)r * F + k);
+    uv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r < BR) uv[q] = MODE == 1 ? ld_sc1(U + (size_t)r * F + k) : ld_plain(U + (size_t)r * F + k);
   }
   if (MODE == 1) wait6(uv, true);
 #pragma unroll
@@ -175,7 +186,7 @@ __device__ __forceinline__ void stage_b(const Params& p, int w, int parity_out, 
   int row, col;
   const float s = reduce_tile(red, c, tid, row, col);
   float* dst = p.P + (size_t)parity_out * 4 * ROWS * D + (size_t)ks * ROWS * D + (size_t)(16 * rb + row) * D + 16 * cb + col;
-  if (MODE == 1) st_sc1(dst, s); else *dst = s;
+  if (row < BR) { if (MODE == 1) st_sc1(dst, s); else *dst = s; }
 }
 
 __device__ __forceinline__ void load_w1(const Params& p, int w, float (&w1)[24], float& b1v) {
@@ -318,8 +329,8 @@ int main() {
       CK(hipEventElapsedTime(&ms_p[mode], e0, e1));
       CK(hipMemcpy(&ab[mode], cnt + 512, 4, hipMemcpyDeviceToHost));
     }
-    printf("%-50s launched (graph of %d pairs): %6.2f us per pair | resident, fences: %6.2f (%.2fx, %s%s) | resident, sc1 payload + drained flag: %6.2f (%.2fx, %s%s) | |P| %.3e\n",
-           c.name, GN, ms_l * 1e3 / T, ms_p[0] * 1e3 / T, ms_l / ms_p[0], same[0] ? "identical" : "DIFFER", ab[0] ? ", SPIN LIMIT" : "",
+    printf("rows %d (%d real per group) | %-50s launched (graph of %d pairs): %6.2f us per pair | resident, fences: %6.2f (%.2fx, %s%s) | resident, sc1 payload + drained flag: %6.2f (%.2fx, %s%s) | |P| %.3e\n",
+           ROWS, BR, c.name, GN, ms_l * 1e3 / T, ms_p[0] * 1e3 / T, ms_l / ms_p[0], same[0] ? "identical" : "DIFFER", ab[0] ? ", SPIN LIMIT" : "",
            ms_p[1] * 1e3 / T, ms_l / ms_p[1], same[1] ? "identical" : "DIFFER", ab[1] ? ", SPIN LIMIT" : "", sqrt(nrm));
     fflush(stdout);
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
