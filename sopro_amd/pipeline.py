@@ -147,7 +147,7 @@ class PipelinedSynthesizer:
 
     _PER_UTT = ("texts", "refs", "text_ids")  # job keys that are per-utterance lists
 
-    def _coalesce(self, jobs: Sequence[Dict[str, Any]], n: int):
+    def _coalesce(self, jobs: Sequence[Dict[str, Any]], n: int, ramp: bool = False):
         """Groups of up to ``n`` CONSECUTIVE jobs with equal sampling parameters become one pass over their concatenated
         utterances (the AR frame chain costs nearly the same for 64 rows as for 32: profiles/r03_experiments.md).  Every
         utterance keeps the sampler stream it has in its own job - that job's nonce and its index within the job (``nonces`` /
@@ -157,7 +157,10 @@ class PipelinedSynthesizer:
         groups: List[List[int]] = []
         for i, j in enumerate(jobs):
             head = jobs[groups[-1][0]] if groups else None
-            same = bool(groups) and len(groups[-1]) < n and all(
+            # ``ramp``: the first pass of a run stays a single job - its conditioning and generation are the shortest possible, so the
+            # throughput partition gets its first refinement / decode phase ~20 ms earlier (an empty pipeline has nothing else for it)
+            cap = 1 if (ramp and len(groups) == 1) else n
+            same = bool(groups) and len(groups[-1]) < cap and all(
                 head.get(k) == j.get(k) for k in (set(j) | set(head)) - set(self._PER_UTT) - {"seed"})
             # ... and the same per-utterance lists present (one job with `texts`, its neighbour with `text_ids` do not merge)
             same = same and all((head.get(k) is None) == (j.get(k) is None) for k in self._PER_UTT)
@@ -185,7 +188,7 @@ class PipelinedSynthesizer:
         """Each job is the keyword dict of ``SoproTTS.synthesize_batch``; results come back in job order.  ``coalesce`` > 1:
         consecutive compatible jobs are generated, refined and decoded together (see ``_coalesce``)."""
         if coalesce > 1 and len(jobs) > 1:
-            passes = self._coalesce(jobs, int(coalesce))
+            passes = self._coalesce(jobs, int(coalesce), ramp=len(jobs) > 2 * int(coalesce) and os.environ.get("SOPRO_PIPE_RAMP", "1") != "0")
             outs = self.run([p[1] for p in passes], timings=timings)
             results: List[Any] = [None] * len(jobs)
             for (g, _m, sizes), out in zip(passes, outs):

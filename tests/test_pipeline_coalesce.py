@@ -63,3 +63,11 @@ def test_jobs_with_different_per_utterance_keys_do_not_merge():
     for g, merged, sizes in PipelinedSynthesizer._coalesce(_stub(), [b, b, c, c], 2):
         n = sum(sizes)
         assert all(len(merged[k]) == n for k in PipelinedSynthesizer._PER_UTT if merged.get(k) is not None)
+
+
+def test_ramp_keeps_the_first_pass_single():
+    """The first pass of a long run is one job (the pipeline's fill: the throughput partition gets work sooner); the rest merge."""
+    jobs = [_job(2) for _ in range(7)]
+    groups = [g for g, _m, _s in PipelinedSynthesizer._coalesce(_stub(), jobs, 2, ramp=True)]
+    assert groups == [[0], [1, 2], [3, 4], [5, 6]]
+    assert [g for g, _m, _s in PipelinedSynthesizer._coalesce(_stub(), jobs, 2)] == [[0, 1], [2, 3], [4, 5], [6]]
