@@ -569,6 +569,9 @@ int sopro_engine_create(const sopro_engine_cfg* cfg, sopro_engine** out);
 /* name: a key of sopro_amd.pack.pack_sopro / pack_mimi ("ar.blocks.0.glu.w", "nar.heads.B.w", "tr.3.qkv.w", "sea.up1.w", ...)
  * plus "rope.cos" / "rope.sin" [positions, head_dim / 2].  The engine keeps the pointer; the caller keeps the memory. */
 int sopro_engine_set_tensor(sopro_engine* e, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim);
+/* The same from HOST memory: the engine allocates device memory of its own for the tensor (freed by sopro_engine_destroy), copies and
+ * registers it.  For hosts that hold the weights on the CPU (sopro_engine_from_checkpoint below). */
+int sopro_engine_upload_tensor(sopro_engine* e, const char* name, const float* host_ptr, const int64_t* shape, int32_t ndim, void* stream);
 /* builds the packed operand forms (allocates device memory).  A stage family takes part when its marker tensor was given -
  * "ar.head.w" (AR), "nar.pre.w" (NAR), "rvq_proj.w" (Mimi decoder), "text_enc.embed" (conditioning + reference preparation,
  * with the position table "pe" [positions, D]) - and must then be complete; a stage call on an engine
@@ -588,6 +591,24 @@ int sopro_ar_fold_text_uk(const float* txt, const float* nkv_weight, const float
 int sopro_engine_destroy(sopro_engine* e);
 /* workgroup shapes of the AR-step stage kinds, (mt << 4) | nt each (see sopro_skinny_args; 0 = 1 x 1).  Drops a recorded frame graph. */
 int sopro_engine_set_ar_tiles(sopro_engine* e, int32_t glu, int32_t ff1, int32_t ff2, int32_t head);
+
+/* ---- checkpoint -> engine without Python (round 4; csrc/checkpoint.hip).  A host starts where the reference starts
+ * (src/sopro/model.py:419-451, src/sopro/hub.py:30-52): from model.safetensors - the reference's own state_dict keys
+ * ("ar.blocks.0.glu.pro.weight", "ar.x_attns.1.q_proj.weight", "cb_embed.emb.weight", "nar.heads.B.0.weight", ...; config JSON in the
+ * header's __metadata__["cfg"], key-intersection load as hub.py:44-48) - and the Mimi codec's model.safetensors (HuggingFace
+ * MimiModel.state_dict() keys; src/sopro/codec/mimi.py:28-31).  sopro_checkpoint_open reads both (F32 / F16 / BF16 / F64 -> fp32) and
+ * applies on the host the repacking sopro_amd/pack.py applies (GLU interleave, tap-major convolution weights, folded norm vectors /
+ * head-id embeddings / unfolded-key query operands in float64, codebooks, softmax / tanh of the scalar parameters, the position and
+ * RoPE tables) under the packed names sopro_engine_set_tensor takes; mimi_path may be NULL (no codec family).
+ * sopro_engine_from_checkpoint = sopro_engine_create + sopro_engine_upload_tensor for every packed tensor + sopro_engine_finalize.
+ * sopro_checkpoint_tensor enumerates the packed tensors (host pointers valid until sopro_checkpoint_close; shape4 padded with 1s). */
+typedef struct sopro_checkpoint sopro_checkpoint;
+int sopro_checkpoint_open(const char* sopro_path, const char* mimi_path, sopro_checkpoint** out);
+int sopro_checkpoint_close(sopro_checkpoint* ck);
+int32_t sopro_checkpoint_count(const sopro_checkpoint* ck);
+int sopro_checkpoint_tensor(const sopro_checkpoint* ck, int32_t i, const char** name, const float** data, int64_t* shape4, int32_t* ndim);
+int sopro_checkpoint_engine_cfg(const sopro_checkpoint* ck, int32_t precision, sopro_engine_cfg* cfg);
+int sopro_engine_from_checkpoint(const sopro_checkpoint* ck, int32_t precision, void* stream, sopro_engine** out);
 
 /* ---- conditioning stage (src/sopro/model.py:172-216 for B utterances at once): text encoder (src/sopro/nn/text.py:29-44),
  * pooled text + frame positions (model.py:200-202), SpeakerFiLM with per-row coefficients (src/sopro/nn/speaker.py:76-85; made

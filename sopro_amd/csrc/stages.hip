@@ -335,6 +335,21 @@ int sopro_engine_set_tensor(sopro_engine* e, const char* name, const void* dev_p
   return 0;
 }
 
+int sopro_engine_upload_tensor(sopro_engine* e, const char* name, const float* host_ptr, const int64_t* shape, int32_t ndim, void* stream) {
+  SOPRO_CHECK_ARG(e && name && host_ptr && shape && ndim >= 1 && ndim <= 4, "bad arguments");
+  SOPRO_CHECK_ARG(!e->final, "the engine is finalized");
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    SOPRO_CHECK_ARG(shape[i] > 0, "empty dimension");
+    n *= (size_t)shape[i];
+  }
+  float* d = nullptr;
+  STG(dev_alloc(e, n, &d));  // engine-owned: freed by sopro_engine_destroy
+  (void)stream;              // (pageable host memory: the copy is synchronous either way)
+  SOPRO_HIP(hipMemcpy(d, host_ptr, n * sizeof(float), hipMemcpyHostToDevice));
+  return sopro_engine_set_tensor(e, name, d, shape, ndim);
+}
+
 int sopro_engine_set_ar_tiles(sopro_engine* e, int32_t glu, int32_t ff1, int32_t ff2, int32_t head) {
   SOPRO_CHECK_ARG(e != nullptr, "engine is NULL");
   e->ar_tiles[0] = glu; e->ar_tiles[1] = ff1; e->ar_tiles[2] = ff2; e->ar_tiles[3] = head;

@@ -202,6 +202,13 @@ SYMBOLS = {
     "sopro_ar_issue_frame": (C.c_int, [C.POINTER(ArFrame), _p]),
     "sopro_ar_fold_text": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p]),
     "sopro_ar_fold_text_uk": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p]),
+    "sopro_engine_upload_tensor": (C.c_int, [_p, C.c_char_p, _p, C.POINTER(_i64), _i32, _p]),
+    "sopro_checkpoint_open": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_p)]),
+    "sopro_checkpoint_close": (C.c_int, [_p]),
+    "sopro_checkpoint_count": (_i32, [_p]),
+    "sopro_checkpoint_tensor": (C.c_int, [_p, _i32, C.POINTER(C.c_char_p), C.POINTER(_p), C.POINTER(_i64), C.POINTER(_i32)]),
+    "sopro_checkpoint_engine_cfg": (C.c_int, [_p, _i32, C.POINTER(EngineCfg)]),
+    "sopro_engine_from_checkpoint": (C.c_int, [_p, _i32, _p, C.POINTER(_p)]),
     "sopro_engine_set_ar_tiles": (C.c_int, [_p, _i32, _i32, _i32, _i32]),
     "sopro_cond_workspace_bytes": (_i64, [_p, _i32, _i32, _i32]),
     "sopro_cond_prepare": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),

@@ -231,6 +231,38 @@ class StageEngine(EngineHandle):
         return wav
 
 
+class CheckpointEngine(StageEngine):
+    """The same driver over an engine the LIBRARY built from the reference's own files (csrc/checkpoint.hip:
+    sopro_checkpoint_open + sopro_engine_from_checkpoint): model.safetensors with SoproTTSModel.state_dict() keys and the Mimi
+    codec's safetensors with HuggingFace keys - no pack.py, no weights.py, no torch tensor of a weight on the Python side.  What
+    INTEGRATION.md's C host does; tests/test_gpu_stages.py runs the reference's 200-frame fixture on it."""
+
+    def __init__(self, sopro_path: str, mimi_path: str, device: str = "cuda:0", precision: str = "f32"):
+        import types
+
+        from .config import MimiDecoderConfig
+        from .weights import load_cfg_from_safetensors
+
+        self.lib = lib = hip.load()
+        self.device = torch.device(device)
+        cfg = load_cfg_from_safetensors(sopro_path)  # (shapes of the driver's own buffers only)
+        self.tts = types.SimpleNamespace(cfg=cfg, codec=types.SimpleNamespace(mc=MimiDecoderConfig(num_quantizers=int(cfg.num_codebooks))))
+        ck = C.c_void_p()
+        hip._check(lib.sopro_checkpoint_open(sopro_path.encode(), mimi_path.encode(), C.byref(ck)), "sopro_checkpoint_open")
+        try:
+            with torch.cuda.device(self.device):
+                self.stream = torch.cuda.Stream(device=self.device)
+                h = C.c_void_p()
+                hip._check(lib.sopro_engine_from_checkpoint(ck, 1 if precision == "bf16" else 0, self.stream.cuda_stream, C.byref(h)),
+                           "sopro_engine_from_checkpoint")
+                self.stream.synchronize()
+        finally:
+            lib.sopro_checkpoint_close(ck)
+        self.h = h
+        self._keep = []
+        self._ws = {}
+
+
 class StageStreamDecoder:
     """MimiStreamDecoder.decode_step (src/sopro/codec/mimi.py:115-181) over ``sopro_mimi_decode_stream``: the 2-frame token
     overlap and the cropping are the host's few lines, the decode with the cached keys / values is the C call."""

@@ -173,3 +173,33 @@ def test_missing_tensor_is_reported_by_name(tts_noeos):
         assert lib.sopro_ar_run_graph(h, 1, None) == -2
     finally:
         lib.sopro_engine_destroy(h)
+
+
+def test_engine_built_by_the_c_loader_from_reference_state_dict_files(tmp_path, cfg, mc, sopro_np_noeos, mimi_np):
+    """Round 4 ("names = reference state_dict keys"): the library reads model.safetensors (SoproTTSModel.state_dict() keys,
+    config JSON in the header: src/sopro/hub.py:30-52) and the Mimi codec's safetensors (HuggingFace keys) itself, repacks on the
+    host and builds the engine - no Python packing.  The reference's 200-frame fixture through that engine: all 32 codebooks
+    strict-equal, waveform within 1e-4 of peak."""
+    from safetensors.numpy import save_file
+
+    from sopro_amd.stages import CheckpointEngine
+    from sopro_amd.weights import save_sopro_checkpoint
+
+    sp, mp = str(tmp_path / "model.safetensors"), str(tmp_path / "mimi.safetensors")
+    save_sopro_checkpoint(sp, sopro_np_noeos, cfg)
+    save_file({k: np.require(v, requirements="C") for k, v in mimi_np.items()}, mp)
+    e = CheckpointEngine(sp, mp)
+    try:
+        g = golden("full200")
+        maxf = int(g["max_frames"])
+        want = _t(g["tokens"].astype(np.int64))
+        voice = e.reference(_t(g["ref_tq"]))
+        prep = e.conditioning(_t(g["ids"]), voice, maxf, style_strength=1.0)
+        hist, feos = e.ar_generate(prep["cond_ar"], prep["txt_seq"], None, **GREEDY)
+        assert int(feos[0]) == -1 and torch.equal(hist[0].cpu().long(), want[:, 0]), "codebook-0 tokens differ from the reference"
+        toks = e.nar_refine(prep["cond_ar"], hist)
+        assert torch.equal(toks[0].cpu().long(), want), "refined tokens differ from the reference's fixture"
+        wav = e.mimi_decode(toks)
+        assert float((wav[0].cpu() - _t(g["wav"])).abs().max()) < 1e-4 * float(np.abs(g["wav"]).max())
+    finally:
+        e.close()
