@@ -157,8 +157,10 @@ class PipelinedSynthesizer:
         groups: List[List[int]] = []
         for i, j in enumerate(jobs):
             head = jobs[groups[-1][0]] if groups else None
-            # ``ramp``: the first pass of a run stays a single job - its conditioning and generation are the shortest possible, so the
-            # throughput partition gets its first refinement / decode phase ~20 ms earlier (an empty pipeline has nothing else for it)
+            # ``ramp`` (SOPRO_PIPE_RAMP=1; off by default): the first pass of a run stays a single job - its conditioning and
+            # generation are the shortest possible, so the throughput partition gets its first phase ~20 ms earlier.  Measured
+            # (profiles/r04_experiments.md): within the run-to-run spread, and the extra pass shape (32 rows next to 64) can land on
+            # a lane that has not recorded its launch sequences yet - one run in four fell to 14.7 k
             cap = 1 if (ramp and len(groups) == 1) else n
             same = bool(groups) and len(groups[-1]) < cap and all(
                 head.get(k) == j.get(k) for k in (set(j) | set(head)) - set(self._PER_UTT) - {"seed"})
@@ -188,7 +190,7 @@ class PipelinedSynthesizer:
         """Each job is the keyword dict of ``SoproTTS.synthesize_batch``; results come back in job order.  ``coalesce`` > 1:
         consecutive compatible jobs are generated, refined and decoded together (see ``_coalesce``)."""
         if coalesce > 1 and len(jobs) > 1:
-            passes = self._coalesce(jobs, int(coalesce), ramp=len(jobs) > 2 * int(coalesce) and os.environ.get("SOPRO_PIPE_RAMP", "1") != "0")
+            passes = self._coalesce(jobs, int(coalesce), ramp=len(jobs) > 2 * int(coalesce) and os.environ.get("SOPRO_PIPE_RAMP", "0") == "1")
             outs = self.run([p[1] for p in passes], timings=timings)
             results: List[Any] = [None] * len(jobs)
             for (g, _m, sizes), out in zip(passes, outs):
