@@ -689,9 +689,11 @@ def main() -> None:
             tts16 = build_engine(device, "bf16")[0]
             b16 = run_leg(tts16, ids, refs, frames=FRAMES, steps=args.steps, lanes=args.lanes, args=args)
             b16["dtype"] = "bf16"
-            b16["dtype_detail"] = ("bf16 mode: NAR + Mimi contractions with both operands rounded to bf16 once (one MFMA pass); the AR frame streams bf16 "
-                                   "weights with bf16 MFMA operands; fp32 accumulators, norms, softmax, ring buffers and residual streams; conditioning "
-                                   "stays fp32.  A throughput mode, not a parity mode: quote it with its quality block")
+            b16["dtype_detail"] = ("bf16 mode (round 4: bf16 IN MEMORY, not only in flight): the AR frame streams bf16 weights, bf16 folded text operands "
+                                   "K' / V' and bf16 ring buffers; the SEANet decoder's activations are bf16 rows in memory (contractions read / write "
+                                   "them directly, the three fused kernels have bf16-row forms); NAR + Mimi contractions one MFMA pass on bf16 operands; "
+                                   "fp32 accumulators, norms, softmax, residual streams, the codec transformer's stream and the conditioning.  A "
+                                   "throughput mode, not a parity mode: quote it with its quality block (gate: tests/test_gpu_bf16_mode.py)")
             b16["quality"] = bf16_quality(tts, tts16, ids, refs, FRAMES, cfg)
             legs["bf16_32x200"] = b16
             b16_400 = run_leg(tts16, ids, refs, frames=400, steps=6, lanes=args.lanes, args=args)
@@ -750,14 +752,15 @@ def main() -> None:
                                       "launch sequences are recorded hipGraphs"
                                       + (f"; {COALESCE} consecutive batches are coalesced into one {COALESCE * BATCH}-row pass (every utterance keeps its "
                                          "own sampler stream: outputs are bit-identical to un-coalesced steps)" if COALESCE > 1 else "")) if args.lanes > 1 else "none"},
-            "dtype_detail": ("fp32 tensors and accumulation everywhere; conditioning + AR on v_mfma_f32_*_f32 (the two encoders' contractions on three "
+            "dtype_detail": ("fp32 tensors and accumulation everywhere; conditioning + AR on v_mfma_f32_*_f32 (round 4: the text cross-attention reads unfolded "
+                             "keys, its query rides on the feed-forward launches; the two encoders' contractions on three "
                              "bf16 pieces / 6 MFMA passes, 24 mantissa bits); NAR contractions with operands split into two fp16 pieces (22 mantissa bits, "
                              "3 MFMA passes, power-of-two operand scaling: as accurate as the six-pass bf16 form, profiles/r03_f16x3_probe.txt); Mimi decoder "
                              "contractions with two bf16 pieces (16 bits, 3 passes)")
                             if args.precision == "f32" else
-                            ("bf16 mode (SURVEY 8d config 2): NAR + Mimi contractions with both operands rounded to bf16 once, one MFMA pass, fp32 accumulators, "
-                             "norms, softmax and residual streams; the AR frame streams bf16 weights with bf16 MFMA operands (fp32 accumulate, norms, ring buffers, residual); "
-                             "only conditioning stays fp32.  Not a parity line: see tests/test_gpu_bf16_mode.py"),
+                            ("bf16 mode (SURVEY 8d config 2; round 4: bf16 in memory): NAR + Mimi contractions one MFMA pass on bf16 operands, the SEANet decoder's "
+                             "activations as bf16 rows in memory, the AR frame with bf16 weights, bf16 folded text operands and bf16 ring buffers; fp32 accumulators, "
+                             "norms, softmax, residual streams, codec transformer stream; conditioning stays fp32.  Not a parity line: see tests/test_gpu_bf16_mode.py"),
             "phase_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phases.items()},
             "kernel_families": families,
             "ttfa_ms_p50": None if ttfa is None else round(ttfa, 3),

@@ -500,6 +500,10 @@ int launch_argmax(sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_ge
   SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE && g.prologue == SOPRO_PRO_NONE && !ext.rms_norm && ext.a_format == 0,
                   "arg-max output takes a plain contraction (no prologue / epilogue / fused norm)");
   SOPRO_CHECK_ARG(ext.C2 && ext.ldc2 >= (g.N + 63) / 64, "arg-max output: C2 = [M][ldc2 >= ceil(N / 64)] (value, index) pairs");
+  // 128-row tiles for many-row problems (the refinement of a whole batch: 12800 rows): every W fragment serves twice the rows; the
+  // (max, column) pairs stay per 64-column tile, the arithmetic per element is unchanged.  SOPRO_ARGMAX_TM=1: 64-row tiles always.
+  static const bool tm1 = getenv("SOPRO_ARGMAX_TM") != nullptr && getenv("SOPRO_ARGMAX_TM")[0] == '1';
+  if (g.M >= 8192 && !tm1) return launch_one<NPL, 2, 2, 2, 1, SOPRO_EPI_NONE, 0, 5, F16>(g, wp, ksubs, ext, s);
   return launch_one<NPL, 2, 2, 1, 1, SOPRO_EPI_NONE, 0, 5, F16>(g, wp, ksubs, ext, s);
 }
 

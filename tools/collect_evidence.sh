@@ -1,30 +1,40 @@
 #!/bin/bash
-# The round's measured evidence in one call (run on an MI355X box through gpurun from the repo root):
-#   tools/collect_evidence.sh r02 profiles    -> rocprofv3 kernel stats (pipelined / sequential), PMC passes, AR kernel table
-#   tools/collect_evidence.sh r02 bench       -> the bench lines (driver's form, default, bf16 mode, other shapes)
+# The round's measured evidence in one call (run on an MI355X box through gpurun from the repo root) - make it the LAST call of the
+# round, on the final binary:
+#   tools/collect_evidence.sh r04 profiles    -> rocprofv3 kernel stats (pipelined fp32 / bf16, sequential), PMC passes, AR kernel table
+#   tools/collect_evidence.sh r04 bench       -> the bench lines (driver's form, default, bf16 mode, other shapes)
+#   tools/collect_evidence.sh r04 all         -> both
 # Results land in gpurun_out/<tag>/; copy what is to be kept into profiles/ (see profiles/README.md for the names).
-TAG=${1:-r03}; WHAT=${2:-bench}
+TAG=${1:-r04}; WHAT=${2:-bench}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/$TAG
 mkdir -p $O
-if [ "$WHAT" = profiles ]; then
+if [ "$WHAT" = profiles ] || [ "$WHAT" = all ]; then
   cd /tmp && export TMPDIR=/tmp
   B="python $R/bench.py --no-cpu-baseline --ttfa-runs 0 --profile-steps 0 --no-legs"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/l4 -o l4 -- $B --steps 8 --warmup 5 > $O/l4.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/l4b -o l4b -- $B --steps 8 --warmup 5 --precision bf16 > $O/l4b.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/l1 -o l1 -- $B --lanes 1 --steps 4 --warmup 2 > $O/l1.log 2>&1
-  # counters in passes of their own, with the kernel trace only (no --stats, no sys / runtime traces)
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o f -- $B --lanes 1 --steps 1 --warmup 2 > $O/fetch.log 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- $B --lanes 1 --steps 1 --warmup 2 > $O/write.log 2>&1
-  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -o m -- $B --lanes 1 --steps 1 --warmup 2 > $O/mfma.log 2>&1
+  # counters in passes of their own, with the kernel trace only (no --stats, no sys / runtime traces).  The AR frame under the
+  # counters is the PIPELINE's frame: 64 rows (two coalesced jobs), 1 x 2 workgroups, non-temporal folded operands - run as one
+  # sequential 64-utterance batch (the counter collection serialises kernels anyway).  PMC_* tell tools/pmc_summary.py what ran.
+  export SOPRO_AR_TILES=1x2 PMC_ROWS=64 PMC_PRECISION=f32
+  export PMC_COMMAND="SOPRO_AR_TILES=1x2 python bench.py --lanes 1 --batch 64 --steps 1 --warmup 2 --profile-steps 0 --no-cpu-baseline --ttfa-runs 0 --no-legs (3 passes of a 64 x 200 step: the pipeline's coalesced frame)"
+  P="$B --lanes 1 --batch 64 --steps 1 --warmup 2"
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o f -- $P > $O/fetch.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- $P > $O/write.log 2>&1
+  timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -o m -- $P > $O/mfma.log 2>&1
+  unset SOPRO_AR_TILES
   cd $R
   python tools/pmc_summary.py $O/fetch/f_counter_collection.csv $O/write/w_counter_collection.csv $O/${TAG}_pmc_summary.json | head -60
   python tools/pmc_summary.py --mfma $O/mfma/m_counter_collection.csv $O/${TAG}_pmc_mfma_busy.json | head -40
   python tools/ar_kernel_table.py $O/l1/l1_kernel_stats.csv $O/${TAG}_ar_kernels.json | head -40
   rm -f $O/*/*_kernel_trace.csv $O/*/*_counter_collection.csv  # the traces are large: keep the stats only
   ls $O/*/
-else
+fi
+if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   cd $R
-  timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
-  timeout 400 python bench.py > $O/bench_line_default.json 2> $O/bench_line_default.err
+  timeout 500 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
+  timeout 500 python bench.py > $O/bench_line_default.json 2> $O/bench_line_default.err
   timeout 300 python bench.py --steps 20 --warmup 5 --precision bf16 > $O/bench_line_bf16.json 2> $O/bench_line_bf16.err
   Q="--no-cpu-baseline --ttfa-runs 0 --profile-steps 0"
   ( echo '{"runs": [';
@@ -36,7 +46,7 @@ else
   for f in bench_line bench_line_default bench_line_bf16; do python -c "
 import json
 d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1]); r=d['roofline']
-print('$f', d['value'], d['ms_per_step'], d['phase_ms_per_step'], 'ttfa', d['ttfa_ms_p50'], '| roofline', r['kernel'][:28], r['achieved'], r['frac'], 'us', r['avg_launch_us'], '| parity ok', d['parity'].get('ok'), d['parity']['timed_steps_identical'], '| cpu', (d.get('cpu_baseline') or {}).get('value'))"; done
+print('$f', d['value'], d['ms_per_step'], d['phase_ms_per_step'], 'ttfa', d['ttfa_ms_p50'], '| roofline', r['kernel'][:28], r['achieved'], r['frac'], 'us', r['avg_launch_us'], '| parity ok', d['parity'].get('ok'), d['parity']['timed_steps_identical'], '| cpu', (d.get('cpu_baseline') or {}).get('value'), '| host cpu', d['host_cpu_s_per_step'], '| legs', {k: v.get('value') for k, v in (d.get('legs') or {}).items() if isinstance(v, dict)})"; done
   python -c "
 import json
 d=json.load(open('$O/bench_other_shapes.json'))
