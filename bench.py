@@ -268,6 +268,41 @@ def bf16_quality(tts, tts16, ids, refs, frames: int, cfg, n: int = 4) -> dict:
             "waveform_max_err_of_peak": float(f"{err:.3e}"), "waveform_snr_db": round(snr, 1)}
 
 
+LEGS = ("one_voice_32x200", "f32_32x400", "f32_1x400_sequential", "bf16_32x200", "bf16_32x400")
+BF16_DETAIL = ("bf16 mode (round 4: bf16 IN MEMORY, not only in flight): the AR frame streams bf16 weights, bf16 folded text operands "
+               "K' / V' and bf16 ring buffers; the SEANet decoder's activations are bf16 rows in memory (contractions read / write "
+               "them directly, the three fused kernels have bf16-row forms); NAR + Mimi contractions one MFMA pass on bf16 operands; "
+               "fp32 accumulators, norms, softmax, residual streams, the codec transformer's stream and the conditioning.  A "
+               "throughput mode, not a parity mode: quote it with its quality block (gate: tests/test_gpu_bf16_mode.py)")
+
+
+def leg_main(name: str, args, device: str) -> dict:
+    """One extra leg of the default line in a process of its own (see main): same inputs as the headline (rank 0), another shape /
+    voice set / engine."""
+    bf16 = name.startswith("bf16")
+    tts, cfg, _mc, _wn, _mn = build_engine(device, "bf16" if bf16 else "f32")
+    ids, _ref_tq = make_inputs(0)
+    voices = [tts.prepare_reference(ref_tokens_tq=v) for v in make_voices(0, BATCH)]
+    if name == "one_voice_32x200":
+        return run_leg(tts, ids, [voices[0]] * BATCH, frames=FRAMES, steps=args.steps, lanes=args.lanes, args=args)
+    if name == "f32_32x400":
+        return run_leg(tts, ids, voices, frames=400, steps=6, lanes=args.lanes, args=args)
+    if name == "f32_1x400_sequential":
+        return run_leg(tts, ids[:1], voices[:1], frames=400, steps=8, lanes=1, args=args)
+    if name == "bf16_32x200":
+        out = run_leg(tts, ids, voices, frames=FRAMES, steps=args.steps, lanes=args.lanes, args=args)
+        out["dtype"], out["dtype_detail"] = "bf16", BF16_DETAIL
+        tts32 = build_engine(device, "f32")[0]
+        v32 = [tts32.prepare_reference(ref_tokens_tq=v) for v in make_voices(0, 4)]
+        out["quality"] = bf16_quality(tts32, tts, ids, v32, FRAMES, cfg)
+        return out
+    if name == "bf16_32x400":
+        out = run_leg(tts, ids, voices, frames=400, steps=6, lanes=args.lanes, args=args)
+        out["dtype"] = "bf16"
+        return out
+    raise SystemExit(f"unknown leg {name!r}")
+
+
 _T0 = time.perf_counter()
 
 
@@ -298,6 +333,7 @@ def main() -> None:
     ap.add_argument("--voices", type=int, default=-1, help="distinct reference voices per batch (default: one per utterance, SURVEY 8d; 1 = one shared voice)")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs of the default run (one shared voice, 32x400 / 1x400 frames, bf16 mode)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--leg", type=str, default="", help=argparse.SUPPRESS)  # child process of the default run: one extra leg (see LEGS)
     ap.add_argument("--parity-tokens", type=str, default="", help=argparse.SUPPRESS)
     ap.add_argument("--input-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: a 1-GPU run on the inputs of rank R
     args = ap.parse_args()
@@ -341,6 +377,9 @@ def main() -> None:
     blocking_wait = (args.lanes > 1 or world > 1) and os.environ.get("SOPRO_BLOCKING_WAIT", "1") != "0"
     if blocking_wait:
         hip.set_host_wait(True, dev_index)
+    if args.leg:  # child process of the default run: one extra leg, one JSON object on stdout
+        print(json.dumps(leg_main(args.leg, args, device)), flush=True)
+        return
     import torch.distributed as dist
 
     # One rank per GPU means 1 + lanes host threads per rank, all latency-sensitive (they keep the AR launch queues fed).  With
@@ -673,37 +712,35 @@ def main() -> None:
             del it, first
         ttfa = float(np.percentile(lat, 50))
 
-    # ---- extra legs of the default run (BASELINE.json configs the headline does not cover), rank 0 of a single-GPU run only
+    # ---- extra legs of the default run (BASELINE.json configs the headline does not cover), rank 0 of a single-GPU run only.
+    # Every leg runs in a CHILD PROCESS of its own (`bench.py --leg NAME`): a leg that dies - call 7 of round 4: SIGSEGV inside
+    # torch's caching allocator in the fifth leg of one process, whose earlier legs had left cached blocks of destroyed CU-masked
+    # streams behind - must not take the headline with it, and every leg starts from an empty device.  The parent's engines are
+    # released first.
     legs = None
     default_shape = (BATCH, FRAMES) == (32, 200) and args.precision == "f32"
     if rank == 0 and world == 1 and default_shape and not args.no_legs:
+        import subprocess
+
         legs = {}
-        try:
-            log("leg: one shared voice")
-            legs["one_voice_32x200"] = run_leg(tts, ids, [ref] * BATCH, frames=FRAMES, steps=args.steps, lanes=args.lanes, args=args)
-            log("leg: 32 x 400 frames")
-            legs["f32_32x400"] = run_leg(tts, ids, refs, frames=400, steps=6, lanes=args.lanes, args=args)
-            log("leg: 1 x 400 frames, strictly sequential")
-            legs["f32_1x400_sequential"] = run_leg(tts, ids[:1], refs[:1], frames=400, steps=8, lanes=1, args=args)
-            log("leg: bf16 mode")
-            tts16 = build_engine(device, "bf16")[0]
-            b16 = run_leg(tts16, ids, refs, frames=FRAMES, steps=args.steps, lanes=args.lanes, args=args)
-            b16["dtype"] = "bf16"
-            b16["dtype_detail"] = ("bf16 mode (round 4: bf16 IN MEMORY, not only in flight): the AR frame streams bf16 weights, bf16 folded text operands "
-                                   "K' / V' and bf16 ring buffers; the SEANet decoder's activations are bf16 rows in memory (contractions read / write "
-                                   "them directly, the three fused kernels have bf16-row forms); NAR + Mimi contractions one MFMA pass on bf16 operands; "
-                                   "fp32 accumulators, norms, softmax, residual streams, the codec transformer's stream and the conditioning.  A "
-                                   "throughput mode, not a parity mode: quote it with its quality block (gate: tests/test_gpu_bf16_mode.py)")
-            b16["quality"] = bf16_quality(tts, tts16, ids, refs, FRAMES, cfg)
-            legs["bf16_32x200"] = b16
-            b16_400 = run_leg(tts16, ids, refs, frames=400, steps=6, lanes=args.lanes, args=args)
-            b16_400["dtype"] = "bf16"
-            legs["bf16_32x400"] = b16_400
-            del tts16
-            torch.cuda.empty_cache()
-        except Exception as e:  # noqa: BLE001  (a failed leg must not void the headline)
-            log(f"legs failed: {e!r}")
-            legs["error"] = repr(e)
+        job.clear()
+        kept.clear()
+        del tts, voices, refs, ref
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        for name in LEGS:
+            log(f"leg: {name} (child process)")
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", name, "--steps", str(args.steps), "--lanes", str(args.lanes),
+                                    "--ar-cus", str(args.ar_cus), "--ar-parts", str(args.ar_parts), "--ar-shared", str(args.ar_shared),
+                                    "--bulk-slots", str(args.bulk_slots), "--coalesce", str(args.coalesce)],
+                                   capture_output=True, text=True, timeout=240)
+                legs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:  # noqa: BLE001  (a failed leg must not void the headline)
+                log(f"leg {name} failed: {e!r}")
+                legs[name] = {"error": repr(e)}
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -141,6 +141,10 @@ class PipelinedSynthesizer:
 
         gc.collect()  # Graph.__del__ of the dropped plans parks the handles ...
         hip.reap_parked_graphs()  # ... and the device is idle, no recording is open: destroy them before their streams go
+        # torch's caching allocator keeps freed blocks per STREAM: the scratch just dropped was allocated on streams that are about to
+        # be destroyed, could never be reused by any other stream, and was seen to take the process down later (a SIGSEGV inside
+        # torch.empty in the fifth pipeline of one process: profiles/r04_experiments.md).  Hand it back while its streams exist.
+        torch.cuda.empty_cache()
         for st in self._streams:
             hip.destroy_stream(st)
         self._streams = []
