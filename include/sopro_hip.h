@@ -171,6 +171,15 @@ int sopro_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t
  * RMSNorm) at half its passes.  fp16 has a narrow exponent: activations are scaled by sopro_f16x3_a_scale() (a power of two)
  * while they are staged, the weight by `wscale` (a power of two chosen by the host so that max|W| * wscale <= ~2^14) when it is
  * packed (sopro_packed_w_bytes(N, K, 2) bytes), and ext->acc_scale = 1 / (a_scale * wscale) undoes both exactly. */
+/* INPUT-RANGE CONTRACT of the f16 path: an activation is staged as round_fp16(a * 8) + a second fp16 piece, so
+ *   |a| <= 8188      is in range (exact scaling; 22 mantissa bits);
+ *   |a| >  8188      SATURATES at +-65504 / 8 - finite, wrong, and not reported: callers keep their streams below it (the NAR
+ *                    stream is O(1-10): its contraction inputs are RMS-normalised rows or GELU outputs; with the fused RMSNorm
+ *                    the RAW residual row is what is staged, so the residual stream itself must stay below 8188);
+ *   |a| <  2^-17     loses relative precision to the absolute resolution 2^-24 / 8 = 7.5e-9 of a scaled fp16 piece (a row of
+ *                    RMS << 1e-2 in front of a fused RMSNorm has its round-off amplified by 1 / rms).
+ * The fp32 reference has no such limits (src/sopro/nn/blocks.py:26-37, nar.py:89-116); paths whose inputs are not bounded like
+ * that use sopro_gemm_bf16x6 (8 exponent bits). */
 int sopro_pack_w_f16x2(const float* W, int64_t ldw, int32_t N, int32_t K, float wscale, void* packed, void* stream);
 float sopro_f16x3_a_scale(void);
 int sopro_gemm_f16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);

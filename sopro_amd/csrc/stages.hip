@@ -47,6 +47,8 @@ struct ArPlan {
   int B = 0, S = 0, S_cap = 0, Tar = 0;
   void* ws = nullptr;
   float *cond, *x[4], *part, *u, *logits, *kp[16], *vp[16], *xp, *params, *rings[16], *nkv, *kvd;
+  float *qa = nullptr, *qpart = nullptr;       // unfolded keys (fp32 frame): the raw query's `Wq' out` part and its four K-slice partials
+  bool k_unfold = false;
   float *fold_k = nullptr, *fold_v = nullptr;  // bf16 mode: fp32 scratch the text operands are folded into before they are rounded to bf16
   int32_t *klens, *hist, *ctr, *first_eos, *stop_t, *recent;
   uint32_t* nonce;
@@ -406,6 +408,11 @@ int sopro_engine_finalize(sopro_engine* e, void* stream) {
       if (c.ar_xattn[i]) {
         const std::string pa = "ar.x_attns." + std::to_string(i);
         for (const char* nm : {".nkv.weight", ".kv.w", ".q.wT", ".o.w"}) STG(need(e, pa + nm, &t));
+        // unfolded keys (sopro_ar_frame.k_unfold; the fp32 frame): the query operands ride on the feed-forward launches
+        if (!bf16 && e->t.count(pa + ".qa.w") && e->t.count(pa + ".qu.w") && e->t.count(pa + ".q.b")) {
+          STG(pack_skinny(pa + ".qa.w", 0));
+          STG(pack_skinny(pa + ".qu.w", 0));
+        }
       }
     }
     STG(pack_skinny("ar.head.w", 0));
@@ -780,6 +787,8 @@ static size_t ar_carve(const sopro_engine* e, ArPlan& p, void* ws, int B, int S,
   for (int i = 0; i < c.n_layers_ar; ++i) p.rings[i] = cv.take<float>((size_t)((c.ar_kernel - 1) * c.ar_dilations[i] + 1) * B * D);
   p.nkv = cv.take<float>((size_t)B * S * D);
   p.kvd = cv.take<float>((size_t)B * S * 2 * D);
+  p.qa = cv.take<float>((size_t)B * D);
+  p.qpart = cv.take<float>((size_t)4 * B * D);
   p.fold_k = p.fold_v = nullptr;
   if (c.precision == 1) {  // bf16 mode: kp / vp / rings hold bf16 elements (the first half of their fp32-sized buffers)
     p.fold_k = cv.take<float>((size_t)B * H * S_cap * D);
@@ -816,12 +825,17 @@ static int ar_issue_step(sopro_engine* e, hipStream_t s) {
     b.ff1_w = e->sk[pr + ".ff1.w"]; b.ff1_b = F(e, pr + ".ff1.b"); b.ff2_w = e->sk[pr + ".ff2.w"]; b.ff2_b = F(e, pr + ".ff2.b");
     b.ring = p.rings[i]; b.dil = c.ar_dilations[i]; b.xattn = c.ar_xattn[i] ? 1 : 0; b.gate = c.ar_gate[i];
     b.kp = p.kp[i]; b.vp = p.vp[i];
+    if (p.k_unfold && c.ar_xattn[i]) {
+      const std::string pa = "ar.x_attns." + std::to_string(i);
+      b.qa_w = e->sk[pa + ".qa.w"]; b.qu_w = e->sk[pa + ".qu.w"]; b.q_b = F(e, pa + ".q.b");
+    }
   }
   f.head_w = e->sk["ar.head.w"]; f.head_b = F(e, "ar.head.b");
   f.x0 = p.x[0]; f.xa = p.x[1]; f.xb = p.x[2]; f.part = p.part; f.u = p.u; f.xp = p.xp; f.logits = p.logits; f.klens = p.klens;
   f.n_layers = c.n_layers_ar; f.B = p.B; f.D = c.d_model; f.S_cap = p.S_cap; f.V1 = c.codebook_size + 1; f.H = 4; f.ksize = c.ar_kernel;
   f.w_layout = c.precision == 1 ? 2 : 1;
   f.store_format = c.precision == 1 ? 1 : 0;  // bf16 mode: ring buffers and folded text operands as bf16 in memory
+  if (p.k_unfold) { f.k_unfold = 1; f.qa = p.qa; f.qpart = p.qpart; }
   f.tile_glu = e->ar_tiles[0]; f.tile_ff1 = e->ar_tiles[1]; f.tile_ff2 = e->ar_tiles[2]; f.tile_head = e->ar_tiles[3];
   f.eps = RMS_EPS;
   f.st = p.st;
@@ -845,10 +859,24 @@ int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* con
   } else {
     SOPRO_HIP(hipMemsetD32Async((hipDeviceptr_t)p.klens, S, B, s));
   }
+  // unfolded keys whenever the engine was given the query operands (fp32 frame; the Python host takes the same decision)
+  {
+    static const bool off = getenv("SOPRO_AR_KUNFOLD") != nullptr && getenv("SOPRO_AR_KUNFOLD")[0] == '0';
+    bool all = c.precision == 0 && !off;
+    for (int i = 0; i < c.n_layers_ar; ++i)
+      if (c.ar_xattn[i] && !e->sk.count("ar.x_attns." + std::to_string(i) + ".qa.w")) all = false;
+    if (p.graph && p.k_unfold != all) { STG(sopro_graph_destroy(p.graph)); p.graph = nullptr; }
+    p.k_unfold = all;
+  }
   // K/V of the text for the cross-attention layers (src/sopro/nn/text.py:75-83), query / output projections folded in
   for (int i = 0; i < c.n_layers_ar; ++i) {
     if (!c.ar_xattn[i]) continue;
     const std::string pa = "ar.x_attns." + std::to_string(i);
+    if (p.k_unfold) {  // K as it is ([B, S_cap, D] in the first quarter of the layer's kp buffer), V' folded
+      STG(sopro_ar_fold_text_uk(txt_seq, F(e, pa + ".nkv.weight"), F(e, pa + ".kv.w"), F(e, pa + ".o.w"), p.nkv, p.kvd, p.kp[i], p.vp[i], B, S, p.S_cap, D,
+                                H, RMS_EPS, s));
+      continue;
+    }
     float* kdst = c.precision == 1 ? p.fold_k : p.kp[i];
     float* vdst = c.precision == 1 ? p.fold_v : p.vp[i];
     STG(sopro_ar_fold_text(txt_seq, F(e, pa + ".nkv.weight"), F(e, pa + ".kv.w"), F(e, pa + ".q.wT"), F(e, pa + ".o.w"), p.nkv, p.kvd, kdst,
