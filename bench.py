@@ -223,7 +223,8 @@ def run_leg(tts, ids, refs, *, frames: int, steps: int, lanes: int, args, seed: 
         pipe = PipelinedSynthesizer(tts, lanes=lanes, ar_cus=args.ar_cus, ar_parts=args.ar_parts, ar_shared=bool(args.ar_shared), bulk_slots=args.bulk_slots)
 
     def go(n):
-        outs = pipe.run([job] * n, coalesce=(args.coalesce if (frames <= 256 or B * args.coalesce <= 32) else 1)) if pipe is not None else [tts.synthesize_batch(**job) for _ in range(n)]
+        long_ok = os.environ.get("SOPRO_BENCH_COALESCE_LONG", "1") != "0"
+        outs = pipe.run([job] * n, coalesce=(args.coalesce if (long_ok or frames <= 256 or B * args.coalesce <= 32) else 1)) if pipe is not None else [tts.synthesize_batch(**job) for _ in range(n)]
         for out in outs:
             assert all(o.shape[-1] == frames * 1920 for o in out)
 
@@ -338,9 +339,10 @@ def main() -> None:
     ap.add_argument("--input-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: a 1-GPU run on the inputs of rank R
     args = ap.parse_args()
     BATCH, FRAMES = int(args.batch), int(args.frames)
-    # passes of two jobs pay off up to ~256 frames or while a pass stays within 32 rows; beyond that the decoder of a 64 x 400 pass
-    # outgrows what the generation phases hide (32 x 400: 17.5 k coalesced against 18.2 k, profiles/r03_experiments.md)
-    COALESCE = int(args.coalesce) if (FRAMES <= 256 or BATCH * int(args.coalesce) <= 32) else 1
+    # passes of two jobs at every length (round 4: the decoder takes a 64 x 400 pass as two 32-row chunks - in one call it was slower
+    # per utterance than two, which is why round 3 did not coalesce long-form jobs); SOPRO_BENCH_COALESCE_LONG=0 = the round-3 rule
+    long_ok = os.environ.get("SOPRO_BENCH_COALESCE_LONG", "1") != "0"
+    COALESCE = int(args.coalesce) if (long_ok or FRAMES <= 256 or BATCH * int(args.coalesce) <= 32) else 1
 
     if args.cpu_baseline_only:  # child process of the N=1 run: CPU only, bounded by the parent's timeout
         from sopro_amd.config import MimiDecoderConfig, SoproTTSConfig

@@ -198,33 +198,45 @@ class MimiCodec:
             self._graphs.clear()
             ws.clear()
         lib, eng = hip.load(), self.eng
+        # Large batches are decoded in row chunks of ~12800 frames (32 x 400, 64 x 200): a 64 x 400 decode in one call measured
+        # slower per utterance than two 32 x 400 calls (39.5 vs 33.9 ms per 32; its scratch is 148 GB) - with chunks a scheduler can
+        # still coalesce two long-form jobs into one 64-row generation / refinement pass (profiles/r04_experiments.md).
+        rows_max = max(1, int(os.environ.get("SOPRO_MIMI_CHUNK_CELLS", "12800")) // T)
+        chunks = [(b0, min(B, b0 + rows_max)) for b0 in range(0, B, rows_max)] if (state is None and B > rows_max) else [(0, B)]
+        hop = int(mc.frame_samples)
         with self.on_stream():
-            # codes land in a persistent buffer so that the call of a (B, T) shape can be recorded once
-            tok = ws.get("rvq.tok", (B * T, Q), dtype=torch.int32)
-            tok.copy_(codes_btq.to(dev).reshape(B * T, Q))
-            out = ws.get("sea.wav", (B, T * int(mc.frame_samples)))
-            scratch = ws.get(f"mimi.stage_ws.{B}x{T}", (int(lib.sopro_mimi_workspace_bytes(eng.h, B, T)),), dtype=torch.uint8)
-            if state is None:
-                def issue():
-                    hip._check(lib.sopro_mimi_decode(eng.h, scratch.data_ptr(), tok.data_ptr(), B, T, out.data_ptr(), hip._stream()), "sopro_mimi_decode")
+            wav = torch.empty(B, T * hop, device=dev) if len(chunks) > 1 else None
+            for b0, b1 in chunks:
+                Bc = b1 - b0
+                # codes land in a persistent buffer so that the call of a (B, T) shape can be recorded once
+                tok = ws.get("rvq.tok", (Bc * T, Q), dtype=torch.int32)
+                tok.copy_(codes_btq[b0:b1].to(dev).reshape(Bc * T, Q))
+                out = ws.get("sea.wav", (Bc, T * hop))
+                scratch = ws.get(f"mimi.stage_ws.{Bc}x{T}", (int(lib.sopro_mimi_workspace_bytes(eng.h, Bc, T)),), dtype=torch.uint8)
+                if state is None:
+                    def issue(tok=tok, out=out, scratch=scratch, Bc=Bc):
+                        hip._check(lib.sopro_mimi_decode(eng.h, scratch.data_ptr(), tok.data_ptr(), Bc, T, out.data_ptr(), hip._stream()), "sopro_mimi_decode")
 
-                if self.use_graph:
-                    self._graphs.run((B, T), issue)
+                    if self.use_graph:
+                        self._graphs.run((Bc, T), issue)
+                    else:
+                        issue()
                 else:
-                    issue()
-            else:
-                if state.cst is None:  # first call of a stream: the cache buffer (window + chunk rows under the evicting policy)
+                    if state.cst is None:  # first call of a stream: the cache buffer (window + chunk rows under the evicting policy)
+                        import ctypes as C
+
+                        cap = self.stream_cap_rows
+                        state.kv_buf = torch.empty(int(lib.sopro_mimi_stream_kv_bytes(eng.h, cap)), dtype=torch.uint8, device=dev)
+                        state.cst = hip.MimiStreamState()
+                        hip._check(lib.sopro_mimi_stream_init(eng.h, C.byref(state.cst), state.kv_buf.data_ptr(), cap), "sopro_mimi_stream_init")
                     import ctypes as C
 
-                    cap = self.stream_cap_rows
-                    state.kv_buf = torch.empty(int(lib.sopro_mimi_stream_kv_bytes(eng.h, cap)), dtype=torch.uint8, device=dev)
-                    state.cst = hip.MimiStreamState()
-                    hip._check(lib.sopro_mimi_stream_init(eng.h, C.byref(state.cst), state.kv_buf.data_ptr(), cap), "sopro_mimi_stream_init")
-                import ctypes as C
-
-                hip._check(lib.sopro_mimi_decode_stream(eng.h, scratch.data_ptr(), C.byref(state.cst), tok.data_ptr(), T, out.data_ptr(), hip._stream()),
-                           "sopro_mimi_decode_stream")
-            wav = out.clone()  # the caller owns its result
+                    hip._check(lib.sopro_mimi_decode_stream(eng.h, scratch.data_ptr(), C.byref(state.cst), tok.data_ptr(), T, out.data_ptr(), hip._stream()),
+                               "sopro_mimi_decode_stream")
+                if wav is not None:
+                    wav[b0:b1].copy_(out)
+            if wav is None:
+                wav = out.clone()  # the caller owns its result
         self.stream.synchronize()
         return wav
 

@@ -392,3 +392,17 @@ def test_full_size_properties_32x200(tts, cfg, sopro_np, mimi_np):
     assert tuple(wav.shape) == (4, (F + 1) * 1920) and bool(torch.isfinite(wav).all())
     pre = big.codec.decode_batch(codes[:, :50])
     assert _err(wav[:, : 50 * 1920], pre) < 1e-4 * float(wav.abs().max()), "decoder is not causal in the frame index"
+
+
+def test_decode_batch_in_row_chunks_equals_one_call(tts, monkeypatch):
+    """Round 4: large batches are decoded in row chunks (a 64 x 400 decode in one call is slower than two 32 x 400 calls);
+    every utterance's samples must not depend on the chunking (rows are independent; no few-row split-K at these sizes)."""
+    rng = np.random.default_rng(91)
+    codes = torch.from_numpy(rng.integers(0, 2048, size=(5, 300, 32)))
+    monkeypatch.setenv("SOPRO_MIMI_CHUNK_CELLS", "100000")
+    one = tts.codec.decode_batch(codes)
+    monkeypatch.setenv("SOPRO_MIMI_CHUNK_CELLS", "600")  # 2 rows per chunk: 2 + 2 + 1
+    chunked = tts.codec.decode_batch(codes)
+    again = tts.codec.decode_batch(codes)  # (the chunk shapes replay their recorded sequences)
+    assert tuple(one.shape) == (5, 300 * 1920) and torch.equal(chunked, again)
+    assert float((one - chunked).abs().max()) <= 2e-6 * float(one.abs().max())  # (another tile walk for another row count: round-off class)
