@@ -53,8 +53,10 @@ def mfma(path, out_path):
         out[f] = {"launches": int(v["n"]), "dispatch_ms": round(ns / 1e6, 3), "mfma_busy_cycles": round(busy),
                   "mfma_busy_cycles_per_launch": round(busy / v["n"]), "clock_ghz_from_gui_active": round(gui / ns, 3),
                   "mfma_busy_share_at_2p4ghz": round(busy / (ns * 2.4 * 1024), 4), "mfma_busy_share_at_measured_clock": round(busy / (gui * 1024), 4)}
-    json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --lanes 1 --steps 1 "
-                          "--warmup 2 --profile-steps 0 --no-cpu-baseline --ttfa-runs 0 (3 passes of the step, whole chip per kernel)",
+    import os
+
+    json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- " +
+                          os.environ.get("PMC_COMMAND", "python bench.py --lanes 1 --steps 1 --warmup 2 --profile-steps 0 --no-cpu-baseline --ttfa-runs 0 (3 passes of the step, whole chip per kernel)"),
                "note": "1024 = 256 CUs x 4 SIMDs; one v_mfma_f32_32x32x16_bf16 keeps a SIMD's matrix core busy for 32 cycles, v_mfma_f32_32x32x2_f32 for 64",
                "families": out}, open(out_path, "w"), indent=1)
     print(json.dumps(out, indent=1))
