@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 37
+#define SOPRO_ABI_VERSION 38
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -431,6 +431,21 @@ int sopro_seanet_up128_bf16(const void* x, int64_t x_seg_stride, const float* w,
 int sopro_seanet_tail_bf16(const void* h, int64_t h_seg_stride, const float* w1, const float* b1, const float* w2, const float* b2,
                            const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B, int32_t T, void* stream);
 int sopro_seanet_up_set_tiles(int tiles); /* developer probe / tests: 64-row tiles per workgroup, 0 = by size */
+/* The whole last level in ONE kernel (round 4, csrc/seanet_uptail.hip): the last transposed convolution (128 -> 64, k = 8, s = 4),
+ * the last residual block and the last layer - sopro_seanet_up128_* followed by sopro_seanet_tail_* without the round trip of the
+ * 64-channel activation through memory (HF:modeling_mimi.py:931-961, 408-447).  x as for sopro_seanet_up128_f32 / _bf16 (activated
+ * input, [B][>= 1 + T][128], the pointer at the zero row in front of the first input row; strides in elements), the weights of the
+ * two kernels it replaces, wav [B][4 T] fp32.  passes 3 = three-pass split-bf16 (the decoder's class), 1 = one pass (bf16 mode).
+ * Same operand rounding and accumulation per contraction as the two kernels; the sums of the last layer are taken in the order of
+ * the sixteen-wave tail.  Written for long inputs (a workgroup walks >= 24 tiles of 32 input rows): the engine uses it from
+ * 512 Ki input rows per call, the two kernels below that. */
+int sopro_seanet_uptail_f32(const float* x, int64_t x_seg_stride, const float* wu, const float* bu, const float* w1, const float* b1,
+                            const float* w2, const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
+                            int32_t T, int32_t passes, void* stream);
+int sopro_seanet_uptail_bf16(const void* x, int64_t x_seg_stride, const float* wu, const float* bu, const float* w1, const float* b1,
+                             const float* w2, const float* b2, const float* wf, float bf, float* wav, int64_t wav_seg_stride, int32_t B,
+                             int32_t T, void* stream);
+int sopro_seanet_uptail_set_tiles(int tiles); /* developer probe / tests: 32-row tiles per workgroup, 0 = by size */
 int sopro_seanet_tail_set_tiles(int tiles); /* developer probe / tests: 126-sample tiles per workgroup of the four-wave kernel, 0 = by size
                                              * (long inputs: the sixteen-wave kernel), < 0 = the sixteen-wave kernel at any size */
 

@@ -1039,6 +1039,14 @@ static bool mimi_half(const sopro_engine* e) {
   return e->c.precision == 1 && !off;
 }
 
+// The last level (128 -> 64 channels, x 4) as ONE kernel (csrc/seanet_uptail.hip) for long inputs: its workgroups walk >= 24 tiles
+// of 32 input rows each, so below ~512 Ki input rows per call the two kernels - which spread a short input over the chip - stay
+// (streaming chunks, single short utterances).  SOPRO_SEANET_FUSE=0: always the two kernels (the round-3 sequence).
+static bool seanet_fused(int B, int rows) {
+  static const bool off = getenv("SOPRO_SEANET_FUSE") != nullptr && getenv("SOPRO_SEANET_FUSE")[0] == '0';
+  return !off && (int64_t)B * rows >= 512 * 1024;
+}
+
 static size_t mimi_carve(const sopro_engine* e, MimiWs& w, void* ws, int B, int T) {
   const sopro_engine_cfg& c = e->c;
   const bool half = mimi_half(e);
@@ -1202,6 +1210,11 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
       float* A = HP(He16, (size_t)(pad_in - 1) * ch);
       if (last) {
         SOPRO_CHECK_ARG(co == 64 && hid == 32, "the fused tail is written for a 64-channel last stage");
+        if (ch == 128 && r == 4 && seanet_fused(B, rows)) {  // the whole level in one kernel: h never reaches memory
+          sopro_prof_scope prof("seanet_uptail_kernel", 2.0 * B * rows * 256 * 256 + 2.0 * B * orow * (3 * 64 * 32 + 32 * 64 + 3 * 64), s);
+          return sopro_seanet_uptail_bf16(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"),
+                                          F(e, rs + ".c2.b"), F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, rows, s);
+        }
         if (ch == 128 && r == 4) {
           sopro_prof_scope prof("seanet_up128_kernel", 2.0 * B * rows * 256 * 256, s);
           STG(sopro_seanet_up128_bf16(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), HP(Ho, 2 * co), up.c_seg, B, rows, s));
@@ -1251,6 +1264,11 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     const float* A = He + (size_t)(pad_in - 1) * ch;
     if (last) {
       SOPRO_CHECK_ARG(co == 64 && hid == 32, "the fused tail is written for a 64-channel last stage");
+      if (ch == 128 && r == 4 && seanet_fused(B, rows)) {  // the whole level in one kernel: h never reaches memory
+        sopro_prof_scope prof("seanet_uptail_kernel", 2.0 * B * rows * 256 * 256 + 2.0 * B * orow * (3 * 64 * 32 + 32 * 64 + 3 * 64), s);
+        return sopro_seanet_uptail_f32(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"),
+                                       F(e, rs + ".c2.b"), F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, rows, sea_passes, s);
+      }
       if (ch == 128 && r == 4) {  // weight-stationary form of the K = 256, N = 256 contraction (same results)
         sopro_prof_scope prof("seanet_up128_kernel", 2.0 * B * rows * 256 * 256, s);
         STG(sopro_seanet_up128_f32(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), Ho + 2 * co, up.c_seg, B, rows, c.precision == 1 ? 1 : 3, s));

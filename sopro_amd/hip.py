@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -149,6 +149,9 @@ SYMBOLS = {
     "sopro_seanet_up128_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _p]),
     "sopro_seanet_tail_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _f32, _p, _i64, _i32, _i32, _p]),
     "sopro_seanet_up_set_tiles": (C.c_int, [C.c_int]),
+    "sopro_seanet_uptail_set_tiles": (C.c_int, [C.c_int]),
+    "sopro_seanet_uptail_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _f32, _p, _i64, _i32, _i32, _i32, _p]),
+    "sopro_seanet_uptail_bf16": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _f32, _p, _i64, _i32, _i32, _p]),
     "sopro_seanet_up128_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_seanet_res128_f32": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "sopro_gemm_set_tile_override": (C.c_int, [C.c_int]),
@@ -781,6 +784,19 @@ def seanet_tail_bf16(h: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: to
     """sopro_seanet_tail_bf16: the fused 24 kHz tail on bf16 rows (h_seg_stride in bf16 elements)."""
     _check(load().sopro_seanet_tail_bf16(ptr(h, torch.bfloat16), h_seg_stride, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(wf), bf, ptr(wav),
                                          wav_seg_stride, B, T, _stream()), "sopro_seanet_tail_bf16")
+
+
+def seanet_uptail(x: torch.Tensor, wu: torch.Tensor, bu: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+                  wf: torch.Tensor, bf: float, wav: torch.Tensor, *, B: int, T: int, x_seg_stride: int, wav_seg_stride: int, x_off: int = 0,
+                  passes: int = 3) -> None:
+    """The last SEANet level in one kernel (sopro_seanet_uptail_f32 / _bf16 by the dtype of ``x``): the last transposed convolution,
+    the last residual block and the last layer; offsets / strides in elements of ``x``."""
+    if x.dtype == torch.bfloat16:
+        _check(load().sopro_seanet_uptail_bf16(ptr(x, torch.bfloat16) + 2 * x_off, x_seg_stride, ptr(wu), ptr(bu), ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+                                               ptr(wf), bf, ptr(wav), wav_seg_stride, B, T, _stream()), "sopro_seanet_uptail_bf16")
+    else:
+        _check(load().sopro_seanet_uptail_f32(ptr(x) + 4 * x_off, x_seg_stride, ptr(wu), ptr(bu), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(wf), bf,
+                                              ptr(wav), wav_seg_stride, B, T, passes, _stream()), "sopro_seanet_uptail_f32")
 
 
 def set_lds_floor(nbytes: int) -> None:
