@@ -194,7 +194,7 @@ def rocprof_family_table() -> dict:
            "gemm_bf16s_kernel<3,": "gemm_bf16x6_kernel",  # (<2, ..., true> = the fp16 pieces of the NAR path: told apart below)
            "attention_kernel": "attention_kernel", "attn_window_mfma_kernel": "attention_kernel", "attn_mfma_kernel": "attention_kernel",
            "attn_decode_kernel": "attention_kernel", "attn_mfma_split_kernel": "attention_split_kernel", "seanet_tail_kernel": "seanet_tail_kernel", "seanet_tail16_kernel": "seanet_tail_kernel", "seanet_res128_kernel": "seanet_res128_kernel",
-           "seanet_up128_kernel": "seanet_up128_kernel"}
+           "seanet_up128_kernel": "seanet_up128_kernel", "seanet_uptail_kernel": "seanet_uptail_kernel"}
     out: dict = {}
     try:
         for r in csv.DictReader(open(files[-1])):
@@ -582,7 +582,8 @@ def main() -> None:
         entries.append((fam["gemm_f32_kernel"]["ms"], mfma_entry(
             "gemm_f32_kernel", "gemm_f32_kernel (all tile shapes; v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1, "")))
     mimi_passes = 1 if args.precision == "bf16" else 3
-    for key, what in (("seanet_tail_kernel", "fused 24 kHz tail: last residual block + final convolution"),
+    for key, what in (("seanet_uptail_kernel", "the whole last level in one kernel: last transposed convolution + last residual block + last layer"),
+                      ("seanet_tail_kernel", "fused 24 kHz tail: last residual block + final convolution"),
                       ("seanet_res128_kernel", "fused residual block of the 128-channel level"),
                       ("seanet_up128_kernel", "weight-stationary last transposed convolution")):
         if key in fam:

@@ -28,7 +28,7 @@ def fam(name: str) -> str:
         return "attention_kernel"
     if "seanet_tail" in name:  # (the four-wave and the sixteen-wave kernel)
         return "seanet_tail_kernel"
-    for k in ("gemm_f32_kernel", "skinny_kernel", "xattn_step_kernel", "ar_sample_kernel", "seanet_tail_kernel", "seanet_res128_kernel", "seanet_up128_kernel",
+    for k in ("gemm_f32_kernel", "skinny_kernel", "xattn_step_kernel", "ar_sample_kernel", "seanet_uptail_kernel", "seanet_tail_kernel", "seanet_res128_kernel", "seanet_up128_kernel",
               "attention_kernel", "argmax_partials_kernel"):
         if k in name:
             return k

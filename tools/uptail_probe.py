@@ -2,7 +2,8 @@
 """Developer probe: the last SEANet level as one kernel (sopro_seanet_uptail_*) against the two kernels it replaces
 (sopro_seanet_up128_* + sopro_seanet_tail_*) at the pipeline's pass shape (64 utterances x 96000 input rows by default), on the
 whole chip and on the 192-CU throughput partition, three-pass fp32 rows and one-pass bf16 rows, for several tiles-per-workgroup
-settings.  usage: uptail_probe.py [B] [T]"""
+settings.  usage: uptail_probe.py [B] [T] [fused]   (fused: only the one-kernel form at its default tiling - the ablation builds of
+tools/micro/build_uptail_abl.sh, SOPRO_HIP_LIB=...)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +12,7 @@ from sopro_amd import hip
 DEV = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 96000
+FUSED_ONLY = len(sys.argv) > 3 and sys.argv[3] == "fused"
 ci, co, r = 128, 64, 4
 S = r * T
 g = torch.Generator(device=DEV).manual_seed(1)
@@ -65,6 +67,9 @@ total = hip.device_info(0)["cus"]
 streams = [("whole chip", torch.cuda.Stream(device=DEV)), ("192-CU partition", hip.cu_range_stream(64, total - 64, DEV))]
 for name, st in streams:
     for what, two, one in (("three-pass, fp32 rows", two32, one32), ("one pass, bf16 rows", two16, one16)):
+        if FUSED_ONLY:
+            print(f"{name:18s} {what:22s} one kernel ({os.path.basename(os.environ.get('SOPRO_HIP_LIB', 'product'))}): {timed(one, st):9.1f} us", flush=True)
+            continue
         us2 = timed(two, st)
         print(f"{name:18s} {what:22s} two kernels {us2:9.1f} us  {flop / us2 / 1e6:6.1f} TF", flush=True)
         for tiles in (0, 24, 47, 94, 375):
