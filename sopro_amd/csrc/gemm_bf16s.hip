@@ -534,7 +534,19 @@ extern "C" int sopro_gemm_set_group_m(int g) {
   return 0;
 }
 
-static int g_tile_override = 0;  // developer probe: 1: 128x128, 2: 256x128, 4: 128x64 (x6: 64x128), 5: 64x64
+// 128x128 tiles on EIGHT waves (2 x 4 waves of 64 x 32: 104 registers, so two workgroups = four waves per SIMD share a CU; the
+// four-wave form holds 198 and runs two per SIMD).  Vector work issued behind an MFMA does not run under it within a wave
+// (profiles/r04_mfma_valu_overlap.txt) - what overlaps the matrix cores with the split / staging instructions is OTHER waves of the
+// SIMD.  Measured (profiles/r04_experiments.md section 6): alone, +2-12 % on the decoder's shapes with N >= 512 (-4-9 % for N <= 256);
+// in the pipeline NOTHING - the refinement gets 0.2-0.3 ms per step faster and the generation partition next door as much slower.
+// Kept as a developer override (tile override 7 / SOPRO_GEMM_W8=1) for the three-pass decoder path; same K loop per output
+// element: bit-identical results.
+static bool eight_waves(const sopro_gemm_args& g) {
+  static const bool on = getenv("SOPRO_GEMM_W8") != nullptr && getenv("SOPRO_GEMM_W8")[0] == '1';
+  return on && g.N >= 512 && g.M >= 1024;
+}
+
+static int g_tile_override = 0;  // developer probe: 1: 128x128, 2: 256x128, 4: 128x64 (x6: 64x128), 5: 64x64, 7 / 8: 128x128 on eight waves (bf16x3)
 extern "C" int sopro_gemm_bf16_set_tile_override(int cfg) {
   g_tile_override = cfg;
   return 0;
@@ -600,10 +612,12 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
     case 2: return launch_cfg3<2, 2, 2, 4, 2>(g, wp, ksubs, ext, s);
     case 4: return launch_cfg3<2, 2, 2, 2, 1>(g, wp, ksubs, ext, s);
     case 5: return launch_cfg3<2, 2, 2, 1, 1>(g, wp, ksubs, ext, s);
+    case 7: return launch_cfg3<2, 2, 4, 2, 1>(g, wp, ksubs, ext, s);  // 128x128 on eight waves
     default: break;
   }
   // few columns, or few rows (streaming chunks, batch 1: small tiles keep the split-K partial sums small): 64x64
   if (g.N <= 64 || g.M <= 64) return launch_cfg3<2, 2, 2, 1, 1>(g, wp, ksubs, ext, s);
+  if (eight_waves(g)) return launch_cfg3<2, 2, 4, 2, 1>(g, wp, ksubs, ext, s);
   return launch_cfg3<2, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
 }
 

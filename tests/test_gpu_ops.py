@@ -348,6 +348,43 @@ def test_gemm_f16x3_is_fp32_class(M, N, K):
         assert torch.equal(got[:, 0].cpu().long(), C.cpu().argmax(-1))
 
 
+def test_gemm_eight_wave_tiles_are_the_same_function():
+    """128x128 tiles on eight waves (round 4 developer form of the three-pass decoder contraction, tile override 7: four waves per
+    SIMD; measured faster alone, not in the pipeline - profiles/r04_experiments.md) against the four-wave form: every output element
+    runs the same K loop, so every form of that path is bit-identical - plain, GELU, residual, activated copies, ELU prologue -
+    with a ragged last row tile and a K that ends in an odd step."""
+    M, N, K = 1300, 640, 416  # ragged last row tile, 5 column tiles, 13 K-steps
+    A, W, b, R = rnd(M, K, seed=81), rnd(N, K, seed=82, scale=K ** -0.5), rnd(N, seed=83), rnd(M, N, seed=84)
+    Ad, bd, Rd = dev(A), dev(b), dev(R)
+    lib, Wp = hip.load(), hip.pack_w_bf16x3(dev(W))
+
+    def both(fn):
+        outs = []
+        try:
+            for cfg in (1, 7):
+                lib.sopro_gemm_bf16_set_tile_override(cfg)
+                C = torch.full((M, N), float("nan"), device=DEV)
+                extra = fn(C)
+                torch.cuda.synchronize()
+                outs.append([C.cpu()] + [e.cpu() for e in (extra or [])])
+        finally:
+            lib.sopro_gemm_bf16_set_tile_override(0)
+        for x, y in zip(*outs):
+            assert bool(torch.isfinite(x).all()) and torch.equal(x, y)
+
+    both(lambda C: hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd))
+    both(lambda C: hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd, epilogue=hip.EPI_GELU))
+    both(lambda C: hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd, epilogue=hip.EPI_RES, R=Rd))
+    both(lambda C: hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd, c_mode=3))
+    both(lambda C: hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd, prologue=hip.PRO_ELU))
+
+    def raw_and_act(C):
+        C2 = torch.full((M, N), float("nan"), device=DEV)
+        hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd, c_mode=4, C2=C2)
+        return [C2]
+    both(raw_and_act)
+
+
 @pytest.mark.parametrize("pieces,M,N,K,epi", [(3, 6, 384, 1536, "res"), (3, 6, 768, 1152, "glu"), (3, 12, 2048, 1024, "none"), (2, 12, 512, 2048, "res"),
                                               (2, 12, 1024, 3584, "none"), (2, 33, 4096, 2048, "none"), (3, 1, 64, 1536, "gelu")])
 def test_gemm_split_k_small_m_is_exact_class_and_deterministic(pieces, M, N, K, epi):
