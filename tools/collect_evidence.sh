@@ -28,6 +28,8 @@ if [ "$WHAT" = profiles ] || [ "$WHAT" = all ]; then
   python tools/pmc_summary.py $O/fetch/f_counter_collection.csv $O/write/w_counter_collection.csv $O/${TAG}_pmc_summary.json | head -60
   python tools/pmc_summary.py --mfma $O/mfma/m_counter_collection.csv $O/${TAG}_pmc_mfma_busy.json | head -40
   python tools/ar_kernel_table.py $O/l1/l1_kernel_stats.csv $O/${TAG}_ar_kernels.json | head -40
+  # (when the table is copied to profiles/rNN_ar_kernels.json, set its "source" to the committed name of the CSV it was made from:
+  #  profiles/rNN_bench_lanes1_kernel_stats.csv - bench.py stamps that file's hash into the line)
   rm -f $O/*/*_kernel_trace.csv $O/*/*_counter_collection.csv  # the traces are large: keep the stats only
   ls $O/*/
 fi
