@@ -1,3 +1,5 @@
+// DEVELOPER COPY of sopro_amd/csrc/seanet_uptail.hip (round 4, second form) with the SOPRO_UPTAIL_ABL hooks that leave stages out -
+// wrong results, timing only (tools/micro/build_uptail_abl.sh; profiles/r04_uptail_ablation.txt).  Not part of the product library.
 // Last level of the SEANet decoder in ONE kernel: the last transposed convolution and everything behind it
 // (HF:modeling_mimi.py:931-961 - the fourth `MimiConvTranspose1d`, the last `MimiResnetBlock` 408-447, the last layer):
 //     h[4t + r, co] = bu[co] + sum_k A[t, k] * Wu[r*64 + co, k],   A[t, :] = [ x[t-1, 0..127] | x[t, 0..127] ]      (seanet_up.hip)
@@ -23,7 +25,7 @@
 // through two 544-byte side buffers; a workgroup that does not start at the head of an utterance runs the tile in front of its
 // range as a warm-up (stores masked), which leaves exactly these rows.  Arithmetic as in the two kernels: operands x = hi + lo in
 // bf16, lo*hi + hi*lo + hi*hi with fp32 accumulation (PASSES 3), or hi*hi only (PASSES 1, the engine's bf16 mode; XH: x arrives
-// as bf16 rows).  (What each stage costs was measured on a copy with stages left out: tools/micro/seanet_uptail_ablate.hip.)
+// as bf16 rows).
 #include <type_traits>
 #include <utility>
 
@@ -80,6 +82,10 @@ __device__ __forceinline__ void sfor(F&& f) {
 template <int V>
 using IC = std::integral_constant<int, V>;
 
+#ifndef SOPRO_UPTAIL_ABL  // developer timing builds (tools/micro/build_uptail_abl.sh, never the product library): stages left out - wrong results
+#define SOPRO_UPTAIL_ABL 0
+#endif
+
 // x: row p of utterance b at x + b * x_seg_stride + p * 128 (fp32, or bf16 with XH); the caller points x at the row BEFORE the
 // first input row (a zero row), as for sopro_seanet_up128_*.  wav: sample s of utterance b at wav + b * wav_seg_stride + s.
 template <int PASSES, bool XH>
@@ -121,6 +127,7 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
   // their results are never stored)
   constexpr int NV = XH ? 2 : 3;  // pieces per thread: 33 rows x 16 (bf16) or x 32 (fp32)
   auto request = [&](int t0, int q) -> uint4 {
+    if (SOPRO_UPTAIL_ABL & 32) return make_uint4(0u, 0u, 0u, 0u);
     const int idx = tid + q * 512;
     const int rr = XH ? idx >> 4 : idx >> 5, cc = XH ? idx & 15 : idx & 31;
     const int p = t0 + rr;
@@ -129,6 +136,7 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
     else return *reinterpret_cast<const uint4*>(xb + (int64_t)pc * FC + cc * 4);
   };
   auto stage = [&](unsigned char* xbuf, int q, const uint4& val) {
+    if (SOPRO_UPTAIL_ABL & 32) return;
     const int idx = tid + q * 512;
     const int rr = XH ? idx >> 4 : idx >> 5, cc = XH ? idx & 15 : idx & 31;
     if (rr < FXR) {
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
   };
   auto p_mfma = [&](const unsigned char* xt, auto j_) {
     constexpr int J = decltype(j_)::value, s = J / PASSES, piece = J % PASSES;
+    if (SOPRO_UPTAIL_ABL & 1) return;
     if constexpr (piece == 0) {
       pah = nah;
       if (PASSES == 3) pal = nal;
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
   unsigned char* const hp0 = hs + (2 + ph + (odd ? 4 : 0)) * FHROW + (cbase + (frow & ~1)) * 2;
   auto h_elu = [&](auto i_) {  // chunk I of 8: registers 2 I, 2 I + 1
     constexpr int q = 2 * decltype(i_)::value;
+    if (SOPRO_UPTAIL_ABL & 16) return;
     const int t = 8 * (q >> 2) + 4 * fg + (q & 3);
     unsigned hi, lo;
     split2_bf16(eluf_(hraw[q]), eluf_(hraw[q + 1]), hi, lo);
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
     const unsigned char* a = hs + (16 * wave + col) * FHROW + kq * 16;
     sfor<6>([&](auto s_) {
       constexpr int s = decltype(s_)::value;
-      {
+      if (!(SOPRO_UPTAIL_ABL & 2)) {
         const unsigned char* p = a + (s >> 1) * FHROW + (s & 1) * 64;
         const uint4 ah = *reinterpret_cast<const uint4*>(p);
         if constexpr (PASSES == 3) {
@@ -285,6 +295,8 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ffrag(ah), ffrag(w1r[0][PASSES == 1 ? s : 0]), acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ffrag(ah), ffrag(w1r[PASSES == 1 ? 1 : 0][PASSES == 1 ? s : 0]), acc[1], 0, 0, 0);
         }
+      } else {
+        p_slot(xt, IC<JA>(), IC<JB>(), s_, IC<10>());
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
     sfor<4>([&](auto c_) {
       constexpr int c = decltype(c_)::value, nt = c >> 1, i = (c & 1) * 2;
       p_slot(xt, IC<JA>(), IC<JB>(), IC<6 + c>(), IC<10>());
-      {
+      if (!(SOPRO_UPTAIL_ABL & 2)) {
         unsigned hi, lo;
         split2_bf16(eluf_(acc[nt][i] + b1v[nt]), eluf_(acc[nt][i + 1] + b1v[nt]), hi, lo);
         unsigned char* yp = yp0 + i * 32 * FYROW + 32 * nt;
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
     for (int q = 0; q < 16; ++q) acc2[q] = 0.f;
     const unsigned char* a = ys + (ph * 32 + frow) * FYROW + fg * 16;
     uint4 ah[2], al[2], bh[2], bl[2];
-    {
+    if (!(SOPRO_UPTAIL_ABL & 4)) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         ah[s] = *reinterpret_cast<const uint4*>(a + s * 32);
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
     sfor<NC2>([&](auto m_) {
       constexpr int m = decltype(m_)::value, s = m / PASSES, piece = m % PASSES;
       p_slot(xt, IC<JB>(), IC<NP>(), m_, IC<NC2 + 8>());
-      {
+      if (!(SOPRO_UPTAIL_ABL & 4)) {
         if constexpr (PASSES == 3) {
           if constexpr (piece == 0) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ffrag(al[s]), ffrag(bh[s]), acc2, 0, 0, 0);
           else if constexpr (piece == 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ffrag(ah[s]), ffrag(bl[s]), acc2, 0, 0, 0);
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
     sfor<8>([&](auto c_) {
       constexpr int q0 = 2 * decltype(c_)::value;
       p_slot(xt, IC<JB>(), IC<NP>(), IC<NC2 + decltype(c_)::value>(), IC<NC2 + 8>());
-      {
+      if (!(SOPRO_UPTAIL_ABL & 4)) {
 #pragma unroll
         for (int q = q0; q < q0 + 2; ++q) {
           const int t = 8 * (q >> 2) + 4 * fg + (q & 3);
@@ -362,8 +374,10 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
     constexpr int NS3 = 8 + 8 + 8 + 4 + 2 + 1;  // slots: h chunks, FMA pairs of outputs, exchange steps
     const float* hf = reinterpret_cast<const float*>(hp);
     float xr[18], p16[16];
+    if (!(SOPRO_UPTAIL_ABL & 8)) {
 #pragma unroll
-    for (int rr = 0; rr < 18; ++rr) xr[rr] = hf[(16 * wave + rr) * FHLD + lane];
+      for (int rr = 0; rr < 18; ++rr) xr[rr] = hf[(16 * wave + rr) * FHLD + lane];
+    }
     if constexpr (NEXT) {
       p_read(xt, 0);
       sfor<8>([&](auto c_) {
@@ -375,10 +389,16 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
     sfor<8>([&](auto c_) {
       constexpr int i0 = 2 * decltype(c_)::value;
       if constexpr (NEXT) p_slot(xt, IC<0>(), IC<JA>(), IC<8 + decltype(c_)::value>(), IC<NS3>());
+      if (!(SOPRO_UPTAIL_ABL & 8)) {
 #pragma unroll
-      for (int i = i0; i < i0 + 2; ++i) p16[i] = fmaf(wl2, xr[i + 2], fmaf(wl1, xr[i + 1], wl0 * xr[i]));
+        for (int i = i0; i < i0 + 2; ++i) p16[i] = fmaf(wl2, xr[i + 2], fmaf(wl1, xr[i + 1], wl0 * xr[i]));
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
+    if (SOPRO_UPTAIL_ABL & 8) {
+      if constexpr (NEXT) sfor<15>([&](auto c_) { p_slot(xt, IC<0>(), IC<JA>(), IC<16 + decltype(c_)::value>(), IC<NS3>()); });
+      return;
+    }
     // Transpose-reduction over the 64 lanes without LDS traffic.  An exchange step on lane bit B: lanes with the bit set keep the
     // upper half of their values, the others the lower half, and add what the partner lane (lane ^ B) gives away:
     //   B = 32, 16: v_permlane32_swap / v_permlane16_swap (gfx950) swap the upper lanes (odd 16-lane rows) of the register holding
