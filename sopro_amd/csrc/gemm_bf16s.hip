@@ -535,9 +535,8 @@ extern "C" int sopro_gemm_set_group_m(int g) {
 }
 
 // 128x128 tiles on EIGHT waves (2 x 4 waves of 64 x 32: 104 registers, so two workgroups = four waves per SIMD share a CU; the
-// four-wave form holds 198 and runs two per SIMD).  Vector work issued behind an MFMA does not run under it within a wave
-// (profiles/r04_mfma_valu_overlap.txt) - what overlaps the matrix cores with the split / staging instructions is OTHER waves of the
-// SIMD.  Measured (profiles/r04_experiments.md section 6): alone, +2-12 % on the decoder's shapes with N >= 512 (-4-9 % for N <= 256);
+// four-wave form holds 198 and runs two per SIMD): twice the operand requests in flight per CU.
+// Measured (profiles/r04_experiments.md section 6): alone, +2-12 % on the decoder's shapes with N >= 512 (-4-9 % for N <= 256);
 // in the pipeline NOTHING - the refinement gets 0.2-0.3 ms per step faster and the generation partition next door as much slower.
 // Kept as a developer override (tile override 7 / SOPRO_GEMM_W8=1) for the three-pass decoder path; same K loop per output
 // element: bit-identical results.

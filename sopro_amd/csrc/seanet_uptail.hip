@@ -9,9 +9,10 @@
 // Eight waves, one workgroup per CU.  The transposed convolution is WEIGHT-STATIONARY as in seanet_up.hip: wave w owns output
 // columns 32w .. 32w+31 (sample phase r = w / 2, channels 32 (w % 2) .. + 31) over all of K = 256 - 128 registers of split-bf16
 // B fragments for the life of the workgroup.  Its accumulation only reads a staged x tile and registers, so it runs AHEAD of the
-// rest and its MFMAs are dealt out one at a time between the vector instructions of the other stages (a wave issues in order: a
-// matrix-core instruction followed by independent vector work runs under it; phase by phase - first measured form of this kernel,
-// profiles/r04_experiments.md - every stage's time simply added up).  Three phases per tile, one workgroup barrier behind each:
+// rest and its MFMAs are dealt out one at a time between the vector instructions of the other stages: the matrix cores and the
+// vector ALU overlap across the two waves of a SIMD, not within a wave (profiles/r04_mfma_valu_overlap.txt), so both waves should
+// have both kinds of work to offer at any time (the first form of this kernel ran stage by stage: profiles/r04_experiments.md).
+// Three phases per tile, one workgroup barrier behind each:
 //     I1  conv k=3, 64 -> 32 on the split ELU(h) tile of tile k (LDS), wave w = samples 16w .. 16w+15 (v_mfma 16x16x32) -> split
 //         ELU(y) tile, rows grouped by sample phase                                        | substeps 10-11 of tile k+1
 //     I2  conv k=1, 32 -> 64 in the PRODUCER's layout (wave w: its 32 samples of phase r x its 32 channels), so the skip operand

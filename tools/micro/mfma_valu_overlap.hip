@@ -1,7 +1,8 @@
 // Developer probe: does vector work issued behind a matrix-core instruction run under it?  One workgroup of eight waves per CU (two
 // per SIMD, as in seanet_uptail.hip); every wave loops over [1 x v_mfma_f32_32x32x16_bf16 (a dependent chain on one accumulator),
-// N x v_fma_f32 (independent chains on other registers)] and reports shader clocks per iteration:
-//   overlapped:   ~ max(MFMA passes, 4 N) per wave, the two waves of a SIMD sharing both pipes;   serialised: their sum.
+// N x v_fma_f32 (independent chains on other registers)] and reports WALL time per iteration (host events) next to clock64 ticks
+// (a tick lasts 0.46 .. 1.15 ns depending on the load: compare wall times):
+//   overlapped:   ~ max(MFMA, vector) per SIMD, the waves of a SIMD sharing both pipes;   serialised: their sum.
 // ACC = 0: accumulator in VGPRs, 1: in AGPRs.   build: hipcc --offload-arch=gfx950 -O3 mfma_valu_overlap.hip -o mfma_valu_overlap
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -38,9 +39,17 @@ void run(long long* d) {
   const int iters = 4000;
   probe<N, ACC, WAVES><<<256, WAVES * 64>>>(d, iters);
   hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
   probe<N, ACC, WAVES><<<256, WAVES * 64>>>(d, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
   long long h = 0;
   hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+  printf("[%.1f ns per iteration by the host's events -> one clock64 tick = %.2f ns] ", ms * 1e6 / iters, ms * 1e6 / (double)h);
   printf("waves/SIMD %d  acc in %s  N = %2d vector ops per MFMA: %7.1f clocks per iteration (serial %d, overlapped %d per wave; x waves/SIMD sharing)\n", WAVES / 4,
          ACC ? "AGPRs" : "VGPRs", N, (double)h / iters, 32 + 4 * N, 32 > 4 * N ? 32 : 4 * N);
 }
