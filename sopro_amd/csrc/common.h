@@ -77,6 +77,43 @@ __device__ __forceinline__ void split2_bf16(float x, float y, unsigned& hi, unsi
   lo = *reinterpret_cast<const unsigned*>(&l);
 }
 
+// The throughput phases' output streams - every contraction's C / activated copy, the 128-channel residual block's output - and
+// the fused last level's input carry the non-temporal hint: they then displace less of what the generation partition next door
+// re-reads every frame (its weights and folded text operands, ~240 MB).  Measured in the pipeline (profiles/r04_experiments.md
+// section 7, same box, alternating): never 23.45 / 23.66 k audio-s/s, only tensors >= 64 MB 23.65 / 23.74 k, ALWAYS 23.87 / 23.88 k
+// (AR phases 33.3-33.9 against 34.5-34.9 ms per step, Mimi decode 13.5 against 13.8-13.9).  Policy SOPRO_NT_BULK: 1 = always (the
+// product), 2 = by size (`big`), 0 = never (developer A/B: tools/micro/build_nt_bulk.sh).
+#ifndef SOPRO_NT_BULK
+#define SOPRO_NT_BULK 1
+#endif
+__device__ __forceinline__ bool bulk_nt(bool big) { return SOPRO_NT_BULK == 1 || (SOPRO_NT_BULK == 2 && big); }
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bulk_store4(float* p, const float4& v, bool big) {
+  if (bulk_nt(big)) __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<float4*>(p) = v;
+}
+__device__ __forceinline__ void bulk_store1(float* p, float v, bool big) {
+  if (bulk_nt(big)) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+__device__ __forceinline__ void bulk_store_u2(void* p, const uint2& v, bool big) {
+  if (bulk_nt(big)) __builtin_nontemporal_store((u32x2_t){v.x, v.y}, reinterpret_cast<u32x2_t*>(p));
+  else *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void bulk_store_u1(void* p, unsigned v, bool big) {
+  if (bulk_nt(big)) __builtin_nontemporal_store(v, reinterpret_cast<unsigned*>(p));
+  else *reinterpret_cast<unsigned*>(p) = v;
+}
+__device__ __forceinline__ uint4 bulk_load16(const void* p, bool big) {
+  if (bulk_nt(big)) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
+constexpr int64_t SOPRO_BIG_BYTES = (int64_t)64 << 20;
+
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own L2.  This maps
 // the workgroup index so that XCD x walks ONE contiguous range of tile indices: the tiles an L2 serves at the same time
 // share their A rows / W columns instead of every L2 fetching every operand.

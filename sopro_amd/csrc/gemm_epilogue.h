@@ -28,6 +28,7 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int rps = g.rows_per_seg;
+  const bool big = (int64_t)g.M * g.N * (OUT >= 6 ? 2 : 4) >= SOPRO_BIG_BYTES;  // a large output: stored with the non-temporal hint (common.h)
   // ---- epilogue through LDS.  The MFMA accumulator layout gives a lane ONE column of 16 rows, i.e. 4-byte
   // stores/loads (measured: 26k of a workgroup's 119k cycles for a 128x128x256 tile).  The tile buffers are free
   // now, so the accumulators are transposed through LDS and every thread streams whole 16-byte pieces of rows:
@@ -118,13 +119,13 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
           uint2 h;
           split2_bf16(v.x, v.y, h.x, lo_);
           split2_bf16(v.z, v.w, h.y, lo_);
-          *reinterpret_cast<uint2*>(rawb + oraw[q]) = h;
+          bulk_store_u2(rawb + oraw[q], h, big);
         }
         if (OUT != 6) {
           uint2 h;
           split2_bf16(eluf_(v.x), eluf_(v.y), h.x, lo_);
           split2_bf16(eluf_(v.z), eluf_(v.w), h.y, lo_);
-          *reinterpret_cast<uint2*>(actb + oact[q]) = h;
+          bulk_store_u2(actb + oact[q], h, big);
         }
       }
     }
@@ -219,11 +220,11 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
         *reinterpret_cast<uint2*>(dp[q] + 64) = l;
         if (OUT == 1) continue;
       } else if (OUT != 0) {
-        *reinterpret_cast<float4*>(dp[q]) = make_float4(eluf_(v.x), eluf_(v.y), eluf_(v.z), eluf_(v.w));
+        bulk_store4(reinterpret_cast<float*>(dp[q]), make_float4(eluf_(v.x), eluf_(v.y), eluf_(v.z), eluf_(v.w)), big);
         if (OUT == 3) continue;
       }
       if (vec_ok) {
-        *reinterpret_cast<float4*>(cp[q]) = v;
+        bulk_store4(cp[q], v, big);
       } else {
         cp[q][0] = v.x;
         if (ocol + 1 < n_out_total) cp[q][1] = v.y;

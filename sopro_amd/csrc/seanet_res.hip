@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];          // K-half exchange of the first convolution
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
+  const bool big = (int64_t)gridDim.y * T * 128 * 4 >= SOPRO_BIG_BYTES;  // a large output: stored with the non-temporal hint (common.h)
   const int frow = lane & 31, fg = lane >> 5;
   const int nt1 = wave & 1, kh = wave >> 1;
   const float* hb = h + (int64_t)b * h_seg_stride;   // 2 zero rows, then T rows of RC floats
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
-        if (s0 + m < T) ob[(int64_t)(s0 + m + 2) * RC + wave * 32 + frow] = eluf_(skip[r] + acc2[r] + b2v);
+        if (s0 + m < T) bulk_store1(ob + (int64_t)(s0 + m + 2) * RC + wave * 32 + frow, eluf_(skip[r] + acc2[r] + b2v), big);
       }
     }
   }
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_hb_kernel(const unsigned
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];            // K-half exchange of the first convolution
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
+  const bool big = (int64_t)gridDim.y * T * 128 * 2 >= SOPRO_BIG_BYTES;
   const int frow = lane & 31, fg = lane >> 5;
   const int nt1 = wave & 1, kh = wave >> 1;
   const unsigned short* hb = h + (int64_t)b * h_seg_stride;   // 2 zero rows, then T rows of RC bf16
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_hb_kernel(const unsigned
         const unsigned sk = skip[r >> 1];
         unsigned pk, lo_;
         split2_bf16(eluf_(__uint_as_float(sk << 16) + c0), eluf_(__uint_as_float(sk & 0xffff0000u) + c1), pk, lo_);
-        if (s0 + m < T) *reinterpret_cast<unsigned*>(ob + (int64_t)(s0 + m + 2) * RC + colp) = pk;
+        if (s0 + m < T) bulk_store_u1(ob + (int64_t)(s0 + m + 2) * RC + colp, pk, big);
       }
     }
   }

@@ -126,8 +126,9 @@ __global__ __launch_bounds__(512, 1) void seanet_uptail_kernel(const void* __res
     const int rr = XH ? idx >> 4 : idx >> 5, cc = XH ? idx & 15 : idx & 31;
     const int p = t0 + rr;
     const int pc = (rr < FXR && p <= T) ? p : 0;
-    if constexpr (XH) return *reinterpret_cast<const uint4*>(xb16 + (int64_t)pc * FC + cc * 8);
-    else return *reinterpret_cast<const uint4*>(xb + (int64_t)pc * FC + cc * 4);
+    // (this kernel runs on long inputs only: x is read once, hundreds of MB - streamed with the non-temporal hint, common.h)
+    if constexpr (XH) return bulk_load16(xb16 + (int64_t)pc * FC + cc * 8, true);
+    else return bulk_load16(xb + (int64_t)pc * FC + cc * 4, true);
   };
   auto stage = [&](unsigned char* xbuf, int q, const uint4& val) {
     const int idx = tid + q * 512;

@@ -1,0 +1,22 @@
+#!/bin/bash
+# r04 call 28: the split contractions A rows with the non-temporal hint (tools/micro/build_nt_a.sh) against the product (outputs
+# non-temporal, A rows plain): pipeline A/B, fp32 and bf16.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; O=$R/gpurun_out/r04c28; mkdir -p $O; cd $R
+Q="--no-cpu-baseline --ttfa-runs 0 --profile-steps 0 --no-legs --steps 20 --warmup 5"
+for v in prod nta prod nta; do
+  L=""; [ $v = nta ] && L=$R/tools/micro/libsopro_nt_a1.so
+  SOPRO_HIP_LIB=$L timeout 300 python bench.py $Q >> $O/f32_$v.json 2>> $O/f32_$v.err
+done
+for v in prod nta; do
+  L=""; [ $v = nta ] && L=$R/tools/micro/libsopro_nt_a1.so
+  SOPRO_HIP_LIB=$L timeout 300 python bench.py $Q --precision bf16 >> $O/bf16_$v.json 2>> $O/bf16_$v.err
+done
+python - <<'P'
+import json,glob,os
+O=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/r04c28'
+for f in sorted(glob.glob(O+'/*.json')):
+    for l in open(f).read().strip().splitlines():
+        d=json.loads(l)
+        print(os.path.basename(f), d['value'], d['ms_per_step'], d['phase_ms_per_step'], d['parity'].get('timed_steps_identical'))
+P
+grep -i "error\|Traceback" $O/*.err | head
