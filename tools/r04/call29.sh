@@ -1,4 +1,6 @@
 #!/bin/bash
+# (kept as the record of the call: the variant library came from a one-off patch of gload() in csrc/gemm_bf16s.hip - A rows through
+#  __builtin_nontemporal_load - that was not kept; profiles/r04_experiments.md section 7)
 # r04 call 29: A rows non-temporal only for the LAST column tile of a row tile (tools/micro/build_nt_a.sh) against the product (outputs
 # non-temporal, A rows plain): pipeline A/B, fp32 and bf16.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; O=$R/gpurun_out/r04c29; mkdir -p $O; cd $R
