@@ -184,7 +184,7 @@ int sopro_pack_w_f16x2(const float* W, int64_t ldw, int32_t N, int32_t K, float 
 float sopro_f16x3_a_scale(void);
 int sopro_gemm_f16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
 int64_t sopro_packed_w_bytes(int32_t N, int32_t K, int32_t pieces);
-int sopro_gemm_bf16_set_tile_override(int cfg); /* developer probe */
+int sopro_gemm_bf16_set_tile_override(int cfg); /* developer probe: 0 = by shape, 1: 128x128, 2: 256x128, 4: 128x64, 5: 64x64, 7: 128x128 on eight waves (bf16x3 only) */
 int sopro_gemm_set_group_m(int g);              /* default tile-walk group of the split-bf16 contractions (see group_m) */
 
 /* Batch-of-at-most-a-few-dozen-rows contraction for the autoregressive step
