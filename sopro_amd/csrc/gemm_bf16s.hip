@@ -118,6 +118,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     const int t = min((n0 >> 5) + wn * TN + j, ntiles - 1);
     bp[j] = Wp + ((int64_t)t * ksubs * NPL) * 64 + lane;
   }
+  // W fragments as (uniform base of the K-step) + (32-bit lane offset of the column tile) + (immediate of the substep / piece): a
+  // request is ONE instruction, no vector address arithmetic (the packed W of one matrix is far below 2^31 fragments)
+  int boff[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int t = min((n0 >> 5) + wn * TN + j, ntiles - 1);
+    boff[j] = (t * ksubs * NPL) * 64 + lane;
+  }
   float biasv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -237,6 +245,74 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     }
   };
 
+  // The K-step with the NEXT steps' global requests dealt out between its MFMAs instead of issued in one burst behind the barrier.
+  // Shader-clock sums inside the loop (profiles/r04_gemm_kstep_stamps.txt) showed a wave spending 38-40 % of the K loop ISSUING its
+  // twelve requests: all eight waves of a CU push them (12 KB per wave) into the CU's one address path at the same moment, issue is
+  // in order - no MFMA goes out until the path has taken them - and the path then idles through the MFMA phase.  One request behind
+  // every NM / NL MFMAs, W fragments of step kB first (needed next step), then the A rows of step kA; W addresses are (K-step base)
+  // + (lane offset) + immediate, so a request is one instruction.  The fences around a request keep it between those MFMAs; for the
+  // three-pass forms ALU work and LDS traffic (the next substep's fragment reads) may cross them (mask 0x786: strict fences cost
+  // them 3-19 %), for the one-pass form nothing may (strict: +5-14 %, relaxed: +-0).  Same products in the same order: bit-identical.
+  // Measured (tools/gemm_loop_probe.py, profiles/r04_gemm_spread_requests_*.txt): three-pass +5-10 %, one-pass +5-14 %.
+  auto compute_spread = [&](int buf, const uint4 (&rb)[TN][2][NPL], int kA, float4 (&ra)[A_F4], float4& pv, int kB, uint4 (&rbn)[TN][2][NPL]) {
+    constexpr int NB = TN * 2 * NPL, NL = NB + A_F4, NM = 2 * NPAIR * TM * TN;
+    constexpr int STRIDE = NM / NL > 0 ? NM / NL : 1;
+    const int kcol = min(kA * BK + lc4 * 4, klast);
+    if (AMODE == 3) pv = *reinterpret_cast<const float4*>(g.pro_vec + kcol);
+    auto issue = [&](int n) {
+      if (n < NB) {
+        const int j = n / (2 * NPL), ss = (n / NPL) % 2, p = n % NPL;
+        const uint4* wk = Wp + (int64_t)__builtin_amdgcn_readfirstlane(kB) * (2 * NPL * 64);  // uniform: scalar registers
+        rbn[j][ss][p] = wk[boff[j] + (ss * NPL + p) * 64];
+      } else if (n < NL) {
+        const int i = n - NB;
+        if constexpr (AMODE == 5) {
+          const uint2 v = *reinterpret_cast<const uint2*>(ap[i] + (int64_t)kcol * 2);
+          ra[i].x = __uint_as_float(v.x);
+          ra[i].y = __uint_as_float(v.y);
+        } else {
+          ra[i] = *reinterpret_cast<const float4*>(ap[i] + (int64_t)kcol * 4);
+        }
+      }
+    };
+    const unsigned char* a = As + buf * BM * AROW + (wm * TM * 32 + frow) * AROW + fg * 16;
+    int m = 0, nl = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 af[TM][NPL];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) af[i][p] = *reinterpret_cast<const uint4*>(a + i * 32 * AROW + p * 64 + s * 32);
+#pragma unroll
+      for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (F16)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag16(af[i][PA[q]]), as_frag16(rb[j][s][PB[q]]), acc[i][j], 0, 0, 0);
+            else
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af[i][PA[q]]), as_frag(rb[j][s][PB[q]]), acc[i][j], 0, 0, 0);
+            ++m;
+            if (m % STRIDE == 0 && nl < NL) {
+              if constexpr (NPL == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue(nl++);
+                __builtin_amdgcn_sched_barrier(0);
+              } else {
+                __builtin_amdgcn_sched_barrier(0x786);
+                issue(nl++);
+                __builtin_amdgcn_sched_barrier(0x786);
+              }
+            }
+          }
+    }
+#pragma unroll
+    for (int n = 0; n < NL; ++n)  // (whatever the MFMA count left over)
+      if (n >= nl) issue(n);
+  };
+
   // Split-K (ext.ksplit > 1, for problems with too few tiles to fill the chip: a long K loop on a handful of workgroups
   // is one memory latency per K-step): blockIdx.y picks a contiguous range of K-steps; every slice stores its raw
   // accumulators, the LAST slice to arrive at the tile's ticket adds all of them IN SLICE ORDER (deterministic, whoever
@@ -265,14 +341,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     int it = 0;
     for (; it + 1 < nkt; it += 2) {
       const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl), k3 = min(kt0 + it + 3, ktl);
-      gload(k2, raA, pvA);
-      bload(k1, rb1);
-      compute(0, rb0);
+      compute_spread(0, rb0, k2, raA, pvA, k1, rb1);  // step it; requests: A rows of step it + 2, W fragments of step it + 1
       lstore(1, raB, pvB, true);
       __syncthreads();
-      gload(k3, raB, pvB);
-      bload(k2, rb0);
-      compute(1, rb1);
+      compute_spread(1, rb1, k3, raB, pvB, k2, rb0);
       lstore(0, raA, pvA, it + 2 < nkt);
       __syncthreads();
     }
