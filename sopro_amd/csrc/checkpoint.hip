@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <exception>
 #include <map>
 #include <memory>
 #include <string>
@@ -43,10 +44,33 @@ struct Json {
   }
 };
 
+// The buffer [p, end) MUST be followed by a NUL byte (the callers parse std::string copies): strtod needs a terminator.
 struct JsonParser {
   const char* p;
   const char* end;
   bool ok = true;
+  int depth = 0;
+  static const int kMaxDepth = 64;  // a header is two levels deep; "[[[[..." must not overflow the stack
+  static void utf8(std::string* out, uint32_t cp) {
+    if (cp < 0x80) *out += (char)cp;
+    else if (cp < 0x800) { *out += (char)(0xC0 | (cp >> 6)); *out += (char)(0x80 | (cp & 63)); }
+    else if (cp < 0x10000) { *out += (char)(0xE0 | (cp >> 12)); *out += (char)(0x80 | ((cp >> 6) & 63)); *out += (char)(0x80 | (cp & 63)); }
+    else { *out += (char)(0xF0 | (cp >> 18)); *out += (char)(0x80 | ((cp >> 12) & 63)); *out += (char)(0x80 | ((cp >> 6) & 63)); *out += (char)(0x80 | (cp & 63)); }
+  }
+  bool hex4(const char* q, uint32_t* v) const {
+    if (end - q < 4) return false;
+    uint32_t x = 0;
+    for (int i = 0; i < 4; ++i) {
+      const char c = q[i];
+      x <<= 4;
+      if (c >= '0' && c <= '9') x |= (uint32_t)(c - '0');
+      else if (c >= 'a' && c <= 'f') x |= (uint32_t)(c - 'a' + 10);
+      else if (c >= 'A' && c <= 'F') x |= (uint32_t)(c - 'A' + 10);
+      else return false;
+    }
+    *v = x;
+    return true;
+  }
   void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
   bool lit(const char* s) {
     const size_t n = strlen(s);
@@ -66,8 +90,15 @@ struct JsonParser {
           case 'r': out += '\r'; break;
           case 'b': out += '\b'; break;
           case 'f': out += '\f'; break;
-          case 'u': {  // (ASCII only: the tables and configs this reader meets hold nothing else)
-            if (end - p >= 5) { out += (char)strtol(std::string(p + 1, p + 5).c_str(), nullptr, 16); p += 4; }
+          case 'u': {  // \uXXXX (+ a surrogate pair) -> UTF-8
+            uint32_t cp = 0, lo = 0;
+            if (!hex4(p + 1, &cp)) { ok = false; return out; }
+            p += 4;
+            if (cp >= 0xD800 && cp < 0xDC00 && end - p >= 7 && p[1] == '\\' && p[2] == 'u' && hex4(p + 3, &lo) && lo >= 0xDC00 && lo < 0xE000) {
+              cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+              p += 6;
+            } else if (cp >= 0xD800 && cp < 0xE000) cp = 0xFFFD;  // a lone surrogate
+            utf8(&out, cp);
             break;
           }
           default: out += *p;
@@ -82,6 +113,13 @@ struct JsonParser {
     return out;
   }
   Json value() {
+    Json j;
+    if (++depth > kMaxDepth) { ok = false; --depth; return j; }
+    j = value_at_depth();
+    --depth;
+    return j;
+  }
+  Json value_at_depth() {
     Json j;
     ws();
     if (p >= end) { ok = false; return j; }
@@ -121,8 +159,8 @@ struct JsonParser {
     } else {
       char* e = nullptr;
       j.kind = Json::Num;
-      j.num = strtod(p, &e);
-      if (e == p) ok = false;
+      j.num = strtod(p, &e);  // (NUL-terminated buffer: see the struct's note)
+      if (e == p || e > end) { ok = false; return j; }
       p = e;
     }
     return j;
@@ -134,7 +172,16 @@ struct RawTensor {
   std::string dtype;
   std::vector<int64_t> shape;
   size_t begin = 0, end = 0;
+  int64_t numel = 0;
 };
+
+// a JSON number as a non-negative integer that a double holds exactly (offsets, dims): no (size_t)double casts of negative, NaN or huge values
+bool json_index(const Json& j, uint64_t* out) {
+  if (j.kind != Json::Num || !(j.num >= 0.0) || j.num > 9007199254740992.0 || j.num != floor(j.num)) return false;
+  *out = (uint64_t)j.num;
+  return true;
+}
+size_t dtype_size(const std::string& d) { return d == "F32" ? 4 : (d == "F16" || d == "BF16") ? 2 : d == "F64" ? 8 : 0; }
 
 struct SafeFile {
   std::vector<unsigned char> bytes;
@@ -157,21 +204,48 @@ struct SafeFile {
     memcpy(&hl, bytes.data(), 8);
     if (hl > (uint64_t)n - 8) { sopro_set_error("sopro_checkpoint_open: %s: header length %llu exceeds the file", path, (unsigned long long)hl); return -3; }
     data0 = 8 + (size_t)hl;
-    JsonParser jp{(const char*)bytes.data() + 8, (const char*)bytes.data() + 8 + hl};
+    const size_t data_bytes = bytes.size() - data0;
+    // the header as a NUL-terminated copy: strtod must not run into tensor data or past the file
+    const std::string header((const char*)bytes.data() + 8, (size_t)hl);
+    JsonParser jp{header.c_str(), header.c_str() + header.size()};
     Json root = jp.value();
     if (!jp.ok || root.kind != Json::Obj) { sopro_set_error("sopro_checkpoint_open: %s: malformed header", path); return -3; }
     for (const auto& kv : root.obj) {
       if (kv.first == "__metadata__") {
-        if (const Json* c = kv.second.get("cfg")) cfg_json = c->str;
+        if (const Json* c = kv.second.get("cfg")) if (c->kind == Json::Str) cfg_json = c->str;
         continue;
       }
       const Json *dt = kv.second.get("dtype"), *sh = kv.second.get("shape"), *off = kv.second.get("data_offsets");
-      if (!dt || !sh || !off || off->arr.size() != 2) { sopro_set_error("sopro_checkpoint_open: %s: malformed entry %s", path, kv.first.c_str()); return -3; }
+      if (!dt || dt->kind != Json::Str || !sh || sh->kind != Json::Arr || !off || off->kind != Json::Arr || off->arr.size() != 2 || sh->arr.size() > 8) {
+        sopro_set_error("sopro_checkpoint_open: %s: malformed entry %s", path, kv.first.c_str());
+        return -3;
+      }
       RawTensor r;
       r.dtype = dt->str;
-      for (const Json& d : sh->arr) r.shape.push_back((int64_t)d.num);
-      r.begin = (size_t)off->arr[0].num; r.end = (size_t)off->arr[1].num;
-      if (data0 + r.end > bytes.size() || r.begin > r.end) { sopro_set_error("sopro_checkpoint_open: %s: %s lies outside the file", path, kv.first.c_str()); return -3; }
+      uint64_t numel = 1;
+      for (const Json& d : sh->arr) {
+        uint64_t v = 0;
+        const uint64_t lim = (uint64_t)1 << 40;  // elements; far above any checkpoint, far below where a product could wrap
+        if (!json_index(d, &v) || v > lim) {
+          sopro_set_error("sopro_checkpoint_open: %s: %s has a dimension that is not a small non-negative integer", path, kv.first.c_str());
+          return -3;
+        }
+        if (v != 0 && numel > lim / v) { sopro_set_error("sopro_checkpoint_open: %s: %s is too large", path, kv.first.c_str()); return -3; }
+        numel *= v;
+        r.shape.push_back((int64_t)v);
+      }
+      uint64_t b = 0, e = 0;
+      if (!json_index(off->arr[0], &b) || !json_index(off->arr[1], &e) || b > e || e > (uint64_t)data_bytes) {
+        sopro_set_error("sopro_checkpoint_open: %s: %s lies outside the file", path, kv.first.c_str());
+        return -3;
+      }
+      const size_t es = dtype_size(r.dtype);  // other dtypes (integers, bool) may sit in the file; they are refused when something asks for them
+      if (es != 0 && e - b != numel * es) {
+        sopro_set_error("sopro_checkpoint_open: %s: %s holds %llu bytes for %llu %s elements", path, kv.first.c_str(), (unsigned long long)(e - b),
+                        (unsigned long long)numel, r.dtype.c_str());
+        return -3;
+      }
+      r.begin = (size_t)b; r.end = (size_t)e; r.numel = (int64_t)numel;
       t[kv.first] = std::move(r);
     }
     return 0;
@@ -183,7 +257,7 @@ struct T {  // a host tensor, fp32, row-major
   std::vector<int64_t> shape;
   std::vector<float> v;
   int64_t numel() const { int64_t n = 1; for (int64_t d : shape) n *= d; return n; }
-  int64_t dim(int i) const { return shape[(size_t)i]; }
+  int64_t dim(int i) const { return shape.at((size_t)i); }  // (every tensor's rank is checked by rd() before a pack_* routine sees it)
 };
 
 float half_to_float(uint16_t h) {
@@ -204,25 +278,38 @@ float half_to_float(uint16_t h) {
   return f;
 }
 
-int read_f32(const SafeFile& f, const std::string& name, T* out) {
+// want: the shape the config implies, one entry per dimension; -1 = any extent >= 1 (vocabulary sizes, kernel widths that the
+// packed form carries through).  A tensor of another rank or extent is refused BEFORE any pack_* / fold loop indexes it.
+typedef std::vector<int64_t> Want;
+int read_f32(const SafeFile& f, const std::string& name, T* out, const Want& want) {
   auto it = f.t.find(name);
   if (it == f.t.end()) { sopro_set_error("checkpoint: tensor %s is missing", name.c_str()); return -3; }
   const RawTensor& r = it->second;
-  out->shape = r.shape;
-  const int64_t n = out->numel();
-  const unsigned char* src = f.bytes.data() + f.data0 + r.begin;
-  const size_t nbytes = r.end - r.begin;
-  out->v.resize((size_t)n);
-  if (r.dtype == "F32" && nbytes == (size_t)n * 4) memcpy(out->v.data(), src, (size_t)n * 4);
-  else if (r.dtype == "BF16" && nbytes == (size_t)n * 2) {
-    for (int64_t i = 0; i < n; ++i) { uint16_t h; memcpy(&h, src + 2 * i, 2); const uint32_t u = (uint32_t)h << 16; memcpy(&out->v[(size_t)i], &u, 4); }
-  } else if (r.dtype == "F16" && nbytes == (size_t)n * 2) {
-    for (int64_t i = 0; i < n; ++i) { uint16_t h; memcpy(&h, src + 2 * i, 2); out->v[(size_t)i] = half_to_float(h); }
-  } else if (r.dtype == "F64" && nbytes == (size_t)n * 8) {
-    for (int64_t i = 0; i < n; ++i) { double d; memcpy(&d, src + 8 * i, 8); out->v[(size_t)i] = (float)d; }
-  } else {
-    sopro_set_error("checkpoint: tensor %s has dtype %s / %zu bytes for %lld elements (F32, F16, BF16, F64 are read)", name.c_str(), r.dtype.c_str(), nbytes, (long long)n);
+  bool shape_ok = r.shape.size() == want.size();
+  for (size_t d = 0; shape_ok && d < want.size(); ++d) shape_ok = want[d] < 0 ? r.shape[d] >= 1 : r.shape[d] == want[d];
+  if (!shape_ok) {
+    std::string have = "[", exp = "[";
+    for (int64_t d : r.shape) have += std::to_string(d) + ",";
+    for (int64_t d : want) exp += (d < 0 ? std::string("*") : std::to_string(d)) + ",";
+    sopro_set_error("checkpoint: tensor %s has shape %s] where the config implies %s]", name.c_str(), have.c_str(), exp.c_str());
     return -3;
+  }
+  const int64_t n = r.numel;
+  const size_t es = dtype_size(r.dtype);
+  if (es == 0 || r.end - r.begin != (size_t)n * es) {  // (the byte count of a known dtype was checked when the file was opened)
+    sopro_set_error("checkpoint: tensor %s has dtype %s (F32, F16, BF16, F64 are read)", name.c_str(), r.dtype.c_str());
+    return -3;
+  }
+  out->shape = r.shape;
+  const unsigned char* src = f.bytes.data() + f.data0 + r.begin;
+  out->v.resize((size_t)n);
+  if (r.dtype == "F32") { if (n) memcpy(out->v.data(), src, (size_t)n * 4); }
+  else if (r.dtype == "BF16") {
+    for (int64_t i = 0; i < n; ++i) { uint16_t h; memcpy(&h, src + 2 * i, 2); const uint32_t u = (uint32_t)h << 16; memcpy(&out->v[(size_t)i], &u, 4); }
+  } else if (r.dtype == "F16") {
+    for (int64_t i = 0; i < n; ++i) { uint16_t h; memcpy(&h, src + 2 * i, 2); out->v[(size_t)i] = half_to_float(h); }
+  } else {
+    for (int64_t i = 0; i < n; ++i) { double d; memcpy(&d, src + 8 * i, 8); out->v[(size_t)i] = (float)d; }
   }
   return 0;
 }
@@ -257,14 +344,46 @@ struct MimiCfg {  // HF:configuration_mimi.py:86-133 defaults, num_quantizers fr
   double norm_eps = 1e-5, rope_theta = 10000.0;
 };
 
-void cfg_int(const Json& o, const char* k, int* dst) { if (const Json* v = o.get(k)) if (v->kind == Json::Num) *dst = (int)v->num; }
-void cfg_ints(const Json& o, const char* k, std::vector<int>* dst) {
-  if (const Json* v = o.get(k))
-    if (v->kind == Json::Arr) { dst->clear(); for (const Json& e : v->arr) dst->push_back((int)e.num); }
+// Config numbers are converted only when they are integers of a sane size ((int)double of NaN / 1e300 is undefined); anything else
+// sets *bad and the open fails.  Ranges are checked once all keys are in (check_cfg).
+bool cfg_num(const Json& v, int* dst) {
+  if (v.kind != Json::Num || !(v.num >= -1048576.0 && v.num <= 1073741824.0) || v.num != floor(v.num)) return false;
+  *dst = (int)v.num;
+  return true;
 }
-void cfg_pair(const Json& o, const char* k, int (&dst)[2]) {
-  if (const Json* v = o.get(k))
-    if (v->kind == Json::Arr && v->arr.size() == 2) { dst[0] = (int)v->arr[0].num; dst[1] = (int)v->arr[1].num; }
+void cfg_int(const Json& o, const char* k, int* dst, bool* bad) { if (const Json* v = o.get(k)) if (!cfg_num(*v, dst)) *bad = true; }
+void cfg_ints(const Json& o, const char* k, std::vector<int>* dst, bool* bad) {
+  if (const Json* v = o.get(k)) {
+    if (v->kind != Json::Arr || v->arr.size() > 64) { *bad = true; return; }
+    dst->clear();
+    for (const Json& e : v->arr) { int x = 0; if (!cfg_num(e, &x)) { *bad = true; return; } dst->push_back(x); }
+  }
+}
+void cfg_pair(const Json& o, const char* k, int (&dst)[2], bool* bad) {
+  if (const Json* v = o.get(k)) {
+    if (v->kind != Json::Arr || v->arr.size() != 2 || !cfg_num(v->arr[0], &dst[0]) || !cfg_num(v->arr[1], &dst[1])) *bad = true;
+  }
+}
+// what the engine (sopro_engine_cfg's array sizes, the kernels' shape rules) and the loops below can take
+const char* check_cfg(const SoproCfg& c) {
+  if (c.num_codebooks < 2 || c.num_codebooks > 64) return "num_codebooks outside 2..64";
+  if (c.codebook_size < 2 || c.codebook_size > 65536) return "codebook_size outside 2..65536";
+  if (c.d_model < 64 || c.d_model > 8192 || c.d_model % 32 != 0) return "d_model must be a multiple of 32 in 64..8192";
+  if (c.n_layers_text < 0 || c.n_layers_text > 16 || c.ref_enc_layers < 0 || c.ref_enc_layers > 16 || c.ref_xattn_layers < 0 || c.ref_xattn_layers > 16)
+    return "n_layers_text / ref_enc_layers / ref_xattn_layers outside 0..16";
+  if (c.n_layers_ar < 1 || c.n_layers_ar > 16 || c.n_layers_nar < 1 || c.n_layers_nar > 16) return "n_layers_ar / n_layers_nar outside 1..16";
+  if (c.pos_emb_max < 1 || c.pos_emb_max > (1 << 20)) return "pos_emb_max outside 1..2^20";
+  if (c.ar_kernel < 1 || c.ar_kernel > 64 || c.nar_kernel_size < 1 || c.nar_kernel_size > 63) return "ar_kernel / nar_kernel_size outside 1..64";
+  if (c.ar_text_attn_freq < 1) return "ar_text_attn_freq < 1";
+  if (c.nar_head_dim < 8 || c.nar_head_dim > 4096) return "nar_head_dim outside 8..4096";
+  if (c.sv_student_dim < 1 || c.sv_student_dim > 4096) return "sv_student_dim outside 1..4096";
+  if (c.ref_xattn_heads < 1 || c.ref_xattn_heads > 64 || c.d_model % c.ref_xattn_heads != 0) return "ref_xattn_heads must divide d_model";
+  if (!(c.ref_xattn_gmax == c.ref_xattn_gmax) || c.ref_xattn_gmax < -1e6 || c.ref_xattn_gmax > 1e6) return "ref_xattn_gmax is not a finite number";
+  for (int x : c.ar_dilation_cycle) if (x < 1 || x > 4096) return "ar_dilation_cycle entry outside 1..4096";
+  for (int x : c.nar_dilation_cycle) if (x < 1 || x > 4096) return "nar_dilation_cycle entry outside 1..4096";
+  for (int s = 0; s < 4; ++s)
+    if (c.stage[s][0] < 1 || c.stage[s][1] < c.stage[s][0] || c.stage[s][1] > 4096) return "a stage pair is not 1 <= first <= last";
+  return nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------ pack.py, restated
@@ -351,7 +470,7 @@ struct Ck {
   float mix[8][2] = {{0}};
   float final_bias = 0.f;
 
-  int rd(const SafeFile& f, const std::string& k, T* t) { return read_f32(f, k, t); }
+  int rd(const SafeFile& f, const std::string& k, T* t, const Want& want) { return read_f32(f, k, t, want); }
   void put(const std::string& k, T t) {
     if (!p.count(k)) names.push_back(k);
     p[k] = std::move(t);
@@ -359,11 +478,13 @@ struct Ck {
 
 #define CKR(call) do { const int rc_ = (call); if (rc_ != 0) return rc_; } while (0)
 
-  int ssm_block(const std::string& pre, bool packed_glu) {  // pack.py _ssm_block
+  int ssm_block(const std::string& pre, bool packed_glu, int kernel) {  // pack.py _ssm_block; shapes: src/sopro/nn/blocks.py:113-134
     T nw, gw, gb, dw, db, fn, w1, b1, w2, b2;
-    CKR(rd(fs, pre + ".norm.weight", &nw)); CKR(rd(fs, pre + ".glu.pro.weight", &gw)); CKR(rd(fs, pre + ".glu.pro.bias", &gb));
-    CKR(rd(fs, pre + ".dw.dw.weight", &dw)); CKR(rd(fs, pre + ".dw.dw.bias", &db)); CKR(rd(fs, pre + ".ff.0.weight", &fn));
-    CKR(rd(fs, pre + ".ff.1.weight", &w1)); CKR(rd(fs, pre + ".ff.1.bias", &b1)); CKR(rd(fs, pre + ".ff.3.weight", &w2)); CKR(rd(fs, pre + ".ff.3.bias", &b2));
+    const int64_t d = c.d_model;
+    CKR(rd(fs, pre + ".norm.weight", &nw, {d})); CKR(rd(fs, pre + ".glu.pro.weight", &gw, {2 * d, d})); CKR(rd(fs, pre + ".glu.pro.bias", &gb, {2 * d}));
+    CKR(rd(fs, pre + ".dw.dw.weight", &dw, {d, 1, kernel})); CKR(rd(fs, pre + ".dw.dw.bias", &db, {d})); CKR(rd(fs, pre + ".ff.0.weight", &fn, {d}));
+    CKR(rd(fs, pre + ".ff.1.weight", &w1, {4 * d, d})); CKR(rd(fs, pre + ".ff.1.bias", &b1, {4 * d}));
+    CKR(rd(fs, pre + ".ff.3.weight", &w2, {d, 4 * d})); CKR(rd(fs, pre + ".ff.3.bias", &b2, {d}));
     put(pre + ".norm.weight", nw);
     if (packed_glu) { put(pre + ".glu.w", pack_glu_w(gw)); put(pre + ".glu.b", pack_glu_b(gb)); }
     else { put(pre + ".glu.w", gw); put(pre + ".glu.b", gb); }
@@ -374,9 +495,10 @@ struct Ck {
 
   int xattn(const std::string& pre, double gate_mul, int heads, float* gate_out) {  // pack.py _xattn
     T g, nq, nkv, q, k, v, o;
-    CKR(rd(fs, pre + ".gate", &g)); CKR(rd(fs, pre + ".nq.weight", &nq)); CKR(rd(fs, pre + ".nkv.weight", &nkv)); CKR(rd(fs, pre + ".q_proj.weight", &q));
-    CKR(rd(fs, pre + ".k_proj.weight", &k)); CKR(rd(fs, pre + ".v_proj.weight", &v)); CKR(rd(fs, pre + ".out_proj.weight", &o));
-    const int64_t d = q.dim(0);
+    const int64_t d = c.d_model;
+    CKR(rd(fs, pre + ".gate", &g, {})); CKR(rd(fs, pre + ".nq.weight", &nq, {d})); CKR(rd(fs, pre + ".nkv.weight", &nkv, {d}));
+    CKR(rd(fs, pre + ".q_proj.weight", &q, {d, d})); CKR(rd(fs, pre + ".k_proj.weight", &k, {d, d})); CKR(rd(fs, pre + ".v_proj.weight", &v, {d, d}));
+    CKR(rd(fs, pre + ".out_proj.weight", &o, {d, d}));
     put(pre + ".nq.weight", nq); put(pre + ".nkv.weight", nkv); put(pre + ".q.w", q);
     put(pre + ".kv.w", cat0({&k, &v})); put(pre + ".o.w", o);
     if (heads) {  // [H, d, dh]: q.wT[h][c][j] = q[h*dh + j][c]  (x RMSNorm_nq's weight, folded by the caller)
@@ -395,37 +517,42 @@ struct Ck {
   }
 
   int pack_sopro() {
-    // text encoder
-    for (int i = 0; i < c.n_layers_text; ++i) CKR(ssm_block("text_enc.layers." + std::to_string(i), true));
+    const int64_t d = c.d_model, Q = c.num_codebooks, V = c.codebook_size, HD = c.nar_head_dim, SV = c.sv_student_dim;
+    // text encoder (src/sopro/nn/text.py:16-27: kernel 7)
+    for (int i = 0; i < c.n_layers_text; ++i) CKR(ssm_block("text_enc.layers." + std::to_string(i), true, 7));
     T t;
-    CKR(rd(fs, "text_enc.embed.emb.weight", &t)); put("text_enc.embed", t);
-    CKR(rd(fs, "text_enc.norm.weight", &t)); put("text_enc.norm.weight", t);
-    CKR(rd(fs, "cb_embed.emb.weight", &t)); put("cb_embed", t);
-    CKR(rd(fs, "nar_prev_cb_weights", &t)); put("nar_prev_cb_weights", t);
-    // Token2SV (src/sopro/nn/speaker.py:12-61)
-    CKR(rd(fs, "token2sv.emb.weight", &t)); put("token2sv.emb", t);
-    CKR(rd(fs, "token2sv.cb_weights", &t)); put("token2sv.cw", softmax1(t));
+    CKR(rd(fs, "text_enc.embed.emb.weight", &t, {-1, d})); put("text_enc.embed", t);
+    CKR(rd(fs, "text_enc.norm.weight", &t, {d})); put("text_enc.norm.weight", t);
+    CKR(rd(fs, "cb_embed.emb.weight", &t, {Q * V + 1, d})); put("cb_embed", t);
+    CKR(rd(fs, "nar_prev_cb_weights", &t, {Q})); put("nar_prev_cb_weights", t);
+    // Token2SV (src/sopro/nn/speaker.py:12-61): width sd and kernel from the file, every other tensor tied to them
+    CKR(rd(fs, "token2sv.emb.weight", &t, {Q * V, -1})); put("token2sv.emb", t);
+    const int64_t sd = t.dim(1);
+    CKR(rd(fs, "token2sv.cb_weights", &t, {Q})); put("token2sv.cw", softmax1(t));
     for (int i : {0, 3}) {
       T w, b;
-      CKR(rd(fs, "token2sv.enc." + std::to_string(i) + ".dw.weight", &w)); CKR(rd(fs, "token2sv.enc." + std::to_string(i) + ".dw.bias", &b));
+      CKR(rd(fs, "token2sv.enc." + std::to_string(i) + ".dw.weight", &w, {sd, 1, -1})); CKR(rd(fs, "token2sv.enc." + std::to_string(i) + ".dw.bias", &b, {sd}));
       put("token2sv.enc." + std::to_string(i) + ".w", pack_dw(w)); put("token2sv.enc." + std::to_string(i) + ".b", b);
     }
-    for (const char* n : {"pool.attn.0", "pool.attn.2", "proj"}) {
+    {
       T w, b;
-      CKR(rd(fs, std::string("token2sv.") + n + ".weight", &w)); CKR(rd(fs, std::string("token2sv.") + n + ".bias", &b));
-      put(std::string("token2sv.") + n + ".w", w); put(std::string("token2sv.") + n + ".b", b);
+      CKR(rd(fs, "token2sv.pool.attn.0.weight", &w, {sd, sd})); CKR(rd(fs, "token2sv.pool.attn.0.bias", &b, {sd}));
+      put("token2sv.pool.attn.0.w", w); put("token2sv.pool.attn.0.b", b);
+      CKR(rd(fs, "token2sv.pool.attn.2.weight", &w, {1, sd})); CKR(rd(fs, "token2sv.pool.attn.2.bias", &b, {1}));
+      put("token2sv.pool.attn.2.w", w); put("token2sv.pool.attn.2.b", b);
+      CKR(rd(fs, "token2sv.proj.weight", &w, {SV, 2 * sd})); CKR(rd(fs, "token2sv.proj.bias", &b, {SV}));
+      put("token2sv.proj.w", w); put("token2sv.proj.b", b);
+      CKR(rd(fs, "spk_film.mlp.0.weight", &w, {d, SV})); CKR(rd(fs, "spk_film.mlp.0.bias", &b, {d}));
+      put("spk_film.mlp.0.w", w); put("spk_film.mlp.0.b", b);
+      CKR(rd(fs, "spk_film.mlp.2.weight", &w, {2 * d, d})); CKR(rd(fs, "spk_film.mlp.2.bias", &b, {2 * d}));
+      put("spk_film.mlp.2.w", w); put("spk_film.mlp.2.b", b);
     }
-    for (const char* n : {"mlp.0", "mlp.2"}) {
-      T w, b;
-      CKR(rd(fs, std::string("spk_film.") + n + ".weight", &w)); CKR(rd(fs, std::string("spk_film.") + n + ".bias", &b));
-      put(std::string("spk_film.") + n + ".w", w); put(std::string("spk_film.") + n + ".b", b);
-    }
-    CKR(rd(fs, "spk_film.norm.weight", &t)); put("spk_film.norm.weight", t);
-    CKR(rd(fs, "spk_film.norm.bias", &t)); put("spk_film.norm.bias", t);
+    CKR(rd(fs, "spk_film.norm.weight", &t, {d})); put("spk_film.norm.weight", t);
+    CKR(rd(fs, "spk_film.norm.bias", &t, {d})); put("spk_film.norm.bias", t);
     // AR generator: natural GLU layout, RMSNorm weights folded into the projections they feed (blocks.py:26-37)
     for (int i = 0; i < c.n_layers_ar; ++i) {
       const std::string pre = "ar.blocks." + std::to_string(i);
-      CKR(ssm_block(pre, false));
+      CKR(ssm_block(pre, false, c.ar_kernel));
       p[pre + ".glu.w"] = scale_cols(p[pre + ".glu.w"], p[pre + ".norm.weight"]);
       p[pre + ".ff1.w"] = scale_cols(p[pre + ".ff1.w"], p[pre + ".ff.norm.weight"]);
     }
@@ -435,7 +562,7 @@ struct Ck {
       CKR(xattn(pre, 1.0, 4, &gate[i]));  // 4 heads: src/sopro/nn/generator.py:36
       T& wt = p[pre + ".q.wT"];
       const T& nq = p[pre + ".nq.weight"];
-      const int64_t d = c.d_model, dh = d / 4;
+      const int64_t dh = d / 4;
       for (int64_t h = 0; h < 4; ++h)
         for (int64_t cc = 0; cc < d; ++cc)
           for (int64_t j = 0; j < dh; ++j) wt.v[(size_t)((h * d + cc) * dh + j)] *= nq.v[(size_t)cc];
@@ -467,19 +594,23 @@ struct Ck {
       put(pre + ".qa.w", qa); put(pre + ".qu.w", qu); put(pre + ".q.b", qb);
     }
     T an, hw, hb;
-    CKR(rd(fs, "ar.norm.weight", &an)); CKR(rd(fs, "ar.head.weight", &hw)); CKR(rd(fs, "ar.head.bias", &hb));
+    CKR(rd(fs, "ar.norm.weight", &an, {d})); CKR(rd(fs, "ar.head.weight", &hw, {V + 1, d})); CKR(rd(fs, "ar.head.bias", &hb, {V + 1}));
     put("ar.norm.weight", an); put("ar.head.w", scale_cols(hw, an)); put("ar.head.b", hb);
     // NAR refiner
-    for (int i = 0; i < c.n_layers_nar; ++i) CKR(ssm_block("nar.blocks." + std::to_string(i), true));
-    CKR(rd(fs, "nar.norm.weight", &t)); put("nar.norm.weight", t);
-    CKR(rd(fs, "nar.pre.weight", &t)); put("nar.pre.w", t);
-    CKR(rd(fs, "nar.pre.bias", &t)); put("nar.pre.b", t);
-    CKR(rd(fs, "nar.stage_emb.weight", &t)); put("nar.stage_emb", t);
-    CKR(rd(fs, "nar.adapter.norm.weight", &t)); put("nar.adapter.norm.weight", t);
-    for (const char* n : {"mlp.0", "mlp.2"}) {
+    for (int i = 0; i < c.n_layers_nar; ++i) CKR(ssm_block("nar.blocks." + std::to_string(i), true, c.nar_kernel_size));
+    CKR(rd(fs, "nar.norm.weight", &t, {d})); put("nar.norm.weight", t);
+    CKR(rd(fs, "nar.pre.weight", &t, {HD, d})); put("nar.pre.w", t);
+    CKR(rd(fs, "nar.pre.bias", &t, {HD})); put("nar.pre.b", t);
+    CKR(rd(fs, "nar.stage_emb.weight", &t, {-1, d})); put("nar.stage_emb", t);
+    CKR(rd(fs, "nar.adapter.norm.weight", &t, {d})); put("nar.adapter.norm.weight", t);
+    {
       T w, b;
-      CKR(rd(fs, std::string("nar.adapter.") + n + ".weight", &w)); CKR(rd(fs, std::string("nar.adapter.") + n + ".bias", &b));
-      put(std::string("nar.adapter.") + n + ".w", w); put(std::string("nar.adapter.") + n + ".b", b);
+      CKR(rd(fs, "nar.adapter.mlp.0.weight", &w, {-1, d}));
+      const int64_t ah = w.dim(0);
+      CKR(rd(fs, "nar.adapter.mlp.0.bias", &b, {ah}));
+      put("nar.adapter.mlp.0.w", w); put("nar.adapter.mlp.0.b", b);
+      CKR(rd(fs, "nar.adapter.mlp.2.weight", &w, {2 * d, ah})); CKR(rd(fs, "nar.adapter.mlp.2.bias", &b, {2 * d}));
+      put("nar.adapter.mlp.2.w", w); put("nar.adapter.mlp.2.b", b);
     }
     const char* stage_names[4] = {"B", "C", "D", "E"};
     const char* pos_names = "BCDEFGHI";
@@ -490,13 +621,12 @@ struct Ck {
       const std::string sn = stage_names[s];
       // logits_j = (z + e_j) W_j^T + b_j = z W_j^T + (b_j + W_j e_j)   (src/sopro/nn/nar.py:100-116), folded in float64
       T hid;
-      CKR(rd(fs, "nar.head_id_emb." + sn + ".weight", &hid));
+      CKR(rd(fs, "nar.head_id_emb." + sn + ".weight", &hid, {(int64_t)cbs.size(), HD}));
       std::vector<T> ws(cbs.size()), bs(cbs.size());
       std::vector<const T*> wp, bp;
       for (size_t j = 0; j < cbs.size(); ++j) {
-        CKR(rd(fs, "nar.heads." + sn + "." + std::to_string(j) + ".weight", &ws[j]));
-        CKR(rd(fs, "nar.heads." + sn + "." + std::to_string(j) + ".bias", &bs[j]));
-        const int64_t V = ws[j].dim(0), HD = ws[j].dim(1);
+        CKR(rd(fs, "nar.heads." + sn + "." + std::to_string(j) + ".weight", &ws[j], {V, HD}));
+        CKR(rd(fs, "nar.heads." + sn + "." + std::to_string(j) + ".bias", &bs[j], {V}));
         for (int64_t r = 0; r < V; ++r) {
           double a = (double)bs[j].v[(size_t)r];
           double dot = 0;
@@ -509,20 +639,20 @@ struct Ck {
       put("nar.heads." + sn + ".w", W); put("nar.heads." + sn + ".b", Bv);
       put(std::string("nar.heads.") + pos_names[pos] + ".w", W); put(std::string("nar.heads.") + pos_names[pos] + ".b", Bv);  // the engine names the stages by position
       T mx;
-      CKR(rd(fs, "nar.mix." + sn, &mx));
+      CKR(rd(fs, "nar.mix." + sn, &mx, {2}));
       T sm = softmax1(mx);
       mix[pos][0] = sm.v[0]; mix[pos][1] = sm.v[1];
       put("nar.mix." + sn, sm);
       ++pos;
     }
-    CKR(rd(fs, "cond_norm.weight", &t)); put("cond_norm.weight", t);
-    for (int i = 0; i < c.ref_enc_layers; ++i) CKR(ssm_block("ref_enc_blocks." + std::to_string(i), true));
-    CKR(rd(fs, "ref_enc_norm.weight", &t)); put("ref_enc_norm.weight", t);
-    CKR(rd(fs, "ref_cb_weights", &t)); put("ref_cw", softmax1(t));
+    CKR(rd(fs, "cond_norm.weight", &t, {d})); put("cond_norm.weight", t);
+    for (int i = 0; i < c.ref_enc_layers; ++i) CKR(ssm_block("ref_enc_blocks." + std::to_string(i), true, 7));  // src/sopro/model.py:100-104
+    CKR(rd(fs, "ref_enc_norm.weight", &t, {d})); put("ref_enc_norm.weight", t);
+    CKR(rd(fs, "ref_cb_weights", &t, {Q})); put("ref_cw", softmax1(t));
     for (int i = 0; i < c.ref_xattn_layers; ++i) CKR(xattn("ref_xattn.blocks." + std::to_string(i), c.ref_xattn_gmax, 0, nullptr));
     // position table of the conditioning (src/sopro/nn/embeddings.py:11-25; src/sopro/model.py:62-64: pos_emb_max + 8 rows)
     {
-      const int n = c.pos_emb_max + 8, d = c.d_model;
+      const int n = c.pos_emb_max + 8;
       T pe; pe.shape = {n, d}; pe.v.assign((size_t)n * d, 0.f);
       const float k = (float)(-log(10000.0) / d);
       for (int j = 0; j < d; j += 2) {
@@ -538,44 +668,47 @@ struct Ck {
     return 0;
   }
 
-  int transformer(const std::string& pre, const std::string& name) {  // pack.py _pack_transformer
+  int transformer(const std::string& pre, const std::string& name) {  // pack.py _pack_transformer; shapes: HF:modeling_mimi.py:568-700
+    const int64_t hs = m.hidden, inter = m.inter;
     for (int li = 0; li < m.layers; ++li) {
       const std::string q = name + ".layers." + std::to_string(li), o = pre + "." + std::to_string(li);
       T a, b, cc, t;
-      CKR(rd(fm, q + ".self_attn.q_proj.weight", &a)); CKR(rd(fm, q + ".self_attn.k_proj.weight", &b)); CKR(rd(fm, q + ".self_attn.v_proj.weight", &cc));
+      CKR(rd(fm, q + ".self_attn.q_proj.weight", &a, {hs, hs})); CKR(rd(fm, q + ".self_attn.k_proj.weight", &b, {hs, hs}));
+      CKR(rd(fm, q + ".self_attn.v_proj.weight", &cc, {hs, hs}));
       put(o + ".qkv.w", cat0({&a, &b, &cc}));
-      CKR(rd(fm, q + ".self_attn.o_proj.weight", &t)); put(o + ".o.w", t);
-      CKR(rd(fm, q + ".mlp.fc1.weight", &t)); put(o + ".fc1.w", t);
-      CKR(rd(fm, q + ".mlp.fc2.weight", &t)); put(o + ".fc2.w", t);
-      CKR(rd(fm, q + ".input_layernorm.weight", &t)); put(o + ".ln1.w", t);
-      CKR(rd(fm, q + ".input_layernorm.bias", &t)); put(o + ".ln1.b", t);
-      CKR(rd(fm, q + ".post_attention_layernorm.weight", &t)); put(o + ".ln2.w", t);
-      CKR(rd(fm, q + ".post_attention_layernorm.bias", &t)); put(o + ".ln2.b", t);
-      CKR(rd(fm, q + ".self_attn_layer_scale.scale", &t)); put(o + ".ls1", t);
-      CKR(rd(fm, q + ".mlp_layer_scale.scale", &t)); put(o + ".ls2", t);
+      CKR(rd(fm, q + ".self_attn.o_proj.weight", &t, {hs, hs})); put(o + ".o.w", t);
+      CKR(rd(fm, q + ".mlp.fc1.weight", &t, {inter, hs})); put(o + ".fc1.w", t);
+      CKR(rd(fm, q + ".mlp.fc2.weight", &t, {hs, inter})); put(o + ".fc2.w", t);
+      CKR(rd(fm, q + ".input_layernorm.weight", &t, {hs})); put(o + ".ln1.w", t);
+      CKR(rd(fm, q + ".input_layernorm.bias", &t, {hs})); put(o + ".ln1.b", t);
+      CKR(rd(fm, q + ".post_attention_layernorm.weight", &t, {hs})); put(o + ".ln2.w", t);
+      CKR(rd(fm, q + ".post_attention_layernorm.bias", &t, {hs})); put(o + ".ln2.b", t);
+      CKR(rd(fm, q + ".self_attn_layer_scale.scale", &t, {hs})); put(o + ".ls1", t);
+      CKR(rd(fm, q + ".mlp_layer_scale.scale", &t, {hs})); put(o + ".ls2", t);
     }
     return 0;
   }
 
   int pack_mimi(int rope_positions) {
     const int ns = m.num_semantic;
-    T cb; cb.shape = {(int64_t)m.num_quantizers * m.codebook_size, m.codebook_dim};
+    const int64_t CS = m.codebook_size, CD = m.codebook_dim, H = m.hidden;
+    T cb; cb.shape = {(int64_t)m.num_quantizers * CS, CD};
+    cb.v.reserve((size_t)(m.num_quantizers * CS * CD));
     for (int q = 0; q < m.num_quantizers; ++q) {
       const std::string grp = q < ns ? "semantic" : "acoustic";
       const std::string pp = "quantizer." + grp + "_residual_vector_quantizer.layers." + std::to_string(q < ns ? q : q - ns) + ".codebook";
       T es, cu;
-      CKR(rd(fm, pp + ".embed_sum", &es)); CKR(rd(fm, pp + ".cluster_usage", &cu));
-      for (int64_t r = 0; r < es.dim(0); ++r) {  // HF:modeling_mimi.py:979-983
+      CKR(rd(fm, pp + ".embed_sum", &es, {CS, CD})); CKR(rd(fm, pp + ".cluster_usage", &cu, {CS}));
+      for (int64_t r = 0; r < CS; ++r) {  // HF:modeling_mimi.py:979-983
         const float den = cu.v[(size_t)r] < 1e-5f ? 1e-5f : cu.v[(size_t)r];
-        for (int64_t k = 0; k < es.dim(1); ++k) cb.v.push_back(es.v[(size_t)(r * es.dim(1) + k)] / den);
+        for (int64_t k = 0; k < CD; ++k) cb.v.push_back(es.v[(size_t)(r * CD + k)] / den);
       }
     }
     put("codebooks", cb);
     T psem, pac;
-    CKR(rd(fm, "quantizer.semantic_residual_vector_quantizer.output_proj.weight", &psem));
-    CKR(rd(fm, "quantizer.acoustic_residual_vector_quantizer.output_proj.weight", &pac));
+    CKR(rd(fm, "quantizer.semantic_residual_vector_quantizer.output_proj.weight", &psem, {H, CD, 1}));
+    CKR(rd(fm, "quantizer.acoustic_residual_vector_quantizer.output_proj.weight", &pac, {H, CD, 1}));
     {
-      const int64_t H = psem.dim(0), CD = psem.dim(1);
       T pj; pj.shape = {H, 2 * CD}; pj.v.resize((size_t)(H * 2 * CD));
       for (int64_t h = 0; h < H; ++h) {
         memcpy(&pj.v[(size_t)(h * 2 * CD)], &psem.v[(size_t)(h * CD)], (size_t)CD * 4);
@@ -584,30 +717,35 @@ struct Ck {
       put("rvq_proj.w", pj);
     }
     T t;
-    CKR(rd(fm, "upsample.conv.weight", &t)); put("upsample.w", view(t, {t.dim(0), t.dim(2)}));
+    CKR(rd(fm, "upsample.conv.weight", &t, {H, 1, 2 * m.upsample_stride})); put("upsample.w", view(t, {t.dim(0), t.dim(2)}));
     if (fm.has("decoder_transformer.layers.0.mlp.fc1.weight")) CKR(transformer("tr", "decoder_transformer"));
     if (fm.has("encoder_transformer.layers.0.mlp.fc1.weight")) CKR(transformer("etr", "encoder_transformer"));
     if (fm.has("encoder.layers.0.conv.weight")) CKR(mimi_encoder());
+    // SEANet decoder (HF:modeling_mimi.py:931-961): channels halve at every ratio
     T w, b;
-    CKR(rd(fm, "decoder.layers.0.conv.weight", &w)); CKR(rd(fm, "decoder.layers.0.conv.bias", &b));
+    int64_t ch = (int64_t)m.num_filters << m.ratios.size();
+    CKR(rd(fm, "decoder.layers.0.conv.weight", &w, {ch, H, m.kernel})); CKR(rd(fm, "decoder.layers.0.conv.bias", &b, {ch}));
     put("sea.conv0.w", pack_conv1d(w)); put("sea.conv0.b", b);
     int li = 1;
     for (size_t si = 0; si < m.ratios.size(); ++si) {
       li += 1;
       T wo, bo;
-      CKR(rd(fm, "decoder.layers." + std::to_string(li) + ".conv.weight", &w)); CKR(rd(fm, "decoder.layers." + std::to_string(li) + ".conv.bias", &b));
+      const int64_t co = ch / 2, hd = co / m.compress;
+      CKR(rd(fm, "decoder.layers." + std::to_string(li) + ".conv.weight", &w, {ch, co, 2 * m.ratios[si]}));
+      CKR(rd(fm, "decoder.layers." + std::to_string(li) + ".conv.bias", &b, {co}));
       pack_convtr1d(w, b, m.ratios[si], &wo, &bo);
       put("sea.up" + std::to_string(si) + ".w", wo); put("sea.up" + std::to_string(si) + ".b", bo);
       li += 1;
       const std::string blk = "decoder.layers." + std::to_string(li) + ".block";
-      CKR(rd(fm, blk + ".1.conv.weight", &w)); put("sea.res" + std::to_string(si) + ".c1.w", pack_conv1d(w));
-      CKR(rd(fm, blk + ".1.conv.bias", &b)); put("sea.res" + std::to_string(si) + ".c1.b", b);
-      CKR(rd(fm, blk + ".3.conv.weight", &w)); put("sea.res" + std::to_string(si) + ".c2.w", pack_conv1d(w));
-      CKR(rd(fm, blk + ".3.conv.bias", &b)); put("sea.res" + std::to_string(si) + ".c2.b", b);
+      CKR(rd(fm, blk + ".1.conv.weight", &w, {hd, co, m.res_kernel})); put("sea.res" + std::to_string(si) + ".c1.w", pack_conv1d(w));
+      CKR(rd(fm, blk + ".1.conv.bias", &b, {hd})); put("sea.res" + std::to_string(si) + ".c1.b", b);
+      CKR(rd(fm, blk + ".3.conv.weight", &w, {co, hd, 1})); put("sea.res" + std::to_string(si) + ".c2.w", pack_conv1d(w));
+      CKR(rd(fm, blk + ".3.conv.bias", &b, {co})); put("sea.res" + std::to_string(si) + ".c2.b", b);
       li += 1;
+      ch = co;
     }
     li += 1;
-    CKR(rd(fm, "decoder.layers." + std::to_string(li) + ".conv.weight", &w));  // [1, 64, 3]
+    CKR(rd(fm, "decoder.layers." + std::to_string(li) + ".conv.weight", &w, {1, m.num_filters, m.last_kernel}));  // [1, 64, 3]
     {
       const int64_t C = w.dim(1), k = w.dim(2);
       T fw; fw.shape = {k, C}; fw.v.resize((size_t)(k * C));
@@ -615,7 +753,7 @@ struct Ck {
         for (int64_t j = 0; j < k; ++j) fw.v[(size_t)(j * C + c2)] = w.v[(size_t)(c2 * k + j)];
       put("sea.final.w", fw);
     }
-    CKR(rd(fm, "decoder.layers." + std::to_string(li) + ".conv.bias", &b));
+    CKR(rd(fm, "decoder.layers." + std::to_string(li) + ".conv.bias", &b, {1}));
     final_bias = b.v[0];
     put("sea.final.b", view(b, {1}));
     // RoPE tables (HF:modeling_mimi.py:511-566; sopro_amd/pack.py rope_tables): cos / sin [npos, dh / 2]
@@ -637,28 +775,32 @@ struct Ck {
     return 0;
   }
 
-  int mimi_encoder() {  // pack.py _pack_mimi_encoder
+  int mimi_encoder() {  // pack.py _pack_mimi_encoder; shapes: HF:modeling_mimi.py MimiEncoder (channels double at every ratio, reversed)
     T w, b;
-    CKR(rd(fm, "encoder.layers.0.conv.weight", &w)); put("enc.conv0.w", view(w, {w.dim(0), w.dim(2)}));
-    CKR(rd(fm, "encoder.layers.0.conv.bias", &b)); put("enc.conv0.b", b);
+    const int64_t H = m.hidden, CD = m.codebook_dim;
+    int64_t ch = m.num_filters;
+    CKR(rd(fm, "encoder.layers.0.conv.weight", &w, {ch, 1, m.kernel})); put("enc.conv0.w", view(w, {w.dim(0), w.dim(2)}));
+    CKR(rd(fm, "encoder.layers.0.conv.bias", &b, {ch})); put("enc.conv0.b", b);
     int li = 1;
     for (size_t si = 0; si < m.ratios.size(); ++si) {
       const std::string blk = "encoder.layers." + std::to_string(li) + ".block", s = std::to_string(si);
-      CKR(rd(fm, blk + ".1.conv.weight", &w)); put("enc.res" + s + ".c1.w", pack_conv1d(w));
-      CKR(rd(fm, blk + ".1.conv.bias", &b)); put("enc.res" + s + ".c1.b", b);
-      CKR(rd(fm, blk + ".3.conv.weight", &w)); put("enc.res" + s + ".c2.w", pack_conv1d(w));
-      CKR(rd(fm, blk + ".3.conv.bias", &b)); put("enc.res" + s + ".c2.b", b);
+      const int64_t hd = ch / m.compress, r = m.ratios[m.ratios.size() - 1 - si];
+      CKR(rd(fm, blk + ".1.conv.weight", &w, {hd, ch, m.res_kernel})); put("enc.res" + s + ".c1.w", pack_conv1d(w));
+      CKR(rd(fm, blk + ".1.conv.bias", &b, {hd})); put("enc.res" + s + ".c1.b", b);
+      CKR(rd(fm, blk + ".3.conv.weight", &w, {ch, hd, 1})); put("enc.res" + s + ".c2.w", pack_conv1d(w));
+      CKR(rd(fm, blk + ".3.conv.bias", &b, {ch})); put("enc.res" + s + ".c2.b", b);
       li += 2;
-      CKR(rd(fm, "encoder.layers." + std::to_string(li) + ".conv.weight", &w)); put("enc.down" + s + ".w", pack_conv1d(w));
-      CKR(rd(fm, "encoder.layers." + std::to_string(li) + ".conv.bias", &b)); put("enc.down" + s + ".b", b);
+      CKR(rd(fm, "encoder.layers." + std::to_string(li) + ".conv.weight", &w, {2 * ch, ch, 2 * r})); put("enc.down" + s + ".w", pack_conv1d(w));
+      CKR(rd(fm, "encoder.layers." + std::to_string(li) + ".conv.bias", &b, {2 * ch})); put("enc.down" + s + ".b", b);
       li += 1;
+      ch *= 2;
     }
     li += 1;
-    CKR(rd(fm, "encoder.layers." + std::to_string(li) + ".conv.weight", &w)); put("enc.final.w", pack_conv1d(w));
-    CKR(rd(fm, "encoder.layers." + std::to_string(li) + ".conv.bias", &b)); put("enc.final.b", b);
-    CKR(rd(fm, "downsample.conv.weight", &w)); put("enc.ds.w", pack_conv1d(w));
-    CKR(rd(fm, "quantizer.semantic_residual_vector_quantizer.input_proj.weight", &w)); put("enc.inproj.sem.w", view(w, {w.dim(0), w.dim(1)}));
-    CKR(rd(fm, "quantizer.acoustic_residual_vector_quantizer.input_proj.weight", &w)); put("enc.inproj.ac.w", view(w, {w.dim(0), w.dim(1)}));
+    CKR(rd(fm, "encoder.layers." + std::to_string(li) + ".conv.weight", &w, {H, ch, m.last_kernel})); put("enc.final.w", pack_conv1d(w));
+    CKR(rd(fm, "encoder.layers." + std::to_string(li) + ".conv.bias", &b, {H})); put("enc.final.b", b);
+    CKR(rd(fm, "downsample.conv.weight", &w, {H, H, 2 * m.upsample_stride})); put("enc.ds.w", pack_conv1d(w));
+    CKR(rd(fm, "quantizer.semantic_residual_vector_quantizer.input_proj.weight", &w, {CD, H, 1})); put("enc.inproj.sem.w", view(w, {w.dim(0), w.dim(1)}));
+    CKR(rd(fm, "quantizer.acoustic_residual_vector_quantizer.input_proj.weight", &w, {CD, H, 1})); put("enc.inproj.ac.w", view(w, {w.dim(0), w.dim(1)}));
     const T& cb = p["codebooks"];  // nearest code = argmax_e (r.e - |e|^2 / 2)
     T bias; bias.shape = {cb.dim(0)}; bias.v.resize((size_t)cb.dim(0));
     for (int64_t r = 0; r < cb.dim(0); ++r) {
@@ -680,8 +822,20 @@ struct sopro_checkpoint {
 
 extern "C" {
 
+// Exceptions (std::bad_alloc from a hostile size, std::out_of_range from T::dim / map::at) must not cross the C boundary.
+#define SOPRO_C_GUARD_BEGIN try {
+#define SOPRO_C_GUARD_END(fn_)                                                                   \
+  } catch (const std::exception& ex) {                                                           \
+    sopro_set_error("%s: %s", fn_, ex.what());                                                   \
+    return -3;                                                                                   \
+  } catch (...) {                                                                                \
+    sopro_set_error("%s: unknown exception", fn_);                                              \
+    return -3;                                                                                   \
+  }
+
 int sopro_checkpoint_open(const char* sopro_path, const char* mimi_path, sopro_checkpoint** out) {
   SOPRO_CHECK_ARG(sopro_path && out, "sopro_path / out is NULL");
+  SOPRO_C_GUARD_BEGIN
   std::unique_ptr<sopro_checkpoint> ck(new sopro_checkpoint());
   Ck& k = ck->k;
   if (int rc = k.fs.open(sopro_path)) return rc;
@@ -690,21 +844,24 @@ int sopro_checkpoint_open(const char* sopro_path, const char* mimi_path, sopro_c
     return -3;
   }
   {
-    JsonParser jp{k.fs.cfg_json.data(), k.fs.cfg_json.data() + k.fs.cfg_json.size()};
+    JsonParser jp{k.fs.cfg_json.c_str(), k.fs.cfg_json.c_str() + k.fs.cfg_json.size()};
     Json o = jp.value();
     if (!jp.ok || o.kind != Json::Obj) { sopro_set_error("sopro_checkpoint_open: malformed cfg JSON in %s", sopro_path); return -3; }
     SoproCfg& c = k.c;  // key-intersection load: unknown keys are ignored, missing ones keep their defaults (hub.py:44-48)
-    cfg_int(o, "num_codebooks", &c.num_codebooks); cfg_int(o, "codebook_size", &c.codebook_size); cfg_int(o, "d_model", &c.d_model);
-    cfg_int(o, "n_layers_text", &c.n_layers_text); cfg_int(o, "pos_emb_max", &c.pos_emb_max); cfg_int(o, "n_layers_ar", &c.n_layers_ar);
-    cfg_int(o, "ar_kernel", &c.ar_kernel); cfg_ints(o, "ar_dilation_cycle", &c.ar_dilation_cycle); cfg_int(o, "ar_text_attn_freq", &c.ar_text_attn_freq);
-    cfg_int(o, "n_layers_nar", &c.n_layers_nar); cfg_int(o, "nar_head_dim", &c.nar_head_dim); cfg_int(o, "nar_kernel_size", &c.nar_kernel_size);
-    cfg_ints(o, "nar_dilation_cycle", &c.nar_dilation_cycle);
-    cfg_pair(o, "stage_B", c.stage[0]); cfg_pair(o, "stage_C", c.stage[1]); cfg_pair(o, "stage_D", c.stage[2]); cfg_pair(o, "stage_E", c.stage[3]);
-    cfg_int(o, "sv_student_dim", &c.sv_student_dim); cfg_int(o, "ref_enc_layers", &c.ref_enc_layers); cfg_int(o, "ref_xattn_heads", &c.ref_xattn_heads);
-    cfg_int(o, "ref_xattn_layers", &c.ref_xattn_layers);
-    if (const Json* v = o.get("ref_xattn_gmax")) if (v->kind == Json::Num) c.ref_xattn_gmax = v->num;
-    SOPRO_CHECK_ARG(c.n_layers_ar >= 1 && c.n_layers_ar <= 16 && c.n_layers_nar >= 1 && c.n_layers_nar <= 16 && c.ar_text_attn_freq >= 1 && c.d_model % 4 == 0,
-                    "checkpoint config outside what the engine takes (1..16 AR / NAR layers)");
+    bool bad = false;
+    cfg_int(o, "num_codebooks", &c.num_codebooks, &bad); cfg_int(o, "codebook_size", &c.codebook_size, &bad); cfg_int(o, "d_model", &c.d_model, &bad);
+    cfg_int(o, "n_layers_text", &c.n_layers_text, &bad); cfg_int(o, "pos_emb_max", &c.pos_emb_max, &bad); cfg_int(o, "n_layers_ar", &c.n_layers_ar, &bad);
+    cfg_int(o, "ar_kernel", &c.ar_kernel, &bad); cfg_ints(o, "ar_dilation_cycle", &c.ar_dilation_cycle, &bad);
+    cfg_int(o, "ar_text_attn_freq", &c.ar_text_attn_freq, &bad);
+    cfg_int(o, "n_layers_nar", &c.n_layers_nar, &bad); cfg_int(o, "nar_head_dim", &c.nar_head_dim, &bad); cfg_int(o, "nar_kernel_size", &c.nar_kernel_size, &bad);
+    cfg_ints(o, "nar_dilation_cycle", &c.nar_dilation_cycle, &bad);
+    cfg_pair(o, "stage_B", c.stage[0], &bad); cfg_pair(o, "stage_C", c.stage[1], &bad); cfg_pair(o, "stage_D", c.stage[2], &bad);
+    cfg_pair(o, "stage_E", c.stage[3], &bad);
+    cfg_int(o, "sv_student_dim", &c.sv_student_dim, &bad); cfg_int(o, "ref_enc_layers", &c.ref_enc_layers, &bad);
+    cfg_int(o, "ref_xattn_heads", &c.ref_xattn_heads, &bad); cfg_int(o, "ref_xattn_layers", &c.ref_xattn_layers, &bad);
+    if (const Json* v = o.get("ref_xattn_gmax")) { if (v->kind == Json::Num) c.ref_xattn_gmax = v->num; else bad = true; }
+    if (bad) { sopro_set_error("sopro_checkpoint_open: a cfg entry of %s is not an integer (list) of a usable size", sopro_path); return -3; }
+    if (const char* why = check_cfg(c)) { sopro_set_error("sopro_checkpoint_open: checkpoint config outside what the engine takes: %s", why); return -3; }
   }
   k.m.num_quantizers = k.c.num_codebooks;
   if (int rc = k.pack_sopro()) return rc;
@@ -715,6 +872,7 @@ int sopro_checkpoint_open(const char* sopro_path, const char* mimi_path, sopro_c
   }
   *out = ck.release();
   return 0;
+  SOPRO_C_GUARD_END("sopro_checkpoint_open")
 }
 
 int sopro_checkpoint_close(sopro_checkpoint* ck) {
@@ -726,6 +884,7 @@ int32_t sopro_checkpoint_count(const sopro_checkpoint* ck) { return ck ? (int32_
 
 int sopro_checkpoint_tensor(const sopro_checkpoint* ck, int32_t i, const char** name, const float** data, int64_t* shape4, int32_t* ndim) {
   SOPRO_CHECK_ARG(ck && i >= 0 && i < (int32_t)ck->k.names.size() && name && data && shape4 && ndim, "bad index or NULL output");
+  SOPRO_C_GUARD_BEGIN
   const std::string& n = ck->k.names[(size_t)i];
   const T& t = ck->k.p.at(n);
   *name = n.c_str();
@@ -733,10 +892,12 @@ int sopro_checkpoint_tensor(const sopro_checkpoint* ck, int32_t i, const char** 
   *ndim = (int32_t)t.shape.size();
   for (int d = 0; d < 4; ++d) shape4[d] = d < (int)t.shape.size() ? t.shape[(size_t)d] : 1;
   return 0;
+  SOPRO_C_GUARD_END("sopro_checkpoint_tensor")
 }
 
 int sopro_checkpoint_engine_cfg(const sopro_checkpoint* ck, int32_t precision, sopro_engine_cfg* cfg) {
   SOPRO_CHECK_ARG(ck && cfg && (precision == 0 || precision == 1), "NULL argument, or precision not 0 (fp32 parity) / 1 (bf16 mode)");
+  SOPRO_C_GUARD_BEGIN
   const SoproCfg& c = ck->k.c;
   const MimiCfg& m = ck->k.m;
   memset(cfg, 0, sizeof(*cfg));
@@ -772,10 +933,12 @@ int sopro_checkpoint_engine_cfg(const sopro_checkpoint* ck, int32_t precision, s
   cfg->n_layers_text = c.n_layers_text; cfg->ref_enc_layers = c.ref_enc_layers; cfg->ref_xattn_layers = c.ref_xattn_layers;
   cfg->ref_xattn_heads = c.ref_xattn_heads; cfg->sv_student_dim = c.sv_student_dim; cfg->enc_kernel = 7;
   return 0;
+  SOPRO_C_GUARD_END("sopro_checkpoint_engine_cfg")
 }
 
 int sopro_engine_from_checkpoint(const sopro_checkpoint* ck, int32_t precision, void* stream, sopro_engine** out) {
   SOPRO_CHECK_ARG(ck && out, "NULL argument");
+  SOPRO_C_GUARD_BEGIN
   sopro_engine_cfg cfg;
   if (int rc = sopro_checkpoint_engine_cfg(ck, precision, &cfg)) return rc;
   sopro_engine* e = nullptr;
@@ -790,6 +953,7 @@ int sopro_engine_from_checkpoint(const sopro_checkpoint* ck, int32_t precision, 
   if (int rc = sopro_engine_finalize(e, stream)) { sopro_engine_destroy(e); return rc; }
   *out = e;
   return 0;
+  SOPRO_C_GUARD_END("sopro_engine_from_checkpoint")
 }
 
 }  // extern "C"

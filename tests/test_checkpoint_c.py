@@ -127,3 +127,108 @@ def test_c_loader_error_paths(tmp_path):
     save_sopro_checkpoint(p2, wn, cfg)
     assert lib.sopro_checkpoint_open(p2.encode(), None, C.byref(ck)) != 0
     assert b"ar.head.bias" in lib.sopro_last_error()
+
+
+def _write_raw_safetensors(path, header: bytes, data: bytes = b""):
+    import struct
+
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(header)) + header + data)
+
+
+def _open_rc(lib, sp, mp=None):
+    ck = C.c_void_p()
+    rc = lib.sopro_checkpoint_open(sp.encode(), mp.encode() if mp else None, C.byref(ck))
+    if rc == 0:
+        lib.sopro_checkpoint_close(ck)
+    return rc, lib.sopro_last_error().decode(errors="replace")
+
+
+def test_c_loader_refuses_tensors_that_do_not_fit_the_config(tmp_path):
+    """the loader indexes tensors with extents taken from the cfg JSON, so every tensor's rank and shape is
+    checked against the config BEFORE a pack / fold loop runs, config integers are range-checked, and no exception leaves the C
+    entry points.  Each case used to corrupt the heap, terminate the process or return rc 0 with garbage."""
+    lib = hip.load()
+    cfg = SoproTTSConfig()
+    wn = synth_sopro_weights(cfg, 64, 3)
+    # (a) cfg d_model = 1536 over 384-wide tensors
+    big = SoproTTSConfig(d_model=1536)
+    p = str(tmp_path / "a.safetensors")
+    save_sopro_checkpoint(p, wn, big)
+    rc, err = _open_rc(lib, p)
+    assert rc != 0 and "shape" in err and "config implies" in err, err
+    # (b) a tensor of the wrong rank (1-D depthwise weight)
+    w2 = dict(wn)
+    w2["ar.blocks.0.dw.dw.weight"] = wn["ar.blocks.0.dw.dw.weight"].reshape(-1)
+    p = str(tmp_path / "b.safetensors")
+    save_sopro_checkpoint(p, w2, cfg)
+    rc, err = _open_rc(lib, p)
+    assert rc != 0 and "ar.blocks.0.dw.dw.weight" in err, err
+    # (c) config integers out of range / not integers at all
+    import json
+
+    from safetensors.numpy import save_file
+
+    for bad in ({"pos_emb_max": -5}, {"d_model": 1e300}, {"n_layers_ar": 400}, {"num_codebooks": 0}, {"ar_dilation_cycle": [1, -2]},
+                {"stage_B": [5, 2]}, {"ref_xattn_heads": 7}, {"d_model": "384"}, {"nar_head_dim": 2.5}):
+        d = json.loads(cfg.to_json())
+        d.update(bad)
+        p = str(tmp_path / "c.safetensors")
+        save_file({k: np.require(v, requirements="C") for k, v in wn.items()}, p, metadata={"cfg": json.dumps(d)})
+        rc, err = _open_rc(lib, p)
+        assert rc != 0 and ("config" in err or "cfg" in err), (bad, err)
+    # (d) a norm vector shorter than the K it scales
+    w3 = dict(wn)
+    w3["ar.blocks.1.norm.weight"] = wn["ar.blocks.1.norm.weight"][:100].copy()
+    p = str(tmp_path / "d.safetensors")
+    save_sopro_checkpoint(p, w3, cfg)
+    rc, err = _open_rc(lib, p)
+    assert rc != 0 and "ar.blocks.1.norm.weight" in err, err
+    # Mimi side: a transposed-convolution weight with swapped channel extents
+    mc = MimiDecoderConfig()
+    mn = synth_mimi_weights(mc, 3)
+    mn["decoder.layers.2.conv.weight"] = np.ascontiguousarray(mn["decoder.layers.2.conv.weight"].transpose(1, 0, 2))
+    sp, mp = str(tmp_path / "ok.safetensors"), str(tmp_path / "mimi_bad.safetensors")
+    save_sopro_checkpoint(sp, wn, cfg)
+    save_file({k: np.require(v, requirements="C") for k, v in mn.items()}, mp)
+    rc, err = _open_rc(lib, sp, mp)
+    assert rc != 0 and "decoder.layers.2.conv.weight" in err, err
+
+
+def test_c_loader_survives_hostile_safetensors_headers(tmp_path):
+    """offsets / dims are checked non-negative integers, byte counts must equal numel * element size before anything
+    is allocated, numbers are parsed from a NUL-terminated copy of the header, the JSON depth is capped, \\u escapes become UTF-8."""
+    import json
+
+    lib = hip.load()
+    cases = {
+        "neg_offset": (json.dumps({"a": {"dtype": "F32", "shape": [2], "data_offsets": [-8, 0]}}).encode(), b"\0" * 8),
+        "nan_dim": (b'{"a":{"dtype":"F32","shape":[NaN],"data_offsets":[0,8]}}', b"\0" * 8),
+        "neg_dim": (json.dumps({"a": {"dtype": "F32", "shape": [-2], "data_offsets": [0, 8]}}).encode(), b"\0" * 8),
+        "huge_dim": (json.dumps({"a": {"dtype": "F32", "shape": [2 ** 40, 2 ** 40], "data_offsets": [0, 8]}}).encode(), b"\0" * 8),
+        "huge_off": (b'{"a":{"dtype":"F32","shape":[2],"data_offsets":[0,1e300]}}', b"\0" * 8),
+        "wrap_off": (json.dumps({"a": {"dtype": "F32", "shape": [2], "data_offsets": [0, 2 ** 64 - 4]}}).encode(), b"\0" * 8),
+        "bytes_vs_numel": (json.dumps({"a": {"dtype": "F32", "shape": [1000000], "data_offsets": [0, 8]}}).encode(), b"\0" * 8),
+        "frac_dim": (b'{"a":{"dtype":"F32","shape":[1.5],"data_offsets":[0,8]}}', b"\0" * 8),
+        "deep": (b"[" * 100000, b""),
+        "deep_obj": (b'{"a":' * 50000, b""),
+        "digits_at_end": (b'{"a":{"dtype":"F32","shape":[2],"data_offsets":[0,8', b"99999999"),  # the number runs into the tensor data
+        "shape_not_list": (json.dumps({"a": {"dtype": "F32", "shape": 2, "data_offsets": [0, 8]}}).encode(), b"\0" * 8),
+        "dtype_not_str": (json.dumps({"a": {"dtype": 7, "shape": [2], "data_offsets": [0, 8]}}).encode(), b"\0" * 8),
+        "bad_escape": (b'{"a\\uZZZZ":{"dtype":"F32","shape":[2],"data_offsets":[0,8]}}', b"\0" * 8),
+    }
+    for name, (hdr, data) in cases.items():
+        p = str(tmp_path / f"{name}.safetensors")
+        _write_raw_safetensors(p, hdr, data)
+        rc, err = _open_rc(lib, p)
+        assert rc != 0 and err, name
+    # a well-formed header whose cfg string holds escapes: a surrogate pair and a BMP character survive as UTF-8 in an ignored key
+    cfg = SoproTTSConfig()
+    d = json.loads(cfg.to_json())
+    d["note é\U0001F600"] = 1
+    hdr = json.dumps({"__metadata__": {"cfg": json.dumps(d)}, "x": {"dtype": "F32", "shape": [2], "data_offsets": [0, 8]}}).encode()
+    assert b"\\\\ud83d" in hdr  # (json.dumps escaped the pair inside the nested string)
+    p = str(tmp_path / "esc.safetensors")
+    _write_raw_safetensors(p, hdr, b"\0" * 8)
+    rc, err = _open_rc(lib, p)
+    assert rc != 0 and "is missing" in err, err  # the header and the cfg parse; the first tensor the packer asks for is absent
