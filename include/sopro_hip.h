@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 38
+#define SOPRO_ABI_VERSION 39
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -146,6 +146,10 @@ typedef struct sopro_gemm_split_ext {
    * instead of streaming the whole W once per row tile.  Filled from sopro_gemm_set_group_m when 0. */
   int32_t group_m;
   float acc_scale;     /* sopro_gemm_f16x3 only: 1 / (sopro_f16x3_a_scale() * the weight's pack scale), applied to the accumulator */
+  int32_t* range_events; /* sopro_gemm_f16x3 only, optional (round 5): a device word; every workgroup that had to SATURATE a staged activation
+                          * at fp16's largest finite value (|a * scale| > 65504: the result is finite and wrong) adds 1.  Plain forms scale by
+                          * sopro_f16x3_a_scale() (|a| <= 8188 is in range); fused-RMSNorm forms choose a power of two per row from the row's
+                          * first 32 elements (256x headroom).  A caller that finds the word changed repeats the work on sopro_gemm_bf16x6. */
 } sopro_gemm_split_ext;
 int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
 /* Six-pass variant for token paths (NAR refinement, conditioning: src/sopro/nn/nar.py, blocks.py): operands split into
@@ -250,6 +254,11 @@ int sopro_pack_skinny_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, 
  * instead of hipMemset* / hipMemcpy* so that a recorded sequence holds kernel nodes only. */
 int sopro_fill2d_u32(void* p, int64_t pitch, int32_t rows, int32_t width, uint32_t value, void* stream);
 int sopro_copy2d_u32(void* dst, int64_t dpitch, const void* src, int64_t spitch, int32_t rows, int32_t width, void* stream);
+/* (Either side of sopro_copy2d_u32 may be page-locked HOST memory from sopro_host_alloc: small parameter blocks travel to the device and
+ * poll words back to the host as kernels of the library - the timed path holds no runtime copy at all, round 5.)
+ * tokens[(b T + t) Q] = clamp(cb0[b cb0_bstride + t], 0, vmax): codebook 0 as the AR loop's history holds it (EOS = V in stopped rows)
+ * into column 0 of the refinement's token matrix (src/sopro/model.py:385-390). */
+int sopro_nar_seed_i32(int32_t* tokens, int32_t Q, const int32_t* cb0, int64_t cb0_bstride, int32_t B, int32_t T, int32_t vmax, void* stream);
 /* fp32 <-> bf16 images of a tensor of n elements (n % 4 == 0; round to nearest even).  The engine's bf16 mode keeps the state the AR
  * frame streams every frame (folded text operands, ring buffers) and the SEANet decoder's activations as bf16 in memory; these
  * make / read such images outside the hot kernels (operand preparation, tests).  No reference counterpart (the reference has
@@ -673,6 +682,25 @@ int sopro_ar_tokens(sopro_engine* e, int32_t* hist, int32_t* first_eos, int32_t*
 int64_t sopro_nar_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T);
 int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_t cond_bstride, const int32_t* rvq1, const int32_t* lens,
                      int32_t B, int32_t T, int32_t* tokens, void* stream);
+/* The same with its operands where the stages in front of it left them (round 5: no copies between the stages of a pass).
+ *   cond / cond_bstride  the first T rows of each utterance's conditioning block (the AR plan's buffer: cond_ar [B, Tar, D])
+ *   cb0 / cb0_bstride    codebook 0 as rows of the AR loop's history [B, >= T] (EOS = codebook_size in rows that stopped: clamped here)
+ *   lens                 [B] or NULL; may live in page-locked host memory (it is copied into the workspace first)
+ *   safe                 0: the f16 three-pass operands (precision 0) - 1: the six-pass bf16 operands, which have fp32's exponent range
+ *   range_out            optional word (device or page-locked host memory) that receives the number of RANGE EVENTS of this call: workgroups
+ *                        of the f16 contractions that had to saturate an activation (sopro_gemm_split_ext.range_events).  Non-zero = this
+ *                        pass's tokens are not trustworthy: repeat it with safe = 1 (sopro_amd/model.py does; a checkpoint whose residual
+ *                        stream leaves fp16's range pays the slower path instead of returning wrong tokens silently).
+ * sopro_nar_refine(...) = this with dense cb0 rows, safe = 0 and no range word. */
+typedef struct sopro_nar_io {
+  const float* cond; int64_t cond_bstride;
+  const int32_t* cb0; int64_t cb0_bstride;
+  const int32_t* lens;
+  int32_t* tokens;      /* [B T, Q] out */
+  int32_t* range_out;
+  int32_t safe;
+} sopro_nar_io;
+int sopro_nar_refine_io(sopro_engine* e, void* workspace, const sopro_nar_io* io, int32_t B, int32_t T, void* stream);
 
 /* ---- Mimi encode (reference audio -> codec tokens; src/sopro/codec/mimi.py:42-63 -> HF MimiModel.encode): SEANet encoder,
  * encoder transformer, stride-2 downsample, split residual VQ, every contraction in exact fp32.  Family marker "enc.conv0.w"
@@ -684,6 +712,17 @@ int sopro_mimi_encode(sopro_engine* e, void* workspace, const float* wav, int32_
 /* ---- Mimi decode: tokens [B, T, Q] int32 -> wav [B, T * 1920] fp32 */
 int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T);
 int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream);
+/* Large batches are decoded in balanced row chunks of at most ~12800 frames each (SOPRO_MIMI_CHUNK_CELLS; a 64 x 400 decode in one
+ * piece measured slower per utterance than two 32 x 400 ones and needs 148 GB of scratch): sopro_mimi_decode does that itself and
+ * sopro_mimi_workspace_bytes sizes the workspace for ONE chunk, so every host gets it (round 5; it lived in the Python host).
+ * sopro_mimi_chunk_rows: the rows per chunk sopro_mimi_decode uses for (B, T).
+ * sopro_mimi_decode_parts: ONE chunk (B rows, workspace of sopro_mimi_workspace_bytes(e, B, T) bytes or more) in two parts - 1: every
+ * launch but the last, 2: the last launch alone, the only one that touches `wav` (the fused last SEANet level or its tail kernel), 3: both.
+ * A host that replays part 1 from a recorded graph launches part 2 itself with the destination of THIS call: the decoder writes straight
+ * into the caller's buffer and a recorded sequence holds no pointer of the caller's (src/sopro/codec/mimi.py:65-72: what decode_full
+ * returns).  `tokens` is only read by part 1. */
+int32_t sopro_mimi_chunk_rows(int32_t B, int32_t T);
+int sopro_mimi_decode_parts(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, int32_t parts, void* stream);
 
 /* ---- streaming decode (MimiStreamDecoder.decode_step's MimiModel.decode(..., decoder_past_key_values=...) call,
  * src/sopro/codec/mimi.py:152-156): one utterance, T frames at a time, the decoder transformer attending over the cached

@@ -193,50 +193,53 @@ class MimiCodec:
             raise ValueError("streaming decode state is single-utterance")
         if self.eng is None:
             raise hip.SoproHipError("this Mimi checkpoint was loaded without its decoder-side tensors")
-        if ws.over(self.ws_budget) and (B, T) not in self._graphs.graphs:  # many batch shapes seen: start over
+        if ws.over(self.ws_budget) and not any(k[1] == T for k in self._graphs.graphs):  # many batch shapes seen: start over
             torch.cuda.synchronize(self.device)
             self._graphs.clear()
             ws.clear()
         lib, eng = hip.load(), self.eng
-        # Large batches are decoded in row chunks of ~12800 frames (32 x 400, 64 x 200): a 64 x 400 decode in one call measured
-        # slower per utterance than two 32 x 400 calls (39.5 vs 33.9 ms per 32; its scratch is 148 GB) - with chunks a scheduler can
-        # still coalesce two long-form jobs into one 64-row generation / refinement pass (profiles/r04_experiments.md).
-        rows_max = max(1, int(os.environ.get("SOPRO_MIMI_CHUNK_CELLS", "12800")) // T)
-        chunks = [(b0, min(B, b0 + rows_max)) for b0 in range(0, B, rows_max)] if (state is None and B > rows_max) else [(0, B)]
+        # Large batches are decoded in balanced row chunks of ~12800 frames (32 x 400, 64 x 200): a 64 x 400 decode in one call
+        # measured slower per utterance than two 32 x 400 calls (39.5 vs 33.9 ms per 32; its scratch is 148 GB) - with chunks a
+        # scheduler can still coalesce two long-form jobs into one 64-row generation / refinement pass (profiles/r04_experiments.md).
+        # The rule lives in the library (sopro_mimi_chunk_rows; sopro_mimi_decode applies it for hosts without this class).
+        rows = int(lib.sopro_mimi_chunk_rows(B, T)) if state is None else B
+        chunks = [(b0, min(B, b0 + rows)) for b0 in range(0, B, rows)]
         hop = int(mc.frame_samples)
         with self.on_stream():
-            wav = torch.empty(B, T * hop, device=dev) if len(chunks) > 1 else None
+            # The codes are read WHERE THEY ARE when they are the refinement's own int32 matrix on this device (a scheduler's pass:
+            # SoproTTSModel.phase_nar(raw=True)); anything else is staged once into a persistent buffer.
+            src = codes_btq
+            if not (src.is_cuda and src.device == dev and src.dtype == torch.int32 and src.is_contiguous()):
+                src = ws.get(f"rvq.tok.{B}x{T}", (B, T, Q), dtype=torch.int32)
+                src.copy_(codes_btq.to(dev))
+            # The result is a fresh tensor the caller owns, and the decoder's LAST launch (the only one that touches it) writes
+            # straight into it: that launch is issued here with this call's destination, everything in front of it is replayed
+            # from the sequence recorded for (rows, T, source) - no `clone`, no `copy_` of a 98 MB waveform per pass (round 5).
+            wav = torch.empty(B, T * hop, device=dev)
             for b0, b1 in chunks:
                 Bc = b1 - b0
-                # codes land in a persistent buffer so that the call of a (B, T) shape can be recorded once
-                tok = ws.get("rvq.tok", (Bc * T, Q), dtype=torch.int32)
-                tok.copy_(codes_btq[b0:b1].to(dev).reshape(Bc * T, Q))
-                out = ws.get("sea.wav", (Bc, T * hop))
+                tok_ptr = src.data_ptr() + b0 * T * Q * 4
+                out_ptr = wav.data_ptr() + b0 * T * hop * 4
                 scratch = ws.get(f"mimi.stage_ws.{Bc}x{T}", (int(lib.sopro_mimi_workspace_bytes(eng.h, Bc, T)),), dtype=torch.uint8)
                 if state is None:
-                    def issue(tok=tok, out=out, scratch=scratch, Bc=Bc):
-                        hip._check(lib.sopro_mimi_decode(eng.h, scratch.data_ptr(), tok.data_ptr(), Bc, T, out.data_ptr(), hip._stream()), "sopro_mimi_decode")
+                    def body(tok_ptr=tok_ptr, out_ptr=out_ptr, scratch=scratch, Bc=Bc):
+                        hip._check(lib.sopro_mimi_decode_parts(eng.h, scratch.data_ptr(), tok_ptr, Bc, T, out_ptr, 1, hip._stream()), "sopro_mimi_decode_parts")
 
                     if self.use_graph:
-                        self._graphs.run((Bc, T), issue)
+                        self._graphs.run((Bc, T, tok_ptr), body)
                     else:
-                        issue()
+                        body()
+                    hip._check(lib.sopro_mimi_decode_parts(eng.h, scratch.data_ptr(), tok_ptr, Bc, T, out_ptr, 2, hip._stream()), "sopro_mimi_decode_parts")
                 else:
-                    if state.cst is None:  # first call of a stream: the cache buffer (window + chunk rows under the evicting policy)
-                        import ctypes as C
+                    import ctypes as C
 
+                    if state.cst is None:  # first call of a stream: the cache buffer (window + chunk rows under the evicting policy)
                         cap = self.stream_cap_rows
                         state.kv_buf = torch.empty(int(lib.sopro_mimi_stream_kv_bytes(eng.h, cap)), dtype=torch.uint8, device=dev)
                         state.cst = hip.MimiStreamState()
                         hip._check(lib.sopro_mimi_stream_init(eng.h, C.byref(state.cst), state.kv_buf.data_ptr(), cap), "sopro_mimi_stream_init")
-                    import ctypes as C
-
-                    hip._check(lib.sopro_mimi_decode_stream(eng.h, scratch.data_ptr(), C.byref(state.cst), tok.data_ptr(), T, out.data_ptr(), hip._stream()),
+                    hip._check(lib.sopro_mimi_decode_stream(eng.h, scratch.data_ptr(), C.byref(state.cst), tok_ptr, T, out_ptr, hip._stream()),
                                "sopro_mimi_decode_stream")
-                if wav is not None:
-                    wav[b0:b1].copy_(out)
-            if wav is None:
-                wav = out.clone()  # the caller owns its result
         self.stream.synchronize()
         return wav
 

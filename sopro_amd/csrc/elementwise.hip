@@ -438,6 +438,16 @@ __global__ __launch_bounds__(256) void copy2d_kernel(unsigned* __restrict__ d, i
   d[(i / width) * dpitch + (i % width)] = s[(i / width) * spitch + (i % width)];
 }
 
+// codebook 0 of a batch, as the AR loop left it (rows of a longer history buffer; EOS = V in rows that stopped early), into column 0
+// of the refinement's token matrix [B T, Q], clamped to valid codes (src/sopro/model.py:385-390: frames past a row's own length are
+// ignored downstream, they only have to be valid indices)
+__global__ __launch_bounds__(256) void nar_seed_kernel(int* __restrict__ tokens, int Q, const int* __restrict__ cb0, int64_t bstride, int B, int T, int vmax) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * T) return;
+  const int b = (int)(i / T), t = (int)(i - (int64_t)b * T);
+  tokens[i * Q] = min(max(cb0[(int64_t)b * bstride + t], 0), vmax);
+}
+
 // fp32 <-> bf16 images of a tensor (round to nearest even), 4 elements per thread
 __global__ __launch_bounds__(256) void cvt_f32_bf16_kernel(const float* __restrict__ src, uint2* __restrict__ dst, int64_t n4) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -613,6 +623,12 @@ int sopro_copy2d_u32(void* dst, int64_t dpitch, const void* src, int64_t spitch,
   SOPRO_CHECK_ARG(dst && src && rows > 0 && width > 0 && dpitch >= width && spitch >= width, "bad pointers or sizes");
   hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)rows * width, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<unsigned*>(dst), dpitch,
                      reinterpret_cast<const unsigned*>(src), spitch, rows, width);
+  SOPRO_LAUNCH_CHECK();
+}
+
+int sopro_nar_seed_i32(int32_t* tokens, int32_t Q, const int32_t* cb0, int64_t cb0_bstride, int32_t B, int32_t T, int32_t vmax, void* stream) {
+  SOPRO_CHECK_ARG(tokens && cb0 && Q > 0 && B > 0 && T > 0 && cb0_bstride >= T && vmax >= 0, "bad pointers or sizes");
+  hipLaunchKernelGGL(nar_seed_kernel, dim3(nblk((int64_t)B * T, 256)), dim3(256), 0, (hipStream_t)stream, tokens, Q, cb0, cb0_bstride, B, T, vmax);
   SOPRO_LAUNCH_CHECK();
 }
 

@@ -38,6 +38,14 @@ __device__ __forceinline__ f16x8 as_frag16(const uint4& v) { return *reinterpret
 // the scaled value, i.e. ~7e-9 of the unscaled activation - small against 2^-22 of an O(1) row (the NAR stream is O(1-10): its
 // contraction inputs are RMS-normalised or GELU outputs; rows of energy << 1e-2 lose relative precision to that floor).
 constexpr float A16_SCALE = 8.0f;  // |activation| <= 8188 is exact in range; beyond it the operand saturates (finite, wrong)
+// Round 5 (the range contract was documented, not enforced):
+//  * fused-RMSNorm forms (AMODE 4) stage the UN-NORMALISED residual stream, whose row scale is whatever the checkpoint makes it:
+//    there the scale is chosen PER ROW, a power of two that puts the largest of the row's first 32 elements into [2^7, 2^8) - 2^8
+//    of headroom before fp16 saturates, subnormal floor at 2^-31 of that element - and is undone, exactly, with the row's RMS scale
+//    in the epilogue.  Rows of RMS 1e-3 and 1e+3 therefore keep the same 22 bits.
+//  * every f16 form tracks the largest scaled magnitude it staged; a workgroup that had to saturate an element adds one to
+//    ext.range_events (device word, optional).  The engine's refinement checks the word after a pass and repeats the pass on the
+//    six-pass bf16 operands, which have fp32's exponent range (sopro_nar_refine; tests/test_gpu_range.py).
 
 // two fp32 values -> NPL packed 16-bit pairs (piece p of x in the low half, of y in the high half)
 template <int NPL, bool F16 = false>
@@ -135,8 +143,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
 
   float4 raA[A_F4], raB[A_F4];  // A rows are requested TWO K-steps ahead (they come from HBM; W, one step ahead, from L2)
   float ssq[A_F4];
+  float rsc[A_F4];    // f16 fused-RMSNorm form: the row's power-of-two staging scale (set by the first lstore)
+  float a16max = 0.f; // f16 forms: largest scaled magnitude this thread staged (range guard)
 #pragma unroll
-  for (int i = 0; i < A_F4; ++i) ssq[i] = 0.f;
+  for (int i = 0; i < A_F4; ++i) { ssq[i] = 0.f; rsc[i] = A16_SCALE; }
   float4 pvA = make_float4(0.f, 0.f, 0.f, 0.f), pvB = pvA;
   const int KT = (g.K + BK - 1) / BK;
   const int klast = g.K - 4;
@@ -164,7 +174,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
 #pragma unroll
         for (int p = 0; p < NPL; ++p) rb[j][s][p] = bp[j][((int64_t)(kt * 2 + s) * NPL + p) * 64];
   };
-  auto lstore = [&](int buf, float4 (&ra)[A_F4], const float4& pv, bool fresh = true) {  // fresh: not the clamped re-stage of the last step (RMSNorm sums count once)
+  // fresh: not the clamped re-stage of the last step (RMSNorm sums count once); first: the slice's first K-step (f16 row scales are chosen)
+  auto lstore = [&](int buf, float4 (&ra)[A_F4], const float4& pv, bool fresh = true, bool first = false) {
     if constexpr (AMODE == 5) {  // the row piece is already what the MFMA reads: 8-byte copy into the piece-0 plane
       unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 8;
 #pragma unroll
@@ -195,10 +206,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
         unsigned c0[NPL], c1[NPL];
-        if constexpr (F16) {  // scaled, and saturated at fp16's largest finite value (|a| > 8188: no inf / NaN downstream)
+        if constexpr (F16) {  // scaled, and saturated at fp16's largest finite value (no inf / NaN downstream; counted: range guard)
           const float F16MAX = 65504.0f;
-          split_pair<NPL, true>(__builtin_amdgcn_fmed3f(ra[i].x * A16_SCALE, -F16MAX, F16MAX), __builtin_amdgcn_fmed3f(ra[i].y * A16_SCALE, -F16MAX, F16MAX), c0);
-          split_pair<NPL, true>(__builtin_amdgcn_fmed3f(ra[i].z * A16_SCALE, -F16MAX, F16MAX), __builtin_amdgcn_fmed3f(ra[i].w * A16_SCALE, -F16MAX, F16MAX), c1);
+          if constexpr (AMODE == 4) {
+            if (first) {  // the eight lanes that stage a row's K-step agree on its scale: 2^(7 - exponent of the largest of 32 elements)
+              float mx = fmaxf(fmaxf(fabsf(ra[i].x), fabsf(ra[i].y)), fmaxf(fabsf(ra[i].z), fabsf(ra[i].w)));
+              mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+              mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+              mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+              const int ex = (int)((__float_as_uint(mx) >> 23) & 255u);  // biased exponent; 0: zero / subnormal lead-in, 255: inf / NaN
+              rsc[i] = (ex == 0 || ex == 255) ? A16_SCALE : __uint_as_float((unsigned)min(max(261 - ex, 2), 252) << 23);
+            }
+          }
+          const float sa = AMODE == 4 ? rsc[i] : A16_SCALE;
+          const float vx = ra[i].x * sa, vy = ra[i].y * sa, vz = ra[i].z * sa, vw = ra[i].w * sa;
+          a16max = fmaxf(a16max, fmaxf(fmaxf(fabsf(vx), fabsf(vy)), fmaxf(fabsf(vz), fabsf(vw))));
+          split_pair<NPL, true>(__builtin_amdgcn_fmed3f(vx, -F16MAX, F16MAX), __builtin_amdgcn_fmed3f(vy, -F16MAX, F16MAX), c0);
+          split_pair<NPL, true>(__builtin_amdgcn_fmed3f(vz, -F16MAX, F16MAX), __builtin_amdgcn_fmed3f(vw, -F16MAX, F16MAX), c1);
         } else {
           split_pair<NPL>(ra[i].x, ra[i].y, c0);
           split_pair<NPL>(ra[i].z, ra[i].w, c1);
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   gload(min(kt0, KT - 1), raA, pvA);
   bload(min(kt0, KT - 1), rb0);
   if (DEEP) gload(min(min(kt0 + 1, ktl), KT - 1), raB, pvB);
-  lstore(0, raA, pvA);
+  lstore(0, raA, pvA, true, true);
   __syncthreads();
   if (dbg && tid == 0) dbg[1] = clock64();
   {
@@ -411,7 +435,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     }
   }
   if constexpr (F16) {  // undo the operand scales (powers of two: exact)
-    const float sc = ext.acc_scale;
+    // (fused-RMSNorm form: the activation scale is per row and leaves with the row's RMS scale below; acc_scale holds the constant one)
+    const float sc = AMODE == 4 ? ext.acc_scale * A16_SCALE : ext.acc_scale;
+    if (ext.range_events && !(a16max <= 65504.0f)) atomicAdd(ext.range_events, 1);  // saturated (or NaN) operands: see the header note
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -430,7 +456,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
       v += __shfl_xor(v, 1, 64);
       v += __shfl_xor(v, 2, 64);
       v += __shfl_xor(v, 4, 64);
-      if (lc4 == 0) rsl[lrow + i * RSTEP] = rsqrtf(v / (float)g.K + ext.rms_eps);
+      float r = rsqrtf(v / (float)g.K + ext.rms_eps);
+      if constexpr (F16) r *= __uint_as_float(0x7f000000u - __float_as_uint(rsc[i]));  // 1 / (a power of two), exactly: exponent 254 - e
+      if (lc4 == 0) rsl[lrow + i * RSTEP] = r;
     }
     __syncthreads();
     rs = rsl;

@@ -22,7 +22,7 @@ std::vector<Rec*> g_recs;
 }  // namespace
 
 sopro_prof_scope::sopro_prof_scope(const char* family, double flops, hipStream_t st) : rec(nullptr), s(st) {
-  if (!g_on.load(std::memory_order_relaxed)) return;
+  if (!family || !g_on.load(std::memory_order_relaxed)) return;  // (family NULL: a launch this call skips - see mimi_decode_core's parts)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();

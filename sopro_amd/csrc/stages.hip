@@ -132,6 +132,7 @@ int dev_upload(sopro_engine* e, const std::vector<T>& h, T** out) {
 }
 
 constexpr int F16X2 = 22;  // pack_pieces: two fp16 pieces (the NAR contractions, sopro_gemm_f16x3)
+const char* const NAR_SAFE = "#x6";  // key suffix of the refinement's six-pass twins (sopro_nar_io.safe)
 
 // [N, K] fp32 device matrix (optionally with its columns scaled by a device vector: an RMSNorm weight folded in) -> bf16 pieces
 int pack_pieces(sopro_engine* e, const std::string& key, const std::string& out_key, int pieces, const char* fold_vec, hipStream_t s) {
@@ -233,6 +234,7 @@ struct G {  // one contraction: mirrors sopro_amd.hip.gemm's keyword arguments
   int64_t ldc2 = -1, c2_seg = 0;
   float rms_eps = 0.f;
   const SplitK* sk = nullptr;  // non-NULL: few-row problems may run split-K on this scratch
+  int32_t* range_events = nullptr;  // f16 operands: the call's range-event word (sopro_gemm_split_ext.range_events)
 };
 
 // attention launch with its timing scope: 4 * dh flops per visible (query, key) pair
@@ -292,6 +294,7 @@ int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override
     }
     if (w.f16) {
       x.acc_scale = w.acc_scale;
+      x.range_events = o.range_events;
       return sopro_gemm_f16x3(&g, w.packed, &x, s);
     }
     if (w.pieces == 3) return sopro_gemm_bf16x6(&g, w.packed, &x, s);
@@ -428,14 +431,21 @@ int sopro_engine_finalize(sopro_engine* e, void* stream) {
       STG(pack_pieces(e, p + ".glu.w", p + ".glu.wn", np, (p + ".norm.weight").c_str(), s));
       STG(pack_pieces(e, p + ".ff1.w", p + ".ff1.wn", np, (p + ".ff.norm.weight").c_str(), s));
       STG(pack_pieces(e, p + ".ff2.w", p + ".ff2.w", np, nullptr, s));
+      if (!bf16) {  // the range guard's fallback operands: three bf16 pieces / six passes (fp32's exponent range)
+        STG(pack_pieces(e, p + ".glu.w", p + ".glu.wn" + NAR_SAFE, 3, (p + ".norm.weight").c_str(), s));
+        STG(pack_pieces(e, p + ".ff1.w", p + ".ff1.wn" + NAR_SAFE, 3, (p + ".ff.norm.weight").c_str(), s));
+        STG(pack_pieces(e, p + ".ff2.w", p + ".ff2.w" + NAR_SAFE, 3, nullptr, s));
+      }
       for (const char* nm : {".glu.b", ".dw.w", ".dw.b", ".ff1.b", ".ff2.b"}) STG(need(e, p + nm, &t));
     }
     STG(pack_pieces(e, "nar.pre.w", "nar.pre.w", np, nullptr, s));
+    if (!bf16) STG(pack_pieces(e, "nar.pre.w", std::string("nar.pre.w") + NAR_SAFE, 3, nullptr, s));
     const char* stage_names[8] = {"B", "C", "D", "E", "F", "G", "H", "I"};
     std::vector<int> known = {0};
     for (int sgi = 0; sgi < c.n_stages; ++sgi) {
       const std::string hk = std::string("nar.heads.") + stage_names[sgi];
       STG(pack_pieces(e, hk + ".w", hk + ".w", np, nullptr, s));
+      if (!bf16) STG(pack_pieces(e, hk + ".w", hk + ".w" + NAR_SAFE, 3, nullptr, s));
       STG(need(e, hk + ".b", &t));
       // prev = sum_j softmax(w[known])_j * E[cb_j * V + tok_j]   (src/sopro/nn/embeddings.py:77-112)
       std::vector<int32_t> cols(known.begin(), known.end()), offs;
@@ -612,7 +622,8 @@ int sopro_ar_fold_text_uk(const float* txt, const float* nkv_weight, const float
 
 // ------------------------------------------------------------------------------------------------ conditioning stage
 static int ssm_block_bufs(sopro_engine* e, hipStream_t s, float* h, float* x1, float* u, const SplitK* sk, const float* x, float* out,
-                          const std::string& p, int B, int T, int ksize, int dil, const int32_t* lens);  // (with the NAR stage below)
+                          const std::string& p, int B, int T, int ksize, int dil, const int32_t* lens, const char* sfx = "",
+                          int32_t* range = nullptr);  // (with the NAR stage below)
 struct CondWs { float *xa, *xb, *h, *x1, *u, *base, *cond, *nq, *q, *a, *am; SplitK sk; };
 static size_t cond_carve(const sopro_engine* e, CondWs& w, void* ws, int B, int S, int Tar) {
   const size_t M = (size_t)B * S, R = (size_t)B * Tar, D = e->c.d_model;
@@ -853,11 +864,12 @@ int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* con
   const int D = c.d_model, H = 4;
   ar_carve(e, p, workspace, B, S, Tar);
   p.B = B; p.S = S; p.S_cap = (S + 63) / 64 * 64; p.Tar = Tar; p.ws = workspace;
-  SOPRO_HIP(hipMemcpyAsync(p.cond, cond_ar, (size_t)B * Tar * D * 4, hipMemcpyDeviceToDevice, s));
+  // (kernels of the library for every copy and clear, as in the recorded sequences: one kind of node on a C host's timeline too)
+  STG(sopro_copy2d_u32(p.cond, (int64_t)Tar * D, cond_ar, (int64_t)Tar * D, B, Tar * D, s));
   if (text_lens) {
-    SOPRO_HIP(hipMemcpyAsync(p.klens, text_lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    STG(sopro_copy2d_u32(p.klens, B, text_lens, B, 1, B, s));
   } else {
-    SOPRO_HIP(hipMemsetD32Async((hipDeviceptr_t)p.klens, S, B, s));
+    STG(sopro_fill2d_u32(p.klens, B, 1, B, (uint32_t)S, s));
   }
   // unfolded keys whenever the engine was given the query operands (fp32 frame; the Python host takes the same decision)
   {
@@ -886,14 +898,20 @@ int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* con
       STG(sopro_cvt_f32_bf16(vdst, p.vp[i], (int64_t)B * H * p.S_cap * D, s));
     }
   }
-  for (int i = 0; i < c.n_layers_ar; ++i)
-    SOPRO_HIP(hipMemsetAsync(p.rings[i], 0, (size_t)((c.ar_kernel - 1) * c.ar_dilations[i] + 1) * B * D * 4, s));
-  SOPRO_HIP(hipMemsetAsync(p.hist, 0, (size_t)B * Tar * 4, s));
-  SOPRO_HIP(hipMemcpyAsync(p.params, params, 8 * sizeof(float), hipMemcpyHostToDevice, s));
-  SOPRO_HIP(hipMemsetD32Async((hipDeviceptr_t)p.nonce, (int)nonce, B, s));
+  for (int i = 0; i < c.n_layers_ar; ++i) {
+    const int64_t n = (int64_t)((c.ar_kernel - 1) * c.ar_dilations[i] + 1) * B * D;  // the whole buffer (bf16 state uses its first half)
+    STG(sopro_fill2d_u32(p.rings[i], n, 1, (int32_t)n, 0u, s));
+  }
+  STG(sopro_fill2d_u32(p.hist, (int64_t)B * Tar, 1, B * Tar, 0u, s));
+  for (int k = 0; k < 8; ++k) {  // eight scalars from the caller's (pageable) host array: by value
+    uint32_t u;
+    memcpy(&u, &params[k], 4);
+    STG(sopro_fill2d_u32(p.params + k, 1, 1, 1, u, s));
+  }
+  STG(sopro_fill2d_u32(p.nonce, B, 1, B, nonce, s));
   // the Philox key lives in device memory: the recorded frame graph serves every seed
-  SOPRO_HIP(hipMemsetD32Async((hipDeviceptr_t)p.key, (int)(uint32_t)seed, 1, s));
-  SOPRO_HIP(hipMemsetD32Async((hipDeviceptr_t)(p.key + 1), (int)(uint32_t)(seed >> 32), 1, s));
+  STG(sopro_fill2d_u32(p.key, 1, 1, 1, (uint32_t)seed, s));
+  STG(sopro_fill2d_u32(p.key + 1, 1, 1, 1, (uint32_t)(seed >> 32), s));
   sopro_ar_state& st = p.st;
   memset(&st, 0, sizeof(st));
   st.x_cur = p.x[0]; st.cond = p.cond; st.emb = F(e, "cb_embed"); st.hist = p.hist;
@@ -929,14 +947,15 @@ int sopro_ar_tokens(sopro_engine* e, int32_t* hist, int32_t* first_eos, int32_t*
   SOPRO_CHECK_ARG(e && e->ar.ws, "sopro_ar_begin first");
   hipStream_t s = (hipStream_t)stream;
   const ArPlan& p = e->ar;
-  if (hist) SOPRO_HIP(hipMemcpyAsync(hist, p.hist, (size_t)p.B * p.Tar * 4, hipMemcpyDeviceToDevice, s));
-  if (first_eos) SOPRO_HIP(hipMemcpyAsync(first_eos, p.first_eos, (size_t)p.B * 4, hipMemcpyDeviceToDevice, s));
-  if (n_stopped) SOPRO_HIP(hipMemcpyAsync(n_stopped, p.ctr + 2, 4, hipMemcpyDeviceToDevice, s));
+  // (destinations may be device or page-locked host memory: the copies are kernels)
+  if (hist) STG(sopro_copy2d_u32(hist, (int64_t)p.B * p.Tar, p.hist, (int64_t)p.B * p.Tar, 1, p.B * p.Tar, s));
+  if (first_eos) STG(sopro_copy2d_u32(first_eos, p.B, p.first_eos, p.B, 1, p.B, s));
+  if (n_stopped) STG(sopro_copy2d_u32(n_stopped, 1, p.ctr + 2, 1, 1, 1, s));
   return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ NAR refinement
-struct NarWs { float *xa, *xb, *h, *x1, *u, *z, *part, *cond; int32_t* lens; SplitK sk; };
+struct NarWs { float *xa, *xb, *h, *x1, *u, *z, *part, *cond; int32_t *lens, *range; SplitK sk; };
 static size_t nar_carve(const sopro_engine* e, NarWs& w, void* ws, int B, int T) {
   const sopro_engine_cfg& c = e->c;
   const size_t M = (size_t)B * T, D = c.d_model;
@@ -948,6 +967,7 @@ static size_t nar_carve(const sopro_engine* e, NarWs& w, void* ws, int B, int T)
   w.part = cv.take<float>(M * nh_max * (c.codebook_size / 64) * 2);
   w.cond = cv.take<float>(M * D);
   w.lens = cv.take<int32_t>(B);
+  w.range = cv.take<int32_t>(4);
   w.sk.tickets = cv.take<int32_t>(SPLITK_TICKETS);
   w.sk.ws = M <= 1024 ? cv.take<float>(SPLITK_WS_BYTES / 4) : nullptr;  // few rows (streaming windows, batch 1): K loops may be split
   return cv.off;
@@ -962,44 +982,49 @@ int64_t sopro_nar_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T) {
 // full-sequence SSMLiteBlock over dense [B*T, D] rows (reference: src/sopro/nn/blocks.py:143-148), norms fused into the contractions;
 // h, x1 [B*T, D] and u [B*T, 4D] are scratch, sk the split-K scratch of the last contraction (few-row problems)
 static int ssm_block_bufs(sopro_engine* e, hipStream_t s, float* h, float* x1, float* u, const SplitK* sk, const float* x, float* out,
-                          const std::string& p, int B, int T, int ksize, int dil, const int32_t* lens) {
+                          const std::string& p, int B, int T, int ksize, int dil, const int32_t* lens, const char* sfx, int32_t* range) {
   const int D = e->c.d_model, M = B * T;
   const int total = (ksize - 1) * dil, left = total / 2;  // non-causal: symmetric zero padding (blocks.py:68-72)
-  G g; g.M = M; g.N = 2 * D; g.K = D; g.bias = F(e, p + ".glu.b"); g.epi = SOPRO_EPI_GLU; g.rms_eps = RMS_EPS;
-  STG(gemm(s, x, WT(e, p + ".glu.wn"), nullptr, h, g));
+  G g; g.M = M; g.N = 2 * D; g.K = D; g.bias = F(e, p + ".glu.b"); g.epi = SOPRO_EPI_GLU; g.rms_eps = RMS_EPS; g.range_events = range;
+  STG(gemm(s, x, WT(e, p + ".glu.wn" + sfx), nullptr, h, g));
   STG(sopro_dwconv_f32(h, F(e, p + ".dw.w"), F(e, p + ".dw.b"), x, x1, lens, B, T, D, ksize, dil, left, 1, s));
-  G f1; f1.M = M; f1.N = 4 * D; f1.K = D; f1.bias = F(e, p + ".ff1.b"); f1.epi = SOPRO_EPI_GELU; f1.rms_eps = RMS_EPS;
-  STG(gemm(s, x1, WT(e, p + ".ff1.wn"), nullptr, u, f1));
-  G f2; f2.M = M; f2.N = D; f2.K = 4 * D; f2.bias = F(e, p + ".ff2.b"); f2.epi = SOPRO_EPI_RES; f2.R = x1; f2.sk = sk;
-  return gemm(s, u, WT(e, p + ".ff2.w"), nullptr, out, f2);
+  G f1; f1.M = M; f1.N = 4 * D; f1.K = D; f1.bias = F(e, p + ".ff1.b"); f1.epi = SOPRO_EPI_GELU; f1.rms_eps = RMS_EPS; f1.range_events = range;
+  STG(gemm(s, x1, WT(e, p + ".ff1.wn" + sfx), nullptr, u, f1));
+  G f2; f2.M = M; f2.N = D; f2.K = 4 * D; f2.bias = F(e, p + ".ff2.b"); f2.epi = SOPRO_EPI_RES; f2.R = x1; f2.sk = sk; f2.range_events = range;
+  return gemm(s, u, WT(e, p + ".ff2.w" + sfx), nullptr, out, f2);
 }
 static int ssm_block_seq(sopro_engine* e, hipStream_t s, const NarWs& w, const float* x, float* out, const std::string& p, int B, int T,
-                         int ksize, int dil, const int32_t* lens) {
-  return ssm_block_bufs(e, s, w.h, w.x1, w.u, &w.sk, x, out, p, B, T, ksize, dil, lens);
+                         int ksize, int dil, const int32_t* lens, const char* sfx) {
+  return ssm_block_bufs(e, s, w.h, w.x1, w.u, &w.sk, x, out, p, B, T, ksize, dil, lens, sfx, w.range);
 }
 
-int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_t cond_bstride, const int32_t* rvq1, const int32_t* lens,
-                     int32_t B, int32_t T, int32_t* tokens, void* stream) {
-  SOPRO_CHECK_ARG(e && e->final && e->has_nar && workspace && cond && rvq1 && tokens && B > 0 && T > 0,
+int sopro_nar_refine_io(sopro_engine* e, void* workspace, const sopro_nar_io* io, int32_t B, int32_t T, void* stream) {
+  SOPRO_CHECK_ARG(e && e->final && e->has_nar && workspace && io && io->cond && io->cb0 && io->tokens && B > 0 && T > 0,
                   "bad arguments (finalize the engine with the NAR tensors first)");
   hipStream_t s = (hipStream_t)stream;
   const sopro_engine_cfg& c = e->c;
   const int D = c.d_model, V = c.codebook_size, Q = c.num_codebooks, HD = c.nar_head_dim, M = B * T;
   SOPRO_CHECK_ARG(V % 64 == 0, "codebook_size must be a multiple of 64 (arg-max partials per 64 columns)");
+  SOPRO_CHECK_ARG(io->cond_bstride >= (int64_t)T * D && io->cb0_bstride >= T, "cond / cb0 blocks shorter than T rows");
+  const bool safe = io->safe != 0 && c.precision == 0;  // (bf16 mode: one operand set, bf16 has fp32's exponent range already)
+  const char* sfx = safe ? NAR_SAFE : "";
+  int32_t* tokens = io->tokens;
   NarWs w;
   nar_carve(e, w, workspace, B, T);
   if (w.sk.ws) STG(sopro_fill2d_u32(w.sk.tickets, SPLITK_TICKETS, 1, SPLITK_TICKETS, 0u, s));  // split-K tickets start (and are left) at zero
+  STG(sopro_fill2d_u32(w.range, 4, 1, 4, 0u, s));
   int nh_max = 0;
   for (int i = 0; i < c.n_stages; ++i) nh_max = c.stage_n_cb[i] > nh_max ? c.stage_n_cb[i] : nh_max;
-  const float* cnd = cond;
-  if (cond_bstride != (int64_t)T * D) {  // the first T rows of longer conditioning blocks (cond_ar has max_frames + 1 rows): densify once
-    STG(sopro_copy2d_u32(w.cond, (int64_t)T * D, cond, cond_bstride, B, T * D, s));
+  const float* cnd = io->cond;
+  if (io->cond_bstride != (int64_t)T * D) {  // the first T rows of longer conditioning blocks (cond_ar has max_frames + 1 rows): densify once
+    STG(sopro_copy2d_u32(w.cond, (int64_t)T * D, io->cond, io->cond_bstride, B, T * D, s));
     cnd = w.cond;
   }
-  STG(sopro_copy2d_u32(tokens, Q, rvq1, 1, M, 1, s));  // column 0 <- codebook 0
+  STG(sopro_nar_seed_i32(tokens, Q, io->cb0, io->cb0_bstride, B, T, V - 1, s));  // column 0 <- codebook 0
   const int32_t* lens_d = nullptr;
-  if (lens) {
-    lens_d = lens;  // (a device pointer of the caller: read by the kernels of this call, stream-ordered)
+  if (io->lens) {  // device or page-locked host memory of the caller: read once, here
+    STG(sopro_copy2d_u32(w.lens, B, io->lens, B, 1, B, s));
+    lens_d = w.lens;
   }
   const char* stage_names[8] = {"B", "C", "D", "E", "F", "G", "H", "I"};
   for (int sid = 0; sid < c.n_stages; ++sid) {
@@ -1010,20 +1035,30 @@ int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_
     STG(norm(s, xa, xb, F(e, "nar.adapter.norm.weight"), M, D, RMS_EPS, SOPRO_NORM_RMS, nullptr, e->ad_mul[sid], e->ad_add[sid], M));
     std::swap(xa, xb);
     for (int i = 0; i < c.n_layers_nar; ++i) {
-      STG(ssm_block_seq(e, s, w, xa, xb, "nar.blocks." + std::to_string(i), B, T, c.nar_kernel, c.nar_dilations[i], lens_d));
+      STG(ssm_block_seq(e, s, w, xa, xb, "nar.blocks." + std::to_string(i), B, T, c.nar_kernel, c.nar_dilations[i], lens_d, sfx));
       std::swap(xa, xb);
     }
     STG(norm(s, xa, xb, F(e, "nar.norm.weight"), M, D, RMS_EPS));
-    G pz; pz.M = M; pz.N = HD; pz.K = D; pz.bias = F(e, "nar.pre.b");
-    STG(gemm(s, xb, WT(e, "nar.pre.w"), nullptr, w.z, pz));
+    G pz; pz.M = M; pz.N = HD; pz.K = D; pz.bias = F(e, "nar.pre.b"); pz.range_events = w.range;
+    STG(gemm(s, xb, WT(e, std::string("nar.pre.w") + sfx), nullptr, w.z, pz));
     // all heads of the stage in one contraction, arg-max in its epilogue (head-id embeddings live in the bias)
     const int nh = c.stage_n_cb[sid];
     const std::string hk = std::string("nar.heads.") + stage_names[sid];
     G hg; hg.M = M; hg.N = nh * V; hg.K = HD; hg.bias = F(e, hk + ".b"); hg.c_mode = 5; hg.C2 = w.part; hg.ldc2 = (int64_t)nh_max * (V / 64);
-    STG(gemm(s, w.z, WT(e, hk + ".w"), nullptr, nullptr, hg));
+    hg.range_events = w.range;
+    STG(gemm(s, w.z, WT(e, hk + ".w" + sfx), nullptr, nullptr, hg));
     STG(sopro_argmax_partials_i32(w.part, (int64_t)nh_max * (V / 64), tokens + c.stage_first_cb[sid], Q, nh, V / 64, V, M, s));
   }
+  if (io->range_out) STG(sopro_copy2d_u32(io->range_out, 1, w.range, 1, 1, 1, s));
   return 0;
+}
+
+int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_t cond_bstride, const int32_t* rvq1, const int32_t* lens,
+                     int32_t B, int32_t T, int32_t* tokens, void* stream) {
+  sopro_nar_io io;
+  memset(&io, 0, sizeof(io));
+  io.cond = cond; io.cond_bstride = cond_bstride; io.cb0 = rvq1; io.cb0_bstride = T; io.lens = lens; io.tokens = tokens;
+  return sopro_nar_refine_io(e, workspace, &io, B, T, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ Mimi decode
@@ -1078,7 +1113,7 @@ static size_t mimi_carve(const sopro_engine* e, MimiWs& w, void* ws, int B, int 
 int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T) {
   if (!e || B <= 0 || T <= 0) return 0;
   MimiWs w;
-  return (int64_t)mimi_carve(e, w, nullptr, B, T);
+  return (int64_t)mimi_carve(e, w, nullptr, sopro_mimi_chunk_rows(B, T), T);  // one chunk's worth (see sopro_mimi_decode)
 }
 
 // Pre-norm causal sliding-window RoPE transformer over the zero-padded residual stream X [B, pad + n (+ tail), HS], in place
@@ -1138,8 +1173,13 @@ static int transformer_stack(sopro_engine* e, hipStream_t s, const char* pre, fl
   return 0;
 }
 
+// parts: 1 = every launch but the last, 2 = the last launch alone (the only one that writes `wav`), 3 = both (sopro_mimi_decode_parts)
+#define BODY(call)                 \
+  do {                             \
+    if (parts & 1) STG(call);      \
+  } while (0)
 static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream,
-                            sopro_mimi_stream_state* sst) {
+                            sopro_mimi_stream_state* sst, int parts = 3) {
   SOPRO_CHECK_ARG(e && e->final && e->has_mimi && workspace && tokens && wav && B > 0 && T > 0,
                   "bad arguments (finalize the engine with the Mimi tensors first)");
   hipStream_t s = (hipStream_t)stream;
@@ -1152,38 +1192,38 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   SOPRO_CHECK_ARG(c.mimi_res_kernel == 3 && c.mimi_last_kernel == 3 && c.mimi_compress == 2, "the SEANet sequence is written for k = 3 residual / last convs, compress 2");
   MimiWs w;
   mimi_carve(e, w, workspace, B, T);
-  if (w.sk.ws) STG(sopro_fill2d_u32(w.sk.tickets, SPLITK_TICKETS, 1, SPLITK_TICKETS, 0u, s));
+  if (w.sk.ws) BODY(sopro_fill2d_u32(w.sk.tickets, SPLITK_TICKETS, 1, SPLITK_TICKETS, 0u, s));
   // the zero rows in front of every segment of a convolution input are never written by the kernels: clear just those
   {
-    STG(sopro_fill2d_u32(w.X, (int64_t)(PADX + N2) * HS, B, PADX * HS, 0u, s));
+    BODY(sopro_fill2d_u32(w.X, (int64_t)(PADX + N2) * HS, B, PADX * HS, 0u, s));
     size_t chz = (size_t)c.mimi_num_filters << c.mimi_n_ratios, rowz = (size_t)N2;
     const int wd = mimi_half(e) ? 2 : 1;  // activation elements per 32-bit word
-    STG(sopro_fill2d_u32(w.e0, (int64_t)((1 + rowz) * chz / wd), B, (int)(chz / wd), 0u, s));
+    BODY(sopro_fill2d_u32(w.e0, (int64_t)((1 + rowz) * chz / wd), B, (int)(chz / wd), 0u, s));
     for (int si = 0; si < c.mimi_n_ratios; ++si) {
       const size_t co = chz / 2, orow = rowz * c.mimi_ratios[si];
-      STG(sopro_fill2d_u32(w.hraw[si], (int64_t)((2 + orow) * co / wd), B, (int)(2 * co / wd), 0u, s));
-      if (w.hact[si]) STG(sopro_fill2d_u32(w.hact[si], (int64_t)((2 + orow) * co / wd), B, (int)(2 * co / wd), 0u, s));
+      BODY(sopro_fill2d_u32(w.hraw[si], (int64_t)((2 + orow) * co / wd), B, (int)(2 * co / wd), 0u, s));
+      if (w.hact[si]) BODY(sopro_fill2d_u32(w.hact[si], (int64_t)((2 + orow) * co / wd), B, (int)(2 * co / wd), 0u, s));
       chz = co; rowz = orow;
     }
   }
   // ---- RVQ decode + output projections (HF:modeling_mimi.py:1128-1137)
   const int64_t cb_rows = e->t["codebooks"].shape[0];
-  STG(sopro_codebook_sum_f32(tokens, Q, e->sem_col, e->sem_off, e->ones, ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb, 2 * CD, 0,
+  BODY(sopro_codebook_sum_f32(tokens, Q, e->sem_col, e->sem_off, e->ones, ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb, 2 * CD, 0,
                              B * T, B * T, CD, s));
-  STG(sopro_codebook_sum_f32(tokens, Q, e->ac_col, e->ac_off, e->ones, Q - ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb + CD, 2 * CD,
+  BODY(sopro_codebook_sum_f32(tokens, Q, e->ac_col, e->ac_off, e->ones, Q - ns, F(e, "codebooks"), cb_rows, nullptr, 0.f, 1.f, w.emb + CD, 2 * CD,
                              0, B * T, B * T, CD, s));
   G pj; pj.sk = &w.sk; pj.M = B * T; pj.N = HS; pj.K = 2 * CD;
-  STG(gemm(s, w.emb, WT(e, "rvq_proj.w"), nullptr, w.q, pj));
+  BODY(gemm(s, w.emb, WT(e, "rvq_proj.w"), nullptr, w.q, pj));
   // ---- upsample into the zero-padded transformer stream (HF:1208-1216)
   const int64_t xs = (int64_t)(PADX + N2) * HS;
-  STG(sopro_upsample2_f32(w.q, F(e, "upsample.w"), w.X + (size_t)PADX * HS, xs, B, T, HS, s));
+  BODY(sopro_upsample2_f32(w.q, F(e, "upsample.w"), w.X + (size_t)PADX * HS, xs, B, T, HS, s));
   // ---- transformer: 8 pre-LN layers, RoPE, causal window (HF:729-928)
   // the decoder's attention on the waveform path's operand precision (two bf16 pieces, three passes; one in bf16 mode when
   // SOPRO_ATTN_PASSES=1); SOPRO_ATTN_SPLIT=0 keeps the exact-fp32 kernel the encoder uses
   static const bool attn_exact = getenv("SOPRO_ATTN_SPLIT") != nullptr && getenv("SOPRO_ATTN_SPLIT")[0] == '0';
   static const bool attn_one = getenv("SOPRO_ATTN_PASSES") != nullptr && getenv("SOPRO_ATTN_PASSES")[0] == '1';
   const int attn_split = attn_exact ? 0 : ((c.precision == 1 && attn_one) ? 1 : 3);
-  STG(transformer_stack(e, s, "tr", w.X, PADX, xs, w.y, w.qkv, w.ao, w.hd, &w.sk, B, N2, past, sst, attn_split));
+  BODY(transformer_stack(e, s, "tr", w.X, PADX, xs, w.y, w.qkv, w.ao, w.hd, &w.sk, B, N2, past, sst, attn_split));
   static const bool three = getenv("SOPRO_SEANET_PASSES3") != nullptr;  // developer A/B: the fused kernels' three-pass form in bf16 mode too
   const int sea_passes = (c.precision == 1 && !three) ? 1 : 3;
   // ---- SEANet decoder (HF:931-961), activated-copy flow of sopro_amd.codec.MimiCodec._seanet_act
@@ -1197,7 +1237,7 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     {
       G g; g.sk = &w.sk; g.M = B * rows; g.N = ch; g.K = c.mimi_kernel * HS; g.lda = HS; g.bias = F(e, "sea.conv0.b"); g.rows_per_seg = rows; g.a_seg = xs;
       g.c_seg = (int64_t)(1 + rows) * ch; g.ldc = ch; g.c_mode = 7;
-      STG(gemm(s, w.X, WT(e, "sea.conv0.w"), nullptr, HP(w.e0, ch), g));
+      BODY(gemm(s, w.X, WT(e, "sea.conv0.w"), nullptr, HP(w.e0, ch), g));
     }
     float* He16 = w.e0;
     for (int si = 0; si < c.mimi_n_ratios; ++si) {
@@ -1211,17 +1251,19 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
       if (last) {
         SOPRO_CHECK_ARG(co == 64 && hid == 32, "the fused tail is written for a 64-channel last stage");
         if (ch == 128 && r == 4 && seanet_fused(B, rows)) {  // the whole level in one kernel: h never reaches memory
+          if (!(parts & 2)) return 0;
           sopro_prof_scope prof("seanet_uptail_kernel", 2.0 * B * rows * 256 * 256 + 2.0 * B * orow * (3 * 64 * 32 + 32 * 64 + 3 * 64), s);
           return sopro_seanet_uptail_bf16(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"),
                                           F(e, rs + ".c2.b"), F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, rows, s);
         }
         if (ch == 128 && r == 4) {
-          sopro_prof_scope prof("seanet_up128_kernel", 2.0 * B * rows * 256 * 256, s);
-          STG(sopro_seanet_up128_bf16(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), HP(Ho, 2 * co), up.c_seg, B, rows, s));
+          sopro_prof_scope prof((parts & 1) ? "seanet_up128_kernel" : nullptr, 2.0 * B * rows * 256 * 256, s);
+          BODY(sopro_seanet_up128_bf16(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), HP(Ho, 2 * co), up.c_seg, B, rows, s));
         } else {
           up.c_mode = 6;
-          STG(gemm(s, A, WT(e, u + ".w"), nullptr, HP(Ho, 2 * co), up));
+          BODY(gemm(s, A, WT(e, u + ".w"), nullptr, HP(Ho, 2 * co), up));
         }
+        if (!(parts & 2)) return 0;
         sopro_prof_scope prof("seanet_tail_kernel", 2.0 * B * orow * (3 * 64 * 32 + 32 * 64 + 3 * 64), s);
         return sopro_seanet_tail_bf16(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"),
                                       F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, orow, s);
@@ -1229,19 +1271,19 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
       float* Hn = w.hact[si];
       if (co == 128 && hid == 64) {
         up.c_mode = 6;
-        STG(gemm(s, A, WT(e, u + ".w"), nullptr, HP(Ho, 2 * co), up));
-        sopro_prof_scope prof("seanet_res128_kernel", 2.0 * B * orow * (3 * 128 * 64 + 64 * 128), s);
-        STG(sopro_seanet_res128_bf16(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
+        BODY(gemm(s, A, WT(e, u + ".w"), nullptr, HP(Ho, 2 * co), up));
+        sopro_prof_scope prof((parts & 1) ? "seanet_res128_kernel" : nullptr, 2.0 * B * orow * (3 * 128 * 64 + 64 * 128), s);
+        BODY(sopro_seanet_res128_bf16(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
                                      (int64_t)(2 + orow) * co, B, orow, s));
       } else {
         up.c_mode = 8; up.C2 = HP(Hn, 2 * co); up.ldc2 = (int64_t)r * co; up.c2_seg = (int64_t)(2 + orow) * co;
-        STG(gemm(s, A, WT(e, u + ".w"), nullptr, HP(Ho, 2 * co), up));
+        BODY(gemm(s, A, WT(e, u + ".w"), nullptr, HP(Ho, 2 * co), up));
         G c1; c1.sk = &w.sk; c1.M = B * orow; c1.N = hid; c1.K = 3 * co; c1.lda = co; c1.bias = F(e, rs + ".c1.b"); c1.rows_per_seg = orow; c1.a_fmt = 2;
         c1.a_seg = (int64_t)(2 + orow) * co; c1.c_mode = 7;
-        STG(gemm(s, Hn, WT(e, rs + ".c1.w"), nullptr, w.y1[si], c1));
+        BODY(gemm(s, Hn, WT(e, rs + ".c1.w"), nullptr, w.y1[si], c1));
         G c2; c2.sk = &w.sk; c2.M = B * orow; c2.N = co; c2.K = hid; c2.bias = F(e, rs + ".c2.b"); c2.epi = SOPRO_EPI_RES; c2.R = HP(Ho, 2 * co); c2.rows_per_seg = orow;
         c2.a_fmt = 2; c2.c_seg = (int64_t)(2 + orow) * co; c2.r_seg = (int64_t)(2 + orow) * co; c2.ldc = co; c2.ldr = co; c2.c_mode = 7;
-        STG(gemm(s, w.y1[si], WT(e, rs + ".c2.w"), nullptr, HP(Hn, 2 * co), c2));
+        BODY(gemm(s, w.y1[si], WT(e, rs + ".c2.w"), nullptr, HP(Hn, 2 * co), c2));
       }
       He16 = Hn; ch = co; rows = orow; pad_in = 2;
     }
@@ -1251,7 +1293,7 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   {  // first conv k = 7 -> ELU; one zero row in front = x[t-1] of the transposed conv
     G g; g.sk = &w.sk; g.M = B * rows; g.N = ch; g.K = c.mimi_kernel * HS; g.lda = HS; g.bias = F(e, "sea.conv0.b"); g.rows_per_seg = rows; g.a_seg = xs;
     g.c_seg = (int64_t)(1 + rows) * ch; g.ldc = ch; g.c_mode = 3;
-    STG(gemm(s, w.X, WT(e, "sea.conv0.w"), nullptr, w.e0 + ch, g));
+    BODY(gemm(s, w.X, WT(e, "sea.conv0.w"), nullptr, w.e0 + ch, g));
   }
   const float* He = w.e0;
   for (int si = 0; si < c.mimi_n_ratios; ++si) {
@@ -1265,43 +1307,47 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     if (last) {
       SOPRO_CHECK_ARG(co == 64 && hid == 32, "the fused tail is written for a 64-channel last stage");
       if (ch == 128 && r == 4 && seanet_fused(B, rows)) {  // the whole level in one kernel: h never reaches memory
+        if (!(parts & 2)) return 0;
         sopro_prof_scope prof("seanet_uptail_kernel", 2.0 * B * rows * 256 * 256 + 2.0 * B * orow * (3 * 64 * 32 + 32 * 64 + 3 * 64), s);
         return sopro_seanet_uptail_f32(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"),
                                        F(e, rs + ".c2.b"), F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, rows, sea_passes, s);
       }
       if (ch == 128 && r == 4) {  // weight-stationary form of the K = 256, N = 256 contraction (same results)
-        sopro_prof_scope prof("seanet_up128_kernel", 2.0 * B * rows * 256 * 256, s);
-        STG(sopro_seanet_up128_f32(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), Ho + 2 * co, up.c_seg, B, rows, c.precision == 1 ? 1 : 3, s));
+        sopro_prof_scope prof((parts & 1) ? "seanet_up128_kernel" : nullptr, 2.0 * B * rows * 256 * 256, s);
+        BODY(sopro_seanet_up128_f32(A, up.a_seg, F(e, u + ".w"), F(e, u + ".b"), Ho + 2 * co, up.c_seg, B, rows, c.precision == 1 ? 1 : 3, s));
       } else {
-        STG(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
+        BODY(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
       }
       // last residual block (k=3 conv 64->32, k=1 conv 32->64) + final k=3 conv 64->1 per output sample
+      if (!(parts & 2)) return 0;
       sopro_prof_scope prof("seanet_tail_kernel", 2.0 * B * orow * (3 * 64 * 32 + 32 * 64 + 3 * 64), s);
       return sopro_seanet_tail_p_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"),
                                      F(e, "sea.final.w"), c.mimi_final_bias, wav, orow, B, orow, sea_passes, s);
     }
     float* Hn = w.hact[si];
     if (co == 128 && hid == 64) {
-      STG(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
-      sopro_prof_scope prof("seanet_res128_kernel", 2.0 * B * orow * (3 * 128 * 64 + 64 * 128), s);
-      STG(sopro_seanet_res128_p_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
+      BODY(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
+      sopro_prof_scope prof((parts & 1) ? "seanet_res128_kernel" : nullptr, 2.0 * B * orow * (3 * 128 * 64 + 64 * 128), s);
+      BODY(sopro_seanet_res128_p_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
                                     (int64_t)(2 + orow) * co, B, orow, sea_passes, s));
     } else {
       up.c_mode = 4; up.C2 = Hn + 2 * co; up.ldc2 = (int64_t)r * co; up.c2_seg = (int64_t)(2 + orow) * co;
-      STG(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
+      BODY(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
       // residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x)))); its output is only ever read through ELU
       G c1; c1.sk = &w.sk; c1.M = B * orow; c1.N = hid; c1.K = 3 * co; c1.lda = co; c1.bias = F(e, rs + ".c1.b"); c1.rows_per_seg = orow;
       c1.a_seg = (int64_t)(2 + orow) * co; c1.c_mode = 3;
-      STG(gemm(s, Hn, WT(e, rs + ".c1.w"), nullptr, w.y1[si], c1));
+      BODY(gemm(s, Hn, WT(e, rs + ".c1.w"), nullptr, w.y1[si], c1));
       G c2; c2.sk = &w.sk; c2.M = B * orow; c2.N = co; c2.K = hid; c2.bias = F(e, rs + ".c2.b"); c2.epi = SOPRO_EPI_RES; c2.R = Ho + 2 * co; c2.rows_per_seg = orow;
       c2.c_seg = (int64_t)(2 + orow) * co; c2.r_seg = (int64_t)(2 + orow) * co; c2.ldc = co; c2.ldr = co; c2.c_mode = 3;
-      STG(gemm(s, w.y1[si], WT(e, rs + ".c2.w"), nullptr, Hn + 2 * co, c2));
+      BODY(gemm(s, w.y1[si], WT(e, rs + ".c2.w"), nullptr, Hn + 2 * co, c2));
     }
     He = Hn; ch = co; rows = orow; pad_in = 2;
   }
   sopro_set_error("sopro_mimi_decode: the decoder has no last stage");
   return -2;
 }
+
+#undef BODY
 
 // ------------------------------------------------------------------------------------------------ Mimi encode
 // HF:modeling_mimi.py MimiModel._encode_frame: SEANet encoder (strided convs = overlapping-row windows of the padded level
@@ -1408,8 +1454,33 @@ int sopro_mimi_encode(sopro_engine* e, void* workspace, const float* wav, int32_
   return 0;
 }
 
+// Balanced row chunks of at most ~`cells` frames each: 64 x 400 -> 2 x 32 rows, 65 x 200 -> 33 + 32 (never a one-row remainder with a
+// workspace and a recorded sequence of its own: ADVICE r4)
+int32_t sopro_mimi_chunk_rows(int32_t B, int32_t T) {
+  if (B <= 0 || T <= 0) return 0;
+  const char* env = getenv("SOPRO_MIMI_CHUNK_CELLS");  // (read per call: a host may change it between calls)
+  const int64_t cells = env ? std::max<int64_t>(1, atoll(env)) : 12800;
+  const int64_t rows_max = std::max<int64_t>(1, cells / T);
+  if (B <= rows_max) return B;
+  const int64_t nchunks = (B + rows_max - 1) / rows_max;
+  return (int32_t)((B + nchunks - 1) / nchunks);
+}
+
+int sopro_mimi_decode_parts(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, int32_t parts, void* stream) {
+  SOPRO_CHECK_ARG(parts >= 1 && parts <= 3, "parts: 1 = all launches but the last, 2 = the last, 3 = both");
+  return mimi_decode_core(e, workspace, tokens, B, T, wav, stream, nullptr, parts);
+}
+
 int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, void* stream) {
-  return mimi_decode_core(e, workspace, tokens, B, T, wav, stream, nullptr);
+  SOPRO_CHECK_ARG(e && B > 0 && T > 0, "bad arguments");
+  const int rows = sopro_mimi_chunk_rows(B, T);
+  int64_t hop = 2;  // samples per frame: the x2 upsample times the SEANet ratios (1920)
+  for (int i = 0; i < e->c.mimi_n_ratios; ++i) hop *= e->c.mimi_ratios[i];
+  for (int b0 = 0; b0 < B; b0 += rows) {  // stream order: a chunk's launches follow the previous chunk's last reader of the shared workspace
+    const int bc = std::min(rows, B - b0);
+    STG(mimi_decode_core(e, workspace, tokens + (int64_t)b0 * T * e->c.num_codebooks, bc, T, wav + (int64_t)b0 * T * hop, stream, nullptr));
+  }
+  return 0;
 }
 
 int64_t sopro_mimi_stream_kv_bytes(const sopro_engine* e, int32_t cap_rows) {

@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
 class SplitExt(C.Structure):
     _fields_ = [("a_format", _i32), ("c_mode", _i32), ("C2", _p), ("ldc2", _i64), ("c2_seg_stride", _i64),
                 ("rms_norm", _i32), ("rms_eps", _f32), ("ksplit", _i32), ("n_tickets", _i32), ("ws", _p), ("ws_bytes", _i64),
-                ("tickets", _p), ("group_m", _i32), ("acc_scale", _f32)]
+                ("tickets", _p), ("group_m", _i32), ("acc_scale", _f32), ("range_events", _p)]
 
 
 class SkinnyArgs(C.Structure):
@@ -105,6 +105,12 @@ class EngineCfg(C.Structure):
                 ("mimi_n_semantic", _i32), ("mimi_rope_positions", _i32), ("mimi_norm_eps", _f32), ("mimi_final_bias", _f32), ("precision", _i32),
                 ("n_layers_text", _i32), ("ref_enc_layers", _i32), ("ref_xattn_layers", _i32), ("ref_xattn_heads", _i32), ("sv_student_dim", _i32),
                 ("enc_kernel", _i32)]
+
+
+class NarIO(C.Structure):
+    """sopro_nar_io: the refinement's operands where the stages in front of it left them (round 5)."""
+    _fields_ = [("cond", _p), ("cond_bstride", _i64), ("cb0", _p), ("cb0_bstride", _i64), ("lens", _p), ("tokens", _p), ("range_out", _p),
+                ("safe", _i32)]
 
 
 class MimiStreamState(C.Structure):
@@ -193,8 +199,12 @@ SYMBOLS = {
     "sopro_ar_tokens": (C.c_int, [_p, _p, _p, _p, _p]),
     "sopro_nar_workspace_bytes": (_i64, [_p, _i32, _i32]),
     "sopro_nar_refine": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i32, _i32, _p, _p]),
+    "sopro_nar_refine_io": (C.c_int, [_p, _p, C.POINTER(NarIO), _i32, _i32, _p]),
+    "sopro_nar_seed_i32": (C.c_int, [_p, _i32, _p, _i64, _i32, _i32, _i32, _p]),
     "sopro_mimi_workspace_bytes": (_i64, [_p, _i32, _i32]),
     "sopro_mimi_decode": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p]),
+    "sopro_mimi_chunk_rows": (_i32, [_i32, _i32]),
+    "sopro_mimi_decode_parts": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _i32, _p]),
     "sopro_mimi_stream_kv_bytes": (_i64, [_p, _i32]),
     "sopro_mimi_stream_init": (C.c_int, [_p, C.POINTER(MimiStreamState), _p, _i32]),
     "sopro_mimi_stream_trim": (C.c_int, [C.POINTER(MimiStreamState), _i32]),
@@ -799,6 +809,27 @@ def seanet_uptail(x: torch.Tensor, wu: torch.Tensor, bu: torch.Tensor, w1: torch
                                               ptr(wav), wav_seg_stride, B, T, passes, _stream()), "sopro_seanet_uptail_f32")
 
 
+def fill_u32(t: torch.Tensor, value: int = 0) -> None:
+    """Every 32-bit word of a contiguous device tensor <- value, as a kernel of the library (sopro_fill2d_u32) on the current stream."""
+    n = t.numel() * t.element_size() // 4
+    if not t.is_contiguous() or t.numel() * t.element_size() % 4 or n <= 0:
+        raise SoproHipError("fill_u32: a contiguous tensor of whole 32-bit words")
+    rows = 1
+    while n // rows > (1 << 30):
+        rows *= 2
+    if n % rows:
+        raise SoproHipError("fill_u32: tensor too large for one launch")
+    _check(load().sopro_fill2d_u32(t.data_ptr(), n // rows, rows, n // rows, int(value) & 0xFFFFFFFF, _stream()), "sopro_fill2d_u32")
+
+
+def copy_u32(dst: torch.Tensor, src: torch.Tensor) -> None:
+    """dst <- src (contiguous device tensors of the same byte size, whole 32-bit words) as a kernel of the library."""
+    n = dst.numel() * dst.element_size() // 4
+    if not (dst.is_contiguous() and src.is_contiguous()) or n * 4 != src.numel() * src.element_size() or n <= 0 or n > (1 << 30):
+        raise SoproHipError("copy_u32: contiguous tensors of the same size (< 4 GiB)")
+    _check(load().sopro_copy2d_u32(dst.data_ptr(), n, src.data_ptr(), n, 1, n, _stream()), "sopro_copy2d_u32")
+
+
 def set_lds_floor(nbytes: int) -> None:
     """Minimum dynamic-LDS request of the split-bf16 GEMM launches (> 80 KiB: one workgroup per CU); see sopro_set_lds_floor."""
     _check(load().sopro_set_lds_floor(int(nbytes)), "sopro_set_lds_floor")
@@ -1043,13 +1074,28 @@ class HostMirror:
         self._keep = None
 
     def copy_from(self, t: torch.Tensor) -> None:
-        if t.dtype != torch.int32 or not t.is_contiguous() or t.numel() != self.n or not t.is_cuda:
-            raise SoproHipError(f"HostMirror.copy_from: expected a contiguous device int32 tensor of {self.n} elements")
+        """Queue device -> host behind the current stream's launches.  A KERNEL of the library writes the page-locked words
+        (sopro_copy2d_u32): the timed path holds no runtime copy - no `__amd_rocclr_copyBuffer`, no DMA packet - at all (round 5)."""
+        if t.dtype not in (torch.int32, torch.float32) or not t.is_contiguous() or t.numel() != self.n or not t.is_cuda:
+            raise SoproHipError(f"HostMirror.copy_from: expected a contiguous device int32 / float32 tensor of {self.n} elements")
         self._keep = t  # the source of a queued copy stays alive
-        _check(load().sopro_copy_to_host_async(self.ptr, t.data_ptr(), 4 * self.n, _stream()), "sopro_copy_to_host_async")
+        _check(load().sopro_copy2d_u32(self.ptr, self.n, t.data_ptr(), self.n, 1, self.n, _stream()), "sopro_copy2d_u32")
+
+    def copy_to(self, t: torch.Tensor) -> None:
+        """Queue host -> device: the kernel reads the page-locked words when it RUNS, so the host must leave them alone until the
+        stream has passed this point (the users write a block, queue the launches that read it and synchronise before the next write)."""
+        if t.dtype not in (torch.int32, torch.float32) or not t.is_contiguous() or t.numel() != self.n or not t.is_cuda:
+            raise SoproHipError(f"HostMirror.copy_to: expected a contiguous device int32 / float32 tensor of {self.n} elements")
+        _check(load().sopro_copy2d_u32(t.data_ptr(), self.n, self.ptr, self.n, 1, self.n, _stream()), "sopro_copy2d_u32")
 
     def values(self) -> list:
         return list(self._view)
+
+    def array(self):
+        """The words as a writable numpy int32 view (``.view(np.float32)`` for float parameters)."""
+        import numpy as np
+
+        return np.ctypeslib.as_array(self._view)
 
     def __del__(self):
         try:

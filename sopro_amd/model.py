@@ -10,6 +10,7 @@ recorded once into a hipGraph and replayed.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 
 import math
@@ -104,6 +105,9 @@ class SoproTTSModel:
         self._ar_cache: Dict[Tuple[int, int, int], "_ARPlan"] = {}
         self._voice: Dict[int, Dict[str, Any]] = {}  # per-voice conditioning cache (see _voice_entry)
         self._voice_stacks: Dict[tuple, Any] = {}  # [U, Tr, D] K / V stacks per set of voices (see _voice_stack)
+        self._film_stacks: Dict[tuple, Any] = {}  # [B, D] FiLM coefficient stacks per (set of voices, style strength)
+        self._host_blocks: Dict[tuple, "hip.HostMirror"] = {}  # page-locked parameter blocks (see _host_block)
+        self._consts: Dict[tuple, torch.Tensor] = {}  # small constant int32 device vectors (see _const_i32)
         self._runs = [0]  # generation runs started so far (shared by the lanes of clone_lane): the sampler's default nonce
         self._nar_graphs = hip.GraphCache("nar_graph", cap=64)  # recorded NAR launch sequences per (B, T)
         self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "16")) << 30  # scratch kept per batch shape, per engine
@@ -167,8 +171,32 @@ class SoproTTSModel:
         other._ar_cache = {}
         other._voice = {}  # per-voice tensors are made on this lane's own preparation stream
         other._voice_stacks = {}
+        other._film_stacks = {}
+        other._host_blocks = {}  # a lane writes its blocks while another lane's kernels may still read theirs
+        other._consts = {}
         other._nar_graphs = hip.GraphCache("nar_graph", cap=64)
         return other
+
+    def _host_block(self, key: tuple, n: int) -> "hip.HostMirror":
+        """``n`` page-locked words that kernels of the library read or write (hip.HostMirror.copy_to / copy_from): how the host's
+        small per-call parameters reach the device, and poll words the host, without a runtime copy on the path.  One block per
+        use and shape; the user synchronises before it writes the block again."""
+        hb = self._host_blocks.get(key)
+        if hb is None or hb.n != int(n):
+            if len(self._host_blocks) >= 64:
+                self._host_blocks.pop(next(iter(self._host_blocks)))
+            hb = self._host_blocks[key] = hip.HostMirror(int(n))
+        return hb
+
+    def _const_i32(self, values: Sequence[int]) -> torch.Tensor:
+        """A small constant int32 device vector (key lengths, voice indices of a batch), uploaded once per distinct content."""
+        key = tuple(int(v) for v in values)
+        t = self._consts.get(key)
+        if t is None:
+            if len(self._consts) >= 64:
+                self._consts.pop(next(iter(self._consts)))
+            t = self._consts[key] = _i32(list(key), self.device)
+        return t
 
     def next_nonce(self, seed: Optional[int] = None) -> int:
         """Nonce of a generation run / slot admission, mixed into the sampler's Philox counter.  ``seed`` given: the run is
@@ -284,7 +312,7 @@ class SoproTTSModel:
 
     @torch.inference_mode()
     def prepare_conditioning_batch(self, ids_list: Sequence[torch.Tensor], refs: Sequence[PreparedReference], *,
-                                   max_frames: int, style_strength: float = 1.0) -> Dict[str, Any]:
+                                   max_frames: int, style_strength: float = 1.0, cond_out: Optional[torch.Tensor] = None) -> Dict[str, Any]:
         """B utterances at once (new): text encoder (src/sopro/nn/text.py:29-44), base = pooled text + frame positions
         (model.py:200-202), SpeakerFiLM (src/sopro/nn/speaker.py:76-85), three reference cross-attention blocks
         (src/sopro/nn/ref.py:54-108), cond_norm (model.py:208).  The launch sequence is ``sopro_cond_prepare`` (csrc/stages.hip);
@@ -300,14 +328,19 @@ class SoproTTSModel:
         Tar = int(max_frames) + 1
         if Tar > self.pe.shape[0]:
             raise ValueError("max_frames exceeds the position table")
-        ids = torch.zeros(B, S, dtype=torch.int32)
-        for b, x in enumerate(ids_list):
-            ids[b, : lens_h[b]] = x.detach().to("cpu", torch.int32).view(-1)
         lib, eng = hip.load(), self.eng
         with self.on_stream(prep=True):
-            ids = ids.to(dev)
-            lens = _i32(lens_h, dev)
-            sv = torch.cat([r.sv_ref.to(dev).reshape(1, -1) for r in refs], dim=0).contiguous()
+            # ids and lengths travel through one page-locked block and a kernel of the library (no runtime copy on the path;
+            # the block is rewritten by the next call of this engine, which comes after this call's synchronize below)
+            hb = self._host_block(("cond.in", B, S), B * S + B)
+            arr = hb.array()
+            arr[: B * S] = 0
+            for b, x in enumerate(ids_list):
+                arr[b * S: b * S + lens_h[b]] = x.detach().to("cpu", torch.int32).view(-1).numpy()
+            arr[B * S:] = lens_h
+            blk = torch.empty(B * S + B, dtype=torch.int32, device=dev)
+            hb.copy_to(blk)
+            ids, lens = blk[: B * S].view(B, S), blk[B * S:]
             s = float(style_strength)
             # SpeakerFiLM coefficients depend on the voice (and the style strength) only: computed once per voice and kept
             # with its dense K / V (self._voice), so a call with known voices launches nothing for them  (speaker.py:76-85)
@@ -316,18 +349,29 @@ class SoproTTSModel:
             if todo:
                 uniq = list({id(vcs[i]): i for i in todo}.values())
                 n = len(uniq)
+                sv_u = torch.cat([refs[i].sv_ref.to(dev).reshape(1, -1) for i in uniq], dim=0).contiguous()
                 mul_u, add_u = torch.empty(n, D, device=dev), torch.empty(n, D, device=dev)
-                hip.film_coeffs(eng.h, sv[uniq].contiguous(), s, n, torch.empty(n * 5 * D, device=dev), mul_u, add_u)
+                hip.film_coeffs(eng.h, sv_u, s, n, torch.empty(n * 5 * D, device=dev), mul_u, add_u)
                 for j, i in enumerate(uniq):
                     vcs[i]["film"][s] = (mul_u[j], add_u[j])
-            if all(vc is vcs[0] for vc in vcs):
-                mul, add = (t.unsqueeze(0).expand(B, D).contiguous() for t in vcs[0]["film"][s])
-            else:
-                mul = torch.stack([vc["film"][s][0] for vc in vcs]).contiguous()
-                add = torch.stack([vc["film"][s][1] for vc in vcs]).contiguous()
+            # ... and so do their [B, D] stacks for a SET of voices (a serving process sees the same sets again and again: one
+            # `cat` the first time, nothing afterwards)
+            skey = (tuple(id(vc) for vc in vcs), s)
+            st = self._film_stacks.get(skey)
+            if st is None:
+                if all(vc is vcs[0] for vc in vcs):
+                    mul, add = (t.unsqueeze(0).expand(B, D).contiguous() for t in vcs[0]["film"][s])
+                else:
+                    mul = torch.stack([vc["film"][s][0] for vc in vcs]).contiguous()
+                    add = torch.stack([vc["film"][s][1] for vc in vcs]).contiguous()
+                sv = torch.cat([r.sv_ref.to(dev).reshape(1, -1) for r in refs], dim=0).contiguous()
+                if len(self._film_stacks) >= 16:
+                    self._film_stacks.pop(next(iter(self._film_stacks)))
+                st = self._film_stacks[skey] = (mul, add, sv, list(vcs))  # (the entries keep the ids alive)
+            mul, add, sv = st[0], st[1], st[2]
             tr_h = [int(r.ref_kv_caches[0]["k"].shape[2]) for r in refs]
             Tr = max(tr_h)
-            klens = _i32(tr_h, dev) if min(tr_h) != Tr else None
+            klens = self._const_i32(tr_h) if min(tr_h) != Tr else None
             # rows that share a voice (the same PreparedReference object) share its cached K / V: one dense copy per voice and
             # layer, read through a zero batch stride (one voice), the rows' own blocks (B voices) or an index per row
             order: List[PreparedReference] = []
@@ -337,13 +381,16 @@ class SoproTTSModel:
                     seen[id(r)] = len(order)
                     order.append(r)
             U = len(order)
-            kv_index = None if U in (1, B) else _i32([seen[id(r)] for r in refs], dev)
+            kv_index = None if U in (1, B) else self._const_i32([seen[id(r)] for r in refs])
             if U == 1:  # the voice's own dense [Tr, D] copies, made once (self._voice)
                 kvs = self._voice_entry(order[0])["kv"]
             else:  # one [U, Tr, D] stack per layer, made once per set of voices
                 kvs = self._voice_stack(order, Tr)
             txt_seq, txt_pool = torch.empty(B, S, D, device=dev), torch.empty(B, D, device=dev)
-            cond_ar = torch.empty(B, Tar, D, device=dev)
+            # (a scheduler hands over the AR plan's own conditioning buffer: the AR loop and the refinement then read it in place)
+            cond_ar = cond_out if cond_out is not None else torch.empty(B, Tar, D, device=dev)
+            if tuple(cond_ar.shape) != (B, Tar, D) or not cond_ar.is_contiguous():
+                raise ValueError("cond_out must be a contiguous [B, max_frames + 1, D] tensor")
             wsb = self.ws.get("cond.ws", (int(lib.sopro_cond_workspace_bytes(eng.h, B, S, Tar)) // 4 + 64,))
             hip.cond_prepare(eng.h, wsb, ids, lens, min(lens_h) != S, mul, add, [k for k, _v in kvs], [v for _k, v in kvs],
                              0 if (U == 1 and B > 1) else Tr * D, kv_index, klens, B, S, Tar, Tr, txt_seq, txt_pool, cond_ar)
@@ -370,7 +417,8 @@ class SoproTTSModel:
     def ar_generate_batch(self, cond_ar: torch.Tensor, txt_seq: torch.Tensor, text_lens: Optional[torch.Tensor], *,
                           max_frames: int, top_p: float = 0.9, temperature: float = 1.05, anti_loop: bool = True,
                           min_gen_frames: Optional[int] = None, stop_on_first_eos: bool = False,
-                          poll_every: int = 16, seed: Optional[int] = None, run: Optional["_ARRun"] = None) -> Tuple[torch.Tensor, List[int]]:
+                          poll_every: int = 16, seed: Optional[int] = None, run: Optional["_ARRun"] = None,
+                          inplace: bool = False) -> Tuple[torch.Tensor, List[int]]:
         """Run the AR loop for B rows until every row has stopped or max_frames+1 steps were taken
         (reference loop: src/sopro/model.py:218-305, one row).  Returns (hist [B, steps] int32 on the
         device, per-row frame counts T_b following generate_tokens' cut at the FIRST EOS, model.py:385-390)."""
@@ -410,7 +458,7 @@ class SoproTTSModel:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record(self.stream)
             hip.phase_log.append((steps, B, ev0, ev1))
-        hist, first_eos = run.history(steps)
+        hist, first_eos = run.history(steps, clone=not inplace)  # (``inplace``: a view of the plan's history, see _ARRun.history)
         run.done = True
         lens = [int(f) if f >= 0 else steps for f in first_eos]
         return hist, lens
@@ -455,40 +503,79 @@ class SoproTTSModel:
                    raw: bool = False) -> torch.Tensor:
         """Codebooks 1..Q-1 from codebook 0: [B, T, D], [B, T] -> [B, T, Q] int64
         (reference: src/sopro/model.py:307-347 and src/sopro/nn/nar.py:89-116; B = 1 there).  The launch sequence is
-        ``sopro_nar_refine`` (csrc/stages.hip); this method stages the inputs and records / replays it per (B, T) shape."""
-        dev, D, Q = self.device, self.D, self.Q
+        ``sopro_nar_refine_io`` (csrc/stages.hip); this method stages the inputs and records / replays it per (B, T) shape."""
+        dev, D = self.device, self.D
         B, T, _ = cond_seq.shape
-        M = B * T
         lens_l = [T] * B if lens is None else [int(n) for n in lens]
-        if self.ws.over(self.ws_budget) and (B, T) not in self._nar_graphs.graphs:
-            torch.cuda.synchronize(self.device)
-            self._nar_graphs.clear()
-            self.ws.clear()
-        lib, eng = hip.load(), self.eng
+        self._nar_make_room(B, T)
         with self.on_stream(bulk=True):
             # inputs land in persistent buffers so that the launch sequence of a (B, T) shape can be recorded once
-            cond = self.ws.get("nar.cond", (M, D))
+            cond = self.ws.get("nar.cond", (B * T, D))
             cond.view(B, T, D).copy_(cond_seq.to(dev).float())
             rvq1 = self.ws.get("nar.rvq1", (B, T), dtype=torch.int32)
             rvq1.copy_(tokens_A_1xT.to(dev).reshape(B, T).to(torch.int32))
-            lens_d = self.ws.get("nar.lens", (B,), dtype=torch.int32)
-            lens_d.copy_(torch.tensor(lens_l, dtype=torch.int32), non_blocking=False)
-            toks = self.ws.get("nar.toks", (M, Q), dtype=torch.int32)
+        return self._nar_pass(cond, T * D, rvq1, T, lens_l, B, T, sync=sync, raw=raw)
+
+    def _nar_make_room(self, B: int, T: int) -> None:
+        if self.ws.over(self.ws_budget) and not any(k[:2] == (B, T) for k in self._nar_graphs.graphs):
+            torch.cuda.synchronize(self.device)
+            self._nar_graphs.clear()
+            self.ws.clear()
+
+    @torch.inference_mode()
+    def _nar_pass(self, cond: torch.Tensor, cond_bstride: int, cb0: torch.Tensor, cb0_bstride: int, lens_l: Sequence[int], B: int, T: int, *,
+                  sync: bool, raw: bool, safe: bool = False) -> torch.Tensor:
+        """One refinement pass on operands that stay where they are (``cond``: [B, >= T rows, D] blocks ``cond_bstride`` floats apart,
+        ``cb0``: codebook 0 as rows of a history buffer ``cb0_bstride`` ints apart) - the AR plan's own buffers when a scheduler
+        calls (phase_nar), this engine's staging buffers for the public method.  The lengths reach the device through a page-locked
+        block that the recorded sequence itself reads; the pass's RANGE EVENTS (f16 operands that had to be saturated, see
+        sopro_gemm_split_ext.range_events) come back in another one, checked by ``nar_guard`` once the stream has been synchronised."""
+        Q = self.Q
+        lib, eng = hip.load(), self.eng
+        with self.on_stream(bulk=True):
+            hl = self._host_block(("nar.lens", B), B)
+            hl.array()[:] = [int(n) for n in lens_l]
+            hr = self._host_block(("nar.range",), 1)
+            toks = self.ws.get("nar.toks", (B * T, Q), dtype=torch.int32)
             scratch = self.ws.get(f"nar.stage_ws.{B}x{T}", (int(lib.sopro_nar_workspace_bytes(eng.h, B, T)),), dtype=torch.uint8)
+            io = hip.NarIO(cond.data_ptr(), int(cond_bstride), cb0.data_ptr(), int(cb0_bstride), hl.ptr, toks.data_ptr(), hr.ptr, 1 if safe else 0)
 
             def issue():
-                hip._check(lib.sopro_nar_refine(eng.h, scratch.data_ptr(), cond.data_ptr(), T * D, rvq1.data_ptr(), lens_d.data_ptr(), B, T,
-                                                toks.data_ptr(), hip._stream()), "sopro_nar_refine")
+                hip._check(lib.sopro_nar_refine_io(eng.h, scratch.data_ptr(), C.byref(io), B, T, hip._stream()), "sopro_nar_refine_io")
 
             if self.use_graph and os.environ.get("SOPRO_NO_BULK_GRAPH", "0") != "1":
-                self._nar_graphs.run((B, T), issue)
+                # (the recorded sequence holds the operands' addresses: they are part of its key)
+                self._nar_graphs.run((B, T, cond.data_ptr(), int(cond_bstride), cb0.data_ptr(), int(cb0_bstride), bool(safe)), issue)
             else:
                 issue()
+            self._nar_last = (cond, cond_bstride, cb0, cb0_bstride, list(lens_l), B, T)
             # ``raw`` (a scheduler that decodes on the same stream right away): the engine's own int32 buffer, no widening copy
-            out = toks.view(B, T, Q) if raw else toks.view(B, T, Q).long()
-        if sync:  # (``sync=False``: the caller stays on the bulk stream - e.g. decodes there - and synchronises once, later)
+            out = toks.view(B, T, Q) if raw else None
+        if sync:  # (``sync=False``: the caller stays on the bulk stream - e.g. decodes there - synchronises once, later, and calls nar_guard)
             self.bulk_stream.synchronize()
+            if self.nar_guard(redo=True):
+                self.bulk_stream.synchronize()
+        if out is None:
+            with self.on_stream(bulk=True):
+                out = toks.view(B, T, Q).long()
+            if sync:
+                self.bulk_stream.synchronize()
         return out
+
+    def nar_guard(self, redo: bool = True) -> bool:
+        """After the stream of the last refinement pass has been synchronised: did that pass leave the f16 operands' range?  If so
+        (and ``redo``) the same pass is queued again on the six-pass bf16 operands - fp32's exponent range - into the same token
+        buffer, and True is returned: the caller repeats whatever consumed the tokens (a checkpoint whose residual
+        stream exceeds fp16 pays the slower path instead of getting wrong tokens silently)."""
+        hr = self._host_blocks.get(("nar.range",))
+        if hr is None or self.precision != "f32" or int(hr.values()[0]) == 0:
+            return False
+        self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
+        if redo:
+            cond, cbs, cb0, c0s, lens_l, B, T = self._nar_last
+            hr.array()[0] = 0
+            self._nar_pass(cond, cbs, cb0, c0s, lens_l, B, T, sync=False, raw=True, safe=True)
+        return True
 
     # ------------------------------------------------------------------ text + reference -> tokens
     @torch.inference_mode()
@@ -516,9 +603,18 @@ class SoproTTSModel:
         ev.mark("nar")
         return toks
 
-    def phase_cond(self, ids_list, refs, *, max_frames, style_strength, ev=None):
+    def plan_for(self, ids_list, max_frames: int) -> "_ARPlan":
+        """The AR plan a batch of these texts will generate on (a scheduler asks for it BEFORE the conditioning stage, which then
+        writes ``cond_ar`` straight into the plan's buffer; the refinement later reads that buffer and the plan's token history in
+        place: no copy between the stages of a pass)."""
+        S = max(int(x.numel()) for x in ids_list)
+        return self._ar_plan(len(ids_list), ((S + 63) // 64) * 64, int(max_frames) + 1)
+
+    def phase_cond(self, ids_list, refs, *, max_frames, style_strength, ev=None, plan=None):
         """Per-batch conditioning (GEMM-shaped; runs on the preparation stream, needs no generation slot)."""
-        prep = self.prepare_conditioning_batch(ids_list, refs, max_frames=max_frames, style_strength=style_strength)
+        prep = self.prepare_conditioning_batch(ids_list, refs, max_frames=max_frames, style_strength=style_strength,
+                                               cond_out=plan.cond if plan is not None else None)
+        prep["plan"] = plan
         if ev is not None:
             ev.mark("cond")
         return prep
@@ -529,19 +625,22 @@ class SoproTTSModel:
         GEMM-shaped launches on the preparation stream).  Needs no generation slot: a scheduler calls it while the batch waits
         for one and hands the run to phase_ar, so the slot only ever replays frames."""
         return _ARRun(self, prep["cond_ar"], prep["txt_seq"], prep["text_lens"], top_p=top_p, temperature=temperature,
-                      anti_loop=anti_loop, min_gen_frames=min_gen_frames, seed=seed, nonces=nonces, row_ids=row_ids)
+                      anti_loop=anti_loop, min_gen_frames=min_gen_frames, seed=seed, nonces=nonces, row_ids=row_ids,
+                      text_lens_host=prep.get("text_lens_host"), plan=prep.get("plan"))
 
     def phase_ar(self, ids_list, refs, *, max_frames, top_p, temperature, anti_loop, style_strength, min_gen_frames, ev=None,
                  prep=None, seed=None, run=None):
         """Latency-bound half of generate_tokens_batch: (conditioning +) the AR graph replay."""
         if prep is None:
             prep = self.phase_cond(ids_list, refs, max_frames=max_frames, style_strength=style_strength, ev=ev)
+        # a prepared run on a plan that also holds the conditioning (a scheduler's pass): the history stays in the plan as well
+        inplace = run is not None and prep.get("plan") is not None and run.plan is prep["plan"]
         hist, lens = self.ar_generate_batch(prep["cond_ar"], prep["txt_seq"], prep["text_lens"], max_frames=max_frames,
                                             top_p=top_p, temperature=temperature, anti_loop=anti_loop,
-                                            min_gen_frames=min_gen_frames, seed=seed, run=run)
+                                            min_gen_frames=min_gen_frames, seed=seed, run=run, inplace=inplace)
         if ev is not None:
             ev.mark("ar")
-        return {"cond_ar": prep["cond_ar"], "hist": hist, "lens": lens, "B": len(ids_list)}
+        return {"cond_ar": prep["cond_ar"], "hist": hist, "lens": lens, "B": len(ids_list), "plan": run.plan if inplace else None}
 
     def phase_nar(self, state, full: bool = False, sync: bool = True, raw: bool = False):
         """Throughput-bound half: NAR refinement of the generated codebook-0 tokens -> one [T_b, Q] matrix per utterance, or with
@@ -554,8 +653,16 @@ class SoproTTSModel:
             return [torch.zeros(0, self.Q, dtype=torch.long, device=self.device) for _ in range(B)]
         # a few frames of padding keep the set of batch shapes (scratch + recorded graphs per shape) small
         Tm = min(-(-Tm // 8) * 8, int(hist.shape[1]), int(state["cond_ar"].shape[1]))
-        rvq1 = hist[:, :Tm].clamp(max=self.V - 1)  # rows past their own length are ignored below
-        toks = self.nar_refine(state["cond_ar"][:, :Tm, :], rvq1, lens=[max(1, n) for n in lens], sync=sync, raw=raw)
+        plan = state.get("plan")
+        if plan is not None:
+            # the plan's conditioning rows and token history are read where they are (EOS codes of stopped rows are clamped by the
+            # stage's own seeding kernel; rows past their own length are ignored below)
+            self._nar_make_room(B, Tm)
+            toks = self._nar_pass(plan.cond, plan.Tar * self.D, plan.hist, int(plan.hist.shape[1]), [max(1, n) for n in lens], B, Tm,
+                                  sync=sync, raw=raw)
+        else:
+            rvq1 = hist[:, :Tm].clamp(max=self.V - 1)  # rows past their own length are ignored below
+            toks = self.nar_refine(state["cond_ar"][:, :Tm, :], rvq1, lens=[max(1, n) for n in lens], sync=sync, raw=raw)
         if full:
             return toks
         return [toks[b, : lens[b]] for b in range(B)]
@@ -593,6 +700,15 @@ class _ARPlan:
         self.max_steps = Tar
         V1 = m.V + 1
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        # the small per-run parameters live in ONE device block, filled from one page-locked host block by one kernel of the
+        # library (_ARRun): sampling parameters (8 floats) | Philox key (seed: one recorded frame serves every seed) | per-row run
+        # nonce of the sampler | the row's identity in the sampler's counter (see _ARRun) | text lengths
+        self.pblock = z(10 + 3 * B, dt=torch.int32)
+        self.params = self.pblock[0:8].view(torch.float32)
+        self.key = self.pblock[8:10]
+        self.nonce = self.pblock[10:10 + B]
+        self.row_id = self.pblock[10 + B:10 + 2 * B]
+        self.row_id.copy_(torch.arange(B, dtype=torch.int32, device=dev))
         self.cond = z(B, Tar, D)
         self.x = [z(B, D) for _ in range(4)]
         self.part = z(4 * D // 384, B, D)
@@ -620,19 +736,15 @@ class _ARPlan:
         self.vp = {i: z(B, 4, S_cap, D, dt=sdt) for i in cfg.ar_xattn_layers}
         self.fold32 = (z(B, 4, S_cap, D), z(B, 4, S_cap, D)) if self.bf16_state else None  # (unfolded keys use the first quarter of [0])
         self.xp = z(4, B, D)  # per-head partial outputs of the cross-attention block
-        self.klens = z(B, dt=torch.int32)
+        self.klens = self.pblock[10 + 2 * B:10 + 3 * B] if not slots else z(B, dt=torch.int32)
         k = int(cfg.ar_kernel)
         self.rings = [z((k - 1) * int(d) + 1, B, D, dt=sdt) for d in cfg.ar_dilations]
         self.hist = z(B, self.max_steps, dt=torch.int32)
         self.ctr = z(8, dt=torch.int32)  # step, -, n_stopped
         self.row_step = z(B, dt=torch.int32)  # per-row copy of the frame index (the sampler's own time base: no ticket)
-        self.key = z(2, dt=torch.int32)  # Philox key (seed) in device memory: one recorded frame serves every seed
         self.first_eos = z(B, dt=torch.int32)
         self.stop_t = z(B, dt=torch.int32)
-        self.params = z(8)
         self.recent = z(B, 64, dt=torch.int32)
-        self.nonce = z(B, dt=torch.int32)  # per-row run nonce of the sampler (device memory: the recorded graph reads it)
-        self.row_id = torch.arange(B, dtype=torch.int32, device=dev)  # the row's identity in the sampler's counter (see _ARRun)
         self.owner = None  # weakref to the _ARRun using this plan
         st = hip.ArState()
         st.x_cur = self.x[0].data_ptr()
@@ -795,7 +907,8 @@ class _ARRun:
 
     def __init__(self, m: SoproTTSModel, cond_ar: torch.Tensor, txt_seq: torch.Tensor, text_lens: Optional[torch.Tensor], *,
                  top_p: float, temperature: float, anti_loop: bool, min_gen_frames: Optional[int], seed: Optional[int] = None,
-                 top_k: Optional[int] = None, nonces: Optional[Sequence[int]] = None, row_ids: Optional[Sequence[int]] = None):
+                 top_k: Optional[int] = None, nonces: Optional[Sequence[int]] = None, row_ids: Optional[Sequence[int]] = None,
+                 text_lens_host: Optional[Sequence[int]] = None, plan: Optional["_ARPlan"] = None):
         """``nonces`` / ``row_ids`` (one per row, from a scheduler that coalesces several requests into one batch): every row
         then draws what it would have drawn in its own request (nonce of that request, index within it)."""
         import weakref
@@ -811,15 +924,30 @@ class _ARRun:
         S_cap = ((S + 63) // 64) * 64
         self.m = m
         self.done = False
-        self.plan = plan = m._ar_plan(B, S_cap, Tar)
+        if plan is not None and (plan.B, plan.S_cap, plan.Tar) != (B, S_cap, Tar):
+            raise ValueError("the given plan has another shape")
+        self.plan = plan = plan if plan is not None else m._ar_plan(B, S_cap, Tar)
         plan.owner = weakref.ref(self)
         min_gen = int(min_gen_frames if min_gen_frames is not None else cfg.min_gen_frames)
+        if nonces is not None and len(nonces) != B:
+            raise ValueError("one nonce per row")
         with m.on_stream(prep=True):
-            plan.cond.copy_(cond_ar.to(dev).float())
-            if text_lens is None:
-                plan.klens.fill_(S)
-            else:
-                plan.klens.copy_(text_lens.to(dev).to(torch.int32))
+            # Everything below is a kernel of the library on the preparation stream: nothing of the runtime's (no `copy_`, `fill_`,
+            # `zero_`, no host -> device copy) runs between the recorded launch sequences of a pass (round 5).
+            if cond_ar.data_ptr() != plan.cond.data_ptr():  # (a scheduler has the conditioning stage write into plan.cond directly)
+                hip.copy_u32(plan.cond, cond_ar.to(dev).float().contiguous())
+            # the run's parameters: one page-locked block -> the plan's parameter block, one launch
+            hb = m._host_block(("ar.params", id(plan)), int(plan.pblock.numel()))
+            arr = hb.array()
+            arr[0:8].view(np.float32)[:] = [float(top_p), float(temperature), 1.0 if anti_loop else 0.0, 0.85, 1.2, 1.1, float(top_k), float(min_gen)]
+            arr[8:10].view(np.uint32)[:] = [m.seed & 0xFFFFFFFF, (m.seed >> 32) & 0xFFFFFFFF]
+            arr[10:10 + B].view(np.uint32)[:] = [int(v) & 0xFFFFFFFF for v in nonces] if nonces is not None else m.next_nonce(seed)
+            arr[10 + B:10 + 2 * B] = list(row_ids) if row_ids is not None else list(range(B))
+            lens_known = text_lens is None or text_lens_host is not None
+            arr[10 + 2 * B:10 + 3 * B] = S if text_lens is None else (list(text_lens_host) if text_lens_host is not None else 0)
+            hb.copy_to(plan.pblock)
+            if not lens_known:  # a device tensor of lengths without its host copy (public ar_generate_batch): device -> device, after the block
+                hip.copy_u32(plan.klens, text_lens.to(dev).to(torch.int32).contiguous())
             # K/V of the text for the three cross-attention layers with the query / output projections folded in, once per
             # utterance (src/sopro/nn/text.py:75-83; the sequence is sopro_ar_fold_text, csrc/stages.hip)
             nkv = m.ws.get("ar.nkv", (B * S, D))
@@ -828,20 +956,10 @@ class _ARRun:
             for i in cfg.ar_xattn_layers:
                 plan.fold_text(i, ts, nkv, kvd, B=B, S=S)
             for r in plan.rings:
-                r.zero_()
-            plan.hist.zero_()
-            plan.params.copy_(torch.tensor([float(top_p), float(temperature), 1.0 if anti_loop else 0.0, 0.85, 1.2, 1.1, float(top_k),
-                                            float(min_gen)], dtype=torch.float32), non_blocking=False)
-            plan.key.copy_(torch.tensor([m.seed & 0xFFFFFFFF, (m.seed >> 32) & 0xFFFFFFFF], dtype=torch.int64).to(torch.int32), non_blocking=False)
-            i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v  # noqa: E731  (the uint32 bit pattern in an int32 tensor)
-            if nonces is not None:
-                if len(nonces) != B:
-                    raise ValueError("one nonce per row")
-                plan.nonce.copy_(torch.tensor([i32(int(v) & 0xFFFFFFFF) for v in nonces], dtype=torch.int32), non_blocking=False)
-            else:
-                plan.nonce.fill_(i32(m.next_nonce(seed)))
-            plan.row_id.copy_(torch.tensor(list(row_ids) if row_ids is not None else list(range(B)), dtype=torch.int32), non_blocking=False)
+                hip.fill_u32(r, 0)
+            hip.fill_u32(plan.hist, 0)
             hip.ar_init(plan.state)
+            # (the page-locked block is rewritten by the next run on this plan - which starts after this run's tokens were read)
         plan.ensure_graph()
         self._started = False  # the first advance() orders the generation stream behind this preparation
 
@@ -887,8 +1005,13 @@ class _ARRun:
         with torch.cuda.stream(self.m.stream):
             return self.plan.hist[0, t0:t1].tolist()
 
-    def history(self, steps: int) -> Tuple[torch.Tensor, List[int]]:
-        with torch.cuda.stream(self.m.stream):
-            h = self.plan.hist[:, :steps].clone()
-            fe = self.plan.first_eos.tolist()
-        return h, fe
+    def history(self, steps: int, clone: bool = True) -> Tuple[torch.Tensor, List[int]]:
+        """Token history [B, steps] and the rows' first-EOS frames (-1: none).  ``clone=False``: a view of the plan's own buffer
+        (valid until the next run on this plan starts - a scheduler's refinement reads it in place)."""
+        m, plan = self.m, self.plan
+        with torch.cuda.stream(m.stream):
+            h = plan.hist[:, :steps].clone() if clone else plan.hist[:, :steps]
+            hb = m._host_block(("ar.eos", id(plan)), plan.B)
+            hb.copy_from(plan.first_eos)  # a kernel of the library writes the page-locked words
+        m.stream.synchronize()
+        return h, hb.values()

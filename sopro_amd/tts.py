@@ -154,7 +154,11 @@ class SoproTTS:
         # conditioning needs no generation slot: it overlaps with whatever the other engines are doing
         with torch.cuda.stream(self.model.prep_stream):
             ev = _PhaseTimer(self.model.prep_stream, timings)
-            prep = self.model.phase_cond(ids, refs, max_frames=max_frames, style_strength=ss)
+            # the stages of a pass hand their results over IN PLACE (round 5): conditioning writes into the AR plan's buffer, the
+            # refinement reads that buffer and the plan's token history, the decoder reads the refinement's token matrix and writes
+            # into the tensor this call returns - no copy, fill or cast of the runtime's runs between the library's launch sequences
+            plan = self.model.plan_for(ids, max_frames)
+            prep = self.model.phase_cond(ids, refs, max_frames=max_frames, style_strength=ss, plan=plan)
             # the AR phase's own preparation (plan buffers, folded text operands) belongs here too: the generation slot then
             # only replays frames (it sat idle for 2-3.5 ms per phase while this ran inside it)
             run = self.model.ar_prepare(prep, top_p=top_p, temperature=temperature, anti_loop=anti_loop, min_gen_frames=min_gen_frames,
@@ -193,6 +197,8 @@ class SoproTTS:
             # past its own length never reach the samples that are returned.
             codes = full
             wav = self.codec.decode_batch(codes)  # causal decoder: padding frames never reach earlier samples
+            if fused and self.model.nar_guard(redo=True):  # (decode_batch has synchronised the stream: the pass's range word is in)
+                wav = self.codec.decode_batch(codes)  # the refinement was repeated on the six-pass operands: decode its tokens
             if timings is not None:
                 if evs is not None:
                     evs[2].record(self.model.bulk_stream)
