@@ -222,9 +222,11 @@ def run_leg(tts, ids, refs, *, frames: int, steps: int, lanes: int, args, seed: 
 
         pipe = PipelinedSynthesizer(tts, lanes=lanes, ar_cus=args.ar_cus, ar_parts=args.ar_parts, ar_shared=bool(args.ar_shared), bulk_slots=args.bulk_slots)
 
-    def go(n):
+    phase_s: dict = {}
+
+    def go(n, timings=None):
         long_ok = os.environ.get("SOPRO_BENCH_COALESCE_LONG", "1") != "0"
-        outs = pipe.run([job] * n, coalesce=(args.coalesce if (long_ok or frames <= 256 or B * args.coalesce <= 32) else 1)) if pipe is not None else [tts.synthesize_batch(**job) for _ in range(n)]
+        outs = pipe.run([job] * n, coalesce=(args.coalesce if (long_ok or frames <= 256 or B * args.coalesce <= 32) else 1)) if pipe is not None else [tts.synthesize_batch(timings=timings, **job) for _ in range(n)]
         for out in outs:
             assert all(o.shape[-1] == frames * 1920 for o in out)
 
@@ -235,11 +237,17 @@ def run_leg(tts, ids, refs, *, frames: int, steps: int, lanes: int, args, seed: 
         go(steps)
         torch.cuda.synchronize()
         dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+        if pipe is None:  # sequential leg: one more repeat with the phase timers on (they synchronise between the phases)
+            go(steps, phase_s)
+            torch.cuda.synchronize()
     finally:
         if pipe is not None:
             pipe.close()
-    return {"value": round(steps * B * frames * FRAME_SEC / dt, 2), "unit": "audio-s/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-            "batch": B, "frames": frames, "lanes": lanes, "voices": len({id(r) for r in refs}), "host_cpu_s_per_step": round(cpu / steps, 4)}
+    out = {"value": round(steps * B * frames * FRAME_SEC / dt, 2), "unit": "audio-s/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "batch": B, "frames": frames, "lanes": lanes, "voices": len({id(r) for r in refs}), "host_cpu_s_per_step": round(cpu / steps, 4)}
+    if phase_s:
+        out["phase_ms_per_step"] = {k: round(v / steps * 1e3, 3) for k, v in phase_s.items() if not k.startswith("_")}
+    return out
 
 
 def bf16_quality(tts, tts16, ids, refs, frames: int, cfg, n: int = 4) -> dict:
@@ -289,7 +297,25 @@ def leg_main(name: str, args, device: str) -> dict:
     if name == "f32_32x400":
         return run_leg(tts, ids, voices, frames=400, steps=6, lanes=args.lanes, args=args)
     if name == "f32_1x400_sequential":
-        return run_leg(tts, ids[:1], voices[:1], frames=400, steps=8, lanes=1, args=args)
+        out = run_leg(tts, ids[:1], voices[:1], frames=400, steps=8, lanes=1, args=args)
+        # BASELINE's north star asks for batch 1 "as a fraction of the HBM roofline": the AR frame of ONE utterance against the bytes
+        # it has to move (the frame's weights once + one row's state) and against the floor of a launch-per-stage design
+        ar_ms = (out.get("phase_ms_per_step") or {}).get("ar")
+        if ar_ms:
+            us = ar_ms * 1e3 / 400.0
+            bts = ar_step_bytes(1, TEXT_LEN, 4)
+            out["roofline"] = {"kernel": "AR frame at batch 1 (hipGraph of 23 dependent launches), whole chip, nothing else running",
+                               "bound": "hbm", "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": bts,
+                               "achieved": round(bts / (us * 1e-6) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(bts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 5),
+                               "hbm_floor_us": round(bts / (PEAK_HBM_GBS * 1e9) * 1e6, 2),
+                               "stage_floor_us": round(23 * 4.6, 1),
+                               "frac_of_stage_floor": round(23 * 4.6 / us, 3),
+                               "stage_floor_note": "23 dependent launches x 4.6 us = boundary 1.9 + body on hot operands 1.5 + the activation's trip through "
+                                                   "the fabric 1.2-1.5 (profiles/r03_boundary_probe.txt); two resident-kernel designs were built and measured "
+                                                   "slower at 1 / 4 / 16 / 32 rows (profiles/r03_persist_pair.txt, r04_persist_pair_small_batches.txt): the "
+                                                   "batch-1 frame sits on the floor of a launch-per-stage design, which is 20x above the HBM floor"}
+        return out
     if name == "bf16_32x200":
         out = run_leg(tts, ids, voices, frames=FRAMES, steps=args.steps, lanes=args.lanes, args=args)
         out["dtype"], out["dtype_detail"] = "bf16", BF16_DETAIL
@@ -658,6 +684,9 @@ def main() -> None:
                 d["avg_launch_us_rocprof"] = rocf["families"][k]
         families[k] = d
 
+    # passes of this process (warm-up, timed, instrumented) whose f16 refinement operands left fp16's range and were repeated on
+    # the six-pass operands (sopro_gemm_split_ext.range_events, SoproTTSModel.nar_guard): 0 on an in-range checkpoint
+    range_fallbacks = sum(getattr(l.model, "range_fallbacks", 0) for l in (pipe.lanes if pipe is not None else [tts]))
     if pipe is not None:
         pipe.close()  # the latency leg below runs on the whole chip
 
@@ -769,6 +798,7 @@ def main() -> None:
             log(f"cpu baseline failed: {e!r}")
             cpu = None
     parity = dict(parity or {}, timed_steps_identical=steps_identical, timed_outputs_finite=finite, rank_output_sha16=rank_hashes,
+                  f16_range_fallbacks=range_fallbacks,
                   how="all timed steps run one seeded job: first vs last step compared bit for bit; oracle leg: row 0 of a greedy batch of "
                       "the same shape vs oracle/sopro_oracle.py (codebook 0 exact; refined tokens exact or audited near-ties < 1e-4)")
     if args.precision != "f32":  # the bf16 mode is a throughput mode with its own quality numbers (tests/test_gpu_bf16_mode.py), not a parity mode
@@ -776,6 +806,19 @@ def main() -> None:
 
     if rank == 0:
         audio_sec = world * args.steps * BATCH * FRAMES * FRAME_SEC
+        # what the driver's record keeps are the `config`, `roofline` and `cpu_baseline` objects: BASELINE's second metric (p50 TTFA)
+        # and the other configs' values ride in them as compact summaries (the full leg objects stay under "legs")
+        legs_summary = None
+        if legs:
+            legs_summary = {k: ({"value": v.get("value"), "unit": v.get("unit"), "ms_per_step": v.get("ms_per_step"), "dtype": v.get("dtype", "f32"),
+                                 "batch": v.get("batch"), "frames": v.get("frames"), "lanes": v.get("lanes")} if "value" in v else {"error": v.get("error")})
+                            for k, v in legs.items()}
+            b1 = (legs.get("f32_1x400_sequential") or {}).get("roofline")
+            if b1 and roof is not None:
+                roof["batch1"] = b1
+        second = {"ttfa_ms_p50": None if ttfa is None else round(ttfa, 3), "cpu_ttfa_ms_p50": (cpu or {}).get("ttfa_ms_p50"),
+                  "what": "p50 time to first audio of stream(), batch 1, chunk_frames 6, hipGraph-replayed AR frames (BASELINE configs[2]); "
+                          "cpu = the oracle port on this host's cores"}
         line = {
             "metric": "audio_seconds_per_second", "value": round(audio_sec / dt, 2), "unit": "audio-s/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "warmup_run": warm, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -786,6 +829,7 @@ def main() -> None:
                        "batch_per_gpu": BATCH, "frames": FRAMES, "voices_per_batch": n_voices,
                        "parallelism": f"replicas x{world} (utterance sharding, no collective)",
                        "lanes_per_gpu": args.lanes, "coalesce": (COALESCE if args.lanes > 1 else 1),
+                       "second_metric": second, "legs": legs_summary,
                        "pipelining": (f"{args.lanes} engines per GPU share the weights: up to {args.ar_parts} AR phases at a time on "
                                       f"{'one shared partition' if args.ar_shared else 'partitions'} of {args.ar_cus} CUs while conditioning, NAR and Mimi "
                                       f"decode of other batches run on the other {int(round(256 * share))} CUs (hipExtStreamCreateWithCUMask); NAR and Mimi "

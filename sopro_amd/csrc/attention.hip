@@ -174,7 +174,7 @@ extern "C" int sopro_attention_f32(const sopro_attn_args* p, void* stream) {
   // causal sliding-window self-attention with 64-wide heads (the codec transformers) and dense attention (the reference
   // cross-attention of the conditioning) run on the matrix cores
   if ((a.causal ? a.dh == 64 : (a.dh == 64 || a.dh == 96 || a.dh == 192)) && a.Tq >= 16 && aligned16(a.Q) && aligned16(a.O) &&
-      (a.ldq & 3) == 0 && (a.ldo & 3) == 0 && (a.q_bstride & 3) == 0 && (a.o_bstride & 3) == 0 && !getenv("SOPRO_ATTN_VALU"))
+      (a.ldq & 3) == 0 && (a.ldo & 3) == 0 && (a.q_bstride & 3) == 0 && (a.o_bstride & 3) == 0 && !SOPRO_DEV_ENV("SOPRO_ATTN_VALU"))
     return sopro_attn_mfma(a, s);
   switch (a.dh) {
     case 64: return launch_attn<64>(a, s);
@@ -548,7 +548,7 @@ extern "C" int sopro_xattn_step_f32(const sopro_xattn_args* p, void* stream) {
   SOPRO_CHECK_ARG(aligned16(a.X) && aligned16(a.Kp) && aligned16(a.Vp) && aligned16(a.Y) && (!a.norm_w || aligned16(a.norm_w)) && (a.ldx & 3) == 0 &&
                       (a.xp_stride & 3) == 0 && (a.y_part_stride & 3) == 0,
                   "16-byte alignment / strides % 4");
-  static const bool nt_on = !(getenv("SOPRO_XATTN_NT") != nullptr && getenv("SOPRO_XATTN_NT")[0] == '0');  // default on (r03: +1.7 %)
+  static const bool nt_on = !(SOPRO_DEV_ENV("SOPRO_XATTN_NT") != nullptr && SOPRO_DEV_ENV("SOPRO_XATTN_NT")[0] == '0');  // default on (r03: +1.7 %)
   // only where the operands cannot stay cached from one frame to the next anyway (> 8 MB per layer: the eight L2s hold 32 MB
   // for three layers); a single utterance's 0.8 MB per layer is L2-resident across frames and is asked for normally
   SOPRO_CHECK_ARG(a.kv_format == 0 || a.kv_format == 1, "kv_format: 0 (fp32 Kp / Vp) or 1 (bf16)");

@@ -1,5 +1,13 @@
 // Shared helpers of libsopro_hip (gfx950 only).
 #pragma once
+// Developer A/B switches whose measurement is on record (profiles/rNN_experiments.md) are COMPILE-TIME (round 5 housekeeping): a
+// product build reads none of them.  `make DEV=1` builds libsopro_hip_dev.so (-DSOPRO_DEV_SWITCHES), which reads them from the
+// environment again (load it with SOPRO_HIP_LIB=.../libsopro_hip_dev.so for a re-measurement).
+#ifdef SOPRO_DEV_SWITCHES
+#define SOPRO_DEV_ENV(name) getenv(name)
+#else
+#define SOPRO_DEV_ENV(name) (static_cast<const char*>(nullptr))
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -602,7 +602,7 @@ int launch_argmax(sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_ge
   SOPRO_CHECK_ARG(ext.C2 && ext.ldc2 >= (g.N + 63) / 64, "arg-max output: C2 = [M][ldc2 >= ceil(N / 64)] (value, index) pairs");
   // 128-row tiles for many-row problems (the refinement of a whole batch: 12800 rows): every W fragment serves twice the rows; the
   // (max, column) pairs stay per 64-column tile, the arithmetic per element is unchanged.  SOPRO_ARGMAX_TM=1: 64-row tiles always.
-  static const bool tm1 = getenv("SOPRO_ARGMAX_TM") != nullptr && getenv("SOPRO_ARGMAX_TM")[0] == '1';
+  static const bool tm1 = SOPRO_DEV_ENV("SOPRO_ARGMAX_TM") != nullptr && SOPRO_DEV_ENV("SOPRO_ARGMAX_TM")[0] == '1';
   if (g.M >= 8192 && !tm1) return launch_one<NPL, 2, 2, 2, 1, SOPRO_EPI_NONE, 0, 5, F16>(g, wp, ksubs, ext, s);
   return launch_one<NPL, 2, 2, 1, 1, SOPRO_EPI_NONE, 0, 5, F16>(g, wp, ksubs, ext, s);
 }
@@ -641,7 +641,7 @@ extern "C" int sopro_gemm_set_group_m(int g) {
 // Kept as a developer override (tile override 7 / SOPRO_GEMM_W8=1) for the three-pass decoder path; same K loop per output
 // element: bit-identical results.
 static bool eight_waves(const sopro_gemm_args& g) {
-  static const bool on = getenv("SOPRO_GEMM_W8") != nullptr && getenv("SOPRO_GEMM_W8")[0] == '1';
+  static const bool on = SOPRO_DEV_ENV("SOPRO_GEMM_W8") != nullptr && SOPRO_DEV_ENV("SOPRO_GEMM_W8")[0] == '1';
   return on && g.N >= 512 && g.M >= 1024;
 }
 
@@ -834,7 +834,7 @@ extern "C" int sopro_gemm_f16x3(const sopro_gemm_args* a, const void* packed_w, 
   const uint4* wp = reinterpret_cast<const uint4*>(packed_w);
   const int ksubs = (g.K + 31) / 32 * 2;
   if (ext.c_mode == 5) return launch_argmax<2, true>(g, wp, ksubs, ext, s);
-  static const int env_tile = getenv("SOPRO_F16X3_TILE") ? atoi(getenv("SOPRO_F16X3_TILE")) : 0;  // developer A/B of this family alone
+  static const int env_tile = SOPRO_DEV_ENV("SOPRO_F16X3_TILE") ? atoi(SOPRO_DEV_ENV("SOPRO_F16X3_TILE")) : 0;  // developer A/B of this family alone
   switch (g_tile_override ? g_tile_override : env_tile) {
     case 1: return launch_cfg6<2, 2, 2, 2, 2, true>(g, wp, ksubs, ext, s);
     case 4: return launch_cfg6<2, 2, 2, 1, 2, true>(g, wp, ksubs, ext, s);

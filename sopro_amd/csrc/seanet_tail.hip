@@ -20,18 +20,6 @@
 
 #include "common.h"
 
-// Developer timeline builds (tools/micro/build_tail_dbg.sh, never the product library): shader-clock stamps of one tile group's phases
-#ifdef SOPRO_TAIL_DBG
-__device__ long long* g_tail_dbg = nullptr;
-extern "C" int sopro_tail_dbg_set(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tail_dbg), &p, sizeof(p)); }
-#define TAIL_STAMP(i) do { if (g_tail_dbg && blockIdx.x == 7 && blockIdx.y == 1 && threadIdx.x == 64 * 5 && it < 16) g_tail_dbg[it * 8 + (i)] = clock64(); } while (0)
-#else
-#define TAIL_STAMP(i) do { } while (0)
-#endif
-#ifdef TAIL_EXP_OFF  // (timeline builds: ELU replaced by the identity - wrong results, the time of what is left is the point)
-#define eluf_(v) (v)
-#endif
-
 namespace {
 
 constexpr int TO = 126;        // output samples per tile
@@ -321,11 +309,6 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
   for (int it = 0; it < trips; ++it) {
     const int s0 = (tile0 + it * 16) * T3O;
     if (s0 >= T) break;  // uniform over the wave
-    TAIL_STAMP(0);
-#ifdef SOPRO_TAIL_DBG
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (timeline builds: the tile's arrival gets its own stamp)
-#endif
-    TAIL_STAMP(1);
     // ---- ELU + split once per element
     if constexpr (HB) {
 #pragma unroll
@@ -355,7 +338,6 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
       }
     }
     tail_wave_sync();
-    TAIL_STAMP(2);
     // the staging registers are free: the next tile's rows travel while this one computes
     if (it + 1 < trips && s0 + 16 * T3O < T) request(s0 + 16 * T3O);
     // skip operand of the residual block in the accumulator layout of the second convolution (row 4 kq + i of the intermediate
@@ -371,7 +353,6 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
         else skip[nt][i] = hb[off + 16 * nt];
       }
     }
-    TAIL_STAMP(3);
 
     // ---- conv k=3, 64 -> 32: intermediate row m (sample s0-2+m) reads tile rows m, m+1, m+2.
     // K index = tap * 64 + channel; k-step s covers tap s / 2, channels 32 (s % 2) .. + 31
@@ -412,7 +393,6 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
         }
     }
     tail_wave_sync();  // (this wave is also done reading the split h tile: its memory becomes the ELU(h') tile below)
-    TAIL_STAMP(4);
 
     // ---- conv k=1, 32 -> 64 on the intermediate, + skip operand, ELU(h') -> fp32 tile rows 0 .. 15 (row m = sample s0-2+m)
     {
@@ -443,7 +423,6 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
       }
     }
     tail_wave_sync();
-    TAIL_STAMP(5);
 
     // ---- last conv k=3, 64 -> 1 on the stored ELU(h'): lane = channel; 16 column reads (the whole tile: 4 KB of LDS traffic
     // instead of 48 KB with one output per lane group), three FMAs per output, then a transpose-reduction over the 64 lanes:
@@ -476,8 +455,6 @@ __global__ __launch_bounds__(1024, 1) void seanet_tail16_kernel(const float* __r
       if ((lane & 3) == 0 && i < T3O && s0 + i < T) wav[(int64_t)b * wav_seg_stride + s0 + i] = sum + bf;
     }
     tail_wave_sync();  // the last phase is done with the LDS tiles before the next trip's staging
-    TAIL_STAMP(6);
-    TAIL_STAMP(7);
   }
 }
 

@@ -1078,7 +1078,7 @@ static bool mimi_half(const sopro_engine* e) {
 // of 32 input rows each, so below ~512 Ki input rows per call the two kernels - which spread a short input over the chip - stay
 // (streaming chunks, single short utterances).  SOPRO_SEANET_FUSE=0: always the two kernels (the round-3 sequence).
 static bool seanet_fused(int B, int rows) {
-  static const bool off = getenv("SOPRO_SEANET_FUSE") != nullptr && getenv("SOPRO_SEANET_FUSE")[0] == '0';
+  static const bool off = SOPRO_DEV_ENV("SOPRO_SEANET_FUSE") != nullptr && SOPRO_DEV_ENV("SOPRO_SEANET_FUSE")[0] == '0';
   return !off && (int64_t)B * rows >= 512 * 1024;
 }
 
@@ -1220,11 +1220,11 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   // ---- transformer: 8 pre-LN layers, RoPE, causal window (HF:729-928)
   // the decoder's attention on the waveform path's operand precision (two bf16 pieces, three passes; one in bf16 mode when
   // SOPRO_ATTN_PASSES=1); SOPRO_ATTN_SPLIT=0 keeps the exact-fp32 kernel the encoder uses
-  static const bool attn_exact = getenv("SOPRO_ATTN_SPLIT") != nullptr && getenv("SOPRO_ATTN_SPLIT")[0] == '0';
-  static const bool attn_one = getenv("SOPRO_ATTN_PASSES") != nullptr && getenv("SOPRO_ATTN_PASSES")[0] == '1';
+  static const bool attn_exact = SOPRO_DEV_ENV("SOPRO_ATTN_SPLIT") != nullptr && SOPRO_DEV_ENV("SOPRO_ATTN_SPLIT")[0] == '0';
+  static const bool attn_one = SOPRO_DEV_ENV("SOPRO_ATTN_PASSES") != nullptr && SOPRO_DEV_ENV("SOPRO_ATTN_PASSES")[0] == '1';
   const int attn_split = attn_exact ? 0 : ((c.precision == 1 && attn_one) ? 1 : 3);
   BODY(transformer_stack(e, s, "tr", w.X, PADX, xs, w.y, w.qkv, w.ao, w.hd, &w.sk, B, N2, past, sst, attn_split));
-  static const bool three = getenv("SOPRO_SEANET_PASSES3") != nullptr;  // developer A/B: the fused kernels' three-pass form in bf16 mode too
+  static const bool three = SOPRO_DEV_ENV("SOPRO_SEANET_PASSES3") != nullptr;  // developer A/B: the fused kernels' three-pass form in bf16 mode too
   const int sea_passes = (c.precision == 1 && !three) ? 1 : 3;
   // ---- SEANet decoder (HF:931-961), activated-copy flow of sopro_amd.codec.MimiCodec._seanet_act
   int ch = c.mimi_num_filters << c.mimi_n_ratios, rows = N2, pad_in = 1;

@@ -370,7 +370,7 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
          a_seg_stride: int = 0, c_seg_stride: int = 0, r_seg_stride: int = 0, a_off: int = 0, c_off: int = 0,
          r_off: int = 0, ldw: Optional[int] = None, dbg: Optional[torch.Tensor] = None, a_split: bool = False, c_mode: int = 0,
          C2: Optional[torch.Tensor] = None, ldc2: Optional[int] = None, c2_seg_stride: int = 0,
-         c2_off: int = 0, rms_eps: float = 0.0) -> None:
+         c2_off: int = 0, rms_eps: float = 0.0, range_events: Optional[torch.Tensor] = None) -> None:
     """C = epi(pro(A) @ W^T + bias); offsets are in elements from the tensors' first element.  With a ``PackedW`` weight the
     contraction runs on the split-bf16 path, where ``a_split`` says A is in split form and ``c_mode`` 1 / 2 writes
     ELU(C) in split form (to C, or to C2 next to the fp32 C): see sopro_gemm_split_ext in include/sopro_hip.h."""
@@ -420,6 +420,7 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
         if c_mode == 5:
             x.c_mode, x.C2, x.ldc2 = 5, ptr(C2) + 4 * c2_off, (-(-N // 64) if ldc2 is None else ldc2)
         x.acc_scale = W.acc_scale
+        x.range_events = ptr(range_events, torch.int32)  # optional device word (sopro_gemm_split_ext.range_events)
         _check(load().sopro_gemm_f16x3(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_f16x3")
     elif packed and W.pieces == 1:
         if a_split or c_mode in (1, 2):

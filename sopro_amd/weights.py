@@ -348,3 +348,54 @@ def check_against_spec(weights: Dict[str, np.ndarray], spec: Spec, *, what: str)
         if tuple(weights[name].shape) != tuple(shape):
             raise ValueError(f"{what}: tensor {name} has shape {tuple(weights[name].shape)}, expected {tuple(shape)}")
     return missing
+
+
+# ----------------------------------------------------------------------------
+# badly scaled synthetic checkpoints (range robustness of the split-precision kernels)
+# ----------------------------------------------------------------------------
+def badly_scaled_sopro(weights: Dict[str, np.ndarray], cfg: SoproTTSConfig, overflow: bool = False) -> Dict[str, np.ndarray]:
+    """The same checkpoint with a badly scaled refinement stream.  The reference's arithmetic is range-free fp32
+    (src/sopro/nn/blocks.py:26-37, nn/nar.py:89-116); the f16 three-pass kernels have to earn that:
+      * the adapter in front of every stage shrinks the stream to ~1e-3 RMS (its ``1 + tanh g`` factor, nar.py:25-32), so the first
+        block's fused-RMSNorm contraction stages rows a thousand times smaller than any fixture before;
+      * RMSNorm weights x 64 on some blocks and / 64 on others, one block's FF2 x 3000: the stream then climbs to ~1e+3 RMS, and the
+        rows the later blocks' contractions stage span six decades over a stage;
+      * the rows of ``nar.pre`` are spread over 1e-3 ... 1e+3: the head contraction's operand has that range WITHIN a row.
+    ``overflow``: additionally one feed-forward norm weight x 3e4 - its GELU output (which the FF2 contraction stages with the
+    CONSTANT scale) leaves fp16's range: the kernel's range guard must fire and the engine must fall back to the six-pass operands."""
+    w = {k: v.copy() for k, v in weights.items()}
+    n, d = int(cfg.n_layers_nar), int(cfg.d_model)
+    for i in range(n):
+        w[f"nar.blocks.{i}.norm.weight"] *= np.float32((64.0, 1.0 / 64.0, 1.0)[i % 3])
+        w[f"nar.blocks.{i}.ff.0.weight"] *= np.float32((1.0 / 64.0, 64.0, 1.0)[i % 3])
+    w[f"nar.blocks.{min(2, n - 1)}.ff.3.weight"] *= np.float32(3000.0)
+    w["nar.adapter.mlp.2.weight"] *= np.float32(0.003)
+    w["nar.adapter.mlp.2.bias"][:d] = np.float32(-3.8)  # 1 + tanh(-3.8) = 1.0e-3
+    w["nar.adapter.mlp.2.bias"][d:] *= np.float32(1e-3)
+    hd = w["nar.pre.weight"].shape[0]
+    rng = np.random.Generator(np.random.PCG64(20260925))
+    row_scale = np.logspace(-3.0, 3.0, hd).astype(np.float32)[rng.permutation(hd)]
+    w["nar.pre.weight"] *= row_scale[:, None]
+    w["nar.pre.bias"] *= row_scale
+    if overflow:
+        w[f"nar.blocks.{min(3, n - 1)}.ff.0.weight"] *= np.float32(3e4)
+    return w
+
+
+def badly_scaled_mimi(weights: Dict[str, np.ndarray], mc: MimiDecoderConfig) -> Dict[str, np.ndarray]:
+    """Decoder-side twin: LayerNorm weights and layer scales of the codec transformer x 16 / / 16 on alternating layers, the SEANet
+    transposed convolutions x 4 / / 4 in turn (ELU is not homogeneous: the levels then run in its linear AND its saturated regime)."""
+    w = {k: v.copy() for k, v in weights.items()}
+    for i in range(int(mc.num_hidden_layers)):
+        p = f"decoder_transformer.layers.{i}"
+        f = np.float32(16.0 if i % 2 == 0 else 1.0 / 16.0)
+        w[f"{p}.input_layernorm.weight"] *= f
+        w[f"{p}.self_attn_layer_scale.scale"] /= f
+        w[f"{p}.post_attention_layernorm.weight"] /= f
+        w[f"{p}.mlp_layer_scale.scale"] *= f
+    li = 1
+    for si, _r in enumerate(mc.upsampling_ratios):
+        li += 1
+        w[f"decoder.layers.{li}.conv.weight"] *= np.float32(4.0 if si % 2 == 0 else 0.25)
+        li += 2
+    return w

@@ -4,7 +4,7 @@ container).  This is what pins the oracle; the GPU tests then compare the HIP en
 import numpy as np
 import torch
 
-from conftest import golden
+from conftest import VOCAB, golden
 from oracle import sopro_oracle as O
 
 torch.set_num_threads(4)
@@ -268,3 +268,23 @@ def test_sinc_resample_derivation_pins_alignment_gain_and_length():
     sig = (np.sin(2 * np.pi * 440 * t48) + 0.5 * np.sin(2 * np.pi * 3100 * t48 + 1.0)).astype(np.float32)
     back = O.sinc_resample(O.sinc_resample(_t(sig), 48000, 24000), 24000, 48000).numpy()
     assert back.shape == sig.shape and np.abs(back[2000:-2000] - sig[2000:-2000]).max() < 5e-3
+
+
+def test_badly_scaled_checkpoint_fixture(cfg, mc):
+    """tests/golden/badscale*.npz (make_golden_badscale.py: THE REFERENCE on sopro_amd.weights.badly_scaled_*): the oracle reproduces
+    the reference's refined tokens and waveform there too, and the fixture is as badly scaled as it says (residual-stream rows over
+    more than five decades of RMS) - the GPU tests of the f16 range guard (tests/test_gpu_range.py) stand on it."""
+    from sopro_amd.weights import badly_scaled_mimi, badly_scaled_sopro, synth_mimi_weights, synth_sopro_weights
+
+    for name, overflow in (("badscale", False), ("badscale_overflow", True)):
+        g = golden(name)
+        seed = int(g["seed"])
+        w = O.to_torch(badly_scaled_sopro(synth_sopro_weights(cfg, VOCAB, seed), cfg, overflow=overflow))
+        toks = O.nar_refine(_t(g["cond"]), _t(g["rvq1"]), w, cfg)
+        assert torch.equal(toks, _t(g["tokens"])), name
+        assert float(g["stream_rms_min"]) < 2e-3 and float(g["stream_rms_max"]) > 5e2 and float(g["rel_margin"]) > 1e-6
+        if not overflow:
+            mw = O.to_torch(badly_scaled_mimi(synth_mimi_weights(mc, seed), mc))
+            wav = O.decode_full(toks[0], mw, mc).reshape(-1)
+            ref = _t(g["wav"])
+            assert float((wav - ref).abs().max()) < 1e-5 * float(ref.abs().max())
