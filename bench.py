@@ -483,7 +483,11 @@ def main() -> None:
 
     log("warmup")
     # every lane runs a shape eagerly once (scratch allocation) and records its launch sequences on the second pass
-    warm = max(args.warmup, 2 * args.lanes if pipe is not None else 2)
+    # (a pipeline's warm-up reaches its steady state: EVERY lane has run a pass of the timed shape twice - eagerly, then recording its
+    # launch sequences - i.e. 2 x lanes passes of `coalesce` jobs each; the driver's W is a lower bound and `warmup_run` says what ran.
+    # SOPRO_BENCH_WARM_PASSES=1: the round-4 rule, one pass per lane, which left every lane's recording inside the timed region)
+    wp = int(os.environ.get("SOPRO_BENCH_WARM_PASSES", "2"))
+    warm = max(args.warmup, wp * args.lanes * COALESCE if pipe is not None else 2)
     run_steps(warm)
     fence()
     kept.clear()

@@ -1072,7 +1072,13 @@ def test_host_mirror_copies_behind_the_queued_launches():
     with pytest.raises(hip.SoproHipError):
         m.copy_from(t[:5])
     with pytest.raises(hip.SoproHipError):
-        m.copy_from(t.float())
+        m.copy_from(t.to(torch.int64))  # (32-bit words only: int32 or float32)
+    # the other direction: a kernel reads the page-locked words (parameter blocks of the stage sequences, round 5)
+    m.array()[:] = [5, 4, 3, 2, 1, 0]
+    back = torch.zeros(6, dtype=torch.int32, device=DEV)
+    m.copy_to(back)
+    torch.cuda.synchronize()
+    assert back.tolist() == [5, 4, 3, 2, 1, 0]
 
 
 @pytest.mark.parametrize("passes", [3, 1])
