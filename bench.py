@@ -223,15 +223,17 @@ def run_leg(tts, ids, refs, *, frames: int, steps: int, lanes: int, args, seed: 
         pipe = PipelinedSynthesizer(tts, lanes=lanes, ar_cus=args.ar_cus, ar_parts=args.ar_parts, ar_shared=bool(args.ar_shared), bulk_slots=args.bulk_slots)
 
     phase_s: dict = {}
+    co = coalesce_arg(args.coalesce)
+    if pipe is not None:  # every lane records every pass shape of the timed run before anything is timed
+        pipe.prepare(job, sizes=set(pipe.pass_sizes(steps, co)))
 
     def go(n, timings=None):
-        long_ok = os.environ.get("SOPRO_BENCH_COALESCE_LONG", "1") != "0"
-        outs = pipe.run([job] * n, coalesce=(args.coalesce if (long_ok or frames <= 256 or B * args.coalesce <= 32) else 1)) if pipe is not None else [tts.synthesize_batch(timings=timings, **job) for _ in range(n)]
+        outs = pipe.run([job] * n, coalesce=co) if pipe is not None else [tts.synthesize_batch(timings=timings, **job) for _ in range(n)]
         for out in outs:
             assert all(o.shape[-1] == frames * 1920 for o in out)
 
     try:
-        go(max(2, 2 * lanes if pipe is not None else 2))
+        go(max(2, lanes if pipe is not None else 2))
         torch.cuda.synchronize()
         c0, t0 = time.process_time(), time.perf_counter()
         go(steps)
@@ -248,6 +250,11 @@ def run_leg(tts, ids, refs, *, frames: int, steps: int, lanes: int, args, seed: 
     if phase_s:
         out["phase_ms_per_step"] = {k: round(v / steps * 1e3, 3) for k, v in phase_s.items() if not k.startswith("_")}
     return out
+
+
+def coalesce_arg(v):
+    """--coalesce: an integer (jobs per pass) or "auto" (PipelinedSynthesizer.pass_sizes: 2 per pass for short runs, 4 from 8 queued jobs per lane)."""
+    return "auto" if str(v) == "auto" else max(1, int(v))
 
 
 def bf16_quality(tts, tts16, ids, refs, frames: int, cfg, n: int = 4) -> dict:
@@ -356,7 +363,8 @@ def main() -> None:
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 (default): the parity configuration; bf16: bf16 weights/operands with fp32 accumulation (BASELINE configs[1] wording)")
     ap.add_argument("--frames", type=int, default=FRAMES, help="frames per utterance (default: BASELINE configs[1]; 400 = the long-form case)")
-    ap.add_argument("--coalesce", type=int, default=2, help="consecutive batches the pipeline generates / refines / decodes as ONE pass (per-utterance results are unchanged)")
+    ap.add_argument("--coalesce", default="auto", help="consecutive batches the pipeline generates / refines / decodes as ONE pass (per-utterance results are unchanged): "
+                    "an integer, or 'auto' = sized by the queue depth (2 per pass for short runs, 4 from 8 queued batches per lane)")
     ap.add_argument("--voices", type=int, default=-1, help="distinct reference voices per batch (default: one per utterance, SURVEY 8d; 1 = one shared voice)")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs of the default run (one shared voice, 32x400 / 1x400 frames, bf16 mode)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -365,10 +373,8 @@ def main() -> None:
     ap.add_argument("--input-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: a 1-GPU run on the inputs of rank R
     args = ap.parse_args()
     BATCH, FRAMES = int(args.batch), int(args.frames)
-    # passes of two jobs at every length (round 4: the decoder takes a 64 x 400 pass as two 32-row chunks - in one call it was slower
-    # per utterance than two, which is why round 3 did not coalesce long-form jobs); SOPRO_BENCH_COALESCE_LONG=0 = the round-3 rule
-    long_ok = os.environ.get("SOPRO_BENCH_COALESCE_LONG", "1") != "0"
-    COALESCE = int(args.coalesce) if (long_ok or FRAMES <= 256 or BATCH * int(args.coalesce) <= 32) else 1
+    # (long-form jobs coalesce like short ones: the decoder takes a 64 x 400 pass in two 32-row chunks, sopro_mimi_chunk_rows)
+    COALESCE = coalesce_arg(args.coalesce)
 
     if args.cpu_baseline_only:  # child process of the N=1 run: CPU only, bounded by the parent's timeout
         from sopro_amd.config import MimiDecoderConfig, SoproTTSConfig
@@ -486,9 +492,13 @@ def main() -> None:
     # (a pipeline's warm-up reaches its steady state: EVERY lane has run a pass of the timed shape twice - eagerly, then recording its
     # launch sequences - i.e. 2 x lanes passes of `coalesce` jobs each; the driver's W is a lower bound and `warmup_run` says what ran.
     # SOPRO_BENCH_WARM_PASSES=1: the round-4 rule, one pass per lane, which left every lane's recording inside the timed region)
-    wp = int(os.environ.get("SOPRO_BENCH_WARM_PASSES", "2"))
-    warm = max(args.warmup, wp * args.lanes * COALESCE if pipe is not None else 2)
+    sizes = sorted(set(pipe.pass_sizes(args.steps, COALESCE))) if pipe is not None else [1]
+    if pipe is not None:
+        pipe.prepare(job, sizes=sizes)  # deterministic: every lane, every pass size of the timed run, twice (eager, then recording)
+    warm = max(args.warmup, 2)
     run_steps(warm)
+    warm_desc = (f"every lane ran a pass of {' / '.join(str(v) for v in sizes)} batch(es) twice (PipelinedSynthesizer.prepare), then {warm} pipelined steps"
+                 if pipe is not None else f"{warm} sequential steps")
     fence()
     kept.clear()
     log("timed steps")
@@ -631,9 +641,17 @@ def main() -> None:
         f = fam["ar_step_graph"]
         inst_ms = f["ms"] / max(1, f["launches"])  # instrumented repeat (events around every replay; NAR / Mimi issued eagerly)
         per_launch_ms = ar_ms / ar_frames if ar_frames else inst_ms  # the timed region itself: phase events / frames
-        rows_launch = max([b for _n, b, _e0, _e1 in ar_log] or [BATCH])  # rows of a frame (coalesced passes: 2 x 32)
-        bytes_step = ar_step_bytes(rows_launch, TEXT_LEN, 2 if args.precision == "bf16" else 4)
-        ach = bytes_step / (per_launch_ms * 1e-3) / 1e9
+        # rows of a frame: the passes of a run may differ in size (pass_sizes: a single-batch first pass, then coalesced ones) - the
+        # achieved rate is the algorithmic bytes of EVERY replayed frame at its own row count over the summed phase times; the
+        # per-launch figures describe the most common frame
+        wb = 2 if args.precision == "bf16" else 4
+        by_rows = {}
+        for n_, b_, _e0, _e1 in ar_log:
+            by_rows[b_] = by_rows.get(b_, 0) + n_
+        rows_launch = max(by_rows, key=by_rows.get) if by_rows else BATCH
+        bytes_step = ar_step_bytes(rows_launch, TEXT_LEN, wb)
+        bytes_all = sum(n_ * ar_step_bytes(b_, TEXT_LEN, wb) for b_, n_ in by_rows.items()) if by_rows else bytes_step * max(1, f["launches"])
+        ach = (bytes_all / (ar_ms * 1e-3) / 1e9) if ar_frames else bytes_step / (per_launch_ms * 1e-3) / 1e9
         per_frame = ark.get("launches_per_frame") or {"skinny_kernel": 19, "xattn_step_kernel": 3, "ar_sample_kernel": 1}
         tr = round(sum(pmc.get(k, {}).get("traffic_bytes_per_launch", 0) * n for k, n in per_frame.items())) if pmc else None
         # the PMC pass has its own row count per frame (profiles/rNN_pmc_summary.json "ar_rows_per_frame"; the r03 file was a
@@ -650,7 +668,8 @@ def main() -> None:
              "launches": ar_frames or f["launches"],
              "avg_launch_us": round(per_launch_ms * 1e3, 2), "ms_per_step": round((ar_ms / args.steps) if ar_frames else f["ms"] / max(1, nprof), 3),
              "avg_launch_us_instrumented_repeat": round(inst_ms * 1e3, 2),
-             "algorithmic_bytes_per_launch": bytes_step, "rows_per_launch": rows_launch, "cu_share": ar_share,
+             "algorithmic_bytes_per_launch": bytes_step, "rows_per_launch": rows_launch, "frames_by_rows": {str(k): v for k, v in sorted(by_rows.items())},
+             "cu_share": ar_share,
              "measured": ("two HIP events per AR phase on the AR stream IN the timed region: sum of phase times / frames replayed"
                           if ar_frames else measured),
              "note": (f"one launch = one frame of one {rows_launch}-row pass; in the pipeline two AR phases replay concurrently on the generation "
@@ -688,6 +707,7 @@ def main() -> None:
                 d["avg_launch_us_rocprof"] = rocf["families"][k]
         families[k] = d
 
+    pipe_sizes = pipe.pass_sizes(args.steps, COALESCE) if pipe is not None else None
     # passes of this process (warm-up, timed, instrumented) whose f16 refinement operands left fp16's range and were repeated on
     # the six-pass operands (sopro_gemm_split_ext.range_events, SoproTTSModel.nar_guard): 0 on an in-range checkpoint
     range_fallbacks = sum(getattr(l.model, "range_fallbacks", 0) for l in (pipe.lanes if pipe is not None else [tts]))
@@ -825,7 +845,7 @@ def main() -> None:
                           "cpu = the oracle port on this host's cores"}
         line = {
             "metric": "audio_seconds_per_second", "value": round(audio_sec / dt, 2), "unit": "audio-s/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "warmup_run": warm, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "steps": args.steps, "warmup": args.warmup, "warmup_run": warm, "warmup_detail": warm_desc, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"Sopro-135M synthesize, {BATCH} utterances x {FRAMES} frames per GPU ({'BASELINE configs[1]' if (BATCH, FRAMES) == (32, 200) else 'non-default shape'}), "
                                    f"S={TEXT_LEN} text tokens, {n_voices} distinct {REF_FRAMES}-frame reference voice(s) per batch prepared outside the timed "
@@ -833,13 +853,14 @@ def main() -> None:
                        "batch_per_gpu": BATCH, "frames": FRAMES, "voices_per_batch": n_voices,
                        "parallelism": f"replicas x{world} (utterance sharding, no collective)",
                        "lanes_per_gpu": args.lanes, "coalesce": (COALESCE if args.lanes > 1 else 1),
+                       "pass_sizes": (pipe_sizes if args.lanes > 1 else None),
                        "second_metric": second, "legs": legs_summary,
                        "pipelining": (f"{args.lanes} engines per GPU share the weights: up to {args.ar_parts} AR phases at a time on "
                                       f"{'one shared partition' if args.ar_shared else 'partitions'} of {args.ar_cus} CUs while conditioning, NAR and Mimi "
                                       f"decode of other batches run on the other {int(round(256 * share))} CUs (hipExtStreamCreateWithCUMask); NAR and Mimi "
                                       "launch sequences are recorded hipGraphs"
-                                      + (f"; {COALESCE} consecutive batches are coalesced into one {COALESCE * BATCH}-row pass (every utterance keeps its "
-                                         "own sampler stream: outputs are bit-identical to un-coalesced steps)" if COALESCE > 1 else "")) if args.lanes > 1 else "none"},
+                                      + (f"; consecutive batches are coalesced into passes of {pipe_sizes} batches (every utterance keeps its "
+                                         "own sampler stream: outputs are bit-identical to un-coalesced steps)" if pipe_sizes and max(pipe_sizes) > 1 else "")) if args.lanes > 1 else "none"},
             "dtype_detail": ("fp32 tensors and accumulation everywhere; conditioning + AR on v_mfma_f32_*_f32 (round 4: the text cross-attention reads unfolded "
                              "keys, its query rides on the feed-forward launches; the two encoders' contractions on three "
                              "bf16 pieces / 6 MFMA passes, 24 mantissa bits); NAR contractions with operands split into two fp16 pieces (22 mantissa bits, "

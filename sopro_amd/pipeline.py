@@ -151,7 +151,36 @@ class PipelinedSynthesizer:
 
     _PER_UTT = ("texts", "refs", "text_ids")  # job keys that are per-utterance lists
 
-    def _coalesce(self, jobs: Sequence[Dict[str, Any]], n: int, ramp: bool = False):
+    def pass_sizes(self, n_jobs: int, coalesce) -> List[int]:
+        """How many consecutive jobs each pass of a run takes.  An integer ``coalesce``: that many per pass (the last one what is
+        left).  ``"auto"``: sized by the depth of the queue - two jobs per pass while the run is short (fewer than 8 jobs per lane:
+        every lane should still get several passes), four when it is deep: the AR frame chain costs little more for 128 rows than
+        for 64, the generation partition then has slack and the run is bound by refinement + decoding alone (steady state, four
+        lanes: 25.2 k audio-s/s at two per pass, 26.0-26.2 k at four / six / eight; profiles/r05_experiments.md).
+        (A single-job FIRST pass - the throughput partition gets its first work ~20 ms sooner - was measured again with every lane
+        warmed up on every pass shape: 23.6-23.7 k against 23.9-24.1 k in the 20-job form.  The four generation phases of a starting
+        pipeline share the chip, so the small pass is not ready much earlier, and the single job left over at the end drags a
+        50 ms generation phase behind the run.  Not adopted.)"""
+        if coalesce != "auto":
+            n = max(1, int(coalesce))
+        else:
+            n = 4 if n_jobs >= 8 * len(self.lanes) else 2
+        return [min(n, n_jobs - i) for i in range(0, n_jobs, n)]
+
+    def prepare(self, job: Dict[str, Any], sizes: Sequence[int] = (1, 2)) -> None:
+        """Deterministic warm-up: EVERY lane runs a pass of each size in ``sizes`` (that many copies of ``job`` coalesced) twice - the
+        first time eagerly (scratch allocation), the second time recording its launch sequences - one lane at a time, on its own
+        partition streams.  A scheduler that mixes pass sizes (``coalesce="auto"``) cannot rely on the run itself for that: which
+        lane meets which shape first is a race (round 4's ramp-up experiment fell to 14.7 k in one run of four that way)."""
+        for lane in self.lanes:
+            with torch.cuda.stream(lane.model.stream):
+                for sz in sorted({int(v) for v in sizes}):
+                    merged = self._coalesce([job] * sz, sz)[0][1] if sz > 1 else job
+                    for _ in range(2):
+                        lane.synthesize_batch(**merged)
+        torch.cuda.synchronize(self.device)
+
+    def _coalesce(self, jobs: Sequence[Dict[str, Any]], n, ramp: bool = False, sizes: Optional[Sequence[int]] = None):
         """Groups of up to ``n`` CONSECUTIVE jobs with equal sampling parameters become one pass over their concatenated
         utterances (the AR frame chain costs nearly the same for 64 rows as for 32: profiles/r03_experiments.md).  Every
         utterance keeps the sampler stream it has in its own job - that job's nonce and its index within the job (``nonces`` /
@@ -159,6 +188,8 @@ class PipelinedSynthesizer:
         without a ``seed`` takes the next nonce of the process-wide run counter here, in job order, which is not the order the
         passes later execute in (a seedless job is "a new take" either way)."""
         groups: List[List[int]] = []
+        caps = list(sizes) if sizes is not None else None  # explicit pass sizes (pass_sizes): group g takes at most caps[g] jobs
+        n = max(caps) if caps else int(n)
         for i, j in enumerate(jobs):
             head = jobs[groups[-1][0]] if groups else None
             # ``ramp`` (SOPRO_PIPE_RAMP=1; off by default): the first pass of a run stays a single job - its conditioning and
@@ -166,6 +197,8 @@ class PipelinedSynthesizer:
             # (profiles/r04_experiments.md): within the run-to-run spread, and the extra pass shape (32 rows next to 64) can land on
             # a lane that has not recorded its launch sequences yet - one run in four fell to 14.7 k
             cap = 1 if (ramp and len(groups) == 1) else n
+            if caps is not None and groups:
+                cap = caps[len(groups) - 1] if len(groups) - 1 < len(caps) else n
             same = bool(groups) and len(groups[-1]) < cap and all(
                 head.get(k) == j.get(k) for k in (set(j) | set(head)) - set(self._PER_UTT) - {"seed"})
             # ... and the same per-utterance lists present (one job with `texts`, its neighbour with `text_ids` do not merge)
@@ -190,11 +223,15 @@ class PipelinedSynthesizer:
             passes.append((g, merged, sizes))
         return passes
 
-    def run(self, jobs: Sequence[Dict[str, Any]], timings: Optional[Dict[str, float]] = None, coalesce: int = 1) -> List[Any]:
+    def run(self, jobs: Sequence[Dict[str, Any]], timings: Optional[Dict[str, float]] = None, coalesce=1) -> List[Any]:
         """Each job is the keyword dict of ``SoproTTS.synthesize_batch``; results come back in job order.  ``coalesce`` > 1:
-        consecutive compatible jobs are generated, refined and decoded together (see ``_coalesce``)."""
-        if coalesce > 1 and len(jobs) > 1:
-            passes = self._coalesce(jobs, int(coalesce), ramp=len(jobs) > 2 * int(coalesce) and os.environ.get("SOPRO_PIPE_RAMP", "0") == "1")
+        consecutive compatible jobs are generated, refined and decoded together (see ``_coalesce``); ``"auto"``: pass sizes chosen
+        from the queue depth (``pass_sizes``; call ``prepare`` first so that every lane has recorded every pass shape)."""
+        if (coalesce == "auto" or int(coalesce) > 1) and len(jobs) > 1:
+            if coalesce == "auto":
+                passes = self._coalesce(jobs, 0, sizes=self.pass_sizes(len(jobs), "auto"))
+            else:
+                passes = self._coalesce(jobs, int(coalesce), ramp=len(jobs) > 2 * int(coalesce) and os.environ.get("SOPRO_PIPE_RAMP", "0") == "1")
             outs = self.run([p[1] for p in passes], timings=timings)
             results: List[Any] = [None] * len(jobs)
             for (g, _m, sizes), out in zip(passes, outs):
@@ -240,6 +277,27 @@ class PipelinedSynthesizer:
                 self.ar_locks[slot.part].release()
                 return False
 
+        # Conditioning phases take turns IN JOB ORDER.  When a run starts, every lane conditions its first pass at the same moment
+        # on the same CUs: each took 11-12 ms instead of 3 (lane trace, r05 call 4), so the first generation phases - whose end is
+        # when the throughput partition gets its first work - started 8-9 ms late.  In steady state the phases rarely meet.
+        cond_turn = [0]
+        cond_cv = threading.Condition()
+
+        class _CondGate:
+            def __init__(gate, idx):
+                gate.idx = idx
+
+            def __enter__(gate):
+                with cond_cv:
+                    while cond_turn[0] < gate.idx and not errors:
+                        cond_cv.wait(timeout=0.05)
+
+            def __exit__(gate, *exc):
+                with cond_cv:
+                    cond_turn[0] = max(cond_turn[0], gate.idx + 1)
+                    cond_cv.notify_all()
+                return False
+
         class _BulkSlot:
             def __init__(slot, lane, lane_idx):
                 slot.lane, slot.lane_idx = lane, lane_idx
@@ -273,9 +331,11 @@ class PipelinedSynthesizer:
                     tj = {} if timings is not None else None
                     t_job = time.perf_counter()
                     try:
-                        results[i] = lane.synthesize_batch(phase_locks=(ar_lock, bulk_slot), timings=tj, **jobs[i])
+                        results[i] = lane.synthesize_batch(phase_locks=(ar_lock, bulk_slot, _CondGate(i)), timings=tj, **jobs[i])
                     except BaseException as e:  # noqa: BLE001
                         errors.append(e)
+                        with cond_cv:
+                            cond_cv.notify_all()
                         return
                     if tj is not None:
                         with pick:

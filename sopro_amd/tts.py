@@ -144,7 +144,10 @@ class SoproTTS:
         import time
 
         ids = list(text_ids) if text_ids is not None else [self.encode_text(t) for t in texts]
-        ar_lock, bulk_lock = phase_locks if phase_locks is not None else (contextlib.nullcontext(), contextlib.nullcontext())
+        locks = tuple(phase_locks) if phase_locks is not None else ()
+        ar_lock = locks[0] if len(locks) > 0 else contextlib.nullcontext()
+        bulk_lock = locks[1] if len(locks) > 1 else contextlib.nullcontext()
+        cond_gate = locks[2] if len(locks) > 2 else contextlib.nullcontext()  # (a pipeline: conditioning phases take turns in job order)
         ss = float(style_strength if style_strength is not None else self.cfg.style_strength)
         from .model import _PhaseTimer
 
@@ -152,7 +155,7 @@ class SoproTTS:
         # the phase's kernels are, and no phase ever waits on a stream another engine of a pipeline may be generating on.
         self.model.prep_stream.wait_stream(torch.cuda.current_stream(self.device))  # the caller's inputs
         # conditioning needs no generation slot: it overlaps with whatever the other engines are doing
-        with torch.cuda.stream(self.model.prep_stream):
+        with cond_gate, torch.cuda.stream(self.model.prep_stream):
             ev = _PhaseTimer(self.model.prep_stream, timings)
             # the stages of a pass hand their results over IN PLACE (round 5): conditioning writes into the AR plan's buffer, the
             # refinement reads that buffer and the plan's token history, the decoder reads the refinement's token matrix and writes
