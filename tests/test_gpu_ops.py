@@ -385,6 +385,77 @@ def test_gemm_eight_wave_tiles_are_the_same_function():
     both(raw_and_act)
 
 
+@pytest.mark.parametrize("K", [256, 384, 512])
+def test_gemm_activation_stationary_form_is_the_same_function(K):
+    """Round 5 (csrc/gemm_astat.hip): short-K contractions with the A block resident in LDS and barrier-free column-tile walks, tile
+    override 9, against the 128x128 tile kernel (override 1): the same products in the same order per output element, so plain /
+    GELU / residual (+ layer scale, in place) forms are bit-identical - with a ragged last row block, a ragged last column tile
+    (N % 256 != 0, N % 32 != 0), several column tiles per workgroup, segments with overlapping rows (lda < K: a convolution window)
+    - and both within fp32-fma class of the float64 product."""
+    lib = hip.load()
+    M, N = 4200, 1156  # 66 row blocks (the last one 40 rows), 5 column tiles (the last one 132 columns: 4 full + 1 ragged 32-tile)
+    A, W, b, R, sc = rnd(M, K, seed=91), rnd(N, K, seed=92, scale=K ** -0.5), rnd(N, seed=93), rnd(M, N, seed=94), rnd(N, seed=95)
+    Ad, bd, Rd, scd = dev(A), dev(b), dev(R), dev(sc)
+    Wp = hip.pack_w_bf16x3(dev(W))
+    ref = A.double() @ W.double().t() + b.double()
+    mag = A.double().abs() @ W.double().abs().t() + b.double().abs()
+
+    def both(fn, check=None):
+        outs = []
+        try:
+            for cfg in (1, 9):
+                lib.sopro_gemm_bf16_set_tile_override(cfg)
+                outs.append(fn().cpu())
+        finally:
+            lib.sopro_gemm_bf16_set_tile_override(0)
+        assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
+        if check is not None:
+            check(outs[1])
+
+    def plain():
+        C = torch.full((M, N), float("nan"), device=DEV)
+        hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd)
+        torch.cuda.synchronize()
+        return C
+    both(plain, lambda C: (lambda e: e < 2e-5)(float(((C.double() - ref).abs() / mag).max())) or pytest.fail("three-pass error class"))
+
+    def gelu():
+        C = torch.full((M, N), float("nan"), device=DEV)
+        hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd, epilogue=hip.EPI_GELU)
+        torch.cuda.synchronize()
+        return C
+    both(gelu)
+
+    def res_in_place():  # x <- x + scale * (A W^T + b): R aliases C
+        C = Rd.clone()
+        hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd, epilogue=hip.EPI_RES, R=C, scale=scd)
+        torch.cuda.synchronize()
+        return C
+    both(res_in_place, lambda C: (lambda e: e < 1e-4)(float((C.double() - (R.double() + sc.double() * ref)).abs().max())) or pytest.fail("residual form"))
+
+    # segments of overlapping rows: 3 utterances x (2 zero rows + 700 rows) of K / 2 channels, A-row t = [x[t-1] | x[t]] (lda = K / 2)
+    Cin, T, B = K // 2, 700, 3
+    xs = torch.zeros(B, 1 + T, Cin)
+    xs[:, 1:] = rnd(B, T, Cin, seed=96)
+    xd = dev(xs)
+    N2 = 320
+
+    def conv_window():
+        C = torch.full((B, T, N2), float("nan"), device=DEV)
+        hip.gemm(xd, hip.pack_w_bf16x3(dev(W[:N2])), C, M=B * T, N=N2, K=K, lda=Cin, rows_per_seg=T, a_seg_stride=(1 + T) * Cin, c_seg_stride=T * N2)
+        torch.cuda.synchronize()
+        return C
+    lib.sopro_gemm_bf16_set_tile_override(9)
+    try:
+        got = conv_window().cpu()
+    finally:
+        lib.sopro_gemm_bf16_set_tile_override(0)
+    win = torch.cat([xs[:, :-1], xs[:, 1:]], dim=-1)  # [B, T, K]
+    want = win.double() @ W[:N2].double().t()
+    assert float((got.double() - want).abs().max()) < 1e-4
+    both(conv_window)
+
+
 @pytest.mark.parametrize("pieces,M,N,K,epi", [(3, 6, 384, 1536, "res"), (3, 6, 768, 1152, "glu"), (3, 12, 2048, 1024, "none"), (2, 12, 512, 2048, "res"),
                                               (2, 12, 1024, 3584, "none"), (2, 33, 4096, 2048, "none"), (3, 1, 64, 1536, "gelu")])
 def test_gemm_split_k_small_m_is_exact_class_and_deterministic(pieces, M, N, K, epi):
