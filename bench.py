@@ -253,8 +253,12 @@ def run_leg(tts, ids, refs, *, frames: int, steps: int, lanes: int, args, seed: 
 
 
 def coalesce_arg(v):
-    """--coalesce: an integer (jobs per pass) or "auto" (PipelinedSynthesizer.pass_sizes: 2 per pass for short runs, 4 from 8 queued jobs per lane)."""
-    return "auto" if str(v) == "auto" else max(1, int(v))
+    """--coalesce: an integer (jobs per pass) or "auto" (PipelinedSynthesizer.pass_sizes: 2 per pass for short queues, 4 from 4 queued jobs per lane)."""
+    if str(v) == "auto":
+        return "auto"
+    if "," in str(v):  # explicit pass sizes, e.g. "4,4,6,6" (developer sweeps)
+        return [max(1, int(x)) for x in str(v).split(",")]
+    return max(1, int(v))
 
 
 def bf16_quality(tts, tts16, ids, refs, frames: int, cfg, n: int = 4) -> dict:
@@ -364,7 +368,7 @@ def main() -> None:
                     help="f32 (default): the parity configuration; bf16: bf16 weights/operands with fp32 accumulation (BASELINE configs[1] wording)")
     ap.add_argument("--frames", type=int, default=FRAMES, help="frames per utterance (default: BASELINE configs[1]; 400 = the long-form case)")
     ap.add_argument("--coalesce", default="auto", help="consecutive batches the pipeline generates / refines / decodes as ONE pass (per-utterance results are unchanged): "
-                    "an integer, or 'auto' = sized by the queue depth (2 per pass for short runs, 4 from 8 queued batches per lane)")
+                    "an integer, or 'auto' = sized by the queue depth (2 per pass for short queues, 4 from 4 queued batches per lane)")
     ap.add_argument("--voices", type=int, default=-1, help="distinct reference voices per batch (default: one per utterance, SURVEY 8d; 1 = one shared voice)")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs of the default run (one shared voice, 32x400 / 1x400 frames, bf16 mode)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)

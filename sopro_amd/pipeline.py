@@ -153,18 +153,29 @@ class PipelinedSynthesizer:
 
     def pass_sizes(self, n_jobs: int, coalesce) -> List[int]:
         """How many consecutive jobs each pass of a run takes.  An integer ``coalesce``: that many per pass (the last one what is
-        left).  ``"auto"``: sized by the depth of the queue - two jobs per pass while the run is short (fewer than 8 jobs per lane:
-        every lane should still get several passes), four when it is deep: the AR frame chain costs little more for 128 rows than
-        for 64, the generation partition then has slack and the run is bound by refinement + decoding alone (steady state, four
-        lanes: 25.2 k audio-s/s at two per pass, 26.0-26.2 k at four / six / eight; profiles/r05_experiments.md).
-        (A single-job FIRST pass - the throughput partition gets its first work ~20 ms sooner - was measured again with every lane
-        warmed up on every pass shape: 23.6-23.7 k against 23.9-24.1 k in the 20-job form.  The four generation phases of a starting
-        pipeline share the chip, so the small pass is not ready much earlier, and the single job left over at the end drags a
-        50 ms generation phase behind the run.  Not adopted.)"""
+        left); a list: explicit sizes (developer sweeps).  ``"auto"``: FOUR jobs per pass once the queue holds four jobs per lane,
+        two below that.  The AR frame chain costs little more for 128 rows than for 64 (two phases at a time: 27-30 ms of AR phases
+        per 32-utterance job instead of 35), so the generation partition gets slack and the run is bound by refinement + decoding
+        alone - measured (profiles/r05_experiments.md section 3): steady state 25.2 k audio-s/s at two per pass, 26.0-26.2 k at
+        four / six / eight; the 20-job driver form 23.6-24.0 k at two, 24.6-25.0 k at four (five equal passes on four lanes).
+        Mixed sizes lose: a smaller first pass (the throughput partition gets its first work sooner) was measured with every lane
+        warmed up on every shape - [1, 2 x 9, 1] 23.6-23.7 k, [2, 4, 4, 4, 4, 2] 24.3-24.4 k, [3, 4, 4, 4, 5] 24.1-24.3 k,
+        [2, 2, 4, 4, 4, 4] 23.4 k against 24.9-25.0 k for [4] x 5 on the same box."""
+        if isinstance(coalesce, (list, tuple)):  # explicit sizes (developer sweeps); what they leave over runs n-at-a-time with their last size
+            sizes, left = [], n_jobs
+            for v in coalesce:
+                if left <= 0:
+                    break
+                sizes.append(min(max(1, int(v)), left))
+                left -= sizes[-1]
+            while left > 0:
+                sizes.append(min(sizes[-1], left))
+                left -= sizes[-1]
+            return sizes
         if coalesce != "auto":
             n = max(1, int(coalesce))
         else:
-            n = 4 if n_jobs >= 8 * len(self.lanes) else 2
+            n = 4 if n_jobs >= 4 * len(self.lanes) else 2
         return [min(n, n_jobs - i) for i in range(0, n_jobs, n)]
 
     def prepare(self, job: Dict[str, Any], sizes: Sequence[int] = (1, 2)) -> None:
@@ -227,9 +238,9 @@ class PipelinedSynthesizer:
         """Each job is the keyword dict of ``SoproTTS.synthesize_batch``; results come back in job order.  ``coalesce`` > 1:
         consecutive compatible jobs are generated, refined and decoded together (see ``_coalesce``); ``"auto"``: pass sizes chosen
         from the queue depth (``pass_sizes``; call ``prepare`` first so that every lane has recorded every pass shape)."""
-        if (coalesce == "auto" or int(coalesce) > 1) and len(jobs) > 1:
-            if coalesce == "auto":
-                passes = self._coalesce(jobs, 0, sizes=self.pass_sizes(len(jobs), "auto"))
+        if (coalesce == "auto" or isinstance(coalesce, (list, tuple)) or int(coalesce) > 1) and len(jobs) > 1:
+            if coalesce == "auto" or isinstance(coalesce, (list, tuple)):
+                passes = self._coalesce(jobs, 0, sizes=self.pass_sizes(len(jobs), coalesce))
             else:
                 passes = self._coalesce(jobs, int(coalesce), ramp=len(jobs) > 2 * int(coalesce) and os.environ.get("SOPRO_PIPE_RAMP", "0") == "1")
             outs = self.run([p[1] for p in passes], timings=timings)

@@ -74,15 +74,16 @@ def test_ramp_keeps_the_first_pass_single():
 
 
 def test_pass_sizes_follow_the_queue_depth():
-    """PipelinedSynthesizer.pass_sizes (round 5): an integer = that many jobs per pass; "auto" = 2 per pass for short runs, 4 from 8 queued jobs
-    per lane; every job lands in exactly one pass."""
+    """PipelinedSynthesizer.pass_sizes (round 5): an integer = that many jobs per pass; "auto" = 2 per pass for short queues, 4 from 4 queued jobs
+    per lane; a list = explicit sizes; every job lands in exactly one pass."""
     from sopro_amd.pipeline import PipelinedSynthesizer
 
     p = PipelinedSynthesizer.__new__(PipelinedSynthesizer)
     p.lanes = [None] * 4
     assert p.pass_sizes(20, 2) == [2] * 10 and p.pass_sizes(7, 3) == [3, 3, 1] and p.pass_sizes(5, 1) == [1] * 5
-    assert p.pass_sizes(20, "auto") == [2] * 10
+    assert p.pass_sizes(20, "auto") == [4] * 5 and p.pass_sizes(12, "auto") == [2] * 6
     assert p.pass_sizes(32, "auto") == [4] * 8 and p.pass_sizes(35, "auto") == [4] * 8 + [3]
     assert p.pass_sizes(4, "auto") == [2, 2] and p.pass_sizes(1, "auto") == [1]
+    assert p.pass_sizes(20, [2, 4, 4]) == [2, 4, 4, 4, 4, 2] and p.pass_sizes(5, [8]) == [5]
     for n in range(1, 70):
         assert sum(p.pass_sizes(n, "auto")) == n and min(p.pass_sizes(n, "auto")) >= 1
