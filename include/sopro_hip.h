@@ -76,7 +76,9 @@ int sopro_copy_to_host_async(void* dst_host, const void* src_dev, int64_t bytes,
 /* ---- dense contraction ------------------------------------------------------------------ */
 enum { SOPRO_PRO_NONE = 0, SOPRO_PRO_ELU = 1, SOPRO_PRO_ADDVEC = 2 };
 enum { SOPRO_EPI_NONE = 0, SOPRO_EPI_GELU = 1, SOPRO_EPI_GLU = 2, SOPRO_EPI_RES = 3, SOPRO_EPI_TANH = 4,
-       SOPRO_EPI_GLU_DW = 5 /* skinny only */ };
+       SOPRO_EPI_GLU_DW = 5 /* skinny only */,
+       SOPRO_EPI_ROPE = 6 /* sopro_gemm_bf16x3 / _bf16x1 only (round 5): rotate-half RoPE of the first rope_cols output columns in the
+                           * epilogue - the q | k blocks of a fused qkv projection (HF:modeling_mimi.py:511-566) - see sopro_gemm_split_ext */ };
 
 /* C[m, n] = epi( sum_k pro(A[m, k]) * W[n, k] + bias[n] ),  fp32 in / fp32 accumulate on
  * v_mfma_f32_32x32x2_f32 (bit-equal to an fmaf chain).
@@ -150,6 +152,12 @@ typedef struct sopro_gemm_split_ext {
                           * at fp16's largest finite value (|a * scale| > 65504: the result is finite and wrong) adds 1.  Plain forms scale by
                           * sopro_f16x3_a_scale() (|a| <= 8188 is in range); fused-RMSNorm forms choose a power of two per row from the row's
                           * first 32 elements (256x headroom).  A caller that finds the word changed repeats the work on sopro_gemm_bf16x6. */
+  /* SOPRO_EPI_ROPE: columns [0, rope_cols) are heads of rope_dh columns (a power of two <= 128 that divides the column tile); row m sits at
+   * position rope_pos0 + m % rope_rows_per_seg; cos / sin tables [positions][rope_dh / 2] as sopro_rope_f32 takes them.  The epilogue holds
+   * the whole tile in LDS, so a column's partner (+- rope_dh / 2) is at hand: out[e] = a c - b s, out[e + dh/2] = b c + a s - what
+   * sopro_rope_f32 would do to C in a pass of its own (105 MB read + written per decoder layer at 64 x 200 frames). */
+  const float* rope_cos; const float* rope_sin;
+  int32_t rope_cols, rope_dh, rope_pos0, rope_rows_per_seg;
 } sopro_gemm_split_ext;
 int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
 /* Six-pass variant for token paths (NAR refinement, conditioning: src/sopro/nn/nar.py, blocks.py): operands split into

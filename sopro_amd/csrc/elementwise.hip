@@ -144,6 +144,67 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
   *reinterpret_cast<float4*>(out + o) = acc;
 }
 
+// The same convolution with every input row loaded ONCE per CI outputs instead of once per tap (round 5).  Outputs t, t + dil,
+// t + 2 dil, ... read the same rows: a thread takes a COMB of CI = 8 outputs of one residue class (t = r + (i0 + i) dil) of one
+// channel quad; their ksize taps each touch only the CI + ksize - 1 rows r - left + (i0 + u) dil, u = 0 .. CI + ksize - 2: 18 row
+// loads for 8 outputs at ksize 11 where dwconv_kernel issues 88 (the refinement's 24 launches per 64-row pass ran at 1.6 TB/s of
+// algorithmic traffic, bound by those requests, not by memory).  Per output the taps are accumulated in the same order with the
+// same skips, so results are bit-identical to dwconv_kernel.
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_comb_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, const float* __restrict__ res,
+                                                          float* __restrict__ out, const int* __restrict__ lens, int B, int T,
+                                                          int C, int dil, int left, int mode, int per_r) {
+  constexpr int CI = 8, NW = CI + KS - 1;
+  const int c4n = C >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * dil * per_r * c4n) return;
+  const int c4 = (int)(idx % c4n);
+  int64_t k = idx / c4n;
+  const int chunk = (int)(k % per_r);
+  k /= per_r;
+  const int r = (int)(k % dil), b = (int)(k / dil);
+  const int i0 = chunk * CI;
+  if (r + (int64_t)i0 * dil >= T) return;
+  const int len = lens ? min(lens[b], T) : T;
+  const float* xb = x + (int64_t)b * T * C + c4 * 4;
+  float4 xv[NW];
+  unsigned okm = 0u;
+#pragma unroll
+  for (int u = 0; u < NW; ++u) {
+    const int64_t ts = (int64_t)r - left + (int64_t)(i0 + u) * dil;
+    const bool ok = ts >= 0 && ts < len;
+    okm |= ok ? (1u << u) : 0u;
+    xv[u] = ok ? *reinterpret_cast<const float4*>(xb + ts * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 wv[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) wv[j] = *reinterpret_cast<const float4*>(w + (int64_t)j * C + c4 * 4);
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bv = *reinterpret_cast<const float4*>(bias + c4 * 4);
+#pragma unroll
+  for (int i = 0; i < CI; ++i) {
+    const int t = r + (i0 + i) * dil;
+    if (t >= T) break;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      if (!((okm >> (i + j)) & 1u)) continue;
+      const float4 xq = xv[i + j];
+      acc.x += xq.x * wv[j].x; acc.y += xq.y * wv[j].y; acc.z += xq.z * wv[j].z; acc.w += xq.w * wv[j].w;
+    }
+    if (bias) { acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }
+    const int64_t o = ((int64_t)b * T + t) * C + c4 * 4;
+    if (mode == 1) {
+      const float4 rv = *reinterpret_cast<const float4*>(res + o);
+      acc.x += rv.x; acc.y += rv.y; acc.z += rv.z; acc.w += rv.w;
+    } else if (mode == 2) {
+      acc.x = gelu_erf(acc.x); acc.y = gelu_erf(acc.y); acc.z = gelu_erf(acc.z); acc.w = gelu_erf(acc.w);
+    }
+    *reinterpret_cast<float4*>(out + o) = acc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // embedding gathers
 // ---------------------------------------------------------------------------------------------
@@ -513,6 +574,18 @@ int sopro_dwconv_f32(const float* x, const float* w, const float* bias, const fl
   SOPRO_CHECK_ARG(ksize >= 1 && dil >= 1 && left >= 0 && mode >= 0 && mode <= 2, "bad conv geometry or mode");
   SOPRO_CHECK_ARG(mode != 1 || res, "mode 1 needs res");
   SOPRO_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(out), "pointers must be 16-byte aligned");
+  SOPRO_CHECK_ARG((!bias || aligned16(bias)) && (!res || aligned16(res)), "bias / res must be 16-byte aligned");
+  // long inputs of the two kernel sizes the model has (refinement 11, encoders 7): the comb form (same results, 1 / 5 of the requests)
+  static const bool comb_off = SOPRO_DEV_ENV("SOPRO_DWCONV_COMB") != nullptr && SOPRO_DEV_ENV("SOPRO_DWCONV_COMB")[0] == '0';  // developer A/B
+  if (!comb_off && (ksize == 11 || ksize == 7) && (int64_t)B * T >= 1024 && T >= 8 * dil) {
+    const int per_r = ((T + dil - 1) / dil + 7) / 8;
+    const dim3 grid(nblk((int64_t)B * dil * per_r * (C / 4), 256));
+    if (ksize == 11)
+      hipLaunchKernelGGL(dwconv_comb_kernel<11>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, res, out, lens, B, T, C, dil, left, mode, per_r);
+    else
+      hipLaunchKernelGGL(dwconv_comb_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, res, out, lens, B, T, C, dil, left, mode, per_r);
+    SOPRO_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(dwconv_kernel, dim3(nblk((int64_t)B * T * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                      res, out, lens, B, T, C, ksize, dil, left, mode);
   SOPRO_LAUNCH_CHECK();

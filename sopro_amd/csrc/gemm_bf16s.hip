@@ -536,6 +536,7 @@ int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 0);  // transformer qkv, RVQ output projections
     SOPRO_CASE(SOPRO_EPI_GELU, 0, 0);  // transformer fc1
     SOPRO_CASE(SOPRO_EPI_RES, 0, 0);   // transformer o / fc2 (+ layer scale)
+    SOPRO_CASE(SOPRO_EPI_ROPE, 0, 0);  // transformer qkv with the rotary embedding of q | k in the epilogue (round 5)
     SOPRO_CASE(SOPRO_EPI_NONE, 1, 0);  // fp32 activations with an ELU prologue (SEANet convs)
     SOPRO_CASE(SOPRO_EPI_RES, 1, 0);
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 3);  // activated-copy flow of the SEANet decoder: ELU applied once, by the producer
@@ -605,6 +606,18 @@ int launch_argmax(sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_ge
   static const bool tm1 = SOPRO_DEV_ENV("SOPRO_ARGMAX_TM") != nullptr && SOPRO_DEV_ENV("SOPRO_ARGMAX_TM")[0] == '1';
   if (g.M >= 8192 && !tm1) return launch_one<NPL, 2, 2, 2, 1, SOPRO_EPI_NONE, 0, 5, F16>(g, wp, ksubs, ext, s);
   return launch_one<NPL, 2, 2, 1, 1, SOPRO_EPI_NONE, 0, 5, F16>(g, wp, ksubs, ext, s);
+}
+
+int check_rope(const sopro_gemm_args& g, const sopro_gemm_split_ext& ext) {
+  if (g.epilogue != SOPRO_EPI_ROPE) return 0;
+  const int dh = ext.rope_dh;
+  SOPRO_CHECK_ARG(ext.rope_cos && ext.rope_sin && aligned16(ext.rope_cos) && aligned16(ext.rope_sin), "EPI_ROPE needs 16-byte aligned cos / sin tables");
+  SOPRO_CHECK_ARG(dh >= 8 && dh <= 64 && (dh & (dh - 1)) == 0, "EPI_ROPE: rope_dh must be a power of two in 8..64 (heads must not straddle a 64-column tile)");
+  SOPRO_CHECK_ARG(ext.rope_cols > 0 && ext.rope_cols <= g.N && ext.rope_cols % dh == 0, "EPI_ROPE: rope_cols must be whole heads within N");
+  SOPRO_CHECK_ARG(ext.rope_rows_per_seg > 0 && ext.rope_pos0 >= 0, "EPI_ROPE: rope_rows_per_seg > 0, rope_pos0 >= 0");
+  SOPRO_CHECK_ARG(ext.c_mode == 0 && ext.a_format == 0 && g.prologue == SOPRO_PRO_NONE && !ext.rms_norm, "EPI_ROPE is a plain fp32-rows form");
+  SOPRO_CHECK_ARG((g.N & 3) == 0 && (g.ldc & 3) == 0 && (g.c_seg_stride & 3) == 0 && aligned16(g.C), "EPI_ROPE: 16-byte aligned output rows");
+  return 0;
 }
 
 int check_common(sopro_gemm_args& g, sopro_gemm_split_ext& ext, const void* packed_w) {
@@ -685,8 +698,9 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
   if (ext.group_m == 0) ext.group_m = g_group_m;
   if (int rc = check_common(g, ext, packed_w)) return rc;
   SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ELU, "prologue must be NONE or ELU");
-  SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES,
-                  "epilogue must be NONE, GELU or RES");
+  SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES || g.epilogue == SOPRO_EPI_ROPE,
+                  "epilogue must be NONE, GELU, RES or ROPE");
+  if (int rc = check_rope(g, ext)) return rc;
   SOPRO_CHECK_ARG(ext.a_format == 0 || ext.a_format == 1, "a_format must be 0 (fp32) or 1 (split form)");
   SOPRO_CHECK_ARG(!ext.rms_norm, "fused RMSNorm is a six-pass (sopro_gemm_bf16x6) feature");
   if (ext.a_format == 1) {
@@ -774,7 +788,9 @@ extern "C" int sopro_gemm_bf16x1(const sopro_gemm_args* a, const void* packed_w,
     return small ? launch_cfg6<1, 2, 2, 1, 1>(g, wp, ksubs, ext, s) : launch_cfg6<1, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
   }
   SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ELU, "prologue must be NONE, ELU or ADDVEC");
-  SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES, "epilogue must be NONE, GELU, RES or GLU");
+  SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES || g.epilogue == SOPRO_EPI_ROPE,
+                  "epilogue must be NONE, GELU, RES, GLU or ROPE");
+  if (int rc = check_rope(g, ext)) return rc;
   return small ? launch_cfg3<1, 2, 2, 1, 1>(g, wp, ksubs, ext, s) : launch_cfg3<1, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
 }
 

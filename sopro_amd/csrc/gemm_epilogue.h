@@ -211,6 +211,19 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
         v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
       } else if (res) {
         v.x = rv[q].x + sc4.x * v.x; v.y = rv[q].y + sc4.y * v.y; v.z = rv[q].z + sc4.z * v.z; v.w = rv[q].w + sc4.w * v.w;
+      } else if (EPI == SOPRO_EPI_ROPE) {
+        // rotate-half RoPE of the q | k heads in the leading rope_cols columns: the partner column (+- dh / 2) is in the LDS tile, the
+        // position is the row's index within its utterance (sopro_rope_f32's arithmetic, without its pass over C)
+        if (ncol < ext->rope_cols) {
+          const int half = ext->rope_dh >> 1, e = ncol & (ext->rope_dh - 1);
+          const bool lowh = e < half;
+          const float4 pv = *reinterpret_cast<const float4*>(csrc + (p0 + q) * RPP * CLD + (lowh ? half : -half));
+          const int mq = m0 + prow + (p0 + q) * RPP;
+          const int64_t ti = (int64_t)(ext->rope_pos0 + mq % ext->rope_rows_per_seg) * half + (e & (half - 1));
+          const float4 c4 = *reinterpret_cast<const float4*>(ext->rope_cos + ti), s4 = *reinterpret_cast<const float4*>(ext->rope_sin + ti);
+          if (lowh) { v.x = v.x * c4.x - pv.x * s4.x; v.y = v.y * c4.y - pv.y * s4.y; v.z = v.z * c4.z - pv.z * s4.z; v.w = v.w * c4.w - pv.w * s4.w; }
+          else { v.x = v.x * c4.x + pv.x * s4.x; v.y = v.y * c4.y + pv.y * s4.y; v.z = v.z * c4.z + pv.z * s4.z; v.w = v.w * c4.w + pv.w * s4.w; }
+        }
       }
       if (split_out) {  // host guarantees N % 4 == 0 and 128-byte aligned rows
         uint2 h, l;

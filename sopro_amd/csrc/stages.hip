@@ -235,6 +235,8 @@ struct G {  // one contraction: mirrors sopro_amd.hip.gemm's keyword arguments
   float rms_eps = 0.f;
   const SplitK* sk = nullptr;  // non-NULL: few-row problems may run split-K on this scratch
   int32_t* range_events = nullptr;  // f16 operands: the call's range-event word (sopro_gemm_split_ext.range_events)
+  const float *rope_cos = nullptr, *rope_sin = nullptr;  // epi = SOPRO_EPI_ROPE (sopro_gemm_split_ext.rope_*)
+  int rope_cols = 0, rope_dh = 0, rope_pos0 = 0, rope_rps = 0;
 };
 
 // attention launch with its timing scope: 4 * dh flops per visible (query, key) pair
@@ -285,6 +287,8 @@ int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override
     x.ldc2 = o.ldc2 < 0 ? n_out : o.ldc2;
     x.c2_seg_stride = o.c2_seg;
     if (o.rms_eps > 0.f) { x.rms_norm = 1; x.rms_eps = o.rms_eps; }
+    x.rope_cos = o.rope_cos; x.rope_sin = o.rope_sin; x.rope_cols = o.rope_cols; x.rope_dh = o.rope_dh; x.rope_pos0 = o.rope_pos0;
+    x.rope_rows_per_seg = o.rope_rps;
     static const bool no_splitk = getenv("SOPRO_NO_SPLITK") && getenv("SOPRO_NO_SPLITK")[0] == '1';  // developer switch
     if (!no_splitk && o.sk && o.sk->ws && o.rms_eps <= 0.f && o.c_mode != 5) {
       const int ks = auto_ksplit(o.M, o.N, o.K, w.f16 ? 3 : w.pieces, o.epi);
@@ -1128,9 +1132,17 @@ static int transformer_stack(sopro_engine* e, hipStream_t s, const char* pre, fl
     const std::string p = std::string(pre) + "." + std::to_string(l);
     STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln1.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln1.b"), nullptr, nullptr, n, xs));
     G qg; qg.sk = &w.sk; qg.M = B * n; qg.N = 3 * HS; qg.K = HS;
+    // queries and keys are 2 H consecutive heads of dh columns.  The decoder's packed (split-bf16) contraction rotates them in its
+    // epilogue (round 5: SOPRO_EPI_ROPE - the tile is in LDS, a column's partner is at hand; sopro_rope_f32 re-read and re-wrote
+    // 105 MB per layer at 64 x 200 frames: 67 us x 8 per pass); the encoder's exact-fp32 contraction keeps the pass of its own
+    static const bool rope_off = SOPRO_DEV_ENV("SOPRO_ROPE_FUSE") != nullptr && SOPRO_DEV_ENV("SOPRO_ROPE_FUSE")[0] == '0';  // developer A/B
+    const bool fused_rope = !rope_off && WT(e, p + ".qkv.w").packed != nullptr && dh <= 64 && (dh & (dh - 1)) == 0;
+    if (fused_rope) {
+      qg.epi = SOPRO_EPI_ROPE; qg.rope_cos = F(e, "rope.cos"); qg.rope_sin = F(e, "rope.sin"); qg.rope_cols = 2 * H * dh; qg.rope_dh = dh;
+      qg.rope_pos0 = past; qg.rope_rps = n;
+    }
     STG(gemm(s, w.y, WT(e, p + ".qkv.w"), nullptr, w.qkv, qg));
-    // queries and keys in one launch: their heads are 2 H consecutive blocks of dh columns
-    STG(sopro_rope_f32(w.qkv, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, past, 2 * H, dh, s));
+    if (!fused_rope) STG(sopro_rope_f32(w.qkv, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, past, 2 * H, dh, s));
     sopro_attn_args a;
     memset(&a, 0, sizeof(a));
     a.Q = w.qkv; a.ldq = 3 * HS; a.q_bstride = (int64_t)n * 3 * HS;

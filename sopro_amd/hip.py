@@ -21,6 +21,7 @@ ABI_VERSION = 39
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
+EPI_ROPE = 6  # rotate-half RoPE of the leading columns in the contraction's epilogue (sopro_gemm_split_ext.rope_*)
 EPI_NONE, EPI_GELU, EPI_GLU, EPI_RES, EPI_TANH, EPI_GLU_DW = 0, 1, 2, 3, 4, 5
 NORM_RMS, NORM_LN = 0, 1
 
@@ -38,7 +39,8 @@ class GemmArgs(C.Structure):
 class SplitExt(C.Structure):
     _fields_ = [("a_format", _i32), ("c_mode", _i32), ("C2", _p), ("ldc2", _i64), ("c2_seg_stride", _i64),
                 ("rms_norm", _i32), ("rms_eps", _f32), ("ksplit", _i32), ("n_tickets", _i32), ("ws", _p), ("ws_bytes", _i64),
-                ("tickets", _p), ("group_m", _i32), ("acc_scale", _f32), ("range_events", _p)]
+                ("tickets", _p), ("group_m", _i32), ("acc_scale", _f32), ("range_events", _p), ("rope_cos", _p), ("rope_sin", _p),
+                ("rope_cols", _i32), ("rope_dh", _i32), ("rope_pos0", _i32), ("rope_rows_per_seg", _i32)]
 
 
 class SkinnyArgs(C.Structure):
@@ -370,7 +372,7 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
          a_seg_stride: int = 0, c_seg_stride: int = 0, r_seg_stride: int = 0, a_off: int = 0, c_off: int = 0,
          r_off: int = 0, ldw: Optional[int] = None, dbg: Optional[torch.Tensor] = None, a_split: bool = False, c_mode: int = 0,
          C2: Optional[torch.Tensor] = None, ldc2: Optional[int] = None, c2_seg_stride: int = 0,
-         c2_off: int = 0, rms_eps: float = 0.0, range_events: Optional[torch.Tensor] = None) -> None:
+         c2_off: int = 0, rms_eps: float = 0.0, range_events: Optional[torch.Tensor] = None, rope: Optional[tuple] = None) -> None:
     """C = epi(pro(A) @ W^T + bias); offsets are in elements from the tensors' first element.  With a ``PackedW`` weight the
     contraction runs on the split-bf16 path, where ``a_split`` says A is in split form and ``c_mode`` 1 / 2 writes
     ELU(C) in split form (to C, or to C2 next to the fp32 C): see sopro_gemm_split_ext in include/sopro_hip.h."""
@@ -404,6 +406,9 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
     x = None
     if packed:
         x = SplitExt()
+        if rope is not None:  # (cos table, sin table, columns, head dim, first position, rows per utterance): EPI_ROPE
+            x.rope_cos, x.rope_sin = ptr(rope[0]), ptr(rope[1])
+            x.rope_cols, x.rope_dh, x.rope_pos0, x.rope_rows_per_seg = int(rope[2]), int(rope[3]), int(rope[4]), int(rope[5])
         if rms_eps > 0.0:  # fused RMSNorm of the A rows (W must carry the norm's weight vector)
             if W.pieces == 2 and not W.f16:
                 raise SoproHipError("fused RMSNorm is a six-pass (pieces = 3), f16 three-pass or one-pass (pieces = 1) feature")

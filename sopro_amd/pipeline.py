@@ -22,7 +22,8 @@ from . import hip
 
 
 class PipelinedSynthesizer:
-    def __init__(self, tts, lanes: int = 2, ar_cus: int = 64, ar_parts: int = 1, ar_shared: bool = False, bulk_slots: int = 1):
+    def __init__(self, tts, lanes: int = 2, ar_cus: int = 64, ar_parts: int = 1, ar_shared: bool = False, bulk_slots: int = 1,
+                 prep_on_ar: Optional[bool] = None):
         """``ar_parts`` AR partitions of ``ar_cus`` CUs each (the AR phase is launch-latency bound, so independent
         partitions generate independent batches concurrently); the remaining CUs form the one bulk partition.
         Lane i generates on partition i % ar_parts.  With ``ar_shared`` the partitions are ONE CU range of ``ar_cus`` CUs
@@ -56,6 +57,11 @@ class PipelinedSynthesizer:
             lane.model.stream = mk(0 if ar_shared else (i % ar_parts) * ar_cus, ar_cus)
             lane.model.bulk_stream = mk(bulk0, total - bulk0)
             lane.model.prep_stream = lane.model.bulk_stream  # idle while this lane generates; GEMM-shaped preparation belongs there
+            if prep_on_ar if prep_on_ar is not None else os.environ.get("SOPRO_PREP_ON_AR", "0") == "1":
+                # (with four jobs per pass the generation partition has slack and the throughput partition is the bound: the
+                # per-pass preparation - conditioning, text folding - on a stream of its own over the GENERATION partition's CUs)
+                lane.model.prep_stream = mk(0 if ar_shared else (i % ar_parts) * ar_cus, ar_cus)
+                self._streams.append(lane.model.prep_stream)
             self._streams += [lane.model.stream, lane.model.bulk_stream]
             lane.codec.stream = lane.model.bulk_stream
             lane.model._ar_cache.clear()  # recorded graphs belong to the stream they were captured on

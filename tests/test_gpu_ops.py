@@ -385,6 +385,42 @@ def test_gemm_eight_wave_tiles_are_the_same_function():
     both(raw_and_act)
 
 
+@pytest.mark.parametrize("pieces,M", [(2, 3 * 400), (1, 3 * 400), (2, 2 * 6)])
+def test_gemm_rope_epilogue_equals_the_contraction_followed_by_rope(pieces, M):
+    """Round 5: SOPRO_EPI_ROPE rotates the q | k heads of a fused qkv projection in the contraction's epilogue (the tile is in LDS, a
+    column's partner is at hand) instead of a pass of sopro_rope_f32 over C (HF:modeling_mimi.py:511-566).  Same arithmetic: equal to
+    contraction + rope up to the contraction of a multiply-add (1 ulp class), on 128x128 tiles (many rows), 64x64 tiles and split-K
+    (a streaming chunk's few rows), three-pass and one-pass operands; the v block is left alone; positions restart per utterance."""
+    from sopro_amd.pack import rope_tables
+
+    HS, H, dh, K = 512, 8, 64, 512
+    N = 3 * HS
+    n = M // (3 if M >= 1200 else 2)  # rows per utterance
+    A, W, b = rnd(M, K, seed=71), rnd(N, K, seed=72, scale=K ** -0.5), rnd(N, seed=73)
+    cos_t, sin_t = (t.to(DEV) for t in rope_tables(1024, dh, 10000.0))
+    Ad, bd = dev(A), dev(b)
+    Wp = hip.pack_w_bf16(dev(W), pieces)
+    pos0 = 37
+    want = torch.empty(M, N, device=DEV)
+    hip.gemm(Ad, Wp, want, M=M, N=N, K=K, bias=bd)
+    v_before = want[:, 2 * HS:].clone()
+    hip.rope(want, cos_t, sin_t, rows=M, rows_per_seg=n, pos0=pos0, H=2 * H, dh=dh, ldx=N)
+    got = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(Ad, Wp, got, M=M, N=N, K=K, bias=bd, epilogue=hip.EPI_ROPE, rope=(cos_t, sin_t, 2 * HS, dh, pos0, n))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got).all())
+    assert torch.equal(got[:, 2 * HS:], v_before)  # v: untouched
+    err = float((got - want).abs().max())
+    assert err <= 4e-6 * float(want.abs().max()), err
+    # ... and it is a rotation: norms of (e, e + dh/2) pairs are those of the unrotated projection
+    raw = torch.empty(M, N, device=DEV)
+    hip.gemm(Ad, Wp, raw, M=M, N=N, K=K, bias=bd)
+    pr = lambda t: (t[:, :2 * HS].reshape(M, 2 * H, 2, dh // 2) ** 2).sum(2)
+    assert float((pr(got) - pr(raw)).abs().max()) <= 1e-4 * float(pr(raw).max())
+    with pytest.raises(hip.SoproHipError):  # heads must be whole
+        hip.gemm(Ad, Wp, got, M=M, N=N, K=K, bias=bd, epilogue=hip.EPI_ROPE, rope=(cos_t, sin_t, 2 * HS + 8, dh, pos0, n))
+
+
 @pytest.mark.parametrize("K", [256, 384, 512])
 def test_gemm_activation_stationary_form_is_the_same_function(K):
     """Round 5 (csrc/gemm_astat.hip): short-K contractions with the A block resident in LDS and barrier-free column-tile walks, tile
@@ -902,6 +938,35 @@ def test_dwconv(ksize, dil, causal):
                lens=dev(torch.tensor(lens, dtype=torch.int32)))
     for i, n in enumerate(lens):
         close(out[i, :n], O.dwconv_full(x[i: i + 1, :n], wt, b, dil, causal)[0], 2e-5, f"dwconv ragged {i}")
+
+
+@pytest.mark.parametrize("ksize,dil,causal", [(11, 1, False), (11, 2, False), (11, 4, False), (11, 8, False), (7, 1, False), (7, 3, True)])
+def test_dwconv_comb_form_is_the_same_function(ksize, dil, causal):
+    """Round 5: long inputs run the comb form of the depthwise convolution (a thread = 8 outputs of one residue class mod the
+    dilation: every input row is loaded once per 8 outputs instead of once per tap).  Same taps in the same order per output:
+    bit-identical to the per-output kernel - which single utterances still take (fewer than 1024 rows per call) - with ragged
+    lengths, every epilogue mode, T not a multiple of 8 x dilation; and equal to the oracle's convolution."""
+    B, T, C = 7, 203, 384
+    x, wt, b, res = rnd(B, T, C, seed=54), rnd(C, 1, ksize, seed=55), rnd(C, seed=56), rnd(B, T, C, seed=57)
+    total = (ksize - 1) * dil
+    left = total if causal else total // 2
+    wd, bd, xd, rd = dev(pack.pack_dw(wt)), dev(b), dev(x), dev(res)
+    lens = [203, 17, 200, 96, 1, 150, 203]
+    ld = dev(torch.tensor(lens, dtype=torch.int32))
+    for mode in (0, 1, 2):
+        for use_lens in (False, True):
+            kw = dict(C_=C, ksize=ksize, dil=dil, left=left, mode=mode, res=rd if mode == 1 else None)
+            comb = torch.full((B, T, C), float("nan"), device=DEV)
+            hip.dwconv(xd, wd, bd, comb, B=B, T=T, lens=ld if use_lens else None, **kw)  # 1421 rows: the comb form
+            for i in range(B):  # one utterance per call: the per-output kernel
+                one = torch.full((1, T, C), float("nan"), device=DEV)
+                hip.dwconv(xd[i: i + 1].contiguous(), wd, bd, one, B=1, T=T, lens=ld[i: i + 1].contiguous() if use_lens else None,
+                           **dict(kw, res=rd[i: i + 1].contiguous() if mode == 1 else None))
+                assert torch.equal(comb[i], one[0]), (mode, use_lens, i)
+    out = torch.empty(B, T, C, device=DEV)
+    hip.dwconv(xd, wd, bd, out, B=B, T=T, C_=C, ksize=ksize, dil=dil, left=left, mode=0, lens=ld)
+    for i, n in enumerate(lens):
+        close(out[i, :n], O.dwconv_full(x[i: i + 1, :n], wt, b, dil, causal)[0], 2e-5, f"comb dwconv ragged {i}")
 
 
 def test_gathers():

@@ -1,11 +1,11 @@
 #!/bin/bash
 # The round's measured evidence in one call (run on an MI355X box through gpurun from the repo root) - make it the LAST call of the
 # round, on the final binary:
-#   tools/collect_evidence.sh r04 profiles    -> rocprofv3 kernel stats (pipelined fp32 / bf16, sequential), PMC passes, AR kernel table
-#   tools/collect_evidence.sh r04 bench       -> the bench lines (driver's form, default, bf16 mode, other shapes)
-#   tools/collect_evidence.sh r04 all         -> both
+#   tools/collect_evidence.sh r05 profiles    -> rocprofv3 kernel stats (pipelined fp32 / bf16, sequential), PMC passes, AR kernel table
+#   tools/collect_evidence.sh r05 bench       -> the bench lines (driver's form, default, bf16 mode, other shapes)
+#   tools/collect_evidence.sh r05 all         -> both
 # Results land in gpurun_out/<tag>/; copy what is to be kept into profiles/ (see profiles/README.md for the names).
-TAG=${1:-r04}; WHAT=${2:-bench}
+TAG=${1:-r05}; WHAT=${2:-bench}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 if [ "$WHAT" = profiles ] || [ "$WHAT" = all ]; then
@@ -24,7 +24,18 @@ if [ "$WHAT" = profiles ] || [ "$WHAT" = all ]; then
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- $P > $O/write.log 2>&1
   timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -o m -- $P > $O/mfma.log 2>&1
   unset SOPRO_AR_TILES
+  # round 5: the same counters on the PIPELINED run - four lanes, CU partitions, 128-row passes as the timed run
+  # issues them.  (The counter collection serialises dispatches, so the two partitions do not actually overlap under it; what the pass
+  # adds over the sequential one is the pipeline's own launch shapes: frames of the coalesced row count, partition-sized grids.)
+  SEQ_COMMAND="$PMC_COMMAND"
+  export PMC_ROWS=128 PMC_PRECISION=f32
+  export PMC_COMMAND="python bench.py --steps 8 --warmup 5 --profile-steps 0 --no-cpu-baseline --ttfa-runs 0 --no-legs (pipelined: 4 lanes, 64 + 192 CUs, four jobs per pass)"
+  PP="$B --steps 8 --warmup 5"
+  timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pfetch -o f -- $PP > $O/pfetch.log 2>&1
+  timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pwrite -o w -- $PP > $O/pwrite.log 2>&1
   cd $R
+  python tools/pmc_summary.py $O/pfetch/f_counter_collection.csv $O/pwrite/w_counter_collection.csv $O/${TAG}_pmc_summary_pipelined.json | head -30
+  export PMC_ROWS=64 PMC_COMMAND="$SEQ_COMMAND"
   python tools/pmc_summary.py $O/fetch/f_counter_collection.csv $O/write/w_counter_collection.csv $O/${TAG}_pmc_summary.json | head -60
   python tools/pmc_summary.py --mfma $O/mfma/m_counter_collection.csv $O/${TAG}_pmc_mfma_busy.json | head -40
   python tools/ar_kernel_table.py $O/l1/l1_kernel_stats.csv $O/${TAG}_ar_kernels.json | head -40
