@@ -20,8 +20,8 @@ namespace {
 
 constexpr int BK = 32;
 
-// (The ablation builds that priced this loop's parts - no MFMAs / no A path / no W loads / no barriers - live in the developer
-// copy tools/micro/gemm_bf16s_ablate.hip, built by tools/micro/build_ablate.sh; the product kernel carries no switches.)
+// (The ablation builds that priced this loop's parts - no MFMAs / no A path / no W loads / no barriers - are on record in DESIGN.md
+// section 4 and profiles/r04_*; the product kernel carries no switches.)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

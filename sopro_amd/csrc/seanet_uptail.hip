@@ -24,7 +24,7 @@
 // through two 544-byte side buffers; a workgroup that does not start at the head of an utterance runs the tile in front of its
 // range as a warm-up (stores masked), which leaves exactly these rows.  Arithmetic as in the two kernels: operands x = hi + lo in
 // bf16, lo*hi + hi*lo + hi*hi with fp32 accumulation (PASSES 3), or hi*hi only (PASSES 1, the engine's bf16 mode; XH: x arrives
-// as bf16 rows).  (What each stage costs was measured on a copy with stages left out: tools/micro/seanet_uptail_ablate.hip.)
+// as bf16 rows).  (What each stage costs was measured on a copy with stages left out: profiles/r04_uptail_ablation.txt.)
 #include <type_traits>
 #include <utility>
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Developer probe: time of the split contractions (three-pass bf16x3 and one-pass bf16x1, 128x128 tiles) on a few decoder /
 refinement shapes - meant to be run once with the product library and once with a timing build (SOPRO_HIP_LIB=...: e.g. the K loop
-without its workgroup barriers, tools/micro/gemm_nosync.patch - wrong results, what is left is the point)."""
+without its workgroup barriers: round 4's patch, removed in round 5 - last tree 9bb62d2, numbers in profiles/r04_gemm_no_barriers.txt)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

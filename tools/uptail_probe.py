@@ -3,7 +3,7 @@
 (sopro_seanet_up128_* + sopro_seanet_tail_*) at the pipeline's pass shape (64 utterances x 96000 input rows by default), on the
 whole chip and on the 192-CU throughput partition, three-pass fp32 rows and one-pass bf16 rows, for several tiles-per-workgroup
 settings.  usage: uptail_probe.py [B] [T] [fused]   (fused: only the one-kernel form at its default tiling - the ablation builds of
-tools/micro/build_uptail_abl.sh, SOPRO_HIP_LIB=...)"""
+the ablation builds of round 4 - removed in round 5, last tree 9bb62d2; their numbers: profiles/r04_uptail_ablation.txt)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
