@@ -657,6 +657,11 @@ def main() -> None:
         bytes_all = sum(n_ * ar_step_bytes(b_, TEXT_LEN, wb) for b_, n_ in by_rows.items()) if by_rows else bytes_step * max(1, f["launches"])
         ach = (bytes_all / (ar_ms * 1e-3) / 1e9) if ar_frames else bytes_step / (per_launch_ms * 1e-3) / 1e9
         per_frame = ark.get("launches_per_frame") or {"skinny_kernel": 19, "xattn_step_kernel": 3, "ar_sample_kernel": 1}
+        # round 5: the counters were also collected on the PIPELINED run (tools/collect_evidence.sh: rNN_pmc_summary_pipelined.json, four
+        # lanes, CU partitions, coalesced passes) - when its frames have this run's row count, the traffic figures are THAT pass's
+        pmc_p = latest_profile("pmc_summary_pipelined.json")
+        if pmc_p.get("families") and int(pmc_p.get("ar_rows_per_frame", 0)) == rows_launch and pmc_p.get("precision", "f32") == args.precision:
+            pmc_d, pmc = pmc_p, pmc_p["families"]
         tr = round(sum(pmc.get(k, {}).get("traffic_bytes_per_launch", 0) * n for k, n in per_frame.items())) if pmc else None
         # the PMC pass has its own row count per frame (profiles/rNN_pmc_summary.json "ar_rows_per_frame"; the r03 file was a
         # 32-row --lanes 1 run): traffic is compared with the algorithmic bytes of THAT frame, not of this run's coalesced one
@@ -667,8 +672,9 @@ def main() -> None:
              "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5),
              "traffic": tr or None, "traffic_ratio": round(tr / tr_alg, 3) if tr else None,
              "traffic_rows_per_launch": pmc_rows if tr else None, "traffic_algorithmic_bytes": tr_alg if tr else None,
-             "traffic_note": (f"PMC pass of a {pmc_rows}-row {pmc_prec} frame (kernels serialised by the counter collection): traffic and traffic_ratio "
-                              f"describe that frame; achieved / avg_launch_us describe this run's {rows_launch}-row frames") if tr else None,
+             "traffic_note": (f"PMC pass of a {pmc_rows}-row {pmc_prec} frame ({pmc_d.get('source')}; dispatches are serialised by the counter collection, "
+                              f"so the two partitions do not overlap under it): traffic and traffic_ratio describe that frame; achieved / avg_launch_us "
+                              f"describe this run's {rows_launch}-row frames") if tr else None,
              "launches": ar_frames or f["launches"],
              "avg_launch_us": round(per_launch_ms * 1e3, 2), "ms_per_step": round((ar_ms / args.steps) if ar_frames else f["ms"] / max(1, nprof), 3),
              "avg_launch_us_instrumented_repeat": round(inst_ms * 1e3, 2),
