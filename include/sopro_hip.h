@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 39
+#define SOPRO_ABI_VERSION 40
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -158,6 +158,15 @@ typedef struct sopro_gemm_split_ext {
    * sopro_rope_f32 would do to C in a pass of its own (105 MB read + written per decoder layer at 64 x 200 frames). */
   const float* rope_cos; const float* rope_sin;
   int32_t rope_cols, rope_dh, rope_pos0, rope_rows_per_seg;
+  /* Fused LayerNorm between two contractions of a residual stream (round 5; the Mimi decoder transformer's pre-norms,
+   * HF:modeling_mimi.py:796-833): the PRODUCER of the stream (sopro_gemm_bf16x3 / _bf16x1, SOPRO_EPI_RES, c_mode 0, N % 64 == 0) also writes,
+   * per output row m and 64-column group p, (mean, sum of squared deviations from that mean) to ln_stats_out[(m * (N / 64) + p) * 2 ..];
+   * the CONSUMER (ln_stats != NULL, fp32 rows, K % 64 == 0, epilogues NONE / GELU / ROPE) combines a row's K / 64 pairs (Chan's update:
+   * no E[x^2] - E[x]^2 cancellation) and stages (a - mean) * rsqrt(var + rms_eps) instead of a; the norm's weight is folded into W' and
+   * W lnb into the bias by the host.  The normalised tensor is never written or re-read (105 MB each way per norm at 64 x 200 frames).
+   * sopro_row_stats_f32 writes the same pairs for a stream no contraction produced. */
+  const float* ln_stats;
+  float* ln_stats_out;
 } sopro_gemm_split_ext;
 int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
 /* Six-pass variant for token paths (NAR refinement, conditioning: src/sopro/nn/nar.py, blocks.py): operands split into
@@ -281,6 +290,11 @@ enum { SOPRO_NORM_RMS = 0, SOPRO_NORM_LN = 1 };
 int sopro_norm_f32(const float* x, int64_t ldx, int64_t x_seg_stride /* 0 = dense */, float* out, int64_t ldo, const float* w, const float* b,
                    const float* mul, const float* add, int32_t rows, int32_t rows_per_seg, int32_t C,
                    float eps, int32_t kind, void* stream);
+/* stats[(r * (C / 64) + p) * 2 ..] = (mean, sum of squared deviations from it) of columns 64 p .. 64 p + 63 of row r: the pairs a contraction
+ * with sopro_gemm_split_ext.ln_stats stages its A rows by (C % 64 == 0, 16-byte aligned rows).  Written by the producing contraction's
+ * epilogue where there is one (ln_stats_out); this kernel serves the first norm of a stack (its stream comes from sopro_upsample2_f32). */
+int sopro_row_stats_f32(const float* x, int64_t ldx, int64_t x_seg_stride /* 0 = dense */, int32_t rows, int32_t rows_per_seg, int32_t C,
+                        float* stats, void* stream);
 /* a * clamp(rms(x)/rms(a), 0, 10) per row, rms = sqrt(mean(t^2)+1e-6)   (src/sopro/nn/ref.py:12-13,101-102) */
 int sopro_rms_match_f32(const float* a, const float* x, float* out, int32_t rows, int32_t C, void* stream);
 /* out = c0 + c1 * tanh(in)     (FiLM / adapter coefficients, gates) */

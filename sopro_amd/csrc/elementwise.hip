@@ -527,9 +527,37 @@ __global__ __launch_bounds__(256) void cvt_bf16_f32_kernel(const uint2* __restri
                                                   __uint_as_float(v.y & 0xffff0000u));
 }
 
+// (mean, sum of squared deviations) of every 64-column group of a row: one thread per float4, 16 lanes per group - the same reduction, in
+// the same order, as the contractions' EPI_RES epilogue writes for ln_stats_out (gemm_epilogue.h)
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t seg_stride, int rows, int rps, int C,
+                                                        float* __restrict__ stats) {
+  const int per_row = C >> 2;  // threads per row
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = i / per_row;
+  if (r >= rows) return;  // (whole 16-lane groups leave together: per_row is a multiple of 16)
+  const int c4 = (int)(i - r * per_row);
+  const int64_t seg = r / rps, rr = r - seg * rps;
+  const float4 v = *reinterpret_cast<const float4*>(x + seg * seg_stride + rr * ldx + c4 * 4);
+  float s = (v.x + v.y) + (v.z + v.w);
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+  const float mu = s * (1.0f / 64.0f);
+  const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+  float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+  if ((c4 & 15) == 0) *reinterpret_cast<float2*>(stats + (r * (C >> 6) + (c4 >> 4)) * 2) = make_float2(mu, q);
+}
+
 }  // namespace
 
 extern "C" {
+
+int sopro_row_stats_f32(const float* x, int64_t ldx, int64_t x_seg_stride, int32_t rows, int32_t rows_per_seg, int32_t C, float* stats, void* stream) {
+  SOPRO_CHECK_ARG(x && stats && rows > 0 && rows_per_seg > 0 && C > 0 && (C & 63) == 0, "x, stats non-NULL; rows > 0; C a multiple of 64");
+  SOPRO_CHECK_ARG(aligned16(x) && (ldx & 3) == 0 && (x_seg_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "16-byte aligned rows, 8-byte aligned stats");
+  hipLaunchKernelGGL(row_stats_kernel, dim3(nblk((int64_t)rows * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     x_seg_stride ? x_seg_stride : (int64_t)rows_per_seg * ldx, rows, rows_per_seg, C, stats);
+  SOPRO_LAUNCH_CHECK();
+}
 
 int sopro_norm_f32(const float* x, int64_t ldx, int64_t x_seg_stride, float* out, int64_t ldo, const float* w, const float* b,
                    const float* mul, const float* add, int32_t rows, int32_t rows_per_seg, int32_t C, float eps,

@@ -73,7 +73,10 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned (&pc)[NPL]
 // accumulated while it is staged and rsqrt(mean + eps) scales the accumulator in the epilogue (the norm's weight vector is
 // folded into W by the host; needs K % 32 == 0 and no split-K: every workgroup sees its rows' whole K); 5 (round 4, NPL == 1 only:
 // the bf16 mode's activation flow) = A is bf16 rows in memory (lda / a_seg_stride count bf16 elements): a K-step of a row is 64
-// bytes, staged by pure 8-byte copies - half the operand bytes of the loop that bounds the one-pass kernel, no conversion work.
+// bytes, staged by pure 8-byte copies - half the operand bytes of the loop that bounds the one-pass kernel, no conversion work;
+// 6 (round 5) = fp32 rows whose LayerNorm is fused: (a - mean) * rstd is staged instead of a, mean / rstd from the (mean, squared
+// deviations) pairs the stream's producer left per 64-column group (sopro_gemm_split_ext.ln_stats; weight / bias of the norm folded
+// into W' / the bias by the host; K % 64 == 0).
 template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT, bool SK, bool F16 = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gemm_args g, const uint4* __restrict__ Wp,
                                                                  int ksubs, const sopro_gemm_split_ext ext) {
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   float a16max = 0.f; // f16 forms: largest scaled magnitude this thread staged (range guard)
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) { ssq[i] = 0.f; rsc[i] = A16_SCALE; }
+  float lmu[A_F4], lrs[A_F4];  // fused LayerNorm: the staged rows' -mean * rstd and rstd = 1 / sqrt(var + eps)
   float4 pvA = make_float4(0.f, 0.f, 0.f, 0.f), pvB = pvA;
   const int KT = (g.K + BK - 1) / BK;
   const int klast = g.K - 4;
@@ -194,6 +198,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
       } else if constexpr (AMODE == 3) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) { ra[i].x += pv.x; ra[i].y += pv.y; ra[i].z += pv.z; ra[i].w += pv.w; }
+      } else if constexpr (AMODE == 6) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {  // x * rstd - mean * rstd: two packed fused multiply-adds per row piece (lmu holds -mean * rstd)
+          const f32x2_t r2 = {lrs[i], lrs[i]}, n2 = {lmu[i], lmu[i]};
+          const f32x2_t lo2 = (f32x2_t){ra[i].x, ra[i].y} * r2 + n2, hi2 = (f32x2_t){ra[i].z, ra[i].w} * r2 + n2;
+          ra[i].x = lo2[0]; ra[i].y = lo2[1]; ra[i].z = hi2[0]; ra[i].w = hi2[1];
+        }
       }
       if constexpr (AMODE == 4) {
         if (fresh) {
@@ -354,6 +365,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   gload(min(kt0, KT - 1), raA, pvA);
   bload(min(kt0, KT - 1), rb0);
   if (DEEP) gload(min(min(kt0 + 1, ktl), KT - 1), raB, pvB);
+  if constexpr (AMODE == 6) {
+    // behind the first operand requests (their latency covers these): the eight lanes that stage a row share its K / 64 pairs -
+    // lane c takes pairs c, c + 8, .. - and combine them with Chan's update: sum of the groups' squared deviations + 64 (group mean - mean)^2
+    const int P = g.K >> 6;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const float2* st = reinterpret_cast<const float2*>(ext.ln_stats) + (int64_t)min(m0 + lrow + i * RSTEP, g.M - 1) * P;
+      float sm = 0.f;
+      for (int p = lc4; p < P; p += 8) sm += st[p].x;
+      sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+      const float mean = sm / (float)P;
+      float m2 = 0.f;
+      for (int p = lc4; p < P; p += 8) {
+        const float2 v = st[p];
+        const float d = v.x - mean;
+        m2 += fmaf(64.0f * d, d, v.y);
+      }
+      m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
+      lrs[i] = rsqrtf(m2 / (float)g.K + ext.rms_eps);
+      lmu[i] = -mean * lrs[i];
+    }
+  }
   lstore(0, raA, pvA, true, true);
   __syncthreads();
   if (dbg && tid == 0) dbg[1] = clock64();
@@ -523,6 +556,7 @@ inline int amode_of(const sopro_gemm_args& g, const sopro_gemm_split_ext& ext) {
   if (ext.a_format == 1) return 2;
   if (ext.a_format == 2) return 5;
   if (ext.rms_norm) return 4;
+  if (ext.ln_stats) return 6;
   return g.prologue == SOPRO_PRO_ELU ? 1 : (g.prologue == SOPRO_PRO_ADDVEC ? 3 : 0);
 }
 
@@ -537,6 +571,9 @@ int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
     SOPRO_CASE(SOPRO_EPI_GELU, 0, 0);  // transformer fc1
     SOPRO_CASE(SOPRO_EPI_RES, 0, 0);   // transformer o / fc2 (+ layer scale)
     SOPRO_CASE(SOPRO_EPI_ROPE, 0, 0);  // transformer qkv with the rotary embedding of q | k in the epilogue (round 5)
+    SOPRO_CASE(SOPRO_EPI_NONE, 6, 0);  // the same three behind a fused LayerNorm (round 5: sopro_gemm_split_ext.ln_stats)
+    SOPRO_CASE(SOPRO_EPI_GELU, 6, 0);
+    SOPRO_CASE(SOPRO_EPI_ROPE, 6, 0);
     SOPRO_CASE(SOPRO_EPI_NONE, 1, 0);  // fp32 activations with an ELU prologue (SEANet convs)
     SOPRO_CASE(SOPRO_EPI_RES, 1, 0);
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 3);  // activated-copy flow of the SEANet decoder: ELU applied once, by the producer
@@ -620,6 +657,22 @@ int check_rope(const sopro_gemm_args& g, const sopro_gemm_split_ext& ext) {
   return 0;
 }
 
+int check_ln(const sopro_gemm_args& g, const sopro_gemm_split_ext& ext) {
+  if (ext.ln_stats) {
+    SOPRO_CHECK_ARG((g.K & 63) == 0 && (reinterpret_cast<uintptr_t>(ext.ln_stats) & 7u) == 0, "fused LayerNorm: K % 64 == 0, 8-byte aligned ln_stats");
+    SOPRO_CHECK_ARG(ext.a_format == 0 && g.prologue == SOPRO_PRO_NONE && !ext.rms_norm && ext.c_mode == 0, "fused LayerNorm takes plain fp32 rows (no prologue, c_mode 0)");
+    SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_ROPE, "fused LayerNorm: epilogue NONE, GELU or ROPE");
+    SOPRO_CHECK_ARG(ext.rms_eps > 0.f, "fused LayerNorm: rms_eps carries the norm's eps (> 0)");
+  }
+  if (ext.ln_stats_out) {
+    SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_RES && ext.c_mode == 0 && (g.N & 63) == 0 && (reinterpret_cast<uintptr_t>(ext.ln_stats_out) & 7u) == 0,
+                    "ln_stats_out: an EPI_RES contraction with fp32 output rows, N % 64 == 0, 8-byte aligned pairs");
+    SOPRO_CHECK_ARG((g.ldc & 3) == 0 && (g.c_seg_stride & 3) == 0 && aligned16(g.C) && (g.ldr & 3) == 0 && (g.r_seg_stride & 3) == 0 && aligned16(g.R),
+                    "ln_stats_out: 16-byte aligned output / residual rows");
+  }
+  return 0;
+}
+
 int check_common(sopro_gemm_args& g, sopro_gemm_split_ext& ext, const void* packed_w) {
   if (g.a_seg_stride == 0) g.a_seg_stride = (int64_t)g.rows_per_seg * g.lda;
   if (g.c_seg_stride == 0) g.c_seg_stride = (int64_t)g.rows_per_seg * g.ldc;
@@ -697,6 +750,7 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
   if (x) ext = *x;
   if (ext.group_m == 0) ext.group_m = g_group_m;
   if (int rc = check_common(g, ext, packed_w)) return rc;
+  if (int rc = check_ln(g, ext)) return rc;
   SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ELU, "prologue must be NONE or ELU");
   SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES || g.epilogue == SOPRO_EPI_ROPE,
                   "epilogue must be NONE, GELU, RES or ROPE");
@@ -760,6 +814,7 @@ extern "C" int sopro_gemm_bf16x1(const sopro_gemm_args* a, const void* packed_w,
   SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f && ext.c_mode == 0),
                   "fused RMSNorm needs K % 32 == 0, no split-K, no prologue, eps > 0 and a plain output");
   if (int rc = check_common(g, ext, packed_w)) return rc;
+  if (int rc = check_ln(g, ext)) return rc;
   if (ext.c_mode == 5) return launch_argmax<1>(g, reinterpret_cast<const uint4*>(packed_w), (g.K + 31) / 32 * 2, ext, reinterpret_cast<hipStream_t>(stream));
   if (ext.c_mode >= 6) {  // bf16 rows: C (and C2 for c_mode 8; R for EPI_RES) point at bf16 elements, strides count elements
     SOPRO_CHECK_ARG((g.N & 3) == 0 && g.C && (reinterpret_cast<uintptr_t>(g.C) & 7u) == 0 && (g.ldc & 3) == 0 && (g.c_seg_stride & 3) == 0 && g.ldc >= g.N,
@@ -806,6 +861,7 @@ extern "C" int sopro_gemm_bf16x6(const sopro_gemm_args* a, const void* packed_w,
   SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f),
                   "fused RMSNorm needs K % 32 == 0, no split-K, no prologue and eps > 0");
   if (int rc = check_common(g, ext, packed_w)) return rc;
+  if (int rc = check_ln(g, ext)) return rc;
   SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ADDVEC, "prologue must be NONE or ADDVEC");
   SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES || g.epilogue == SOPRO_EPI_GLU,
                   "epilogue must be NONE, GELU, RES or GLU");
@@ -850,6 +906,7 @@ extern "C" int sopro_gemm_f16x3(const sopro_gemm_args* a, const void* packed_w, 
   SOPRO_CHECK_ARG(!ext.rms_norm || ((g.K & 31) == 0 && ext.ksplit <= 1 && g.prologue == SOPRO_PRO_NONE && ext.rms_eps > 0.f),
                   "fused RMSNorm needs K % 32 == 0, no split-K, no prologue and eps > 0");
   if (int rc = check_common(g, ext, packed_w)) return rc;
+  if (int rc = check_ln(g, ext)) return rc;
   SOPRO_CHECK_ARG(g.prologue == SOPRO_PRO_NONE || g.prologue == SOPRO_PRO_ADDVEC, "prologue must be NONE or ADDVEC");
   SOPRO_CHECK_ARG(g.epilogue == SOPRO_EPI_NONE || g.epilogue == SOPRO_EPI_GELU || g.epilogue == SOPRO_EPI_RES || g.epilogue == SOPRO_EPI_GLU,
                   "epilogue must be NONE, GELU, RES or GLU");

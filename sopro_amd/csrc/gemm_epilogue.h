@@ -211,6 +211,21 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
         v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
       } else if (res) {
         v.x = rv[q].x + sc4.x * v.x; v.y = rv[q].y + sc4.y * v.y; v.z = rv[q].z + sc4.z * v.z; v.w = rv[q].w + sc4.w * v.w;
+        if (OUT == 0 && ext && ext->ln_stats_out) {
+          // LayerNorm statistics of the updated stream for the next contraction (sopro_gemm_split_ext.ln_stats): the 16 lanes that hold a
+          // 64-column group of the row reduce (mean, squared deviations) - row_stats_kernel's arithmetic (host guarantees N % 64 == 0:
+          // a group is entirely inside N or entirely outside, and rows >= M left through the `continue` above group-wise)
+          float s1 = (v.x + v.y) + (v.z + v.w);
+          s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64); s1 += __shfl_xor(s1, 8, 64);
+          const float mu = s1 * (1.0f / 64.0f);
+          const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+          float s2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+          s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64); s2 += __shfl_xor(s2, 8, 64);
+          if ((pc4 & 15) == 0) {
+            const int64_t mq = m0 + prow + (p0 + q) * RPP;
+            *reinterpret_cast<float2*>(ext->ln_stats_out + (mq * (g.N >> 6) + (ncol >> 6)) * 2) = make_float2(mu, s2);
+          }
+        }
       } else if (EPI == SOPRO_EPI_ROPE) {
         // rotate-half RoPE of the q | k heads in the leading rope_cols columns: the partner column (+- dh / 2) is in the LDS tile, the
         // position is the row's index within its utterance (sopro_rope_f32's arithmetic, without its pass over C)

@@ -180,6 +180,29 @@ int pack_pieces(sopro_engine* e, const std::string& key, const std::string& out_
   return 0;
 }
 
+// out[n] = sum_k W[n, k] v[k] (+ b[n]) as a device vector registered under out_key: the bias a contraction behind a fused LayerNorm
+// carries for the norm's bias vector (W (w * xhat + b) = (W * w) xhat + W b)
+int fold_bias(sopro_engine* e, const std::string& w_key, const std::string& v_key, const std::string& out_key) {
+  const Ten *t, *v;
+  STG(need(e, w_key, &t, 2));
+  STG(need(e, v_key, &v));
+  const int N = (int)t->shape[0], K = (int)t->shape[1];
+  std::vector<float> hw((size_t)N * K), hv(K), ho(N);
+  SOPRO_HIP(hipMemcpy(hw.data(), t->p, hw.size() * 4, hipMemcpyDeviceToHost));
+  SOPRO_HIP(hipMemcpy(hv.data(), v->p, (size_t)K * 4, hipMemcpyDeviceToHost));
+  for (int n = 0; n < N; ++n) {
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) acc += (double)hw[(size_t)n * K + k] * hv[k];
+    ho[n] = (float)acc;
+  }
+  float* d;
+  STG(dev_upload(e, ho, &d));
+  Ten o;
+  o.p = d; o.shape[0] = N; o.ndim = 1;
+  e->t[out_key] = o;
+  return 0;
+}
+
 int plain(sopro_engine* e, const std::string& key) {
   const Ten* t;
   STG(need(e, key, &t));
@@ -237,6 +260,9 @@ struct G {  // one contraction: mirrors sopro_amd.hip.gemm's keyword arguments
   int32_t* range_events = nullptr;  // f16 operands: the call's range-event word (sopro_gemm_split_ext.range_events)
   const float *rope_cos = nullptr, *rope_sin = nullptr;  // epi = SOPRO_EPI_ROPE (sopro_gemm_split_ext.rope_*)
   int rope_cols = 0, rope_dh = 0, rope_pos0 = 0, rope_rps = 0;
+  const float* ln_stats = nullptr;  // fused LayerNorm of the A rows (sopro_gemm_split_ext.ln_stats; ln_eps = the norm's eps)
+  float* ln_stats_out = nullptr;    // EPI_RES: the updated stream's statistics for the next contraction
+  float ln_eps = 0.f;
 };
 
 // attention launch with its timing scope: 4 * dh flops per visible (query, key) pair
@@ -289,6 +315,8 @@ int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override
     if (o.rms_eps > 0.f) { x.rms_norm = 1; x.rms_eps = o.rms_eps; }
     x.rope_cos = o.rope_cos; x.rope_sin = o.rope_sin; x.rope_cols = o.rope_cols; x.rope_dh = o.rope_dh; x.rope_pos0 = o.rope_pos0;
     x.rope_rows_per_seg = o.rope_rps;
+    x.ln_stats = o.ln_stats; x.ln_stats_out = o.ln_stats_out;
+    if (o.ln_stats) x.rms_eps = o.ln_eps;
     static const bool no_splitk = getenv("SOPRO_NO_SPLITK") && getenv("SOPRO_NO_SPLITK")[0] == '1';  // developer switch
     if (!no_splitk && o.sk && o.sk->ws && o.rms_eps <= 0.f && o.c_mode != 5) {
       const int ks = auto_ksplit(o.M, o.N, o.K, w.f16 ? 3 : w.pieces, o.epi);
@@ -529,6 +557,12 @@ int sopro_engine_finalize(sopro_engine* e, void* stream) {
       const std::string p = "tr." + std::to_string(l);
       for (const char* nm : {".qkv.w", ".o.w", ".fc1.w", ".fc2.w"}) STG(pack_pieces(e, p + nm, p + nm, mp, nullptr, s));
       for (const char* nm : {".ln1.w", ".ln1.b", ".ln2.w", ".ln2.b", ".ls1", ".ls2"}) STG(need(e, p + nm, &t));
+      if (c.mimi_hidden % 64 == 0) {  // twins behind a fused LayerNorm (transformer_stack): the norm's weight in W', W lnb as the bias
+        STG(pack_pieces(e, p + ".qkv.w", p + ".qkv.w#ln", mp, (p + ".ln1.w").c_str(), s));
+        STG(fold_bias(e, p + ".qkv.w", p + ".ln1.b", p + ".qkv.lnb"));
+        STG(pack_pieces(e, p + ".fc1.w", p + ".fc1.w#ln", mp, (p + ".ln2.w").c_str(), s));
+        STG(fold_bias(e, p + ".fc1.w", p + ".ln2.b", p + ".fc1.lnb"));
+      }
     }
     STG(pack_pieces(e, "sea.conv0.w", "sea.conv0.w", mp, nullptr, s));
     STG(need(e, "sea.conv0.b", &t));
@@ -1069,6 +1103,7 @@ int sopro_nar_refine(sopro_engine* e, void* workspace, const float* cond, int64_
 struct MimiWs {
   int32_t* tok;
   float *emb, *q, *X, *y, *qkv, *ao, *hd, *e0, *hraw[8], *hact[8], *y1[8];
+  float* lnst;  // (mean, squared deviations) per transformer row and 64-column group (fused LayerNorm)
   SplitK sk;
 };
 // bf16 mode (round 4): the SEANet decoder's activations - everything from the first convolution's output on - live in memory as
@@ -1102,6 +1137,7 @@ static size_t mimi_carve(const sopro_engine* e, MimiWs& w, void* ws, int B, int 
   w.qkv = cv.take<float>((size_t)B * N2 * 3 * HS);
   w.ao = cv.take<float>((size_t)B * N2 * HS);
   w.hd = cv.take<float>((size_t)B * N2 * c.mimi_inter);
+  w.lnst = cv.take<float>((size_t)B * N2 * ((HS + 63) / 64) * 2);
   size_t ch = (size_t)c.mimi_num_filters << c.mimi_n_ratios, rows = N2;
   w.e0 = act(cv, (size_t)B * (1 + rows) * ch);
   for (int si = 0; si < c.mimi_n_ratios; ++si) {
@@ -1124,14 +1160,28 @@ int64_t sopro_mimi_workspace_bytes(const sopro_engine* e, int32_t B, int32_t T) 
 // (HF:modeling_mimi.py MimiTransformerModel, 729-928): the decoder's ("tr", packed operands, optional streaming cache) and the
 // encoder's ("etr", fp32 operands).  y [B n, HS], qkv [B n, 3 HS], ao [B n, HS], hd [B n, inter] are scratch.
 static int transformer_stack(sopro_engine* e, hipStream_t s, const char* pre, float* X, int PADX, int64_t xs, float* y, float* qkv, float* ao,
-                             float* hd, const SplitK* sk, int B, int n, int past, sopro_mimi_stream_state* sst, int attn_split = 0) {
+                             float* hd, const SplitK* sk, int B, int n, int past, sopro_mimi_stream_state* sst, int attn_split = 0,
+                             float* lnst = nullptr) {
   const sopro_engine_cfg& c = e->c;
   const int HS = c.mimi_hidden, H = c.mimi_heads, dh = c.mimi_head_dim;
   struct { float *X, *y, *qkv, *ao, *hd; SplitK sk; } w{X, y, qkv, ao, hd, sk ? *sk : SplitK()};
+  // The two pre-norms of a layer ride on the contractions either side of them (round 5; sopro_gemm_split_ext.ln_stats): the o / fc2
+  // contraction that updates the stream leaves each row's (mean, squared deviations) per 64 columns, the qkv / fc1 contraction stages
+  // (x - mean) * rstd with the norm's weight folded into its W' and W lnb as its bias.  The normalised tensor is never written: 16 norm
+  // passes of 105 MB read + 105 MB written at 64 x 200 frames (35 us each) become one statistics pass over the first layer's input.
+  // SOPRO_LN_FUSE=0 (developer A/B): the separate norm kernels.
+  static const bool ln_off = SOPRO_DEV_ENV("SOPRO_LN_FUSE") != nullptr && SOPRO_DEV_ENV("SOPRO_LN_FUSE")[0] == '0';
+  const bool fused_ln = !ln_off && lnst != nullptr && WT(e, std::string(pre) + ".0.qkv.w#ln").packed != nullptr;
+  if (fused_ln) STG(sopro_row_stats_f32(w.X + (size_t)PADX * HS, HS, xs, B * n, n, HS, lnst, s));
   for (int l = 0; l < c.mimi_layers; ++l) {
     const std::string p = std::string(pre) + "." + std::to_string(l);
-    STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln1.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln1.b"), nullptr, nullptr, n, xs));
+    if (!fused_ln)
+      STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln1.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln1.b"), nullptr, nullptr, n, xs));
     G qg; qg.sk = &w.sk; qg.M = B * n; qg.N = 3 * HS; qg.K = HS;
+    if (fused_ln) {  // A = the stream itself (rows of utterance b start at b * xs)
+      qg.ln_stats = lnst; qg.ln_eps = c.mimi_norm_eps; qg.bias = F(e, p + ".qkv.lnb"); qg.a_seg = xs; qg.rows_per_seg = n;
+      qg.c_seg = (int64_t)n * 3 * HS;
+    }
     // queries and keys are 2 H consecutive heads of dh columns.  The decoder's packed (split-bf16) contraction rotates them in its
     // epilogue (round 5: SOPRO_EPI_ROPE - the tile is in LDS, a column's partner is at hand; sopro_rope_f32 re-read and re-wrote
     // 105 MB per layer at 64 x 200 frames: 67 us x 8 per pass); the encoder's exact-fp32 contraction keeps the pass of its own
@@ -1141,7 +1191,7 @@ static int transformer_stack(sopro_engine* e, hipStream_t s, const char* pre, fl
       qg.epi = SOPRO_EPI_ROPE; qg.rope_cos = F(e, "rope.cos"); qg.rope_sin = F(e, "rope.sin"); qg.rope_cols = 2 * H * dh; qg.rope_dh = dh;
       qg.rope_pos0 = past; qg.rope_rps = n;
     }
-    STG(gemm(s, w.y, WT(e, p + ".qkv.w"), nullptr, w.qkv, qg));
+    STG(gemm(s, fused_ln ? w.X + (size_t)PADX * HS : w.y, WT(e, p + (fused_ln ? ".qkv.w#ln" : ".qkv.w")), nullptr, w.qkv, qg));
     if (!fused_rope) STG(sopro_rope_f32(w.qkv, 3 * HS, F(e, "rope.cos"), F(e, "rope.sin"), B * n, n, past, 2 * H, dh, s));
     sopro_attn_args a;
     memset(&a, 0, sizeof(a));
@@ -1174,12 +1224,19 @@ static int transformer_stack(sopro_engine* e, hipStream_t s, const char* pre, fl
   attended:;
     G og; og.sk = &w.sk; og.M = B * n; og.N = HS; og.K = HS; og.epi = SOPRO_EPI_RES; og.R = w.X + (size_t)PADX * HS; og.scale = F(e, p + ".ls1");
     og.c_seg = xs; og.r_seg = xs; og.rows_per_seg = n;
+    if (fused_ln) { og.ln_stats_out = lnst; og.a_seg = (int64_t)n * HS; }
     STG(gemm(s, w.ao, WT(e, p + ".o.w"), nullptr, w.X + (size_t)PADX * HS, og));
-    STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln2.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln2.b"), nullptr, nullptr, n, xs));
+    if (!fused_ln)
+      STG(norm(s, w.X + (size_t)PADX * HS, w.y, F(e, p + ".ln2.w"), B * n, HS, c.mimi_norm_eps, SOPRO_NORM_LN, F(e, p + ".ln2.b"), nullptr, nullptr, n, xs));
     G f1; f1.sk = &w.sk; f1.M = B * n; f1.N = c.mimi_inter; f1.K = HS; f1.epi = SOPRO_EPI_GELU;
-    STG(gemm(s, w.y, WT(e, p + ".fc1.w"), nullptr, w.hd, f1));
+    if (fused_ln) {
+      f1.ln_stats = lnst; f1.ln_eps = c.mimi_norm_eps; f1.bias = F(e, p + ".fc1.lnb"); f1.a_seg = xs; f1.rows_per_seg = n;
+      f1.c_seg = (int64_t)n * c.mimi_inter;
+    }
+    STG(gemm(s, fused_ln ? w.X + (size_t)PADX * HS : w.y, WT(e, p + (fused_ln ? ".fc1.w#ln" : ".fc1.w")), nullptr, w.hd, f1));
     G f2; f2.sk = &w.sk; f2.M = B * n; f2.N = HS; f2.K = c.mimi_inter; f2.epi = SOPRO_EPI_RES; f2.R = w.X + (size_t)PADX * HS; f2.scale = F(e, p + ".ls2");
     f2.c_seg = xs; f2.r_seg = xs; f2.rows_per_seg = n;
+    if (fused_ln) { f2.ln_stats_out = lnst; f2.a_seg = (int64_t)n * c.mimi_inter; }
     STG(gemm(s, w.hd, WT(e, p + ".fc2.w"), nullptr, w.X + (size_t)PADX * HS, f2));
   }
   return 0;
@@ -1235,7 +1292,7 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
   static const bool attn_exact = SOPRO_DEV_ENV("SOPRO_ATTN_SPLIT") != nullptr && SOPRO_DEV_ENV("SOPRO_ATTN_SPLIT")[0] == '0';
   static const bool attn_one = SOPRO_DEV_ENV("SOPRO_ATTN_PASSES") != nullptr && SOPRO_DEV_ENV("SOPRO_ATTN_PASSES")[0] == '1';
   const int attn_split = attn_exact ? 0 : ((c.precision == 1 && attn_one) ? 1 : 3);
-  BODY(transformer_stack(e, s, "tr", w.X, PADX, xs, w.y, w.qkv, w.ao, w.hd, &w.sk, B, N2, past, sst, attn_split));
+  BODY(transformer_stack(e, s, "tr", w.X, PADX, xs, w.y, w.qkv, w.ao, w.hd, &w.sk, B, N2, past, sst, attn_split, w.lnst));
   static const bool three = SOPRO_DEV_ENV("SOPRO_SEANET_PASSES3") != nullptr;  // developer A/B: the fused kernels' three-pass form in bf16 mode too
   const int sea_passes = (c.precision == 1 && !three) ? 1 : 3;
   // ---- SEANet decoder (HF:931-961), activated-copy flow of sopro_amd.codec.MimiCodec._seanet_act

@@ -9,6 +9,7 @@ caching allocator and the kernels agree on ordering (wrap a region in
 from __future__ import annotations
 
 import ctypes as C
+import gc
 import os
 import threading
 from typing import Optional
@@ -17,7 +18,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -40,7 +41,7 @@ class SplitExt(C.Structure):
     _fields_ = [("a_format", _i32), ("c_mode", _i32), ("C2", _p), ("ldc2", _i64), ("c2_seg_stride", _i64),
                 ("rms_norm", _i32), ("rms_eps", _f32), ("ksplit", _i32), ("n_tickets", _i32), ("ws", _p), ("ws_bytes", _i64),
                 ("tickets", _p), ("group_m", _i32), ("acc_scale", _f32), ("range_events", _p), ("rope_cos", _p), ("rope_sin", _p),
-                ("rope_cols", _i32), ("rope_dh", _i32), ("rope_pos0", _i32), ("rope_rows_per_seg", _i32)]
+                ("rope_cols", _i32), ("rope_dh", _i32), ("rope_pos0", _i32), ("rope_rows_per_seg", _i32), ("ln_stats", _p), ("ln_stats_out", _p)]
 
 
 class SkinnyArgs(C.Structure):
@@ -167,6 +168,7 @@ SYMBOLS = {
     "sopro_pack_skinny_w_bf16": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     "sopro_skinny_packed_floats": (_i64, [_i32, _i32, _i32]),
     "sopro_skinny_f32": (C.c_int, [C.POINTER(SkinnyArgs), _p]),
+    "sopro_row_stats_f32": (C.c_int, [_p, _i64, _i64, _i32, _i32, _i32, _p, _p]),
     "sopro_norm_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _i32, _p]),
     "sopro_rms_match_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
     "sopro_tanh_affine_f32": (C.c_int, [_p, _p, _f32, _f32, _i64, _p]),
@@ -372,7 +374,8 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
          a_seg_stride: int = 0, c_seg_stride: int = 0, r_seg_stride: int = 0, a_off: int = 0, c_off: int = 0,
          r_off: int = 0, ldw: Optional[int] = None, dbg: Optional[torch.Tensor] = None, a_split: bool = False, c_mode: int = 0,
          C2: Optional[torch.Tensor] = None, ldc2: Optional[int] = None, c2_seg_stride: int = 0,
-         c2_off: int = 0, rms_eps: float = 0.0, range_events: Optional[torch.Tensor] = None, rope: Optional[tuple] = None) -> None:
+         c2_off: int = 0, rms_eps: float = 0.0, range_events: Optional[torch.Tensor] = None, rope: Optional[tuple] = None,
+         ln_stats: Optional[torch.Tensor] = None, ln_eps: float = 0.0, ln_stats_out: Optional[torch.Tensor] = None) -> None:
     """C = epi(pro(A) @ W^T + bias); offsets are in elements from the tensors' first element.  With a ``PackedW`` weight the
     contraction runs on the split-bf16 path, where ``a_split`` says A is in split form and ``c_mode`` 1 / 2 writes
     ELU(C) in split form (to C, or to C2 next to the fp32 C): see sopro_gemm_split_ext in include/sopro_hip.h."""
@@ -409,6 +412,9 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
         if rope is not None:  # (cos table, sin table, columns, head dim, first position, rows per utterance): EPI_ROPE
             x.rope_cos, x.rope_sin = ptr(rope[0]), ptr(rope[1])
             x.rope_cols, x.rope_dh, x.rope_pos0, x.rope_rows_per_seg = int(rope[2]), int(rope[3]), int(rope[4]), int(rope[5])
+        if ln_stats is not None:  # fused LayerNorm of the A rows from the producer's statistics (W / bias carry the norm's weight / bias)
+            x.ln_stats, x.rms_eps = ptr(ln_stats), float(ln_eps)
+        x.ln_stats_out = ptr(ln_stats_out)  # EPI_RES: statistics of the updated stream (sopro_gemm_split_ext.ln_stats_out)
         if rms_eps > 0.0:  # fused RMSNorm of the A rows (W must carry the norm's weight vector)
             if W.pieces == 2 and not W.f16:
                 raise SoproHipError("fused RMSNorm is a six-pass (pieces = 3), f16 three-pass or one-pass (pieces = 1) feature")
@@ -621,6 +627,13 @@ def norm(x: torch.Tensor, out: torch.Tensor, w: torch.Tensor, *, rows: int, C_: 
     _check(load().sopro_norm_f32(ptr(x) + 4 * x_off, C_ if ldx is None else ldx, x_seg_stride, ptr(out) + 4 * o_off,
                                  C_ if ldo is None else ldo, ptr(w), ptr(b), ptr(mul), ptr(add), rows,
                                  rows if rows_per_seg is None else rows_per_seg, C_, eps, kind, _stream()), "sopro_norm_f32")
+
+
+def row_stats(x: torch.Tensor, rows: int, C_: int, stats: torch.Tensor, ldx: Optional[int] = None, x_seg_stride: int = 0,
+              rows_per_seg: Optional[int] = None, x_off: int = 0) -> None:
+    """stats [rows, C / 64, 2] = (mean, squared deviations) per 64-column group: what a contraction with ``ln_stats`` stages by."""
+    _check(load().sopro_row_stats_f32(ptr(x) + 4 * x_off, C_ if ldx is None else ldx, x_seg_stride, rows, rows if rows_per_seg is None else rows_per_seg,
+                                      C_, ptr(stats), _stream()), "sopro_row_stats_f32")
 
 
 def rms_match(a: torch.Tensor, x: torch.Tensor, out: torch.Tensor, rows: int, C_: int) -> None:
@@ -1043,12 +1056,37 @@ def reap_parked_graphs() -> bool:
 _capture_depth = threading.local()
 
 
+_gc_paused = [0, False]  # (open recordings, was the collector enabled) - guarded by _capture_lock
+
+
+def _gc_pause() -> None:
+    """No cyclic garbage collection while a launch sequence is being recorded: a collection runs finalizers of WHATEVER became garbage
+    in the process - an engine of an earlier module (sopro_engine_destroy: hipFree), page-locked blocks, torch storages - on the thread
+    that happens to allocate next, and a free on the recording thread invalidates the recording ("operation failed due to a previous
+    error during capture", seen once in ~20 suite runs, at the first launch of an AR frame recording)."""
+    if _gc_paused[0] == 0:
+        _gc_paused[1] = gc.isenabled()
+        gc.disable()
+    _gc_paused[0] += 1
+
+
+def _gc_resume() -> None:
+    _gc_paused[0] = max(0, _gc_paused[0] - 1)
+    if _gc_paused[0] == 0 and _gc_paused[1]:
+        gc.enable()
+
+
 def capture_begin() -> None:
     _capture_lock.acquire()
     try:
         if getattr(_capture_depth, "n", 0) == 0:
             reap_graphs()
-        _check(load().sopro_capture_begin(_stream()), "sopro_capture_begin")
+        _gc_pause()
+        try:
+            _check(load().sopro_capture_begin(_stream()), "sopro_capture_begin")
+        except BaseException:
+            _gc_resume()
+            raise
         _capture_depth.n = getattr(_capture_depth, "n", 0) + 1
     except BaseException:
         _capture_lock.release()
@@ -1061,6 +1099,7 @@ def capture_end() -> Graph:
         _check(load().sopro_capture_end(_stream(), C.byref(out)), "sopro_capture_end")
     finally:
         _capture_depth.n = max(0, getattr(_capture_depth, "n", 0) - 1)
+        _gc_resume()
         _capture_lock.release()
     return Graph(out.value)
 

@@ -421,6 +421,61 @@ def test_gemm_rope_epilogue_equals_the_contraction_followed_by_rope(pieces, M):
         hip.gemm(Ad, Wp, got, M=M, N=N, K=K, bias=bd, epilogue=hip.EPI_ROPE, rope=(cos_t, sin_t, 2 * HS + 8, dh, pos0, n))
 
 
+@pytest.mark.parametrize("pieces,M,n", [(2, 3 * 413, 413), (1, 3 * 413, 413), (2, 2 * 6, 6)])
+def test_gemm_fused_layernorm_equals_norm_followed_by_the_contraction(pieces, M, n):
+    """Round 5 (sopro_gemm_split_ext.ln_stats / ln_stats_out): the pre-norms of the Mimi decoder transformer (HF:modeling_mimi.py:796-833)
+    ride on the contractions either side of them.  (1) sopro_row_stats_f32's (mean, squared deviations) per 64 columns are those of the
+    float64 statistics; (2) an EPI_RES contraction with ln_stats_out leaves BIT-IDENTICAL pairs for the stream it wrote (same arithmetic,
+    same order), on 128x128 tiles, 64x64 tiles and split-K, with the stream in padded segments as the engine holds it; (3) a contraction
+    with ln_stats stages (x - mean) * rstd: equal to sopro_norm_f32 (LN) followed by the plain contraction within fp32 round-off, for a
+    stream with a large common offset (mean 30, spread 1: E[x^2] - E[x]^2 would lose 3 digits) and per-row scales over 1e-3 .. 1e3."""
+    HS, N2, eps, PAD = 512, 1536, 1e-5, 2
+    rng = np.random.default_rng(5)
+    xs = (PAD + n) * HS  # one utterance of the padded stream
+    B = M // n
+    X0 = torch.from_numpy(rng.standard_normal((B, PAD + n, HS)).astype(np.float32))
+    X0 = X0 * torch.from_numpy(np.logspace(-3, 3, B * (PAD + n)).astype(np.float32)).reshape(B, PAD + n, 1) + 30.0
+    Xd = dev(X0)
+    rows = Xd[:, PAD:].reshape(M, HS)
+    st = torch.full((M, HS // 64, 2), float("nan"), device=DEV)
+    hip.row_stats(Xd, M, HS, st, x_seg_stride=xs, rows_per_seg=n, x_off=PAD * HS)
+    g64 = rows.double().reshape(M, HS // 64, 64)
+    mag = g64.abs().amax(-1)  # fp32 sums of 64 values: errors are relative to the group's largest magnitude
+    assert bool(((st[..., 0].double() - g64.mean(-1)).abs() <= 4e-7 * mag).all())
+    m2 = ((g64 - g64.mean(-1, keepdim=True)) ** 2).sum(-1)
+    assert bool(((st[..., 1].double() - m2).abs() <= 1e-5 * m2 + 1e-6 * mag * mag).all())
+    # (2) producer: X <- X + scale * (A Wo^T), statistics of the result
+    K = 512
+    A, Wo, sc = rnd(M, K, seed=81), rnd(HS, K, seed=82, scale=K ** -0.5), rnd(HS, seed=83)
+    Wop = hip.pack_w_bf16(dev(Wo), pieces)
+    st_out = torch.full((M, HS // 64, 2), float("nan"), device=DEV)
+    hip.gemm(dev(A), Wop, Xd, M=M, N=HS, K=K, epilogue=hip.EPI_RES, R=Xd, scale=dev(sc), rows_per_seg=n, c_seg_stride=xs, r_seg_stride=xs,
+             c_off=PAD * HS, r_off=PAD * HS, ln_stats_out=st_out)
+    hip.row_stats(Xd, M, HS, st, x_seg_stride=xs, rows_per_seg=n, x_off=PAD * HS)
+    torch.cuda.synchronize()
+    assert torch.equal(st_out, st)
+    # (3) consumer
+    lnw, lnb = rnd(HS, seed=84) * 0.3 + 1.0, rnd(HS, seed=85) * 0.2
+    W = rnd(N2, HS, seed=86, scale=HS ** -0.5)
+    y = torch.empty(M, HS, device=DEV)
+    hip.norm(Xd, y, dev(lnw), rows=M, C_=HS, eps=eps, kind=hip.NORM_LN, b=dev(lnb), rows_per_seg=n, x_seg_stride=xs, x_off=PAD * HS)
+    want = torch.empty(M, N2, device=DEV)
+    hip.gemm(y, hip.pack_w_bf16(dev(W), pieces), want, M=M, N=N2, K=HS, epilogue=hip.EPI_GELU)
+    Wf = hip.pack_w_bf16(dev(W * lnw[None, :]), pieces)
+    bf = dev((W.double() @ lnb.double()).float())
+    got = torch.full((M, N2), float("nan"), device=DEV)
+    hip.gemm(Xd, Wf, got, M=M, N=N2, K=HS, bias=bf, epilogue=hip.EPI_GELU, rows_per_seg=n, a_seg_stride=xs, a_off=PAD * HS, ln_stats=st_out, ln_eps=eps)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got).all())
+    rows = Xd[:, PAD:].reshape(M, HS).double().cpu()
+    ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(rows, (HS,), lnw.double(), lnb.double(), eps) @ W.double().T).to(DEV)
+    tol = (8e-3 if pieces == 1 else 2e-5) * float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) <= tol and float((want.double() - ref).abs().max()) <= tol
+    assert float((got - want).abs().max()) <= tol
+    with pytest.raises(hip.SoproHipError):  # the statistics are per 64 columns
+        hip.gemm(Xd, hip.pack_w_bf16(dev(W[:, :480].contiguous()), pieces), got, M=M, N=N2, K=480, ln_stats=st_out, ln_eps=eps)
+
+
 @pytest.mark.parametrize("K", [256, 384, 512])
 def test_gemm_activation_stationary_form_is_the_same_function(K):
     """Round 5 (csrc/gemm_astat.hip): short-K contractions with the A block resident in LDS and barrier-free column-tile walks, tile
