@@ -515,6 +515,13 @@ def main() -> None:
     dt = time.perf_counter() - t0
     host_cpu = time.process_time() - c0
     log(f"timed region done: {dt:.3f} s for {args.steps} steps; peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    if os.environ.get("SOPRO_BENCH_MEMCENSUS", "0") == "1":  # developer: who holds the device memory (stderr)
+        lanes_ = pipe.lanes if pipe is not None else [tts]
+        for li, ln in enumerate(lanes_):
+            for nm, ws in (("model", ln.model.ws), ("codec", ln.codec.ws)):
+                top = sorted(((t.numel() * t.element_size(), k[0], k[1]) for k, t in ws._bufs.items()), reverse=True)[:6]
+                log(f"lane {li} {nm}.ws {ws.bytes / 2**30:.2f} GiB: " + "; ".join(f"{n} {list(sh)} {b / 2**30:.2f}" for b, n, sh in top))
+        log(f"allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB, reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB, peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     if os.environ.get("SOPRO_BENCH_TRACE") and pipe is not None:  # developer aid: which lane ran which step when, and its phase times
         for rep in range(int(os.environ["SOPRO_BENCH_TRACE"])):
             if rep:

@@ -73,6 +73,7 @@ class MimiCodec:
         self.ws_budget = int(os.environ.get("SOPRO_WS_BUDGET_GB", "32")) << 30  # scratch kept per batch shape, per engine
         self.use_graph = os.environ.get("SOPRO_NO_BULK_GRAPH", "0") != "1"
         self._graphs = hip.GraphCache("mimi_graph", cap=32)  # recorded decode calls per (B, T)
+        self.ws.on_clear.append(self._graphs.clear)  # (the recorded calls point into the scratch)
         self.stream_cap_rows = 1024  # cache rows of a streaming state (MimiStreamDecoder sets it per policy)
         self._rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._rope_n = 0
@@ -95,7 +96,17 @@ class MimiCodec:
         other.ws = Workspace(self.device)
         other.stream = torch.cuda.Stream(device=self.device)
         other._graphs = hip.GraphCache("mimi_graph", cap=32)
+        other.ws.on_clear.append(other._graphs.clear)
         return other
+
+    def share_scratch(self, ws: Workspace) -> None:
+        """Decode in ANOTHER decoder's scratch buffers.  For a scheduler whose decode phases never overlap (PipelinedSynthesizer with one
+        throughput slot): a 64 x 200-frame call needs 12.7 GB of scratch, four lanes held it four times (71 of the 87 GiB a pipelined
+        bench run peaked at, round 5).  Dropping the buffers drops every sharer's recorded calls (Workspace.on_clear)."""
+        self._graphs.clear()
+        self.ws = ws
+        if self._graphs.clear not in ws.on_clear:
+            ws.on_clear.append(self._graphs.clear)
 
     def _rope_tables(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """cos / sin rows for positions [0, n).  Allocated once for 8192 positions (2 MB; a 400-frame stream() reaches ~1100,

@@ -1142,7 +1142,10 @@ static size_t mimi_carve(const sopro_engine* e, MimiWs& w, void* ws, int B, int 
   w.e0 = act(cv, (size_t)B * (1 + rows) * ch);
   for (int si = 0; si < c.mimi_n_ratios; ++si) {
     const size_t co = ch / 2, orow = rows * c.mimi_ratios[si];
-    w.hraw[si] = act(cv, (size_t)B * (2 + orow) * co);
+    // (the last level's 64-channel activation stays on the CU when the level runs as one kernel - seanet_uptail: no buffer for it;
+    // it was 6.3 GB of a 64 x 200-frame call's 19 GB)
+    const bool on_cu = si + 1 == c.mimi_n_ratios && ch == 128 && c.mimi_ratios[si] == 4 && seanet_fused(B, (int)rows);
+    w.hraw[si] = on_cu ? nullptr : act(cv, (size_t)B * (2 + orow) * co);
     w.hact[si] = si + 1 < c.mimi_n_ratios ? act(cv, (size_t)B * (2 + orow) * co) : nullptr;
     w.y1[si] = si + 1 < c.mimi_n_ratios ? act(cv, (size_t)B * orow * (co / c.mimi_compress)) : nullptr;
     ch = co; rows = orow;
@@ -1270,7 +1273,7 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     BODY(sopro_fill2d_u32(w.e0, (int64_t)((1 + rowz) * chz / wd), B, (int)(chz / wd), 0u, s));
     for (int si = 0; si < c.mimi_n_ratios; ++si) {
       const size_t co = chz / 2, orow = rowz * c.mimi_ratios[si];
-      BODY(sopro_fill2d_u32(w.hraw[si], (int64_t)((2 + orow) * co / wd), B, (int)(2 * co / wd), 0u, s));
+      if (w.hraw[si]) BODY(sopro_fill2d_u32(w.hraw[si], (int64_t)((2 + orow) * co / wd), B, (int)(2 * co / wd), 0u, s));
       if (w.hact[si]) BODY(sopro_fill2d_u32(w.hact[si], (int64_t)((2 + orow) * co / wd), B, (int)(2 * co / wd), 0u, s));
       chz = co; rowz = orow;
     }

@@ -44,6 +44,7 @@ class Workspace:
         self.device = device
         self._bufs: Dict[Tuple[str, Tuple[int, ...], torch.dtype], torch.Tensor] = {}
         self.bytes = 0
+        self.on_clear: List = []
 
     def get(self, name: str, shape: Sequence[int], dtype: torch.dtype = torch.float32, zero: bool = False) -> torch.Tensor:
         key = (name, tuple(int(s) for s in shape), dtype)
@@ -56,6 +57,8 @@ class Workspace:
         return t
 
     def clear(self) -> None:
+        for f in self.on_clear:  # recorded launch sequences that point into these buffers (every engine that shares them)
+            f()
         self._bufs.clear()
         self.bytes = 0
 

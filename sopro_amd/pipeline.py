@@ -89,6 +89,7 @@ class PipelinedSynthesizer:
             self._streams += own
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
         self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))
+        self._share_decoder_scratch(bulk_slots)
         self.ar_cus, self.ar_parts, self.bulk_cus = ar_cus, ar_parts, total - bulk0
         tts.model._driver = self
         # (The lane threads spend most of their time WAITING - AR stop polls one chunk behind the launches, the end of a refinement /
@@ -120,8 +121,16 @@ class PipelinedSynthesizer:
         self._whole = None
         self.ar_locks = [threading.Lock() for _ in range(ar_parts)]
         self.bulk_lock = threading.Lock() if bulk_slots <= 1 else threading.BoundedSemaphore(int(bulk_slots))
+        self._share_decoder_scratch(bulk_slots)
         self.ar_cus, self.ar_parts, self.bulk_cus = 0, ar_parts, hip.device_info(self.device.index or 0)["cus"]
         tts.model._driver = self
+
+    def _share_decoder_scratch(self, bulk_slots: int) -> None:
+        """One throughput slot = one refinement / decode phase at a time (``bulk_lock``; ``prepare`` runs the lanes one by one): the
+        lanes decode in lane 0's scratch buffers instead of holding one set each (SOPRO_SHARE_SCRATCH=0: one set per lane)."""
+        if int(bulk_slots) <= 1 and os.environ.get("SOPRO_SHARE_SCRATCH", "1") != "0":
+            for lane in self.lanes[1:]:
+                lane.codec.share_scratch(self.lanes[0].codec.ws)
 
     def close(self) -> None:
         """Drop the extra lanes, destroy the CU-masked streams (and the graphs recorded on them) and give lane 0
@@ -138,6 +147,7 @@ class PipelinedSynthesizer:
             lane.model.ws.clear()
             lane.codec.ws.clear()
         lane0 = self.lanes[0]
+        lane0.codec.ws.on_clear[:] = [lane0.codec._graphs.clear]  # (the dropped lanes' recorded calls are gone)
         lane0.model._driver = None
         lane0.model.ar_tiles_wide = None
         lane0.model.stream, lane0.model.bulk_stream, lane0.codec.stream, lane0.model.prep_stream = self._saved
