@@ -792,6 +792,11 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
   // few columns, or few rows (streaming chunks, batch 1: small tiles keep the split-K partial sums small): 64x64
   if (g.N <= 64 || g.M <= 64) return launch_cfg3<2, 2, 2, 1, 1>(g, wp, ksubs, ext, s);
   if (eight_waves(g)) return launch_cfg3<2, 2, 4, 2, 1>(g, wp, ksubs, ext, s);
+  // developer A/B (SOPRO_GEMM_NARROW=1): 128x64 tiles for the N <= 512 contractions of a many-row pass (o / fc2 of the decoder transformer at
+  // 25600 rows: 800 tiles of 128x128 on 384 slots of the 192-CU partition = a third round that is 8 % full).  Measured in the pipeline
+  // (r05 call 22): decode 13.21 / 13.25 -> 13.38 / 13.37 ms per step - the narrower tile loses more than the fuller last round wins: no-go
+  static const bool narrow = SOPRO_DEV_ENV("SOPRO_GEMM_NARROW") != nullptr && SOPRO_DEV_ENV("SOPRO_GEMM_NARROW")[0] == '1';
+  if (narrow && g.N <= 512 && g.M >= 8192) return launch_cfg3<2, 2, 2, 2, 1>(g, wp, ksubs, ext, s);
   return launch_cfg3<2, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
 }
 
