@@ -33,3 +33,40 @@ def test_workspace_keeps_one_buffer_per_shape_and_counts_bytes():
     assert ws.over(100) and not ws.over(1000)
     ws.clear()
     assert ws.bytes == 0 and ws.get("x", (4, 8)) is not a
+
+
+def test_workspace_tells_every_sharer_when_its_buffers_go():
+    """Scratch shared between engines (MimiCodec.share_scratch: the lanes of a pipeline decode in one set of buffers): dropping the buffers must
+    drop every sharer's recorded launch sequences first - they hold raw pointers into them."""
+    ws = Workspace(torch.device("cpu"))
+    dropped = []
+    ws.on_clear.append(lambda: dropped.append("lane0"))
+    ws.on_clear.append(lambda: dropped.append("lane1"))
+    ws.get("x", (8,))
+    ws.clear()
+    assert dropped == ["lane0", "lane1"] and ws.bytes == 0
+    ws.clear()
+    assert dropped == ["lane0", "lane1"] * 2  # (idempotent for the listeners)
+
+
+def test_no_garbage_collection_while_a_launch_sequence_is_recorded():
+    """hip.capture_begin pauses the cyclic collector until capture_end (a finalizer that frees device memory on the recording thread
+    invalidates the recording); nested / repeated pauses restore the state they found."""
+    import gc
+
+    was = gc.isenabled()
+    try:
+        gc.enable()
+        hip._gc_pause()
+        assert not gc.isenabled()
+        hip._gc_pause()
+        hip._gc_resume()
+        assert not gc.isenabled()
+        hip._gc_resume()
+        assert gc.isenabled()
+        gc.disable()
+        hip._gc_pause()
+        hip._gc_resume()
+        assert not gc.isenabled()  # it was off before: stays off
+    finally:
+        gc.enable() if was else gc.disable()
