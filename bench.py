@@ -341,6 +341,80 @@ def leg_main(name: str, args, device: str) -> dict:
     raise SystemExit(f"unknown leg {name!r}")
 
 
+LINE_LIMIT = 8192  # the driver parses the last stdout line from a bounded buffer (round 5: a 21 kB line came back as parsed = null)
+FULL_RECORD = "bench_full.json"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(full: dict) -> dict:
+    """The ONE stdout line: headline keys, `config` (second metric + compact legs), `roofline` (primary family + the batch-1 frame),
+    `roofline_more` reduced to the figures a reader checks, `cpu_baseline`, `parity`.  Everything else (per-kernel tables, prose,
+    profile stamps, full legs) is in FULL_RECORD next to bench.py, in gpurun_out/ when that exists, and on stderr."""
+    roof_keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio", "launches", "avg_launch_us", "ms_per_step",
+                 "concurrent_phases", "wall_ms_per_step", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "rows_per_launch",
+                 "cu_share", "frac_of_pass_ceiling", "mfma_busy_pmc", "avg_launch_us_rocprof", "phase", "frac_reading")
+    more_keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_pass_ceiling", "ms_per_step", "avg_launch_us", "traffic",
+                 "mfma_busy_pmc", "phase")
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "warmup_run", "ms_per_step", "higher_is_better", "scaling", "dtype", "data"))
+    out["vs_baseline"] = full.get("vs_baseline")
+    cfg = full.get("config") or {}
+    c = _pick(cfg, ("workload", "batch_per_gpu", "frames", "voices_per_batch", "parallelism", "lanes_per_gpu", "pass_sizes", "legs"))
+    if cfg.get("second_metric"):
+        c["second_metric"] = _pick(cfg["second_metric"], ("ttfa_ms_p50", "cpu_ttfa_ms_p50", "what"))
+    out["config"] = c
+    out["phase_ms_per_step"] = full.get("phase_ms_per_step")
+    r = full.get("roofline")
+    if r:
+        rr = _pick(r, roof_keys)
+        rr["kernel"] = rr["kernel"].split(" (")[0] + (" (hipGraph, 23 launches)" if rr["kernel"].startswith("AR frame") else "")
+        if r.get("isolated_whole_chip"):
+            rr["isolated_whole_chip"] = _pick(r["isolated_whole_chip"], ("avg_launch_us", "achieved_GBps", "frac"))
+        if r.get("batch1"):
+            rr["batch1"] = _pick(r["batch1"], ("bound", "avg_launch_us", "achieved", "peak", "unit", "frac", "hbm_floor_us", "stage_floor_us", "frac_of_stage_floor"))
+        out["roofline"] = rr
+    else:
+        out["roofline"] = None
+    more = []
+    for e in full.get("roofline_more") or []:
+        m = _pick(e, more_keys)
+        m["kernel"] = m["kernel"].split(" (")[0]
+        more.append(m)
+    out["roofline_more"] = more
+    cb = full.get("cpu_baseline")
+    if cb:
+        o = _pick(cb, ("value", "unit", "cores", "kind", "sample", "ttfa_ms_p50"))
+        if cb.get("reference_ratio"):
+            o["reference_ratio"] = _pick(cb["reference_ratio"], ("oracle_over_reference", "estimated_reference_value_here", "file"))
+        out["cpu_baseline"] = o
+    else:
+        out["cpu_baseline"] = None
+    par = full.get("parity")
+    out["parity"] = _pick(par, ("ok", "row", "frames", "codebook0_equal", "refined_mismatches", "audit_worst_logit_gap", "timed_steps_identical",
+                                "timed_outputs_finite", "rank_output_sha16", "f16_range_fallbacks", "mode")) if par else None
+    out["full_record"] = FULL_RECORD
+    return out
+
+
+def emit(full: dict, root: str) -> str:
+    """Write the full record to a side file (+ stderr) and print the compact line (< LINE_LIMIT bytes) as the last stdout line."""
+    blob = json.dumps(full)
+    for d in (root, os.path.join(root, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, FULL_RECORD), "w") as fh:
+                    fh.write(blob + "\n")
+            except OSError as e:  # a read-only tree must not void the measurement
+                log(f"could not write {FULL_RECORD} in {d}: {e!r}")
+    print("[bench full record] " + blob, file=sys.stderr, flush=True)
+    text = json.dumps(compact_line(full), separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, f"bench line is {len(text)} bytes (limit {LINE_LIMIT}): trim compact_line()"
+    print(text, flush=True)
+    return text
+
+
 _T0 = time.perf_counter()
 
 
@@ -571,23 +645,47 @@ def main() -> None:
     # attention launch and AR frame replay, recorded on the stream of the launch.  The recorded NAR / Mimi launch sequences
     # are issued eagerly here so that their launches are visible one by one; the timed region above is not instrumented.
     prof = hip.Profiler()
+    phases_prof: dict = {}  # phase times (device events) of the instrumented repeat itself
     nprof = max(0, min(args.profile_steps, args.steps))
     if nprof > 0:
         hip.set_profiler(prof)
-        run_steps(nprof)
+        run_steps(nprof, phases_prof)
         fence()
         hip.set_profiler(None)
 
     # ---- rooflines of the instrumented families (HIP events recorded on the engine streams during the instrumented repeat)
     fam = prof.summary()
+    # The instrumented repeat issues the recorded refinement / decoder sequences EAGERLY, with two events around every heavy launch:
+    # its launches are slower than the same launches replayed from the recorded sequence (round 5: a family's instrumented time
+    # exceeded the timed region's whole phase).  What the repeat measures reliably is each family's SHARE of its phase; the time
+    # that counts is the phase's own device-event time in the timed region.  So: family time = instrumented family time x
+    # (timed phase per step / instrumented phase per step) - by construction a family never exceeds its phase.
+    fam_phase = {"gemm_f16x3_kernel": "nar", "gemm_bf16x3_kernel": "mimi", "seanet_uptail_kernel": "mimi", "seanet_tail_kernel": "mimi",
+                 "seanet_res128_kernel": "mimi", "seanet_up128_kernel": "mimi", "attention_split_kernel": "mimi",
+                 "gemm_f32_kernel": "cond", "gemm_bf16x6_kernel": "cond", "attention_kernel": "cond"}
+    bulk = ("cond", "nar", "mimi")
+    scale_of: dict = {}
+    if nprof > 0:
+        for ph in bulk:
+            if phases.get(ph, 0.0) > 0 and phases_prof.get(ph, 0.0) > 0:
+                scale_of[ph] = (phases[ph] / args.steps) / (phases_prof[ph] / nprof)
+        tot_t, tot_p = sum(phases.get(k, 0.0) for k in bulk) / args.steps, sum(phases_prof.get(k, 0.0) for k in bulk) / nprof
+        scale_of[None] = (tot_t / tot_p) if tot_t > 0 and tot_p > 0 else 1.0
+    for k, v in fam.items():
+        if k == "ar_step_graph":
+            continue
+        ph = fam_phase.get(k)
+        sc = scale_of.get(ph, scale_of.get(None, 1.0))
+        v["ms_instrumented"], v["phase"], v["phase_scale"] = v["ms"], ph, round(sc, 4)
+        v["ms"] = v["ms"] * sc
     pmc_d, busy_d, ark = latest_profile("pmc_summary.json"), latest_profile("pmc_mfma_busy.json"), latest_profile("ar_kernels.json")
     pmc, busy = pmc_d.get("families", {}), busy_d.get("families", {})
     stamp_of = lambda d: profile_stamp(os.path.join(ROOT, d["source"])) if d.get("source") else None  # noqa: E731
     rocf = rocprof_family_table()
     share = (256 - args.ar_cus * (1 if args.ar_shared else args.ar_parts)) / 256.0 if (args.lanes > 1 and args.ar_cus > 0) else 1.0  # CUs of the bulk partition
     ar_share = (args.ar_cus * (1 if args.ar_shared else args.ar_parts)) / 256.0 if (args.lanes > 1 and args.ar_cus > 0) else 1.0
-    measured = (f"HIP events on the launch stream over an instrumented repeat of {nprof} steps right after the timed region; samples whose "
-                "stream was idle at the first event (host-bound span) are excluded and the family time is scaled from the GPU-bound ones")
+    measured = (f"HIP events on the launch stream over an instrumented repeat of {nprof} steps right after the timed region (host-bound samples "
+                "excluded), scaled by timed-phase / instrumented-phase device time so that a family is a share of its phase in the timed region")
 
     def mfma_entry(key, title, peak, passes, extra_note):
         f = fam[key]
@@ -597,6 +695,8 @@ def main() -> None:
              "traffic": pmc.get(key, {}).get("traffic_bytes_per_launch"), "launches": f["launches"],
              "avg_launch_us": round(f["ms"] / max(1, f["launches"]) * 1e3, 2), "ms_per_step": round(f["ms"] / max(1, nprof), 3),
              "algorithmic_flops_per_launch": round(f["flops"] / max(1, f["launches"])), "measured": measured,
+             "phase": f.get("phase"), "phase_scale": f.get("phase_scale"),
+             "avg_launch_us_instrumented": round(f.get("ms_instrumented", f["ms"]) / max(1, f["launches"]) * 1e3, 2),
              "gpu_bound_samples": f.get("gpu_bound"), "samples": f["launches"]}
         if passes > 1:
             e["mfma_passes_per_product"] = passes
@@ -686,7 +786,10 @@ def main() -> None:
              "avg_launch_us": round(per_launch_ms * 1e3, 2), "ms_per_step": round((ar_ms / args.steps) if ar_frames else f["ms"] / max(1, nprof), 3),
              "avg_launch_us_instrumented_repeat": round(inst_ms * 1e3, 2),
              "algorithmic_bytes_per_launch": bytes_step, "rows_per_launch": rows_launch, "frames_by_rows": {str(k): v for k, v in sorted(by_rows.items())},
-             "cu_share": ar_share,
+             "cu_share": ar_share, "concurrent_phases": (args.ar_parts if args.lanes > 1 else 1),
+             "wall_ms_per_step": round(dt / args.steps * 1e3, 3),
+             "frac_reading": "a chain of 23 dependent launches per frame (latency-bound, 3-6 % of HBM peak by construction; batch1 sits on the "
+                             "launch-per-stage floor); with 4 jobs per pass this partition has slack: throughput is bound by roofline_more",
              "measured": ("two HIP events per AR phase on the AR stream IN the timed region: sum of phase times / frames replayed"
                           if ar_frames else measured),
              "note": (f"one launch = one frame of one {rows_launch}-row pass; in the pipeline two AR phases replay concurrently on the generation "
@@ -902,7 +1005,7 @@ def main() -> None:
                          "only - torchaudio is not in the image to generate a fixture from"],
             "roofline": roof, "roofline_more": roof_more, "cpu_baseline": cpu, "parity": parity,
         }
-        print(json.dumps(line), flush=True)
+        emit(line, ROOT)
     if world > 1:
         dist.destroy_process_group()
 

@@ -19,7 +19,18 @@ def _bench(extra, env=None):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, *extra], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, **(env or {})), cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 8192, len(last)  # the driver parses the last stdout line from a bounded buffer (round 5: 21 kB -> parsed = null)
+    line = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "config", "roofline", "roofline_more", "cpu_baseline", "parity", "full_record"):
+        assert k in line, k
+    # everything the compact line leaves out is in the full record (side file + stderr); the line's keys are a subset of it
+    full = [ln for ln in r.stderr.splitlines() if ln.startswith("[bench full record] ")]
+    assert len(full) == 1
+    full = json.loads(full[0][len("[bench full record] "):])
+    assert json.load(open(os.path.join(ROOT, line["full_record"]))) == full
+    assert full["value"] == line["value"] and full["parity"]["rank_output_sha16"] == line["parity"]["rank_output_sha16"]
+    return dict(full, **line)
 
 
 def test_two_ranks_reproduce_two_single_gpu_runs():

@@ -70,3 +70,28 @@ def test_no_garbage_collection_while_a_launch_sequence_is_recorded():
         assert not gc.isenabled()  # it was off before: stays off
     finally:
         gc.enable() if was else gc.disable()
+
+
+def test_bench_line_stays_under_the_drivers_parse_buffer():
+    """Round 5's 21 kB line came back from the driver as parsed = null.  bench.compact_line() keeps the headline, config (second
+    metric, legs), roofline (+ batch 1), roofline_more, cpu_baseline and parity of that very record under 8 kB."""
+    import importlib.util
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(root, "profiles", "r05_bench_line.json")))
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < bench.LINE_LIMIT == 8192
+    assert line["value"] == full["value"] and line["metric"] == full["metric"] and line["dtype"] == "f32"
+    assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["roofline"]["batch1"]["frac"] == full["roofline"]["batch1"]["frac"]
+    assert [e["frac"] for e in line["roofline_more"]] == [e["frac"] for e in full["roofline_more"]]
+    assert line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and line["cpu_baseline"]["kind"] == "port"
+    assert line["config"]["second_metric"]["ttfa_ms_p50"] == full["config"]["second_metric"]["ttfa_ms_p50"]
+    assert set(line["config"]["legs"]) == set(full["config"]["legs"]) and line["parity"]["ok"] is True
+    assert "workload" in line["config"] and not any(k in line["config"] for k in ("model", "seq_len"))
