@@ -738,7 +738,9 @@ int sopro_mimi_decode(sopro_engine* e, void* workspace, const int32_t* tokens, i
  * piece measured slower per utterance than two 32 x 400 ones and needs 148 GB of scratch): sopro_mimi_decode does that itself and
  * sopro_mimi_workspace_bytes sizes the workspace for ONE chunk, so every host gets it (round 5; it lived in the Python host).
  * sopro_mimi_chunk_rows: the rows per chunk sopro_mimi_decode uses for (B, T).
- * sopro_mimi_decode_parts: ONE chunk (B rows, workspace of sopro_mimi_workspace_bytes(e, B, T) bytes or more) in two parts - 1: every
+ * (the setting is read once per process).
+ * sopro_mimi_decode_parts: ONE chunk (B <= sopro_mimi_chunk_rows(B, T) rows - more is refused -, workspace of
+ * sopro_mimi_workspace_bytes(e, B, T) bytes or more) in two parts - 1: every
  * launch but the last, 2: the last launch alone, the only one that touches `wav` (the fused last SEANet level or its tail kernel), 3: both.
  * A host that replays part 1 from a recorded graph launches part 2 itself with the destination of THIS call: the decoder writes straight
  * into the caller's buffer and a recorded sequence holds no pointer of the caller's (src/sopro/codec/mimi.py:65-72: what decode_full

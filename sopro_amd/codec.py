@@ -204,11 +204,14 @@ class MimiCodec:
             raise ValueError("streaming decode state is single-utterance")
         if self.eng is None:
             raise hip.SoproHipError("this Mimi checkpoint was loaded without its decoder-side tensors")
-        if ws.over(self.ws_budget) and not any(k[1] == T for k in self._graphs.graphs):  # many batch shapes seen: start over
-            torch.cuda.synchronize(self.device)
-            self._graphs.clear()
-            ws.clear()
         lib, eng = hip.load(), self.eng
+        if ws.over(self.ws_budget):  # many batch shapes seen: start over, unless THIS call's chunk shapes all have their recorded sequences
+            r0 = int(lib.sopro_mimi_chunk_rows(B, T)) if state is None else B
+            need = {(min(B, b0 + r0) - b0, T) for b0 in range(0, B, r0)}
+            if not need <= {(k[0], k[1]) for k in self._graphs.graphs}:
+                torch.cuda.synchronize(self.device)
+                self._graphs.clear()
+                ws.clear()
         # Large batches are decoded in balanced row chunks of ~12800 frames (32 x 400, 64 x 200): a 64 x 400 decode in one call
         # measured slower per utterance than two 32 x 400 calls (39.5 vs 33.9 ms per 32; its scratch is 148 GB) - with chunks a
         # scheduler can still coalesce two long-form jobs into one 64-row generation / refinement pass (profiles/r04_experiments.md).

@@ -382,7 +382,9 @@ const char* check_cfg(const SoproCfg& c) {
   for (int x : c.ar_dilation_cycle) if (x < 1 || x > 4096) return "ar_dilation_cycle entry outside 1..4096";
   for (int x : c.nar_dilation_cycle) if (x < 1 || x > 4096) return "nar_dilation_cycle entry outside 1..4096";
   for (int s = 0; s < 4; ++s)
-    if (c.stage[s][0] < 1 || c.stage[s][1] < c.stage[s][0] || c.stage[s][1] > 4096) return "a stage pair is not 1 <= first <= last";
+    // (last < first is an EMPTY, disabled stage in the reference - _stage_range_to_indices filters to 1 <= i < Q and stage_order skips
+    // stages without codebooks, src/sopro/model.py:39-42,92-94 -: accepted; stage_cbs applies the same filter)
+    if (c.stage[s][0] < -4096 || c.stage[s][0] > 4096 || c.stage[s][1] < -4096 || c.stage[s][1] > 4096) return "a stage pair is outside -4096..4096";
   return nullptr;
 }
 

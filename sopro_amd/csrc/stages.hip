@@ -1530,8 +1530,12 @@ int sopro_mimi_encode(sopro_engine* e, void* workspace, const float* wav, int32_
 // workspace and a recorded sequence of its own: ADVICE r4)
 int32_t sopro_mimi_chunk_rows(int32_t B, int32_t T) {
   if (B <= 0 || T <= 0) return 0;
-  const char* env = getenv("SOPRO_MIMI_CHUNK_CELLS");  // (read per call: a host may change it between calls)
-  const int64_t cells = env ? std::max<int64_t>(1, atoll(env)) : 12800;
+  // read ONCE per process: the sizing call and the decode call must agree on the chunk (a value that changed in between
+  // made sopro_mimi_decode run chunks larger than the workspace it was given)
+  static const int64_t cells = [] {
+    const char* env = getenv("SOPRO_MIMI_CHUNK_CELLS");
+    return env ? std::max<int64_t>(1, atoll(env)) : (int64_t)12800;
+  }();
   const int64_t rows_max = std::max<int64_t>(1, cells / T);
   if (B <= rows_max) return B;
   const int64_t nchunks = (B + rows_max - 1) / rows_max;
@@ -1540,6 +1544,10 @@ int32_t sopro_mimi_chunk_rows(int32_t B, int32_t T) {
 
 int sopro_mimi_decode_parts(sopro_engine* e, void* workspace, const int32_t* tokens, int32_t B, int32_t T, float* wav, int32_t parts, void* stream) {
   SOPRO_CHECK_ARG(parts >= 1 && parts <= 3, "parts: 1 = all launches but the last, 2 = the last, 3 = both");
+  // ONE chunk: sopro_mimi_workspace_bytes(e, B, T) sizes the workspace for sopro_mimi_chunk_rows(B, T) rows, so more rows than that
+  // would run past it - a host with a larger batch calls sopro_mimi_decode, or this function once per chunk
+  SOPRO_CHECK_ARG(e && B > 0 && T > 0 && B <= sopro_mimi_chunk_rows(B, T),
+                  "sopro_mimi_decode_parts decodes one chunk: B must not exceed sopro_mimi_chunk_rows(B, T)");
   return mimi_decode_core(e, workspace, tokens, B, T, wav, stream, nullptr, parts);
 }
 

@@ -1008,6 +1008,8 @@ class GraphCache:
             g.launch()
             return
         n = self.seen.get(key, 0)
+        if n == 0 and len(self.seen) >= 8 * max(8, self.cap):  # keys may hold caller pointers (temporary tensors): keep the census bounded
+            self.seen.pop(next(iter(self.seen)))
         self.seen[key] = n + 1
         if n == 0:
             issue()
@@ -1129,9 +1131,10 @@ class HostMirror:
     def copy_to(self, t: torch.Tensor) -> None:
         """Queue host -> device: the kernel reads the page-locked words when it RUNS, so the host must leave them alone until the
         stream has passed this point (the users write a block, queue the launches that read it and synchronise before the next write)."""
-        if t.dtype not in (torch.int32, torch.float32) or not t.is_contiguous() or t.numel() != self.n or not t.is_cuda:
-            raise SoproHipError(f"HostMirror.copy_to: expected a contiguous device int32 / float32 tensor of {self.n} elements")
-        _check(load().sopro_copy2d_u32(t.data_ptr(), self.n, self.ptr, self.n, 1, self.n, _stream()), "sopro_copy2d_u32")
+        m = t.numel()  # (a block may be larger than what this call sends: the first m words go)
+        if t.dtype not in (torch.int32, torch.float32) or not t.is_contiguous() or not (0 < m <= self.n) or not t.is_cuda or not self.ptr:
+            raise SoproHipError(f"HostMirror.copy_to: expected a contiguous device int32 / float32 tensor of at most {self.n} elements")
+        _check(load().sopro_copy2d_u32(t.data_ptr(), m, self.ptr, m, 1, m, _stream()), "sopro_copy2d_u32")
 
     def values(self) -> list:
         return list(self._view)
@@ -1142,11 +1145,19 @@ class HostMirror:
 
         return np.ctypeslib.as_array(self._view)
 
+    def free(self) -> None:
+        """Give the page-locked words back NOW.  The caller has made sure no queued kernel and no recorded launch sequence still
+        holds the address.  Under the recording lock, like the allocation: the runtime refuses page-locked (de)allocations made
+        while another thread records."""
+        p, self.ptr = getattr(self, "ptr", None), None
+        if p and _lib is not None:
+            self._view = None
+            with _capture_lock:
+                _lib.sopro_host_free(p)
+
     def __del__(self):
         try:
-            if getattr(self, "ptr", None) and _lib is not None:
-                _lib.sopro_host_free(self.ptr)
-                self.ptr = None
+            self.free()
         except Exception:
             pass
 

@@ -109,7 +109,8 @@ class SoproTTSModel:
         self._voice: Dict[int, Dict[str, Any]] = {}  # per-voice conditioning cache (see _voice_entry)
         self._voice_stacks: Dict[tuple, Any] = {}  # [U, Tr, D] K / V stacks per set of voices (see _voice_stack)
         self._film_stacks: Dict[tuple, Any] = {}  # [B, D] FiLM coefficient stacks per (set of voices, style strength)
-        self._host_blocks: Dict[tuple, "hip.HostMirror"] = {}  # page-locked parameter blocks (see _host_block)
+        self._host_blocks: Dict[tuple, "hip.HostMirror"] = {}  # page-locked parameter blocks (see _host_block): an LRU
+        self._recorded_blocks: Dict[tuple, "hip.HostMirror"] = {}  # ... and the ones recorded launch sequences hold the address of
         self._consts: Dict[tuple, torch.Tensor] = {}  # small constant int32 device vectors (see _const_i32)
         self._runs = [0]  # generation runs started so far (shared by the lanes of clone_lane): the sampler's default nonce
         self._nar_graphs = hip.GraphCache("nar_graph", cap=64)  # recorded NAR launch sequences per (B, T)
@@ -176,20 +177,51 @@ class SoproTTSModel:
         other._voice_stacks = {}
         other._film_stacks = {}
         other._host_blocks = {}  # a lane writes its blocks while another lane's kernels may still read theirs
+        other._recorded_blocks = {}
         other._consts = {}
         other._nar_graphs = hip.GraphCache("nar_graph", cap=64)
         return other
 
-    def _host_block(self, key: tuple, n: int) -> "hip.HostMirror":
-        """``n`` page-locked words that kernels of the library read or write (hip.HostMirror.copy_to / copy_from): how the host's
-        small per-call parameters reach the device, and poll words the host, without a runtime copy on the path.  One block per
-        use and shape; the user synchronises before it writes the block again."""
-        hb = self._host_blocks.get(key)
-        if hb is None or hb.n != int(n):
-            if len(self._host_blocks) >= 64:
-                self._host_blocks.pop(next(iter(self._host_blocks)))
-            hb = self._host_blocks[key] = hip.HostMirror(int(n))
+    def _host_block(self, key: tuple, n: int, recorded: bool = False) -> "hip.HostMirror":
+        """At least ``n`` page-locked words that kernels of the library read or write (hip.HostMirror.copy_to / copy_from): how the
+        host's small per-call parameters reach the device, and poll words the host, without a runtime copy on the path.  One block
+        per use and shape; the user synchronises before it writes the block again.
+
+        ``recorded=True``: the block's ADDRESS is held by recorded launch sequences (the refinement's lengths / range words).  Such
+        blocks live in a dict of their own that is never evicted - a replayed sequence would otherwise read lengths from, and write
+        its range word to, freed page-locked memory - and are dropped only together with the recorded sequences
+        (``_drop_recorded``).  The others are an LRU of 64; an evicted block is freed only after this engine's streams have drained
+        (a queued kernel may still read it), under the recording lock (hip.HostMirror.free)."""
+        if recorded:
+            hb = self._recorded_blocks.get(key)
+            if hb is None or hb.n < int(n):
+                if hb is not None:  # a recorded sequence holds the old address: drop the sequences with it
+                    self._drop_recorded()
+                hb = self._recorded_blocks[key] = hip.HostMirror(int(n))
+            return hb
+        hb = self._host_blocks.pop(key, None)
+        if hb is not None and hb.n >= int(n):
+            self._host_blocks[key] = hb  # most recently used goes last
+            return hb
+        retired = [hb] if hb is not None else []
+        while len(self._host_blocks) >= 64:
+            retired.append(self._host_blocks.pop(next(iter(self._host_blocks))))
+        if retired:
+            for st in {id(x): x for x in (self.stream, self.bulk_stream, self.prep_stream)}.values():
+                st.synchronize()
+            for r in retired:
+                r.free()
+        hb = self._host_blocks[key] = hip.HostMirror(int(n))
         return hb
+
+    def _drop_recorded(self) -> None:
+        """Forget the recorded refinement sequences AND the page-locked blocks whose addresses they hold (in that order, after the
+        stream that replays them has drained)."""
+        self.bulk_stream.synchronize()
+        self._nar_graphs.clear()
+        for hb in self._recorded_blocks.values():
+            hb.free()
+        self._recorded_blocks.clear()
 
     def _const_i32(self, values: Sequence[int]) -> torch.Tensor:
         """A small constant int32 device vector (key lengths, voice indices of a batch), uploaded once per distinct content."""
@@ -335,8 +367,11 @@ class SoproTTSModel:
         with self.on_stream(prep=True):
             # ids and lengths travel through one page-locked block and a kernel of the library (no runtime copy on the path;
             # the block is rewritten by the next call of this engine, which comes after this call's synchronize below)
-            hb = self._host_block(("cond.in", B, S), B * S + B)
-            arr = hb.array()
+            # (keyed on a rounded capacity: a serving process sees every text length, and one block per (B, S) would walk through
+            # the LRU in minutes)
+            S_cap = (S + 31) // 32 * 32
+            hb = self._host_block(("cond.in", B, S_cap), B * S_cap + B)
+            arr = hb.array()[: B * S + B]
             arr[: B * S] = 0
             for b, x in enumerate(ids_list):
                 arr[b * S: b * S + lens_h[b]] = x.detach().to("cpu", torch.int32).view(-1).numpy()
@@ -536,9 +571,9 @@ class SoproTTSModel:
         Q = self.Q
         lib, eng = hip.load(), self.eng
         with self.on_stream(bulk=True):
-            hl = self._host_block(("nar.lens", B), B)
-            hl.array()[:] = [int(n) for n in lens_l]
-            hr = self._host_block(("nar.range",), 1)
+            hl = self._host_block(("nar.lens", B), B, recorded=True)
+            hl.array()[:B] = [int(n) for n in lens_l]
+            hr = self._host_block(("nar.range",), 1, recorded=True)
             toks = self.ws.get("nar.toks", (B * T, Q), dtype=torch.int32)
             scratch = self.ws.get(f"nar.stage_ws.{B}x{T}", (int(lib.sopro_nar_workspace_bytes(eng.h, B, T)),), dtype=torch.uint8)
             io = hip.NarIO(cond.data_ptr(), int(cond_bstride), cb0.data_ptr(), int(cb0_bstride), hl.ptr, toks.data_ptr(), hr.ptr, 1 if safe else 0)
@@ -548,7 +583,7 @@ class SoproTTSModel:
 
             if self.use_graph and os.environ.get("SOPRO_NO_BULK_GRAPH", "0") != "1":
                 # (the recorded sequence holds the operands' addresses: they are part of its key)
-                self._nar_graphs.run((B, T, cond.data_ptr(), int(cond_bstride), cb0.data_ptr(), int(cb0_bstride), bool(safe)), issue)
+                self._nar_graphs.run((B, T, cond.data_ptr(), int(cond_bstride), cb0.data_ptr(), int(cb0_bstride), bool(safe), hl.ptr, hr.ptr), issue)
             else:
                 issue()
             self._nar_last = (cond, cond_bstride, cb0, cb0_bstride, list(lens_l), B, T)
@@ -570,7 +605,7 @@ class SoproTTSModel:
         (and ``redo``) the same pass is queued again on the six-pass bf16 operands - fp32's exponent range - into the same token
         buffer, and True is returned: the caller repeats whatever consumed the tokens (a checkpoint whose residual
         stream exceeds fp16 pays the slower path instead of getting wrong tokens silently)."""
-        hr = self._host_blocks.get(("nar.range",))
+        hr = self._recorded_blocks.get(("nar.range",))
         if hr is None or self.precision != "f32" or int(hr.values()[0]) == 0:
             return False
         self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1

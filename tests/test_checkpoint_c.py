@@ -170,7 +170,7 @@ def test_c_loader_refuses_tensors_that_do_not_fit_the_config(tmp_path):
     from safetensors.numpy import save_file
 
     for bad in ({"pos_emb_max": -5}, {"d_model": 1e300}, {"n_layers_ar": 400}, {"num_codebooks": 0}, {"ar_dilation_cycle": [1, -2]},
-                {"stage_B": [5, 2]}, {"ref_xattn_heads": 7}, {"d_model": "384"}, {"nar_head_dim": 2.5}):
+                {"stage_B": [5, 99999]}, {"ref_xattn_heads": 7}, {"d_model": "384"}, {"nar_head_dim": 2.5}):
         d = json.loads(cfg.to_json())
         d.update(bad)
         p = str(tmp_path / "c.safetensors")
@@ -232,3 +232,20 @@ def test_c_loader_survives_hostile_safetensors_headers(tmp_path):
     _write_raw_safetensors(p, hdr, b"\0" * 8)
     rc, err = _open_rc(lib, p)
     assert rc != 0 and "is missing" in err, err  # the header and the cfg parse; the first tensor the packer asks for is absent
+
+
+def test_c_loader_accepts_a_disabled_stage(tmp_path):
+    """A stage pair with last < first is an EMPTY stage in the reference (_stage_range_to_indices, src/sopro/model.py:39-42; stage_order
+    skips it, :92-94): such a checkpoint opens and packs what pack.py packs (it used to be refused)."""
+    cfg, mc = SoproTTSConfig(stage_C=(5, 16), stage_D=(9, 8)), MimiDecoderConfig()
+    assert cfg.stage_order() == ["B", "C", "E"]
+    wn, mn = synth_sopro_weights(cfg, 512, 13), synth_mimi_weights(mc, 13)
+    lib, ck, got = _open(tmp_path, cfg, wn, mn)
+    try:
+        want = pack_sopro(wn, cfg)
+        for k, w in want.items():
+            if k.startswith("nar.") and w.dim() >= 1:
+                assert k in got and tuple(got[k].shape) == tuple(w.shape), k
+                assert torch.allclose(torch.from_numpy(got[k]), w.float(), rtol=1e-6, atol=1e-7), k
+    finally:
+        lib.sopro_checkpoint_close(ck)
