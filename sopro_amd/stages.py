@@ -218,6 +218,35 @@ class StageEngine(EngineHandle):
         return out
 
     @torch.inference_mode()
+    def nar_refine_guarded(self, cond: torch.Tensor, rvq1: torch.Tensor, lens: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int]:
+        """The refinement with its RANGE GUARD, as a C host writes it (sopro_nar_refine_io): the pass leaves the number of workgroups
+        that had to saturate an fp16 operand in a word of the caller's; a non-zero word means the tokens cannot be trusted, and the
+        host repeats the pass with ``safe = 1`` (six-pass bf16 operands: fp32's exponent range).  -> (tokens [B, T, Q] int32, events
+        of the first pass)."""
+        B, T = rvq1.shape
+        lib, st = self.lib, self.stream
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        ws = self._workspace("nar", int(lib.sopro_nar_workspace_bytes(self.h, B, T)))
+        cond = cond.float()
+        assert cond.stride(2) == 1 and cond.stride(1) == cond.shape[2]
+        rvq1 = rvq1.to(torch.int32).contiguous()
+        lens_d = (lens if lens is not None else torch.full((B,), T)).to(self.device).to(torch.int32).contiguous()
+        out = torch.empty(B, T, int(self.tts.cfg.num_codebooks), dtype=torch.int32, device=self.device)
+        word = torch.zeros(1, dtype=torch.int32, device=self.device)
+        io = hip.NarIO(cond.data_ptr(), int(cond.stride(0)), rvq1.data_ptr(), int(rvq1.stride(0)), lens_d.data_ptr(), out.data_ptr(), word.data_ptr(), 0)
+        with torch.cuda.stream(st):
+            hip._check(lib.sopro_nar_refine_io(self.h, ws.data_ptr(), C.byref(io), B, T, st.cuda_stream), "sopro_nar_refine_io")
+            st.synchronize()
+            events = int(word.item())
+            if events:
+                io.safe = 1
+                word.zero_()
+                hip._check(lib.sopro_nar_refine_io(self.h, ws.data_ptr(), C.byref(io), B, T, st.cuda_stream), "sopro_nar_refine_io")
+                st.synchronize()
+                assert int(word.item()) == 0, "the six-pass operands have fp32's range: no events"
+        return out, events
+
+    @torch.inference_mode()
     def mimi_decode(self, tokens: torch.Tensor) -> torch.Tensor:
         """tokens [B, T, Q] -> wav [B, T * 1920]."""
         B, T, _ = tokens.shape

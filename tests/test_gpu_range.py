@@ -57,7 +57,7 @@ def test_refinement_and_decode_on_a_badly_scaled_checkpoint_match_the_reference(
     assert float(g["stream_rms_min"]) < 2e-3 and float(g["stream_rms_max"]) > 5e2  # the fixture is what it claims to be
     got = tts.model.nar_refine(cond, rvq1).cpu()
     assert getattr(tts.model, "range_fallbacks", 0) == 0, "the in-range fixture must not need the six-pass fallback"
-    assert int(tts.model._host_blocks[("nar.range",)].values()[0]) == 0
+    assert int(tts.model._recorded_blocks[("nar.range",)].values()[0]) == 0
     n_off = _audit(cfg, wn, cond, got, want, scale=1e3)
     assert n_off <= 2
     # waveform of the REFERENCE's tokens through the badly scaled decoder: 1e-4 of peak, like every other waveform fixture
@@ -79,8 +79,49 @@ def test_overflowing_operands_are_counted_and_the_pass_is_repeated_on_six_passes
     for k in (2, 3):
         again = tts.model.nar_refine(cond, rvq1).cpu()
         assert torch.equal(again, got) and tts.model.range_fallbacks == k
-    # the whole-pass path of a scheduler (refinement and decode queued back to back, guard checked after the decoder's sync)
-    from sopro_amd.model import PreparedReference  # noqa: F401  (import check only)
+    # the C stage API (what a host that is not this package writes): sopro_nar_refine_io leaves the events in the caller's word,
+    # the host repeats the pass with safe = 1
+    from sopro_amd.stages import StageEngine
+
+    eng = StageEngine(tts)
+    toks, events = eng.nar_refine_guarded(cond.to("cuda:0"), rvq1.to("cuda:0"))
+    assert events > 0 and torch.equal(toks.cpu().long(), got)
+    eng.close()
+
+
+def test_the_scheduler_path_repeats_an_overflowing_pass(cfg, mc):
+    """The whole-pass path of a scheduler: PipelinedSynthesizer queues refinement and decode back to back on the
+    throughput partition and reads the guard word after the decoder's sync (SoproTTS.synthesize_batch); on the overflow checkpoint
+    every pass must trip the guard, be repeated on the six-pass operands and decoded again - expected waveforms: the ORACLE's
+    generate_tokens + decode_full on the same checkpoint (fp32 has the range).  Reference: src/sopro/model.py:307-347."""
+    from oracle import sopro_oracle as O
+    from sopro_amd.pipeline import PipelinedSynthesizer
+
+    tts, wn, mn = _engine(cfg, mc, overflow=True)
+    w, mw = O.to_torch(wn), O.to_torch(mn)
+    rng = np.random.default_rng(17)
+    ref_tq = torch.from_numpy(rng.integers(0, 2048, size=(20, 32)))
+    ref, oref = tts.prepare_reference(ref_tokens_tq=ref_tq), O.prepare_reference(ref_tq, w, cfg)
+    ids = [torch.from_numpy(rng.integers(1, VOCAB, size=n)) for n in (9, 14)]
+    kw = dict(max_frames=11, top_p=0.0, temperature=1.0, anti_loop=False)
+    want = []
+    for x in ids:
+        toks = O.generate_tokens(x, oref, w, cfg, style_strength=float(cfg.style_strength), **kw)
+        want.append((toks, O.decode_full(toks, mw, mc)))
+    job = dict(texts=[""] * 2, refs=[ref, ref], text_ids=ids, **kw)
+    pipe = PipelinedSynthesizer(tts, lanes=2, ar_cus=64, ar_parts=1)
+    try:
+        outs = pipe.run([job] * 4)  # eager, recording and replayed passes on both lanes
+        fallbacks = sum(getattr(l.model, "range_fallbacks", 0) for l in pipe.lanes)
+    finally:
+        pipe.close()
+    assert fallbacks == 4, fallbacks  # every pass tripped the guard exactly once
+    for out in outs:
+        for b, (toks, owav) in enumerate(want):
+            got = out[b].cpu().reshape(-1)
+            assert got.numel() == owav.numel() == toks.shape[0] * 1920
+            err, peak = float((got - owav.reshape(-1)).abs().max()), float(owav.abs().max())
+            assert err < 1e-4 * peak, (b, err, peak)
 
 
 def test_f16x3_range_word_at_the_operator_level():
