@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SOPRO_ABI_VERSION 40
+#define SOPRO_ABI_VERSION 41
 
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
@@ -169,6 +169,18 @@ typedef struct sopro_gemm_split_ext {
   float* ln_stats_out;
 } sopro_gemm_split_ext;
 int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w, const sopro_gemm_split_ext* ext, void* stream);
+/* LONG-K form of sopro_gemm_bf16x3 (round 6; csrc/gemm_8p.hip): the same three-pass contraction - bit-identical results - on 256 x 256
+ * tiles with BOTH operands in split form in memory, staged by LDS-DMA behind counted waits (no split work, no staging registers in the
+ * main loop).  For the SEANet decoder's K >= 1024 contractions (HF:modeling_mimi.py:350-405 MimiConvTranspose1d as a row-window
+ * contraction; :408-447 the first residual block's k = 3 convolution): 1.3-1.4x the tile kernel there.  A must be split-form rows
+ * (a_format 1: what a producer's c_mode 1 / 2 writes), the weight comes from sopro_pack_w_rows_bf16: [N][K / 32][32 hi | 32 lo] bf16,
+ * sopro_packed_w_rows_bytes(N, K) bytes, 128-byte aligned.  N % 256 == 0, K % 32 == 0; epilogue NONE (+ bias); c_mode 0 / 1 / 2 / 4; no
+ * split-K.  sopro_gemm_8p_takes: 1 when a call with these (args, ext) is one this form takes AND has enough tiles to pay (what the
+ * stage sequences ask before they route a contraction here). */
+int64_t sopro_packed_w_rows_bytes(int32_t N, int32_t K);
+int sopro_pack_w_rows_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, void* packed, void* stream);
+int sopro_gemm_8p_takes(const sopro_gemm_args* a, const sopro_gemm_split_ext* ext);
+int sopro_gemm_bf16x3_8p(const sopro_gemm_args* a, const void* w_rows, const sopro_gemm_split_ext* ext, void* stream);
 /* Six-pass variant for token paths (NAR refinement, conditioning: src/sopro/nn/nar.py, blocks.py): operands split into
  * THREE bf16 pieces (24 mantissa bits), products p2*p0 + p0*p2 + p1*p1 + p1*p0 + p0*p1 + p0*p0; the dropped terms are
  * <= 2^-25 relative, i.e. the accuracy class of an fp32 fma chain, at 16/6 of the fp32-MFMA rate.  fp32 rows in and out;

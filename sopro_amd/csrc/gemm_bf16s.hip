@@ -599,6 +599,7 @@ int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
       SOPRO_CASE(SOPRO_EPI_NONE, 2, 0);
       SOPRO_CASE(SOPRO_EPI_NONE, 2, 1);
       SOPRO_CASE(SOPRO_EPI_NONE, 2, 2);
+      SOPRO_CASE(SOPRO_EPI_NONE, 2, 4);  // (round 6: split-form input, raw + activated fp32 copies out - a level behind a split-form one)
       SOPRO_CASE(SOPRO_EPI_RES, 2, 1);
       default: break;
     }

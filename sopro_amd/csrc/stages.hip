@@ -24,6 +24,7 @@ struct Ten {
 struct Wt {  // weight operand of a contraction: fp32 [N, K] row-major and / or its packed 16-bit pieces
   const float* f32 = nullptr;
   const void* packed = nullptr;
+  const void* rows = nullptr;  // pieces == 2: the matrix as split-form rows too (sopro_pack_w_rows_bf16), for the long-K form (gemm_8p.hip)
   int pieces = 0;
   bool f16 = false;        // two fp16 pieces (sopro_gemm_f16x3) instead of bf16 ones
   float acc_scale = 1.f;   // f16: 1 / (activation scale * pack scale)
@@ -135,7 +136,8 @@ constexpr int F16X2 = 22;  // pack_pieces: two fp16 pieces (the NAR contractions
 const char* const NAR_SAFE = "#x6";  // key suffix of the refinement's six-pass twins (sopro_nar_io.safe)
 
 // [N, K] fp32 device matrix (optionally with its columns scaled by a device vector: an RMSNorm weight folded in) -> bf16 pieces
-int pack_pieces(sopro_engine* e, const std::string& key, const std::string& out_key, int pieces, const char* fold_vec, hipStream_t s) {
+int pack_pieces(sopro_engine* e, const std::string& key, const std::string& out_key, int pieces, const char* fold_vec, hipStream_t s,
+                bool with_rows = false) {
   const Ten* t;
   STG(need(e, key, &t, 2));
   const int N = (int)t->shape[0], K = (int)t->shape[1];
@@ -172,6 +174,13 @@ int pack_pieces(sopro_engine* e, const std::string& key, const std::string& out_
     w.acc_scale = 1.0f / (sopro_f16x3_a_scale() * wscale);
   } else {
     STG(sopro_pack_w_bf16(src, K, N, K, pieces, dst, s));
+  }
+  if (with_rows && pieces == 2 && !f16 && (K & 31) == 0) {  // the long-K form's weight operand (rows must start on 128-byte boundaries)
+    char* rows;
+    STG(dev_alloc(e, (size_t)sopro_packed_w_rows_bytes(N, K) + 128, &rows));
+    rows += (128 - (reinterpret_cast<uintptr_t>(rows) & 127u)) & 127u;
+    STG(sopro_pack_w_rows_bf16(src, K, N, K, rows, s));
+    w.rows = rows;
   }
   w.f32 = fold_vec ? nullptr : t->f();
   w.packed = dst;
@@ -331,6 +340,11 @@ int gemm(hipStream_t s, const float* A, const Wt& w, const float* w_f32_override
     }
     if (w.pieces == 3) return sopro_gemm_bf16x6(&g, w.packed, &x, s);
     if (w.pieces == 1) return sopro_gemm_bf16x1(&g, w.packed, &x, s);
+    if (w.rows) {  // long K, many tiles, split-form A: the 256 x 256 LDS-DMA form (same results bit for bit)
+      sopro_gemm_split_ext x8 = x;
+      x8.ksplit = 0;
+      if (sopro_gemm_8p_takes(&g, &x8)) return sopro_gemm_bf16x3_8p(&g, w.rows, &x8, s);
+    }
     return sopro_gemm_bf16x3(&g, w.packed, &x, s);
   }
   if (!g.W) {
@@ -568,12 +582,14 @@ int sopro_engine_finalize(sopro_engine* e, void* stream) {
     STG(need(e, "sea.conv0.b", &t));
     for (int si = 0; si < c.mimi_n_ratios; ++si) {
       const std::string u = "sea.up" + std::to_string(si), r = "sea.res" + std::to_string(si);
-      STG(pack_pieces(e, u + ".w", u + ".w", mp, nullptr, s));
+      // (K >= 1024 transposed convolutions and the first residual block's k = 3 convolution also as split-form rows: gemm_8p.hip)
+      STG(need(e, u + ".w", &t, 2));
+      STG(pack_pieces(e, u + ".w", u + ".w", mp, nullptr, s, (int)t->shape[1] >= 1024 && (int)t->shape[0] % 256 == 0));
       STG(need(e, u + ".b", &t));
       for (const char* nm : {".c1.w", ".c1.b", ".c2.w", ".c2.b"}) STG(need(e, r + nm, &t));
       STG(need(e, r + ".c1.w", &t, 2));
       if ((int)t->shape[0] >= 64 && (int)t->shape[0] != 64) {  // hidden > 64: generic contractions (64 = the fused 128-channel block)
-        STG(pack_pieces(e, r + ".c1.w", r + ".c1.w", mp, nullptr, s));
+        STG(pack_pieces(e, r + ".c1.w", r + ".c1.w", mp, nullptr, s, (int)t->shape[1] >= 1024 && (int)t->shape[0] % 256 == 0));
         STG(pack_pieces(e, r + ".c2.w", r + ".c2.w", mp, nullptr, s));
       }
     }
@@ -1362,9 +1378,16 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     sopro_set_error("sopro_mimi_decode: the decoder has no last stage");
     return -2;
   }
+  // Round 6: the levels whose contractions have K >= 1024 hand their ACTIVATED tensors over in split form (every 32 channels =
+  // [32 hi | 32 lo] bf16: same bytes, lines and strides as fp32) - the producer's epilogue splits once (c_mode 1 / 2), and the long-K
+  // form of the contraction (gemm_8p.hip: both operands by LDS-DMA) takes them where there are tiles enough; the tile kernel reads the
+  // same tensors (a_format 1) when there are not (streaming chunks).  `in_split`: this level's input is in split form.
+  auto rows_of = [&](const std::string& k) { return WT(e, k).rows != nullptr; };
+  static const bool no_8p = SOPRO_DEV_ENV("SOPRO_GEMM_8P") != nullptr && SOPRO_DEV_ENV("SOPRO_GEMM_8P")[0] == '0';  // developer A/B: the round-5 flow
+  bool in_split = !no_8p && rows_of("sea.up0.w");
   {  // first conv k = 7 -> ELU; one zero row in front = x[t-1] of the transposed conv
     G g; g.sk = &w.sk; g.M = B * rows; g.N = ch; g.K = c.mimi_kernel * HS; g.lda = HS; g.bias = F(e, "sea.conv0.b"); g.rows_per_seg = rows; g.a_seg = xs;
-    g.c_seg = (int64_t)(1 + rows) * ch; g.ldc = ch; g.c_mode = 3;
+    g.c_seg = (int64_t)(1 + rows) * ch; g.ldc = ch; g.c_mode = in_split ? 1 : 3;
     BODY(gemm(s, w.X, WT(e, "sea.conv0.w"), nullptr, w.e0 + ch, g));
   }
   const float* He = w.e0;
@@ -1375,6 +1398,7 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
     float* Ho = w.hraw[si];
     G up; up.sk = &w.sk; up.M = B * rows; up.N = r * co; up.K = 2 * ch; up.lda = ch; up.bias = F(e, u + ".b"); up.rows_per_seg = rows;
     up.a_seg = (int64_t)(pad_in + rows) * ch; up.c_seg = (int64_t)(2 + orow) * co; up.ldc = (int64_t)r * co;
+    up.a_fmt = in_split ? 1 : 0;
     const float* A = He + (size_t)(pad_in - 1) * ch;
     if (last) {
       SOPRO_CHECK_ARG(co == 64 && hid == 32, "the fused tail is written for a 64-channel last stage");
@@ -1402,16 +1426,23 @@ static int mimi_decode_core(sopro_engine* e, void* workspace, const int32_t* tok
       sopro_prof_scope prof((parts & 1) ? "seanet_res128_kernel" : nullptr, 2.0 * B * orow * (3 * 128 * 64 + 64 * 128), s);
       BODY(sopro_seanet_res128_p_f32(Ho, (int64_t)(2 + orow) * co, F(e, rs + ".c1.w"), F(e, rs + ".c1.b"), F(e, rs + ".c2.w"), F(e, rs + ".c2.b"), Hn,
                                     (int64_t)(2 + orow) * co, B, orow, sea_passes, s));
+      in_split = false;
     } else {
-      up.c_mode = 4; up.C2 = Hn + 2 * co; up.ldc2 = (int64_t)r * co; up.c2_seg = (int64_t)(2 + orow) * co;
+      // the block's tensors in split form when its k = 3 convolution has the long-K operand; its output (only ever read through ELU,
+      // by the next level) goes on in split form with them
+      // (never into the last level: its fused kernels read fp32 rows)
+      const bool mid_split = !no_8p && rows_of(rs + ".c1.w") && (co & 31) == 0 && (hid & 31) == 0 && si + 1 < c.mimi_n_ratios - 1;
+      up.c_mode = mid_split ? 2 : 4; up.C2 = Hn + 2 * co; up.ldc2 = (int64_t)r * co; up.c2_seg = (int64_t)(2 + orow) * co;
       BODY(gemm(s, A, WT(e, u + ".w"), nullptr, Ho + 2 * co, up));
       // residual block: x + Conv1d(k=1)(ELU(Conv1d(k=3)(ELU(x)))); its output is only ever read through ELU
       G c1; c1.sk = &w.sk; c1.M = B * orow; c1.N = hid; c1.K = 3 * co; c1.lda = co; c1.bias = F(e, rs + ".c1.b"); c1.rows_per_seg = orow;
-      c1.a_seg = (int64_t)(2 + orow) * co; c1.c_mode = 3;
+      c1.a_seg = (int64_t)(2 + orow) * co; c1.c_mode = mid_split ? 1 : 3; c1.a_fmt = mid_split ? 1 : 0;
       BODY(gemm(s, Hn, WT(e, rs + ".c1.w"), nullptr, w.y1[si], c1));
       G c2; c2.sk = &w.sk; c2.M = B * orow; c2.N = co; c2.K = hid; c2.bias = F(e, rs + ".c2.b"); c2.epi = SOPRO_EPI_RES; c2.R = Ho + 2 * co; c2.rows_per_seg = orow;
-      c2.c_seg = (int64_t)(2 + orow) * co; c2.r_seg = (int64_t)(2 + orow) * co; c2.ldc = co; c2.ldr = co; c2.c_mode = 3;
+      c2.c_seg = (int64_t)(2 + orow) * co; c2.r_seg = (int64_t)(2 + orow) * co; c2.ldc = co; c2.ldr = co; c2.c_mode = mid_split ? 1 : 3;
+      c2.a_fmt = mid_split ? 1 : 0;
       BODY(gemm(s, w.y1[si], WT(e, rs + ".c2.w"), nullptr, Hn + 2 * co, c2));
+      in_split = mid_split;
     }
     He = Hn; ch = co; rows = orow; pad_in = 2;
   }

@@ -18,7 +18,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
-ABI_VERSION = 40
+ABI_VERSION = 41
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -150,6 +150,10 @@ SYMBOLS = {
     "sopro_f16x3_a_scale": (C.c_float, []),
     "sopro_gemm_f16x3": (C.c_int, [_p, _p, _p, _p]),
     "sopro_packed_w_bytes": (C.c_int64, [_i32, _i32, _i32]),
+    "sopro_packed_w_rows_bytes": (C.c_int64, [_i32, _i32]),
+    "sopro_pack_w_rows_bf16": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
+    "sopro_gemm_8p_takes": (C.c_int, [_p, _p]),
+    "sopro_gemm_bf16x3_8p": (C.c_int, [_p, _p, _p, _p]),
     "sopro_gemm_bf16_set_tile_override": (C.c_int, [C.c_int]),
     "sopro_gemm_set_group_m": (C.c_int, [C.c_int]),
     "sopro_seanet_tail_set_tiles": (C.c_int, [C.c_int]),
@@ -375,7 +379,8 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
          r_off: int = 0, ldw: Optional[int] = None, dbg: Optional[torch.Tensor] = None, a_split: bool = False, c_mode: int = 0,
          C2: Optional[torch.Tensor] = None, ldc2: Optional[int] = None, c2_seg_stride: int = 0,
          c2_off: int = 0, rms_eps: float = 0.0, range_events: Optional[torch.Tensor] = None, rope: Optional[tuple] = None,
-         ln_stats: Optional[torch.Tensor] = None, ln_eps: float = 0.0, ln_stats_out: Optional[torch.Tensor] = None) -> None:
+         ln_stats: Optional[torch.Tensor] = None, ln_eps: float = 0.0, ln_stats_out: Optional[torch.Tensor] = None,
+         long_k: Optional[bool] = None) -> None:
     """C = epi(pro(A) @ W^T + bias); offsets are in elements from the tensors' first element.  With a ``PackedW`` weight the
     contraction runs on the split-bf16 path, where ``a_split`` says A is in split form and ``c_mode`` 1 / 2 writes
     ELU(C) in split form (to C, or to C2 next to the fp32 C): see sopro_gemm_split_ext in include/sopro_hip.h."""
@@ -453,7 +458,14 @@ def gemm(A: torch.Tensor, W, Cout: torch.Tensor, *, M: int, N: int, K: int, lda:
         x.a_format, x.c_mode = int(bool(a_split)), c_mode
         x.C2 = (ptr(C2) + 4 * c2_off) if C2 is not None else None
         x.ldc2, x.c2_seg_stride = (n_out if ldc2 is None else ldc2), c2_seg_stride
-        _check(load().sopro_gemm_bf16x3(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_bf16x3")
+        use_8p = long_k if long_k is not None else (W.rows is not None and bool(load().sopro_gemm_8p_takes(C.byref(g), C.byref(x))))
+        if use_8p:  # the long-K form: 256 x 256 tiles, both operands split in memory (csrc/gemm_8p.hip); same results bit for bit
+            if W.rows is None:
+                raise SoproHipError("the long-K form needs the weight's split-form rows (pack_w_bf16x3(W, rows=True))")
+            x.ksplit = 0
+            _check(load().sopro_gemm_bf16x3_8p(C.byref(g), W.rows.data_ptr(), C.byref(x), _stream()), "sopro_gemm_bf16x3_8p")
+        else:
+            _check(load().sopro_gemm_bf16x3(C.byref(g), ptr(W.data, torch.int32), C.byref(x), _stream()), "sopro_gemm_bf16x3")
     elif a_split or c_mode:
         raise SoproHipError("split-plane operands need a PackedW weight (the fp32 kernel reads and writes fp32 rows)")
     else:
@@ -505,10 +517,11 @@ def _splitk_buffers():
 class PackedW:
     """A weight matrix [N, K] as 1, 2 or 3 bf16 pieces in MFMA fragment order (sopro_pack_w_bf16)."""
 
-    __slots__ = ("data", "N", "K", "pieces", "f16", "acc_scale")
+    __slots__ = ("data", "N", "K", "pieces", "f16", "acc_scale", "rows")
 
     def __init__(self, data: torch.Tensor, N: int, K: int, pieces: int, f16: bool = False, acc_scale: float = 1.0):
         self.data, self.N, self.K, self.pieces, self.f16, self.acc_scale = data, N, K, pieces, f16, acc_scale
+        self.rows = None  # pieces == 2: the same matrix as split-form ROWS for the long-K form (pack_w_rows_bf16 / sopro_gemm_bf16x3_8p)
 
 
 def pack_w_bf16(W: torch.Tensor, pieces: int) -> PackedW:
@@ -523,8 +536,21 @@ def pack_w_bf16(W: torch.Tensor, pieces: int) -> PackedW:
     return PackedW(data, N, K, pieces)
 
 
-def pack_w_bf16x3(W: torch.Tensor) -> PackedW:
-    return pack_w_bf16(W, 2)
+def pack_w_bf16x3(W: torch.Tensor, rows: bool = False) -> PackedW:
+    """``rows``: also keep the matrix as split-form rows [N][K / 32][32 hi | 32 lo] (sopro_pack_w_rows_bf16) - the weight operand of the
+    long-K form (csrc/gemm_8p.hip), which ``gemm`` picks when the library says the call is one it takes (or ``long_k=True``)."""
+    pw = pack_w_bf16(W, 2)
+    if rows:
+        N, K = pw.N, pw.K
+        lib = load()
+        nb = int(lib.sopro_packed_w_rows_bytes(N, K))
+        if nb <= 0:
+            raise SoproHipError("split-form weight rows need K % 32 == 0")
+        buf = torch.empty(nb // 4 + 32, dtype=torch.int32, device=W.device)
+        off = (-buf.data_ptr() % 128) // 4  # 128-byte aligned rows
+        pw.rows = buf[off: off + nb // 4]
+        _check(lib.sopro_pack_w_rows_bf16(ptr(W), K, N, K, pw.rows.data_ptr(), _stream()), "sopro_pack_w_rows_bf16")
+    return pw
 
 
 def pack_w_f16x3(W: torch.Tensor) -> PackedW:

@@ -2,6 +2,7 @@
 torch fp32 on the same seeded inputs, through the C ABI (sopro_amd/hip.py is marshalling only).
 Tolerances are fp32 round-off class: the kernels accumulate in fp32 (exact-f32 MFMA), only the
 summation order differs from the CPU."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -1595,3 +1596,75 @@ def test_graph_capture_and_replay():
         g.launch()
     s.synchronize()
     close(out, torch.tanh(1.0 + 2.0 * torch.tanh(x.cpu())), 1e-6, "graph")
+
+
+def _to_split_form(x):
+    """fp32 rows [..., C] (C % 32 == 0) -> the split form a producer's c_mode 1 / 2 writes (without the ELU): every 32 channels =
+    [32 hi bf16 | 32 lo bf16], returned as the fp32-typed tensor of the same shape whose BYTES those are."""
+    sh = x.shape
+    g = x.reshape(-1, sh[-1] // 32, 32).float()
+    hi = g.to(torch.bfloat16)
+    lo = (g - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32).reshape(sh)
+
+
+@pytest.mark.parametrize("K", [1024, 2048 + 32])
+def test_gemm_long_k_form_is_the_same_function(K):
+    """Round 6 (csrc/gemm_8p.hip): 256 x 256 tiles, both operands split in memory and staged by LDS-DMA, against the 128 x 128 tile
+    kernel on the same split-form A: the same products in the same order per output element -> bit-identical for every output mode
+    (fp32 rows; ELU + split form; raw + ELU split; raw + ELU fp32; the tile kernel unsplit in K), with a ragged last row tile, several tiles per CU, an odd K-tile
+    count, and segments of overlapping rows (lda < K: a transposed convolution's row windows).  Both within the three-pass error class
+    of the float64 product."""
+    lib = hip.load()
+    M, N = 3073, 512  # (>= 96 tiles of 128 x 128: the tile kernel runs unsplit in K, as it does on the decoder's shapes)
+    A, W, b = rnd(M, K, seed=191), rnd(N, K, seed=192, scale=K ** -0.5), rnd(N, seed=193)
+    As = dev(_to_split_form(A))
+    Wp = hip.pack_w_bf16x3(dev(W), rows=True)
+    ref = A.double() @ W.double().t() + b.double()
+    mag = A.double().abs() @ W.double().abs().t() + b.double().abs()
+    g = hip.GemmArgs()
+    x = hip.SplitExt()
+    g.M, g.N, g.K, g.prologue, g.epilogue = 25600, N, K, 0, 0
+    x.a_format = 1
+    assert lib.sopro_gemm_8p_takes(C.byref(g), C.byref(x)) == 1   # the decoder's shapes go there by themselves ...
+    g.M = M
+    assert lib.sopro_gemm_8p_takes(C.byref(g), C.byref(x)) == 0   # ... a handful of tiles does not (here it is forced: long_k=True)
+
+    def run(long_k, c_mode):
+        Cm = torch.full((M, N), float("nan"), device=DEV)
+        C2 = torch.full((M, N), float("nan"), device=DEV) if c_mode in (2, 4) else None
+        hip.gemm(As, Wp, Cm, M=M, N=N, K=K, bias=dev(b), a_split=True, c_mode=c_mode, C2=C2, long_k=long_k)
+        torch.cuda.synchronize()
+        return Cm.cpu(), (C2.cpu() if C2 is not None else None)
+
+    for c_mode in (0, 1, 2, 4):
+        (c_t, c2_t), (c_l, c2_l) = run(False, c_mode), run(True, c_mode)
+        assert torch.equal(c_t.view(torch.int32), c_l.view(torch.int32)), c_mode
+        if c2_t is not None:
+            assert torch.equal(c2_t.view(torch.int32), c2_l.view(torch.int32)), c_mode
+        if c_mode in (0, 2, 4):
+            assert bool(torch.isfinite(c_l).all()) and float(((c_l.double() - ref).abs() / mag).max()) < 2e-5
+        if c_mode == 4:
+            close(c2_l, F.elu(c_l), 1e-6, "ELU copy")
+    # row windows: T rows of ci channels per utterance, one zero row in front, window = 2 rows (K = 2 ci), two utterances
+    ci, T, Bn = K // 2, 1600, 2
+    if ci % 32 == 0:
+        xw = torch.zeros(Bn, 1 + T, ci)
+        xw[:, 1:] = rnd(Bn, T, ci, seed=194)
+        xs = dev(_to_split_form(xw))
+        outs = []
+        for long_k in (False, True):
+            Cm = torch.full((Bn, 2 + T * 2, N // 2), float("nan"), device=DEV)
+            Cm[:, :2] = 0.0
+            hip.gemm(xs, Wp, Cm, M=Bn * T, N=N, K=K, lda=ci, bias=dev(b), rows_per_seg=T, a_seg_stride=(1 + T) * ci, a_split=True,
+                     c_off=2 * (N // 2), c_seg_stride=(2 + 2 * T) * (N // 2), ldc=N, long_k=long_k)
+            torch.cuda.synchronize()
+            outs.append(Cm.cpu())
+        assert bool(torch.isfinite(outs[1]).all()) and torch.equal(outs[0], outs[1])
+        win = torch.cat([xw[:, :-1], xw[:, 1:]], dim=-1).reshape(Bn * T, K)
+        wref = (win.double() @ W.double().t() + b.double()).reshape(Bn, T * 2, N // 2)
+        assert float((outs[1][:, 2:].double() - wref).abs().max()) < 2e-4
+    with pytest.raises(hip.SoproHipError):  # fp32 rows are not what the DMA form stages
+        hip.gemm(dev(A), Wp, torch.empty(M, N, device=DEV), M=M, N=N, K=K, long_k=True)
+    with pytest.raises(hip.SoproHipError):  # no rows operand
+        hip.gemm(As, hip.pack_w_bf16x3(dev(W)), torch.empty(M, N, device=DEV), M=M, N=N, K=K, a_split=True, long_k=True)
