@@ -642,6 +642,11 @@ int launch_argmax(sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_ge
   // 128-row tiles for many-row problems (the refinement of a whole batch: 12800 rows): every W fragment serves twice the rows; the
   // (max, column) pairs stay per 64-column tile, the arithmetic per element is unchanged.  SOPRO_ARGMAX_TM=1: 64-row tiles always.
   static const bool tm1 = SOPRO_DEV_ENV("SOPRO_ARGMAX_TM") != nullptr && SOPRO_DEV_ENV("SOPRO_ARGMAX_TM")[0] == '1';
+  // round 6: 128 x 128 tiles for many rows AND many columns (the refinement's stage heads: 25600 rows x up to 32768 logits, K = 256): a
+  // staged A row serves 128 columns instead of 64 - half the A traffic and half the split work per product; pairs stay per 64 columns.
+  // SOPRO_ARGMAX_TN=1 (developer A/B): the round-5 128 x 64 tiles
+  static const bool tn1 = SOPRO_DEV_ENV("SOPRO_ARGMAX_TN") != nullptr && SOPRO_DEV_ENV("SOPRO_ARGMAX_TN")[0] == '1';
+  if (g.M >= 8192 && g.N >= 2048 && (g.N & 127) == 0 && !tm1 && !tn1) return launch_one<NPL, 2, 2, 2, 2, SOPRO_EPI_NONE, 0, 5, F16>(g, wp, ksubs, ext, s);
   if (g.M >= 8192 && !tm1) return launch_one<NPL, 2, 2, 2, 1, SOPRO_EPI_NONE, 0, 5, F16>(g, wp, ksubs, ext, s);
   return launch_one<NPL, 2, 2, 1, 1, SOPRO_EPI_NONE, 0, 5, F16>(g, wp, ksubs, ext, s);
 }

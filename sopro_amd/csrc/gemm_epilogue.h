@@ -9,8 +9,8 @@
 // tensor stays available as a residual operand while the next contraction reads its activated form without any prologue
 // work).  Split form: every aligned group of 32 channels (128 bytes as fp32) becomes [32 hi bf16 | 32 lo bf16], so an
 // element keeps its 128-byte line and every fp32 stride / offset keeps its meaning.
-// OUT: 5 = no C at all: per tile row the maximum of the tile's columns and its column index go to ext.C2 as (float value,
-// int32 index) pairs, [M][ext.ldc2 = column tiles] - the arg-max of a wide projection (the 31 NAR heads: 2048 logits each,
+// OUT: 5 = no C at all: per tile row and 64-column group the maximum of the group's columns and its column index go to ext.C2 as
+// (float value, int32 index) pairs, [M][ext.ldc2 = 64-column groups] - the arg-max of a wide projection (the 31 NAR heads: 2048 logits each,
 // src/sopro/model.py:338-345) without ever writing the logits; sopro_argmax_partials_i32 finishes the reduction.
 // OUT: 6 / 7 / 8 (round 4, the bf16 mode's activation flow; EPI NONE or RES): bf16 rows - 6 = C as bf16 to g.C; 7 = ELU(C) as bf16
 // to g.C; 8 = C as bf16 to g.C AND ELU(C) as bf16 to ext.C2.  g.C / ext.C2 / g.R (the skip operand of EPI_RES) point at bf16
@@ -60,14 +60,18 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
       const float v = Cs[row * CLD + part * CPT + c];
       if (n < g.N && v > best) { best = v; bi = n; }
     }
+    // one (max, column) pair per 64 columns whatever the tile width (round 6: 128-column tiles for many-row problems - every staged A
+    // row serves twice the columns): the GRP threads that share a 64-column group reduce, its first thread writes
+    constexpr int GRP = CPT >= 64 ? 1 : 64 / CPT;
+    static_assert(BN % 64 == 0 && (CPT >= 64 ? CPT == 64 : 64 % CPT == 0), "arg-max partials are per 64 columns");
 #pragma unroll
-    for (int o = 1; o < TPR5; o <<= 1) {
+    for (int o = 1; o < GRP; o <<= 1) {
       const float ov = __shfl_xor(best, o, 64);
       const int oi = __shfl_xor(bi, o, 64);
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    if (part == 0 && m0 + row < g.M) {
-      float* pp = ext->C2 + ((int64_t)(m0 + row) * ext->ldc2 + n0 / BN) * 2;
+    if (part % GRP == 0 && m0 + row < g.M) {
+      float* pp = ext->C2 + ((int64_t)(m0 + row) * ext->ldc2 + n0 / 64 + part / GRP) * 2;
       pp[0] = best;
       pp[1] = __int_as_float(bi);
     }
