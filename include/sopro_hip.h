@@ -35,6 +35,8 @@ extern "C" {
 /* ---- error handling / introspection ------------------------------------------------ */
 const char* sopro_last_error(void);
 int sopro_abi_version(void);
+/* bit 0: a DEVELOPER build (make DEV=1: A/B switches read from the environment, measured no-go kernels compiled in) */
+int sopro_build_flags(void);
 /* Scheduling knob (no reference counterpart): every launch of the long-running split-bf16 contraction kernels requests at
  * least `bytes` of LDS.  Above 80 KiB that caps them at one workgroup per CU, which leaves wave slots, registers and LDS on
  * every CU for the short kernels of an AR frame generated at the same time on another stream - the alternative to carving

@@ -21,6 +21,13 @@ extern "C" {
 const char* sopro_last_error(void) { return g_err; }
 
 int sopro_abi_version(void) { return SOPRO_ABI_VERSION; }
+int sopro_build_flags(void) {
+#ifdef SOPRO_DEV_SWITCHES
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 int sopro_set_lds_floor(int bytes) {
   SOPRO_CHECK_ARG(bytes >= 0 && bytes <= 96 * 1024, "LDS floor must be within 0..96 KiB");

@@ -70,7 +70,11 @@ __device__ __forceinline__ float gelu_erf(float v) { return v * 0.5f * (1.0f + e
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 // ELU(alpha=1).  exp(v)-1 with the hardware exponential: absolute error <= ~2e-7 on v <= 0 (fp32 round-off of the
 // surrounding contractions is larger); expm1f's software expansion was the dominant VALU cost of the SEANet tail.
-__device__ __forceinline__ float eluf_(float v) { return v > 0.0f ? v : __expf(v) - 1.0f; }
+// Round 6: the selection is ONE v_med3_f32 instead of a compare + select: w = exp(v) - 1 >= v everywhere (convexity), so for v > 0 the
+// order is 0 < v < w and for v < 0 it is v < w <= 0 - the median of (v, w, 0) is the ELU either way (w = inf for large v: still v).
+// 7 issue slots per element instead of 8 (v_mul, v_exp_f32 at quarter rate = 4, v_add, v_med3): the fused SEANet kernels are bound by
+// their vector issue and ELU is 44 % of it (profiles/r04_experiments.md section 5).
+__device__ __forceinline__ float eluf_(float v) { return __builtin_amdgcn_fmed3f(v, __expf(v) - 1.0f, 0.0f); }
 
 // fp32 -> two bf16 halves, x = hi + lo with hi = bf16(x), lo = bf16(x - hi), both round-to-nearest-even: |lo| <= 2^-9 |x|
 // with either sign, so products that drop lo*lo are 2^-18-relative and zero-mean (a truncated hi: 2^-14, one-signed).

@@ -717,9 +717,11 @@ static bool eight_waves(const sopro_gemm_args& g) {
   return on && g.N >= 512 && g.M >= 1024;
 }
 
-// activation-stationary form for short K (gemm_astat.hip)
+#ifdef SOPRO_DEV_SWITCHES
+// activation-stationary form for short K (gemm_astat.hip): measured 0.85-1.0x of the tile kernel - compiled into the developer build only
 bool sopro_gemm_astat_takes(const sopro_gemm_args& g, const sopro_gemm_split_ext& ext);
 int sopro_gemm_astat_bf16x3(const sopro_gemm_args& g, const void* packed_w, hipStream_t s);
+#endif
 
 static int g_tile_override = 0;  // developer probe: 9: the activation-stationary form (gemm_astat.hip) wherever it applies; 1: 128x128, 2: 256x128, 4: 128x64 (x6: 64x128), 5: 64x64, 7 / 8: 128x128 on eight waves (bf16x3)
 extern "C" int sopro_gemm_bf16_set_tile_override(int cfg) {
@@ -786,7 +788,9 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
   const int ksubs = (g.K + 31) / 32 * 2;
   // The activation-stationary form for short K (gemm_astat.hip; bit-identical results) is a developer override (9): measured at
   // 0.85-1.0x of the tile kernel on every K <= 512 shape of the decoder / refinement (profiles/r05_experiments.md section 4)
+#ifdef SOPRO_DEV_SWITCHES
   if (g_tile_override == 9 && sopro_gemm_astat_takes(g, ext)) return sopro_gemm_astat_bf16x3(g, packed_w, s);
+#endif
   switch (g_tile_override) {
     case 1: return launch_cfg3<2, 2, 2, 2, 2>(g, wp, ksubs, ext, s);
     case 2: return launch_cfg3<2, 2, 2, 4, 2>(g, wp, ksubs, ext, s);

@@ -927,7 +927,7 @@ int sopro_ar_begin(sopro_engine* e, void* workspace, int32_t B, const float* con
   }
   // unfolded keys whenever the engine was given the query operands (fp32 frame; the Python host takes the same decision)
   {
-    static const bool off = getenv("SOPRO_AR_KUNFOLD") != nullptr && getenv("SOPRO_AR_KUNFOLD")[0] == '0';
+    static const bool off = SOPRO_DEV_ENV("SOPRO_AR_KUNFOLD") != nullptr && SOPRO_DEV_ENV("SOPRO_AR_KUNFOLD")[0] == '0';  // developer A/B
     bool all = c.precision == 0 && !off;
     for (int i = 0; i < c.n_layers_ar; ++i)
       if (c.ar_xattn[i] && !e->sk.count("ar.x_attns." + std::to_string(i) + ".qa.w")) all = false;
@@ -1125,7 +1125,7 @@ struct MimiWs {
 // bf16 mode (round 4): the SEANet decoder's activations - everything from the first convolution's output on - live in memory as
 // bf16 rows (SOPRO_MIMI_BF16=0: fp32 rows with operands rounded in flight, the round-3 form); the transformer stream stays fp32.
 static bool mimi_half(const sopro_engine* e) {
-  static const bool off = getenv("SOPRO_MIMI_BF16") != nullptr && getenv("SOPRO_MIMI_BF16")[0] == '0';
+  static const bool off = getenv("SOPRO_MIMI_BF16") != nullptr && getenv("SOPRO_MIMI_BF16")[0] == '0';  // (run-time: tests/test_gpu_bf16_mode.py compares the two forms)
   return e->c.precision == 1 && !off;
 }
 

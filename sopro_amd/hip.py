@@ -19,6 +19,14 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsopro_hip.so")
 ABI_VERSION = 41
+# Host-side A/B switches whose decision is on record (profiles/rNN_experiments.md) are read from the environment only in DEVELOPER
+# mode (SOPRO_DEV=1) - round 6 housekeeping, the Python twin of the library's `make DEV=1`: a product process ignores them.
+DEV_MODE = os.environ.get("SOPRO_DEV", "0") == "1"
+
+
+def dev_env(name: str, default: str) -> str:
+    return os.environ.get(name, default) if DEV_MODE else default
+
 
 DEFAULT_GROUP_M = 8  # tile-walk group of the split-bf16 contractions (sopro_gemm_set_group_m); measured in tools/pipeline_sweep.sh
 PRO_NONE, PRO_ELU, PRO_ADDVEC = 0, 1, 2
@@ -125,6 +133,7 @@ class MimiStreamState(C.Structure):
 SYMBOLS = {
     "sopro_last_error": (C.c_char_p, []),
     "sopro_abi_version": (C.c_int, []),
+    "sopro_build_flags": (C.c_int, []),
     "sopro_graph_launch_n": (C.c_int, [_p, _p, _i32]),
     "sopro_host_alloc": (C.c_int, [_i64, C.POINTER(_p)]),
     "sopro_host_free": (C.c_int, [_p]),
@@ -269,9 +278,9 @@ def load() -> C.CDLL:
     v = lib.sopro_abi_version()
     if v != ABI_VERSION:
         raise SoproHipError(f"{LIB_PATH} has ABI version {v}, the Python host expects {ABI_VERSION}: rebuild it")
-    lib.sopro_gemm_set_group_m(int(os.environ.get("SOPRO_GEMM_GROUP_M", str(DEFAULT_GROUP_M))))
-    if os.environ.get("SOPRO_GEMM_TILE"):  # developer A/B: tile shape of every split contraction (1: 128x128, 2: 256x128, 4: 128x64, 5: 64x64)
-        lib.sopro_gemm_bf16_set_tile_override(int(os.environ["SOPRO_GEMM_TILE"]))
+    lib.sopro_gemm_set_group_m(int(dev_env("SOPRO_GEMM_GROUP_M", str(DEFAULT_GROUP_M))))
+    if dev_env("SOPRO_GEMM_TILE", ""):  # developer A/B: tile shape of every split contraction (1: 128x128, 2: 256x128, 4: 128x64, 5: 64x64)
+        lib.sopro_gemm_bf16_set_tile_override(int(dev_env("SOPRO_GEMM_TILE", "0")))
     _lib = lib
     return lib
 

@@ -469,7 +469,7 @@ class SoproTTSModel:
         # The stop poll trails the launches by one chunk: chunk k+1 is enqueued before the host looks at chunk k's counter, so
         # the GPU never waits for the host round trip (rows that have stopped are masked on the device; the extra frames of
         # a batch that turns out to be finished are discarded below).
-        poll_every = int(os.environ.get("SOPRO_AR_POLL", poll_every))
+        poll_every = int(hip.dev_env("SOPRO_AR_POLL", str(poll_every)))
         steps = 0
         pending = None
         ev0 = None
@@ -757,7 +757,7 @@ class _ARPlan:
         # folded cross-attention operands per layer: K' = K_h Wq_h, V' = V_h Wo_h^T, [B, H, S_cap, D].  bf16 mode keeps what the
         # frame streams EVERY frame - these operands and the ring buffers - as bf16 in memory (store_format 1 of sopro_ar_frame):
         # half the bytes of the frame's two largest state streams; they are folded in fp32 (one scratch pair) and rounded once.
-        self.bf16_state = m.precision == "bf16" and os.environ.get("SOPRO_BF16_STATE", "1") != "0"
+        self.bf16_state = m.precision == "bf16" and hip.dev_env("SOPRO_BF16_STATE", "1") != "0"
         sdt = torch.bfloat16 if self.bf16_state else torch.float32
         # Unfolded keys (round 4, sopro_ar_frame.k_unfold): kp holds K [B, S_cap, D] instead of the folded K' [B, 4, S_cap, D] - a quarter
         # of the key bytes the frame streams - and the query rides on the feed-forward launches (pack.py "qa.w" / "qu.w" / "q.b").
@@ -765,7 +765,7 @@ class _ARPlan:
         # Measured (profiles/r04_experiments.md): fp32 frame 380 -> 357 us per 64 rows in the pipeline, tokens exact on every fixture;
         # with bf16 operands the keys are small already and the extra feed-forward columns cost what they save (24.3 -> 25.4 ms per
         # step of AR phases) - the bf16 mode keeps the folded form.
-        self.k_unfold = (not slots) and os.environ.get("SOPRO_AR_KUNFOLD", "1" if m.precision == "f32" else "0") != "0"
+        self.k_unfold = (not slots) and hip.dev_env("SOPRO_AR_KUNFOLD", "1" if m.precision == "f32" else "0") != "0"
         if self.k_unfold:
             self.kp = {i: z(B, S_cap, D, dt=sdt) for i in cfg.ar_xattn_layers}
             self.qa, self.qpart = z(B, D), z(4 * D // 384, B, D)
@@ -908,7 +908,7 @@ class _ARPlan:
                 self.graph = hip.capture_end()
             # several frames per replay: the device-side gap between two graph launches (~8 us in a kernel trace) is an order
             # of magnitude above the gap between two nodes of one graph (0.2-0.4 us)
-            self.multi = int(os.environ.get("SOPRO_AR_GRAPH_FRAMES", "8"))
+            self.multi = int(hip.dev_env("SOPRO_AR_GRAPH_FRAMES", "8"))
             self.graph_multi = None
             if self.multi > 1:
                 hip.capture_begin()

@@ -57,7 +57,7 @@ class PipelinedSynthesizer:
             lane.model.stream = mk(0 if ar_shared else (i % ar_parts) * ar_cus, ar_cus)
             lane.model.bulk_stream = mk(bulk0, total - bulk0)
             lane.model.prep_stream = lane.model.bulk_stream  # idle while this lane generates; GEMM-shaped preparation belongs there
-            if prep_on_ar if prep_on_ar is not None else os.environ.get("SOPRO_PREP_ON_AR", "0") == "1":
+            if prep_on_ar if prep_on_ar is not None else hip.dev_env("SOPRO_PREP_ON_AR", "0") == "1":
                 # (with four jobs per pass the generation partition has slack and the throughput partition is the bound: the
                 # per-pass preparation - conditioning, text folding - on a stream of its own over the GENERATION partition's CUs)
                 lane.model.prep_stream = mk(0 if ar_shared else (i % ar_parts) * ar_cus, ar_cus)
@@ -67,8 +67,8 @@ class PipelinedSynthesizer:
             lane.model._ar_cache.clear()  # recorded graphs belong to the stream they were captured on
             lane.model._nar_graphs.clear()
             lane.codec._graphs.clear()
-            if os.environ.get("SOPRO_AR_TILES_WIDE", "1x2") not in ("", "0"):
-                lane.model.ar_tiles_wide = os.environ.get("SOPRO_AR_TILES_WIDE", "1x2")  # coalesced (64-row) frames on the small partition
+            if hip.dev_env("SOPRO_AR_TILES_WIDE", "1x2") not in ("", "0"):
+                lane.model.ar_tiles_wide = hip.dev_env("SOPRO_AR_TILES_WIDE", "1x2")  # coalesced (64-row) frames on the small partition
             self.lanes.append(lane)
         # An empty pipeline has nothing on the throughput partition yet: the first AR phase of each partition lock gets an equal
         # share of the WHOLE chip (the recorded frame graph replays on any stream), which shortens the fill of the pipeline.
@@ -82,7 +82,7 @@ class PipelinedSynthesizer:
         # its AR phase, the remaining refinement / decode phases take the whole chip (CU-masked streams over all CUs: an
         # ordinary stream beside masked ones is the slow combination noted above).  SOPRO_DRAIN_WHOLE=0: stay on the partition.
         self._whole = None
-        if os.environ.get("SOPRO_DRAIN_WHOLE", "1") != "0":
+        if hip.dev_env("SOPRO_DRAIN_WHOLE", "1") != "0":
             # (one stream for all lanes while the throughput slot is exclusive: its phases are serial anyway)
             own = [mk(0, total) for _ in range(int(lanes) if bulk_slots > 1 else 1)]
             self._whole = [own[i % len(own)] for i in range(int(lanes))]
@@ -106,7 +106,7 @@ class PipelinedSynthesizer:
         self.lanes = []
         self._saved = (tts.model.stream, tts.model.bulk_stream, tts.codec.stream, tts.model.prep_stream)
         self._streams = []
-        hip.set_lds_floor(int(__import__("os").environ.get("SOPRO_LDS_FLOOR_KB", "84")) * 1024)
+        hip.set_lds_floor(int(hip.dev_env("SOPRO_LDS_FLOOR_KB", "84")) * 1024)
         for i in range(lanes):
             lane = tts if i == 0 else tts.clone_lane()
             lane.model.stream = torch.cuda.Stream(device=self.device, priority=-1)
@@ -128,7 +128,7 @@ class PipelinedSynthesizer:
     def _share_decoder_scratch(self, bulk_slots: int) -> None:
         """One throughput slot = one refinement / decode phase at a time (``bulk_lock``; ``prepare`` runs the lanes one by one): the
         lanes decode in lane 0's scratch buffers instead of holding one set each (SOPRO_SHARE_SCRATCH=0: one set per lane)."""
-        if int(bulk_slots) <= 1 and os.environ.get("SOPRO_SHARE_SCRATCH", "1") != "0":
+        if int(bulk_slots) <= 1 and hip.dev_env("SOPRO_SHARE_SCRATCH", "1") != "0":
             for lane in self.lanes[1:]:
                 lane.codec.share_scratch(self.lanes[0].codec.ws)
 
@@ -258,7 +258,7 @@ class PipelinedSynthesizer:
             if coalesce == "auto" or isinstance(coalesce, (list, tuple)):
                 passes = self._coalesce(jobs, 0, sizes=self.pass_sizes(len(jobs), coalesce))
             else:
-                passes = self._coalesce(jobs, int(coalesce), ramp=len(jobs) > 2 * int(coalesce) and os.environ.get("SOPRO_PIPE_RAMP", "0") == "1")
+                passes = self._coalesce(jobs, int(coalesce), ramp=len(jobs) > 2 * int(coalesce) and hip.dev_env("SOPRO_PIPE_RAMP", "0") == "1")
             outs = self.run([p[1] for p in passes], timings=timings)
             results: List[Any] = [None] * len(jobs)
             for (g, _m, sizes), out in zip(passes, outs):
