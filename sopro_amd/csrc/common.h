@@ -72,6 +72,8 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // surrounding contractions is larger); expm1f's software expansion was the dominant VALU cost of the SEANet tail.
 // Round 6: the selection is ONE v_med3_f32 instead of a compare + select: w = exp(v) - 1 >= v everywhere (convexity), so for v > 0 the
 // order is 0 < v < w and for v < 0 it is v < w <= 0 - the median of (v, w, 0) is the ELU either way (w = inf for large v: still v).
+// In fp32 the computed w can fall below a small positive v by the exponential's round-off (v < 6e-8: w = 0): the result is then w
+// instead of v, an absolute error <= ~2e-7 - the same class as the negative side's, far inside the waveform contract (1e-4 of peak).
 // 7 issue slots per element instead of 8 (v_mul, v_exp_f32 at quarter rate = 4, v_add, v_med3): the fused SEANet kernels are bound by
 // their vector issue and ELU is 44 % of it (profiles/r04_experiments.md section 5).
 __device__ __forceinline__ float eluf_(float v) { return __builtin_amdgcn_fmed3f(v, __expf(v) - 1.0f, 0.0f); }

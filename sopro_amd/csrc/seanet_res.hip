@@ -37,15 +37,41 @@ __device__ __forceinline__ void rsplit8(const float* __restrict__ p, uint4& hi, 
   split2_bf16(b.z, b.w, hi.w, lo.w);
 }
 
+// Round 6: the NEXT tile's raw rows are brought into LDS by LDS-DMA (global_load_lds_dwordx4) while the current tile's second half runs:
+// the split-ELU tile `es` is dead from the barrier behind the first convolution until the next tile is staged, so the raw fp32 rows of
+// tile k + 1 (66 rows x 512 B, lane-linear) land there - no registers, no extra LDS - and the staging pass reads them from LDS instead of
+// waiting out an HBM round trip per tile (two workgroups per CU were all that hid it: 10.4 us per tile and workgroup, of which the
+// matrix cores were busy 1.3).  One LDS array (several __shared__ objects make the compiler drain the DMA queue in front of unrelated
+// LDS reads).  Same arithmetic, same order: bit-identical results.
+typedef __attribute__((address_space(3))) void r_lds_void;
+typedef const __attribute__((address_space(1))) void r_glb_void;
+// 16 bytes per lane -> LDS (wave-uniform) lds_off + lane * 16.  By inline asm: the builtin form makes the compiler put `s_waitcnt
+// vmcnt(0)` in front of the next LDS read (it cannot tell this kernel's LDS regions apart), i.e. wait the prefetch out where it was
+// issued; like this the compiler does not know of the transfer and every wait for it is written by hand (M0 = the destination base, saved
+// and restored inside the statement: it is compiler-reserved)
+__device__ __forceinline__ void rdma16(const void* g, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(lds_off)
+               : "memory");
+}
+constexpr int RES_ES = RHR * REROW, RES_YS = RTO * RYROW, RES_RED = 4 * 16 * 64 * 4;
+constexpr int RES_LDS = RES_ES + RES_YS + RES_RED;
+static_assert(RES_ES % 16 == 0 && RES_YS % 16 == 0 && RHR * RC * 4 <= RES_ES, "the raw image of a tile fits the split tile's place");
+
 template <int PASSES>
 __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __restrict__ h, int64_t h_seg_stride,
                                                                const float* __restrict__ w1, const float* __restrict__ b1,
                                                                const float* __restrict__ w2, const float* __restrict__ b2,
                                                                float* __restrict__ out, int64_t out_seg_stride, int T, int tiles) {
-  __shared__ __attribute__((aligned(16))) unsigned char es[RHR * REROW];   // split ELU(h)
-  __shared__ __attribute__((aligned(16))) unsigned char ys[RTO * RYROW];   // split ELU(intermediate)
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];          // K-half exchange of the first convolution
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (DYNAMIC LDS: behind a static __shared__ object the compiler puts `s_waitcnt vmcnt(0)` in front of LDS reads that follow an
+  // LDS-DMA - it cannot tell the regions apart - which would wait the prefetch out where it was issued)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_all[];
+  unsigned char* const es = lds_all;                                   // split ELU(h); between tiles: the next tile's raw rows
+  unsigned char* const ys = lds_all + RES_ES;                          // split ELU(intermediate)
+  float* const red = reinterpret_cast<float*>(lds_all + RES_ES + RES_YS);  // K-half exchange of the first convolution
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
   const bool big = (int64_t)gridDim.y * T * 128 * 4 >= SOPRO_BIG_BYTES;  // a large output: stored with the non-temporal hint (common.h)
   const int frow = lane & 31, fg = lane >> 5;
@@ -63,29 +89,46 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
   const float b1v = b1[nt1 * 32 + frow];
   const float b2v = b2[wave * 32 + frow];
 
-  // tile request: rows s0-2 .. s0+RTO-1 (padded rows s0 .. s0+RTO+1).  All requests of a tile are issued back to back (one
-  // memory round); rows past the end are redirected to padded row 0, a zero row, so the loads are branch-free.
-  float4 v[9];
+  // tile request: rows s0-2 .. s0+RTO-1 (padded rows s0 .. s0+RTO+1) as 33 DMA instructions of two rows each (wave w: 2 rows per
+  // instruction, instructions w, w + 4, ..); rows past the end are redirected to padded row 0, a zero row: branch-free
+  const unsigned es_off = (unsigned)(uintptr_t)es;
   auto request = [&](int s0) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      const int idx = tid + q * 256;          // float4 index: 32 per row
-      const int r = idx >> 5, c4 = idx & 31;
-      const int p = s0 + r;                   // padded row
-      const int pc = (r < RHR && p < T + 2) ? p : 0;
-      v[q] = *reinterpret_cast<const float4*>(hb + (int64_t)pc * RC + c4 * 4);
+      // instruction of the tile: rows 2 i, 2 i + 1.  Every wave issues NINE (the counted wait below leaves exactly them in flight):
+      // waves 1-3 repeat instruction 32 as their ninth - the same bytes to the same place
+      const int i = min(wave + 4 * q, RHR / 2 - 1);
+      const int r = 2 * i + (lane >> 5);
+      const int p = s0 + r;
+      const int pc = p < T + 2 ? p : 0;
+      rdma16(hb + (int64_t)pc * RC + (lane & 31) * 4, es_off + i * 1024);
+      __builtin_amdgcn_sched_barrier(0);  // (one source address at a time: nine 64-bit pairs made ahead spill)
     }
   };
+  // barrier that does NOT drain the DMA queue (a __syncthreads() with an LDS-DMA in flight waits vmcnt(0) first): LDS traffic of this
+  // wave retired, then the bare s_barrier
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
 
+  const int it0_s0 = (int)blockIdx.x * tiles * RTO;
+  if (it0_s0 < T) request(it0_s0);
   for (int it = 0; it < tiles; ++it) {
     const int s0 = ((int)blockIdx.x * tiles + it) * RTO;
     if (s0 >= T) break;              // uniform over the workgroup
-    // (no barrier here: the last readers of es finished before the second barrier of the previous tile, ys and red are
-    // rewritten only behind this tile's first barrier)
 
-    // ---- stage the rows: ELU + split once per element.  (Requesting the next tile during the second convolution instead
-    // was measured slower: the 36 extra live registers spill, 1.38 ms against 1.18 ms for 32 x 200 frames.)
-    request(s0);
+    // ---- the tile's raw rows have landed (requested behind the previous tile's first convolution): read, then ELU + split in place
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float4 v[9];
+    {
+      const unsigned char* rp = es + tid * 16;  // float4 index tid + 256 q (32 per row): one address, immediate offsets
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(rp + q * 4096);
+      v[8] = *reinterpret_cast<const float4*>(es + (RHR * 32 - 64 + lane) * 16);  // rows 64, 65: wave 0's ninth piece (the others read and drop it)
+    }
+    __syncthreads();                 // every thread holds its pieces before the split image overwrites the raw one
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       const int idx = tid + q * 256;
@@ -151,6 +194,29 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = kh ? acc[0][r] : acc[1][r];
     __syncthreads();
+    // ---- the skip operand of the second convolution in the accumulator layout (an L2-resident re-read of rows the tile request
+    // brought in), requested NOW - the first convolution's accumulators are free - and by inline asm: loads the compiler does not
+    // count, so that it neither waits for them one by one nor drains the DMA queue behind them (they are older than the DMA
+    // instructions: `s_waitcnt vmcnt(9)` in front of their first use = they have landed, the nine DMA instructions may still fly)
+    // (row tile 0's sixteen only: all 32 at once spill.  Row tile 1's are ordinary loads issued behind row tile 0's epilogue - the
+    // compiler's wait for them drains the DMA queue too, which has had the exchange and a convolution's time by then)
+    // Addresses of the tile's output / skip elements: (utterance base, wave-uniform) + a 32-bit byte offset = this lane's place in the
+    // tile's first row group + a compile-time row term - no 64-bit arithmetic, and for whole tiles (all but an utterance's last) no
+    // per-element bounds test either (the per-store compare + branch + address pair were ~10 instructions per element)
+    const bool whole = s0 + RTO <= T;  // uniform
+    const unsigned lane_off = (unsigned)(((s0 + 2 + 4 * fg) * RC + wave * 32 + frow) * 4);
+    auto row_off = [&](int mt, int r) { return lane_off + (unsigned)((mt * 32 + (r & 3) + 8 * (r >> 2)) * RC * 4); };
+    auto row_ok = [&](int mt, int r) { return whole || s0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg < T; };
+    const unsigned last_off = (unsigned)(((T + 1) * RC + wave * 32 + frow) * 4);  // rows past the end are never stored: read the last padded row
+    float skip0[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned off = row_ok(0, r) ? row_off(0, r) : last_off;
+      asm volatile("global_load_dword %0, %1, %2" : "=v"(skip0[r]) : "v"(off), "s"(hb) : "memory");
+    }
+    // ---- es is dead until the next tile is staged: its raw rows start their way now, under the exchange and the second convolution
+    // (always nine instructions per wave, also past the last tile - rows past the end read the zero row: the counted wait stays exact)
+    request(s0 + RTO);
     {
       const int mt = kh;
 #pragma unroll
@@ -165,19 +231,11 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
         if (PASSES == 3) *reinterpret_cast<unsigned short*>(ys + mr * RYROW + 2 * RH + (nt1 * 32 + frow) * 2) = (unsigned short)(lo & 0xffffu);
       }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- conv k=1, 64 -> 128 (wave w: output columns 32w ..) + skip, ELU, store
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      // skip operand in the accumulator layout (an L2-resident re-read of rows the tile request brought in), requested
-      // ahead of this row tile's MFMAs
-      float skip[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
-        skip[r] = hb[(int64_t)((s0 + m < T) ? s0 + m + 2 : 0) * RC + wave * 32 + frow];  // past the end: zero row 0
-      }
       f32x16 acc2;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
@@ -192,13 +250,32 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
         }
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w2h[s]), acc2, 0, 0, 0);
       }
+      float skip[16];
+      if (mt == 0) {  // the asm loads have landed (in-order returns: all 16 are older than the nine DMA instructions left in flight)
+        asm volatile("s_waitcnt vmcnt(9)"
+                     : "+v"(skip0[0]), "+v"(skip0[1]), "+v"(skip0[2]), "+v"(skip0[3]), "+v"(skip0[4]), "+v"(skip0[5]), "+v"(skip0[6]), "+v"(skip0[7]),
+                       "+v"(skip0[8]), "+v"(skip0[9]), "+v"(skip0[10]), "+v"(skip0[11]), "+v"(skip0[12]), "+v"(skip0[13]), "+v"(skip0[14]), "+v"(skip0[15])
+                     :
+                     : "memory");
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
-        if (s0 + m < T) bulk_store1(ob + (int64_t)(s0 + m + 2) * RC + wave * 32 + frow, eluf_(skip[r] + acc2[r] + b2v), big);
+        for (int r = 0; r < 16; ++r) skip[r] = skip0[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          skip[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(hb) + (row_ok(1, r) ? row_off(1, r) : last_off));
+      }
+      char* const obp = reinterpret_cast<char*>(ob);
+      if (whole) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bulk_store1(reinterpret_cast<float*>(obp + row_off(mt, r)), eluf_(skip[r] + acc2[r] + b2v), big);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (row_ok(mt, r)) bulk_store1(reinterpret_cast<float*>(obp + row_off(mt, r)), eluf_(skip[r] + acc2[r] + b2v), big);
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the DMA instructions of the tile behind the last one: nothing may land in LDS after the workgroup has gone)
 }
 
 // HB (round 4: the bf16 mode's activation flow): h and out are bf16 rows (256 bytes per row) - the 1.57 GB level is read and written
@@ -314,12 +391,17 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_hb_kernel(const unsigned
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       // skip operand: this lane's (row, column pair) of the raw tile, an L2-resident 4-byte re-read per output pair
+      // (round 6: 32-bit byte offsets from the utterance's base + compile-time row terms, and no per-element bounds test for whole tiles:
+      // the compare + branch + 64-bit address pair per element were a third of this epilogue's instructions)
+      const bool whole = s0 + RTO <= T;  // uniform
+      const unsigned lane_off = (unsigned)(((s0 + 2 + 4 * fg + (odd ? 1 : 0)) * RC + colp) * 2);
+      auto row_off = [&](int r) { return lane_off + (unsigned)((mt * 32 + (r & 3) + 8 * (r >> 2)) * RC * 2); };
+      auto row_ok = [&](int r) { return whole || s0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg + (odd ? 1 : 0) < T; };
+      const unsigned last_off = (unsigned)(((T + 1) * RC + colp) * 2);  // rows past the end are never stored: read the last padded row
       unsigned skip[8];
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg + (odd ? 1 : 0);
-        skip[r >> 1] = *reinterpret_cast<const unsigned*>(hb + (int64_t)((s0 + m < T) ? s0 + m + 2 : 0) * RC + colp);  // past the end: zero row 0
-      }
+      for (int r = 0; r < 16; r += 2)
+        skip[r >> 1] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(hb) + (row_ok(r) ? row_off(r) : last_off));
       f32x16 acc2;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
@@ -329,17 +411,25 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_hb_kernel(const unsigned
         const uint4 ah = *reinterpret_cast<const uint4*>(a + s * 32);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w2h[s]), acc2, 0, 0, 0);
       }
+      unsigned pkv[8];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const float mine0 = acc2[r] + b2v, mine1 = acc2[r + 1] + b2v;
         // (the neighbour column's bias travels with its value: mine* already hold it)
         const float got = __shfl_xor(odd ? mine0 : mine1, 1, 64);
         const float c0 = odd ? got : mine0, c1 = odd ? mine1 : got;
-        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg + (odd ? 1 : 0);
         const unsigned sk = skip[r >> 1];
         unsigned pk, lo_;
         split2_bf16(eluf_(__uint_as_float(sk << 16) + c0), eluf_(__uint_as_float(sk & 0xffff0000u) + c1), pk, lo_);
-        if (s0 + m < T) bulk_store_u1(ob + (int64_t)(s0 + m + 2) * RC + colp, pk, big);
+        pkv[r >> 1] = pk;
+      }
+      if (whole) {  // straight-line stores for every tile but an utterance's last
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) bulk_store_u1(reinterpret_cast<char*>(ob) + row_off(r), pkv[r >> 1], big);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+          if (row_ok(r)) bulk_store_u1(reinterpret_cast<char*>(ob) + row_off(r), pkv[r >> 1], big);
       }
     }
   }
@@ -366,10 +456,16 @@ extern "C" int sopro_seanet_res128_p_f32(const float* h, int64_t h_seg_stride, c
   const int64_t all = (int64_t)ntile * B;
   const int tiles = g_res_tiles > 0 ? g_res_tiles : (all >= 16 * 2048 ? 16 : (all >= 8 * 1024 ? 8 : (all >= 2048 ? 2 : 1)));
   dim3 grid((ntile + tiles - 1) / tiles, B);
-  if (passes == 3)
-    hipLaunchKernelGGL(seanet_res128_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride, T, tiles);
-  else  // the engine's bf16 mode: hi * hi only
-    hipLaunchKernelGGL(seanet_res128_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride, T, tiles);
+  SOPRO_CHECK_ARG(T < (1 << 21), "T must stay below 2^21 rows per utterance (32-bit byte offsets of the skip operand)");
+  if (passes == 3) {
+    auto kern = seanet_res128_kernel<3>;
+    SOPRO_SET_MAX_LDS_ONCE(kern, RES_LDS);
+    hipLaunchKernelGGL(kern, grid, dim3(256), RES_LDS, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride, T, tiles);
+  } else {  // the engine's bf16 mode: hi * hi only
+    auto kern = seanet_res128_kernel<1>;
+    SOPRO_SET_MAX_LDS_ONCE(kern, RES_LDS);
+    hipLaunchKernelGGL(kern, grid, dim3(256), RES_LDS, (hipStream_t)stream, h, h_seg_stride, w1, b1, w2, b2, out, out_seg_stride, T, tiles);
+  }
   SOPRO_LAUNCH_CHECK();
 }
 

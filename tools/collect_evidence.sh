@@ -5,7 +5,7 @@
 #   tools/collect_evidence.sh r05 bench       -> the bench lines (driver's form, default, bf16 mode, other shapes)
 #   tools/collect_evidence.sh r05 all         -> both
 # Results land in gpurun_out/<tag>/; copy what is to be kept into profiles/ (see profiles/README.md for the names).
-TAG=${1:-r05}; WHAT=${2:-bench}
+TAG=${1:-r06}; WHAT=${2:-bench}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/$TAG
 mkdir -p $O
 if [ "$WHAT" = profiles ] || [ "$WHAT" = all ]; then
@@ -46,9 +46,10 @@ if [ "$WHAT" = profiles ] || [ "$WHAT" = all ]; then
 fi
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   cd $R
-  timeout 500 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
-  timeout 500 python bench.py > $O/bench_line_default.json 2> $O/bench_line_default.err
-  timeout 300 python bench.py --steps 20 --warmup 5 --precision bf16 > $O/bench_line_bf16.json 2> $O/bench_line_bf16.err
+  # (round 6: stdout = the compact line the driver parses, < 8 kB; the full record is bench_full.json next to bench.py, kept per run)
+  timeout 500 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err; cp bench_full.json $O/bench_line_full.json
+  timeout 500 python bench.py > $O/bench_line_default.json 2> $O/bench_line_default.err; cp bench_full.json $O/bench_line_default_full.json
+  timeout 300 python bench.py --steps 20 --warmup 5 --precision bf16 > $O/bench_line_bf16.json 2> $O/bench_line_bf16.err; cp bench_full.json $O/bench_line_bf16_full.json
   Q="--no-cpu-baseline --ttfa-runs 0 --profile-steps 0"
   ( echo '{"runs": [';
     timeout 300 python bench.py --frames 400 --steps 12 --warmup 4 $Q 2>/dev/null | tail -1; echo ',';
@@ -58,8 +59,9 @@ if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
     echo ']}' ) > $O/bench_other_shapes.json
   for f in bench_line bench_line_default bench_line_bf16; do python -c "
 import json
-d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1]); r=d['roofline']
-print('$f', d['value'], d['ms_per_step'], d['phase_ms_per_step'], 'ttfa', d['ttfa_ms_p50'], '| roofline', r['kernel'][:28], r['achieved'], r['frac'], 'us', r['avg_launch_us'], '| parity ok', d['parity'].get('ok'), d['parity']['timed_steps_identical'], '| cpu', (d.get('cpu_baseline') or {}).get('value'), '| host cpu', d['host_cpu_s_per_step'], '| legs', {k: v.get('value') for k, v in (d.get('legs') or {}).items() if isinstance(v, dict)})"; done
+t=open('$O/$f.json').read().strip().splitlines()[-1]
+d=json.loads(t); r=d['roofline']
+print('$f', len(t), 'bytes |', d['value'], d['ms_per_step'], d['phase_ms_per_step'], 'ttfa', d['config']['second_metric']['ttfa_ms_p50'], '| roofline', r['kernel'][:28], r['achieved'], r['frac'], 'us', r['avg_launch_us'], '| more', [(e['kernel'][:14], e['ms_per_step'], e.get('frac_of_pass_ceiling')) for e in d['roofline_more']], '| parity ok', d['parity'].get('ok'), d['parity']['timed_steps_identical'], '| cpu', (d.get('cpu_baseline') or {}).get('value'), '| legs', {k: v.get('value') for k, v in (d['config'].get('legs') or {}).items() if isinstance(v, dict)})"; done
   python -c "
 import json
 d=json.load(open('$O/bench_other_shapes.json'))
