@@ -67,6 +67,25 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
   } while (0)
 
 __device__ __forceinline__ float gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+// GELU (erf form) for the contraction epilogues of the throughput phases (round 6): erf by Abramowitz-Stegun 7.1.26 - one reciprocal, a
+// degree-5 polynomial, one exp2 - 22 issue slots against the library erff's 41 (a branchy two-range expansion: both ranges run in a
+// divergent wave).  |gelu_fast - gelu| <= 4.7e-7 absolute, 2.9e-7 |v| relative (float64 reference; torch's own fp32 GELU is 1.1e-6 off it
+// at |v| ~ 8): the class of one fp32 rounding of the result, and below what the operand split keeps (2^-17 bf16x3, 2^-22 f16x3).  The
+// 128 x 128 x 384 feed-forward tile of the refinement spent more vector issue on the epilogue's erff (64 elements per thread) than its
+// twelve K-steps spend on the matrix cores.  The exact-fp32 paths (AR frame, conditioning, six-pass) keep erff.
+__device__ __forceinline__ float gelu_fast(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
+  const float y = fmaf(-p, e, 1.0f);  // erf(|v| / sqrt 2)
+  const float h = 0.5f * v;
+  return fmaf(h, copysignf(y, v), h);
+}
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 // ELU(alpha=1).  exp(v)-1 with the hardware exponential: absolute error <= ~2e-7 on v <= 0 (fp32 round-off of the
 // surrounding contractions is larger); expm1f's software expansion was the dominant VALU cost of the SEANet tail.

@@ -564,8 +564,9 @@ inline int amode_of(const sopro_gemm_args& g, const sopro_gemm_split_ext& ext) {
 template <int NPL, int WM, int WN, int TM, int TN>
 int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
   const int key = g.epilogue * 100 + amode_of(g, ext) * 10 + ext.c_mode;
+  // (EPI_GELU runs the fast erf form on the waveform / bf16-mode paths: see gelu_fast in common.h)
 #define SOPRO_CASE(E, A, O) \
-  case (E) * 100 + (A) * 10 + (O): return launch_one<NPL, WM, WN, TM, TN, E, A, O>(g, wp, ksubs, ext, s)
+  case (E) * 100 + (A) * 10 + (O): return launch_one<NPL, WM, WN, TM, TN, ((E) == SOPRO_EPI_GELU ? SOPRO_EPI_GELU_FAST : (E)), A, O>(g, wp, ksubs, ext, s)
   switch (key) {
     SOPRO_CASE(SOPRO_EPI_NONE, 0, 0);  // transformer qkv, RVQ output projections
     SOPRO_CASE(SOPRO_EPI_GELU, 0, 0);  // transformer fc1
@@ -613,8 +614,10 @@ int launch_cfg3(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
 template <int NPL, int WM, int WN, int TM, int TN, bool F16 = false>
 int launch_cfg6(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopro_gemm_split_ext& ext, hipStream_t s) {
   const int key = g.epilogue * 10 + amode_of(g, ext);
+  // (EPI_GELU: the fast erf form for the f16 three-pass and one-pass kernels; the six-pass kernel - conditioning, the refinement's
+  // fallback: fp32-class paths - keeps erff)
 #define SOPRO_CASE(E, A) \
-  case (E) * 10 + (A): return launch_one<NPL, WM, WN, TM, TN, E, A, 0, F16>(g, wp, ksubs, ext, s)
+  case (E) * 10 + (A): return launch_one<NPL, WM, WN, TM, TN, (((E) == SOPRO_EPI_GELU && (F16 || NPL != 3)) ? SOPRO_EPI_GELU_FAST : (E)), A, 0, F16>(g, wp, ksubs, ext, s)
   switch (key) {
     SOPRO_CASE(SOPRO_EPI_NONE, 0);  // plain projections
     SOPRO_CASE(SOPRO_EPI_GELU, 0);  // FF1

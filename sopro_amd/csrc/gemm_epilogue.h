@@ -17,6 +17,8 @@
 // elements and their strides count elements; host guarantees N % 4 == 0 and 8-byte aligned rows.
 // rs (optional, LDS): one scale per tile row applied to the accumulator before the bias: the RMSNorm of the operand row
 // when its weight vector has been folded into W (out = rs * (x W'^T) + b).
+// (internal epilogue id, not part of the ABI: GELU with gelu_fast - what the three-pass / one-pass launchers instantiate for EPI_GELU)
+constexpr int SOPRO_EPI_GELU_FAST = 100;
 template <int WM, int WN, int TM, int TN, int EPI, int OUT = 0>
 __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float* __restrict__ Cs, f32x16 (&acc)[TM][TN],
                                                 const float (&biasv)[TN], int m0, int n0,
@@ -211,6 +213,8 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
         v.x *= sigmoidf_(gt.x); v.y *= sigmoidf_(gt.y); v.z *= sigmoidf_(gt.z); v.w *= sigmoidf_(gt.w);
       } else if (EPI == SOPRO_EPI_GELU) {
         v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+      } else if (EPI == SOPRO_EPI_GELU_FAST) {
+        v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
       } else if (EPI == SOPRO_EPI_TANH) {
         v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
       } else if (res) {
