@@ -191,7 +191,7 @@ def rocprof_family_table() -> dict:
     if not files:
         return {}
     pat = {"gemm_f32_kernel": "gemm_f32_kernel", "gemm_bf16s_kernel<1,": "gemm_bf16x1_kernel", "gemm_bf16s_kernel<2,": "gemm_bf16x3_kernel",
-           "gemm_bf16s_kernel<3,": "gemm_bf16x6_kernel",  # (<2, ..., true> = the fp16 pieces of the NAR path: told apart below)
+           "gemm_bf16s_kernel<3,": "gemm_bf16x6_kernel", "gemm_8p_kernel": "gemm_bf16x3_kernel",  # (the long-K form: the decoder's family)  # (<2, ..., true> = the fp16 pieces of the NAR path: told apart below)
            "attention_kernel": "attention_kernel", "attn_window_mfma_kernel": "attention_kernel", "attn_mfma_kernel": "attention_kernel",
            "attn_decode_kernel": "attention_kernel", "attn_mfma_split_kernel": "attention_split_kernel", "seanet_tail_kernel": "seanet_tail_kernel", "seanet_tail16_kernel": "seanet_tail_kernel", "seanet_res128_kernel": "seanet_res128_kernel",
            "seanet_up128_kernel": "seanet_up128_kernel", "seanet_uptail_kernel": "seanet_uptail_kernel"}

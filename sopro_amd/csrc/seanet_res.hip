@@ -95,8 +95,8 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
   auto request = [&](int s0) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      // instruction of the tile: rows 2 i, 2 i + 1.  Every wave issues NINE (the counted wait below leaves exactly them in flight):
-      // waves 1-3 repeat instruction 32 as their ninth - the same bytes to the same place
+      // instruction of the tile: rows 2 i, 2 i + 1 (waves 1-3 repeat instruction 32 as their ninth: the same bytes to the same place -
+      // one straight-line sequence for every wave)
       const int i = min(wave + 4 * q, RHR / 2 - 1);
       const int r = 2 * i + (lane >> 5);
       const int p = s0 + r;
@@ -128,6 +128,12 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
       for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(rp + q * 4096);
       v[8] = *reinterpret_cast<const float4*>(es + (RHR * 32 - 64 + lane) * 16);  // rows 64, 65: wave 0's ninth piece (the others read and drop it)
     }
+    // row tile 0's skip operand (raw h in the accumulator layout of the second convolution) straight from the raw image: rows the DMA
+    // brought in are not asked for a second time (the re-read used to hit the L2; with a tile in flight ahead it mostly did not any more)
+    float skip0[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      skip0[r] = *reinterpret_cast<const float*>(es + ((r & 3) + 8 * (r >> 2) + 4 * fg + 2) * (RC * 4) + (wave * 32 + frow) * 4);
     __syncthreads();                 // every thread holds its pieces before the split image overwrites the raw one
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
@@ -194,12 +200,6 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = kh ? acc[0][r] : acc[1][r];
     __syncthreads();
-    // ---- the skip operand of the second convolution in the accumulator layout (an L2-resident re-read of rows the tile request
-    // brought in), requested NOW - the first convolution's accumulators are free - and by inline asm: loads the compiler does not
-    // count, so that it neither waits for them one by one nor drains the DMA queue behind them (they are older than the DMA
-    // instructions: `s_waitcnt vmcnt(9)` in front of their first use = they have landed, the nine DMA instructions may still fly)
-    // (row tile 0's sixteen only: all 32 at once spill.  Row tile 1's are ordinary loads issued behind row tile 0's epilogue - the
-    // compiler's wait for them drains the DMA queue too, which has had the exchange and a convolution's time by then)
     // Addresses of the tile's output / skip elements: (utterance base, wave-uniform) + a 32-bit byte offset = this lane's place in the
     // tile's first row group + a compile-time row term - no 64-bit arithmetic, and for whole tiles (all but an utterance's last) no
     // per-element bounds test either (the per-store compare + branch + address pair were ~10 instructions per element)
@@ -208,14 +208,8 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
     auto row_off = [&](int mt, int r) { return lane_off + (unsigned)((mt * 32 + (r & 3) + 8 * (r >> 2)) * RC * 4); };
     auto row_ok = [&](int mt, int r) { return whole || s0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg < T; };
     const unsigned last_off = (unsigned)(((T + 1) * RC + wave * 32 + frow) * 4);  // rows past the end are never stored: read the last padded row
-    float skip0[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned off = row_ok(0, r) ? row_off(0, r) : last_off;
-      asm volatile("global_load_dword %0, %1, %2" : "=v"(skip0[r]) : "v"(off), "s"(hb) : "memory");
-    }
     // ---- es is dead until the next tile is staged: its raw rows start their way now, under the exchange and the second convolution
-    // (always nine instructions per wave, also past the last tile - rows past the end read the zero row: the counted wait stays exact)
+    // (also past the last tile - rows past the end read the zero row; the loop top / the kernel's end wait for them)
     request(s0 + RTO);
     {
       const int mt = kh;
@@ -251,12 +245,7 @@ __global__ __launch_bounds__(256, 2) void seanet_res128_kernel(const float* __re
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(ah), rfrag(w2h[s]), acc2, 0, 0, 0);
       }
       float skip[16];
-      if (mt == 0) {  // the asm loads have landed (in-order returns: all 16 are older than the nine DMA instructions left in flight)
-        asm volatile("s_waitcnt vmcnt(9)"
-                     : "+v"(skip0[0]), "+v"(skip0[1]), "+v"(skip0[2]), "+v"(skip0[3]), "+v"(skip0[4]), "+v"(skip0[5]), "+v"(skip0[6]), "+v"(skip0[7]),
-                       "+v"(skip0[8]), "+v"(skip0[9]), "+v"(skip0[10]), "+v"(skip0[11]), "+v"(skip0[12]), "+v"(skip0[13]), "+v"(skip0[14]), "+v"(skip0[15])
-                     :
-                     : "memory");
+      if (mt == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) skip[r] = skip0[r];
       } else {

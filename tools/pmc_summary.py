@@ -20,6 +20,8 @@ def fam(name: str) -> str:
         return "gemm_bf16x1_kernel"
     if "gemm_bf16s_kernel<2" in name:  # the last template argument tells the fp16 pieces (f16x3: NAR) from the bf16 ones (bf16x3: Mimi)
         return "gemm_f16x3_kernel" if name.split(">(")[0].rstrip().endswith("true") else "gemm_bf16x3_kernel"
+    if "gemm_8p_kernel" in name:  # round 6: the long-K form of the three-pass contraction (csrc/gemm_8p.hip) belongs to the decoder's family
+        return "gemm_bf16x3_kernel"
     if "gemm_bf16s_kernel<3" in name:
         return "gemm_bf16x6_kernel"
     if "attn_mfma_split_kernel" in name:
