@@ -183,7 +183,7 @@ class SoproTTSModel:
         return other
 
     def _host_block(self, key: tuple, n: int, recorded: bool = False) -> "hip.HostMirror":
-        """At least ``n`` page-locked words that kernels of the library read or write (hip.HostMirror.copy_to / copy_from): how the
+        """``n`` page-locked words that kernels of the library read or write (hip.HostMirror.copy_to / copy_from): how the
         host's small per-call parameters reach the device, and poll words the host, without a runtime copy on the path.  One block
         per use and shape; the user synchronises before it writes the block again.
 
@@ -200,7 +200,7 @@ class SoproTTSModel:
                 hb = self._recorded_blocks[key] = hip.HostMirror(int(n))
             return hb
         hb = self._host_blocks.pop(key, None)
-        if hb is not None and hb.n >= int(n):
+        if hb is not None and hb.n == int(n):  # (exact size: a key may carry id(plan), which a NEW plan of another batch size can inherit)
             self._host_blocks[key] = hb  # most recently used goes last
             return hb
         retired = [hb] if hb is not None else []

@@ -42,6 +42,8 @@ def test_recorded_refinement_survives_the_walk_through_the_block_lru(tts, cfg, w
         hb = m._host_block(("test.walk", i), 4 + (i % 3))
         hb.array()[:] = i
     assert len(m._host_blocks) <= 64
+    # a key can be inherited by a user of another size (keys carry id(plan); a collected plan's id is re-used): the block is exact
+    assert m._host_block(("test.size",), 3).n == 3 and m._host_block(("test.size",), 1).n == 1 and m._host_block(("test.size",), 4).n == 4
     assert ("test.walk", 0) not in m._host_blocks and ("test.walk", 79) in m._host_blocks
     # the blocks the recorded sequences hold are where they were, and the replay still gives the oracle's tokens
     assert m._recorded_blocks[("nar.lens", 1)].ptr == p_lens and m._recorded_blocks[("nar.range",)].ptr == p_range
