@@ -800,6 +800,9 @@ extern "C" int sopro_gemm_bf16x3(const sopro_gemm_args* a, const void* packed_w,
     case 4: return launch_cfg3<2, 2, 2, 2, 1>(g, wp, ksubs, ext, s);
     case 5: return launch_cfg3<2, 2, 2, 1, 1>(g, wp, ksubs, ext, s);
     case 7: return launch_cfg3<2, 2, 4, 2, 1>(g, wp, ksubs, ext, s);  // 128x128 on eight waves
+#ifdef SOPRO_DEV_SWITCHES
+    case 3: return launch_cfg3<2, 1, 4, 4, 1>(g, wp, ksubs, ext, s);  // 128x128, four waves of 128 x 32: no W fragment is requested twice
+#endif
     default: break;
   }
   // few columns, or few rows (streaming chunks, batch 1: small tiles keep the split-K partial sums small): 64x64
@@ -935,6 +938,9 @@ extern "C" int sopro_gemm_f16x3(const sopro_gemm_args* a, const void* packed_w, 
   static const int env_tile = SOPRO_DEV_ENV("SOPRO_F16X3_TILE") ? atoi(SOPRO_DEV_ENV("SOPRO_F16X3_TILE")) : 0;  // developer A/B of this family alone
   switch (g_tile_override ? g_tile_override : env_tile) {
     case 1: return launch_cfg6<2, 2, 2, 2, 2, true>(g, wp, ksubs, ext, s);
+#ifdef SOPRO_DEV_SWITCHES
+    case 3: return launch_cfg6<2, 1, 4, 4, 1, true>(g, wp, ksubs, ext, s);
+#endif
     case 4: return launch_cfg6<2, 2, 2, 1, 2, true>(g, wp, ksubs, ext, s);
     case 5: return g.epilogue == SOPRO_EPI_GLU ? launch_cfg6<2, 2, 2, 1, 2, true>(g, wp, ksubs, ext, s) : launch_cfg6<2, 2, 2, 1, 1, true>(g, wp, ksubs, ext, s);
     default: break;
