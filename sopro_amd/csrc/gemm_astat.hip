@@ -186,7 +186,7 @@ __global__ __launch_bounds__(AS_NT, 1) void gemm_astat_kernel(const sopro_gemm_a
         if (!cp[grp]) continue;
         float4 o = v[grp];
         if (EPI == SOPRO_EPI_GELU) {
-          o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w);
+          o.x = gelu_fast(o.x); o.y = gelu_fast(o.y); o.z = gelu_fast(o.z); o.w = gelu_fast(o.w);  // (the three-pass tile kernel's form since round 6)
         } else if (EPI == SOPRO_EPI_RES) {
           o.x = rv[grp].x + sc4.x * o.x; o.y = rv[grp].y + sc4.y * o.y; o.z = rv[grp].z + sc4.z * o.z; o.w = rv[grp].w + sc4.w * o.w;
         }

@@ -81,6 +81,7 @@ template <int NPL, int WM, int WN, int TM, int TN, int EPI, int AMODE, int OUT, 
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gemm_args g, const uint4* __restrict__ Wp,
                                                                  int ksubs, const sopro_gemm_split_ext ext) {
   constexpr int AROW = NPL * 64 + 16;  // bytes per LDS row
+  constexpr bool FOLD = F16;  // the next step's staging inside this step's MFMA stream: see compute_spread
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -150,6 +151,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   float a16max = 0.f; // f16 forms: largest scaled magnitude this thread staged (range guard)
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) { ssq[i] = 0.f; rsc[i] = A16_SCALE; }
+  float sapin[A_F4];  // f16 forms on plain rows: the constant staging scale, one register per row piece (see FOLD)
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) sapin[i] = A16_SCALE;
   float lmu[A_F4], lrs[A_F4];  // fused LayerNorm: the staged rows' -mean * rstd and rstd = 1 / sqrt(var + eps)
   float4 pvA = make_float4(0.f, 0.f, 0.f, 0.f), pvB = pvA;
   const int KT = (g.K + BK - 1) / BK;
@@ -179,43 +183,35 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
         for (int p = 0; p < NPL; ++p) rb[j][s][p] = bp[j][((int64_t)(kt * 2 + s) * NPL + p) * 64];
   };
   // fresh: not the clamped re-stage of the last step (RMSNorm sums count once); first: the slice's first K-step (f16 row scales are chosen)
-  auto lstore = [&](int buf, float4 (&ra)[A_F4], const float4& pv, bool fresh = true, bool first = false) {
+  // one row piece (i) of a K-step: the transform of its A format, the split, the LDS stores
+  auto lstore_piece = [&](int buf, float4 (&ra)[A_F4], const float4& pv, int i, bool fresh, bool first) {
+    if constexpr (FOLD) {  // the operand every first operation on the piece takes is (re)defined HERE: see FOLD at compute_spread
+      if constexpr (AMODE == 4) asm volatile("" : "+v"(rsc[i]), "+v"(ssq[i]));
+      else asm volatile("" : "+v"(sapin[i]));
+    }
     if constexpr (AMODE == 5) {  // the row piece is already what the MFMA reads: 8-byte copy into the piece-0 plane
       unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 8;
-#pragma unroll
-      for (int i = 0; i < A_F4; ++i) *reinterpret_cast<uint2*>(a + i * RSTEP * AROW) = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
+      *reinterpret_cast<uint2*>(a + i * RSTEP * AROW) = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
     } else if constexpr (AMODE == 2) {  // pieces 0-3 of the 128-byte group are the hi halves, 4-7 the lo halves: the LDS row layout
       unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 16;
-#pragma unroll
-      for (int i = 0; i < A_F4; ++i)  // member-wise: whole-struct copies keep the array in scratch memory (no promotion to registers)
-        *reinterpret_cast<f32x4*>(a + i * RSTEP * AROW) = (f32x4){ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      // member-wise: whole-struct copies keep the array in scratch memory (no promotion to registers)
+      *reinterpret_cast<f32x4*>(a + i * RSTEP * AROW) = (f32x4){ra[i].x, ra[i].y, ra[i].z, ra[i].w};
     } else {
       if constexpr (AMODE == 1) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-          ra[i].x = eluf_(ra[i].x); ra[i].y = eluf_(ra[i].y); ra[i].z = eluf_(ra[i].z); ra[i].w = eluf_(ra[i].w);
-        }
+        ra[i].x = eluf_(ra[i].x); ra[i].y = eluf_(ra[i].y); ra[i].z = eluf_(ra[i].z); ra[i].w = eluf_(ra[i].w);
       } else if constexpr (AMODE == 3) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) { ra[i].x += pv.x; ra[i].y += pv.y; ra[i].z += pv.z; ra[i].w += pv.w; }
+        ra[i].x += pv.x; ra[i].y += pv.y; ra[i].z += pv.z; ra[i].w += pv.w;
       } else if constexpr (AMODE == 6) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {  // x * rstd - mean * rstd: two packed fused multiply-adds per row piece (lmu holds -mean * rstd)
-          const f32x2_t r2 = {lrs[i], lrs[i]}, n2 = {lmu[i], lmu[i]};
-          const f32x2_t lo2 = (f32x2_t){ra[i].x, ra[i].y} * r2 + n2, hi2 = (f32x2_t){ra[i].z, ra[i].w} * r2 + n2;
-          ra[i].x = lo2[0]; ra[i].y = lo2[1]; ra[i].z = hi2[0]; ra[i].w = hi2[1];
-        }
+        // x * rstd - mean * rstd: two packed fused multiply-adds per row piece (lmu holds -mean * rstd)
+        const f32x2_t r2 = {lrs[i], lrs[i]}, n2 = {lmu[i], lmu[i]};
+        const f32x2_t lo2 = (f32x2_t){ra[i].x, ra[i].y} * r2 + n2, hi2 = (f32x2_t){ra[i].z, ra[i].w} * r2 + n2;
+        ra[i].x = lo2[0]; ra[i].y = lo2[1]; ra[i].z = hi2[0]; ra[i].w = hi2[1];
       }
       if constexpr (AMODE == 4) {
-        if (fresh) {
-#pragma unroll
-          for (int i = 0; i < A_F4; ++i)
-            ssq[i] = fmaf(ra[i].x, ra[i].x, fmaf(ra[i].y, ra[i].y, fmaf(ra[i].z, ra[i].z, fmaf(ra[i].w, ra[i].w, ssq[i]))));
-        }
+        if (fresh) ssq[i] = fmaf(ra[i].x, ra[i].x, fmaf(ra[i].y, ra[i].y, fmaf(ra[i].z, ra[i].z, fmaf(ra[i].w, ra[i].w, ssq[i]))));
       }
       unsigned char* a = As + buf * BM * AROW + lrow * AROW + lc4 * 8;
-#pragma unroll
-      for (int i = 0; i < A_F4; ++i) {
+      {
         unsigned c0[NPL], c1[NPL];
         if constexpr (F16) {  // scaled, and saturated at fp16's largest finite value (no inf / NaN downstream; counted: range guard)
           const float F16MAX = 65504.0f;
@@ -229,7 +225,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
               rsc[i] = (ex == 0 || ex == 255) ? A16_SCALE : __uint_as_float((unsigned)min(max(261 - ex, 2), 252) << 23);
             }
           }
-          const float sa = AMODE == 4 ? rsc[i] : A16_SCALE;
+          const float sa = AMODE == 4 ? rsc[i] : sapin[i];
           const float vx = ra[i].x * sa, vy = ra[i].y * sa, vz = ra[i].z * sa, vw = ra[i].w * sa;
           a16max = fmaxf(a16max, fmaxf(fmaxf(fabsf(vx), fabsf(vy)), fmaxf(fabsf(vz), fabsf(vw))));
           split_pair<NPL, true>(__builtin_amdgcn_fmed3f(vx, -F16MAX, F16MAX), __builtin_amdgcn_fmed3f(vy, -F16MAX, F16MAX), c0);
@@ -242,6 +238,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
         for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(a + i * RSTEP * AROW + p * 64) = make_uint2(c0[p], c1[p]);
       }
     }
+  };
+  // fresh: not the clamped re-stage of the last step (RMSNorm sums count once); first: the slice's first K-step (f16 row scales are chosen)
+  auto lstore = [&](int buf, float4 (&ra)[A_F4], const float4& pv, bool fresh = true, bool first = false) {
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) lstore_piece(buf, ra, pv, i, fresh, first);
   };
 
   f32x16 acc[TM][TN];
@@ -289,7 +290,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
   // three-pass forms ALU work and LDS traffic (the next substep's fragment reads) may cross them (mask 0x786: strict fences cost
   // them 3-19 %), for the one-pass form nothing may (strict: +5-14 %, relaxed: +-0).  Same products in the same order: bit-identical.
   // Measured (tools/gemm_loop_probe.py, profiles/r04_gemm_spread_requests_*.txt): three-pass +5-10 %, one-pass +5-14 %.
-  auto compute_spread = [&](int buf, const uint4 (&rb)[TN][2][NPL], int kA, float4 (&ra)[A_F4], float4& pv, int kB, uint4 (&rbn)[TN][2][NPL]) {
+  // FOLD (round 6, f16 forms): the staging of the NEXT step's rows (rs: requested during the step before this one) is placed INSIDE this
+  // step's MFMA stream - row piece i behind MFMA NM/2 + i (NM/2) / A_F4.  As a separate lstore() behind the step its arithmetic is pure
+  // register work that the compiler orders by data dependence alone - and it put the f16 forms' scale multiply directly behind the
+  // rows' requests: `s_waitcnt vmcnt(0)` on a load just issued, in every unsplit f16 kernel on plain rows (one memory latency per
+  // trip; the fused-RMSNorm kernels waited for the rows just requested at the top of every other step).  Fences do not hold pure
+  // arithmetic in place (they order the machine scheduler, not instruction selection); a data dependence on a volatile asm statement
+  // does: the first operation on a piece takes an operand (its scale; its running sum of squares) that an empty asm statement
+  // re-defines where the piece's code stands.  A piece is then a K-step old when it is first touched, and the second half of the
+  // step's MFMAs hides its arithmetic.  Measured (192 CUs, shader-clock stamps, profiles/r06_tile_life_*.txt): K-step of the
+  // refinement's ff2 2175 -> 1970 cycles, refinement pass 14.73 -> 14.36 ms.  The bf16 kernels (whose staging the compiler happened
+  // to leave late in one of the two steps of a trip) lose 1-10 % per K-step with it: they keep the separate lstore().
+  auto compute_spread = [&](int buf, const uint4 (&rb)[TN][2][NPL], int kA, float4 (&ra)[A_F4], float4& pv, int kB, uint4 (&rbn)[TN][2][NPL],
+                            float4 (&rs)[A_F4], const float4& pvs, bool fresh_s) {
     constexpr int NB = TN * 2 * NPL, NL = NB + A_F4, NM = 2 * NPAIR * TM * TN;
     constexpr int STRIDE = NM / NL > 0 ? NM / NL : 1;
     const int kcol = min(kA * BK + lc4 * 4, klast);
@@ -330,6 +343,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
             else
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af[i][PA[q]]), as_frag(rb[j][s][PB[q]]), acc[i][j], 0, 0, 0);
             ++m;
+            if constexpr (FOLD) {
+#pragma unroll
+              for (int i = 0; i < A_F4; ++i)
+                if (m == NM / 2 + i * (NM / 2) / A_F4) {
+                  __builtin_amdgcn_sched_barrier(0x104);  // (LDS reads and scalar work may cross; vector work, requests, MFMAs, LDS writes may not)
+                  lstore_piece(buf ^ 1, rs, pvs, i, fresh_s, false);
+                }
+            }
             if (m % STRIDE == 0 && nl < NL) {
               if constexpr (NPL == 1) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -398,11 +419,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
     int it = 0;
     for (; it + 1 < nkt; it += 2) {
       const int k1 = min(kt0 + it + 1, ktl), k2 = min(kt0 + it + 2, ktl), k3 = min(kt0 + it + 3, ktl);
-      compute_spread(0, rb0, k2, raA, pvA, k1, rb1);  // step it; requests: A rows of step it + 2, W fragments of step it + 1
-      lstore(1, raB, pvB, true);
+      // step it; requests: A rows of step it + 2, W fragments of step it + 1; stages the rows of step it + 1
+      compute_spread(0, rb0, k2, raA, pvA, k1, rb1, raB, pvB, true);
+      if constexpr (!FOLD) lstore(1, raB, pvB, true);
       __syncthreads();
-      compute_spread(1, rb1, k3, raB, pvB, k2, rb0);
-      lstore(0, raA, pvA, it + 2 < nkt);
+      compute_spread(1, rb1, k3, raB, pvB, k2, rb0, raA, pvA, it + 2 < nkt);
+      if constexpr (!FOLD) lstore(0, raA, pvA, it + 2 < nkt);
       __syncthreads();
     }
     if (it < nkt) {  // (workgroup-uniform)

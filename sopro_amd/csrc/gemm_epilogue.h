@@ -37,6 +37,38 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
   // residual loads and output stores are fully coalesced dwordx4 accesses.  Residual operands are loaded in
   // batches BEFORE the stores of the same batch (R may alias C: in-place residual updates).
   constexpr int CLD = BN + 4;
+  // EPI_RES on fp32 rows (round 6): the residual pieces this thread adds - one 16-byte piece per pass, BM / RPP passes - are ALL requested
+  // here, in front of the transposition and its barrier.  Requested batch by batch inside the store loop they cost one memory latency
+  // per batch with nothing to hide it (shader-clock stamps, profiles/r06_tile_life.txt: 23.5 k cycles of epilogue for the codec's o
+  // projection against 6.7 k for the same tile without the residual - 42 % of the tile's life).  The accumulators are about to leave
+  // their registers, so the 64 registers are there.  (R may alias C - in-place residual updates: every piece is read before this
+  // workgroup's first store, and no other workgroup writes this tile.)
+  constexpr bool RES_AHEAD = EPI == SOPRO_EPI_RES && OUT < 5;
+  constexpr int RA_TPR = BN / 4, RA_RPP = NT / RA_TPR, RA_NPASS = BM / RA_RPP;
+  float4 rahead[RES_AHEAD ? RA_NPASS : 1];
+  if constexpr (RES_AHEAD) {
+    const int prow = tid / RA_TPR, ocol = n0 + (tid % RA_TPR) * 4;
+    const bool rvec = ((g.N & 3) == 0) && ((g.ldr & 3) == 0) && ((g.r_seg_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.R) & 15u) == 0);
+    int m = m0 + prow;
+    int seg = m / rps, rr = m - seg * rps;
+#pragma unroll
+    for (int q = 0; q < RA_NPASS; ++q) {
+      rahead[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ocol < g.N && m < g.M) {
+        const float* rptr = g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr + ocol;
+        if (rvec) {
+          rahead[q] = *reinterpret_cast<const float4*>(rptr);
+        } else {
+          rahead[q].x = rptr[0];
+          if (ocol + 1 < g.N) rahead[q].y = rptr[1];
+          if (ocol + 2 < g.N) rahead[q].z = rptr[2];
+          if (ocol + 3 < g.N) rahead[q].w = rptr[3];
+        }
+      }
+      m += RA_RPP; rr += RA_RPP;
+      while (rr >= rps) { rr -= rps; ++seg; }
+    }
+  }
   {
     const int col = lane & 31;
 #pragma unroll
@@ -50,6 +82,9 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
         }
   }
   __syncthreads();
+#ifdef SOPRO_DEV_SWITCHES
+  if (g.dbg && tid == 0) g.dbg[(int64_t)blockIdx.x * 8 + 4] = clock64();  // developer probe: behind the transposition
+#endif
   if constexpr (OUT == 5) {
     constexpr int TPR5 = NT / BM;   // threads per tile row
     constexpr int CPT = BN / TPR5;  // consecutive columns per thread
@@ -169,12 +204,11 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
   const int64_t dcol_bytes = split_out ? (int64_t)(ocol >> 5) * 128 + (ocol & 31) * 2 : (int64_t)ocol * 4;
   char* dptr = OUT != 0 ? reinterpret_cast<char*>(dbase + (int64_t)seg * dseg + (int64_t)rr * ldd) + dcol_bytes : nullptr;
   const int64_t dstep = (int64_t)RPP * ldd * 4;
-  const float* rptr = res ? g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr + ocol : nullptr;
-  const int64_t cstep = (int64_t)RPP * g.ldc, rstep = (int64_t)RPP * g.ldr;
+  const int64_t cstep = (int64_t)RPP * g.ldc;
   const float* csrc = Cs + prow * CLD + pc4 * 4;
   constexpr int BATCH = NPASS < 8 ? NPASS : 8;
-#pragma unroll 1
-  for (int p0 = 0; p0 < NPASS; p0 += BATCH) {
+  static_assert(!RES_AHEAD || (RA_NPASS == NPASS && RA_RPP == RPP), "the residual pieces requested ahead are the store loop's");
+  auto batch = [&](int p0, const float4* rvb) {
     float* cp[BATCH];
     char* dp[BATCH];
     float4 rv[BATCH];
@@ -183,25 +217,13 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
       const bool ok = col_ok && m < g.M;
       cp[q] = ok ? cptr : nullptr;
       dp[q] = dptr;
-      rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (res && ok) {
-        if (vec_ok) {
-          rv[q] = *reinterpret_cast<const float4*>(rptr);
-        } else {
-          rv[q].x = rptr[0];
-          if (ocol + 1 < n_out_total) rv[q].y = rptr[1];
-          if (ocol + 2 < n_out_total) rv[q].z = rptr[2];
-          if (ocol + 3 < n_out_total) rv[q].w = rptr[3];
-        }
-      }
+      rv[q] = res ? rvb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
       m += RPP; rr += RPP; cptr += cstep;
       if (OUT != 0) dptr += dstep;
-      if (res) rptr += rstep;
       if (rr >= rps) {
         do { rr -= rps; ++seg; } while (rr >= rps);
         cptr = g.C + (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc + ocol;
         if (OUT != 0) dptr = reinterpret_cast<char*>(dbase + (int64_t)seg * dseg + (int64_t)rr * ldd) + dcol_bytes;
-        if (res) rptr = g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr + ocol;
       }
     }
 #pragma unroll
@@ -267,6 +289,23 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
         if (ocol + 2 < n_out_total) cp[q][2] = v.z;
         if (ocol + 3 < n_out_total) cp[q][3] = v.w;
       }
+    }
+  };
+  if constexpr (RES_AHEAD) {  // (unrolled: the batches index the pieces requested ahead statically)
+#pragma unroll
+    for (int b = 0; b < NPASS / BATCH; ++b) {
+      batch(b * BATCH, rahead + b * BATCH);
+#ifdef SOPRO_DEV_SWITCHES
+      if (g.dbg && tid == 0 && b == 0) g.dbg[(int64_t)blockIdx.x * 8 + 5] = clock64();  // developer probe: behind the first batch of rows
+#endif
+    }
+  } else {
+#pragma unroll 1
+    for (int p0 = 0; p0 < NPASS; p0 += BATCH) {
+      batch(p0, nullptr);
+#ifdef SOPRO_DEV_SWITCHES
+      if (g.dbg && tid == 0 && p0 == 0) g.dbg[(int64_t)blockIdx.x * 8 + 5] = clock64();
+#endif
     }
   }
 }

@@ -33,7 +33,9 @@ def timed(fn, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-SHAPES = (("nar ff1", 25600, 1536, 384, "f16x3", hip.EPI_GELU), ("nar glu-like", 25600, 768, 384, "f16x3", 0), ("nar ff2", 25600, 384, 1536, "f16x3", hip.EPI_RES),
+SHAPES = (("nar ff1 rms", 25600, 1536, 384, "f16x3", -hip.EPI_GELU), ("nar glu rms", 25600, 768, 384, "f16x3", -hip.EPI_GLU), ("nar glu", 25600, 768, 384, "f16x3", hip.EPI_GLU),
+          ("nar plain rms", 25600, 256, 384, "f16x3", -1000),
+          ("nar ff1", 25600, 1536, 384, "f16x3", hip.EPI_GELU), ("nar glu-like", 25600, 768, 384, "f16x3", 0), ("nar ff2", 25600, 384, 1536, "f16x3", hip.EPI_RES),
           ("mimi qkv", 25600, 1536, 512, "bf16x3", 0), ("mimi o", 25600, 512, 512, "bf16x3", hip.EPI_RES), ("mimi fc1", 25600, 2048, 512, "bf16x3", hip.EPI_GELU),
           ("mimi fc2", 25600, 512, 2048, "bf16x3", hip.EPI_RES), ("up2", 307200, 640, 512, "bf16x3", 0), ("res1.c1", 204800, 128, 768, "bf16x3", 0))
 for name, M, N, K, kind, epi in SHAPES:
@@ -42,15 +44,19 @@ for name, M, N, K, kind, epi in SHAPES:
     outs, row = [], [f"{name:13s} {kind:7s} {M} x {N} x {K}:"]
     for t in TILES:
         lib.sopro_gemm_bf16_set_tile_override(t)
-        Cc = torch.empty(M, N, device=DEV)
+        e = abs(epi) if epi != -1000 else 0
+        Cc = torch.empty(M, N // 2 if e == hip.EPI_GLU else N, device=DEV)
         kw = dict(M=M, N=N, K=K, bias=b)
-        if epi:
-            kw["epilogue"] = epi
-        if epi == hip.EPI_RES:
+        if epi < 0:  # fused RMSNorm on the rows
+            kw["rms_eps"] = 1e-6
+        if e:
+            kw["epilogue"] = e
+        if e == hip.EPI_RES:
             kw["R"] = Rr
         us = timed(lambda: hip.gemm(A, Wp, Cc, **kw))
         outs.append(Cc)
         row.append(f"tile {t}: {us:7.1f} us ({2e-6 * M * N * K / us:6.1f} TFLOP/s fp32-eq)")
+        torch.cuda.synchronize()
     lib.sopro_gemm_bf16_set_tile_override(0)
     same = all(torch.equal(outs[0], o) for o in outs[1:])
     print("  ".join(row) + f"  same bits: {same}", flush=True)
