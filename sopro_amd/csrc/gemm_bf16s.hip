@@ -489,16 +489,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
           }
     }
   }
-  if constexpr (F16) {  // undo the operand scales (powers of two: exact)
+  // f16 forms: the operand scales (powers of two: exact) are undone where the accumulators leave for the epilogue's tile - one
+  // multiply-add per element there (acc x cscale + bias, or acc x (row scale x cscale) + bias: the product is exact either way, so
+  // the sum rounds as it did when the accumulators were scaled in place first; round 6: 64 multiplies and their AGPR round trips less)
+  float cscale = 1.0f;
+  if constexpr (F16) {
     // (fused-RMSNorm form: the activation scale is per row and leaves with the row's RMS scale below; acc_scale holds the constant one)
-    const float sc = AMODE == 4 ? ext.acc_scale * A16_SCALE : ext.acc_scale;
+    cscale = AMODE == 4 ? ext.acc_scale * A16_SCALE : ext.acc_scale;
     if (ext.range_events && !(a16max <= 65504.0f)) atomicAdd(ext.range_events, 1);  // saturated (or NaN) operands: see the header note
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] *= sc;
   }
   const float* rs = nullptr;
   if constexpr (AMODE == 4) {
@@ -512,13 +510,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16s_kernel(const sopro_gem
       v += __shfl_xor(v, 2, 64);
       v += __shfl_xor(v, 4, 64);
       float r = rsqrtf(v / (float)g.K + ext.rms_eps);
-      if constexpr (F16) r *= __uint_as_float(0x7f000000u - __float_as_uint(rsc[i]));  // 1 / (a power of two), exactly: exponent 254 - e
+      if constexpr (F16) r *= __uint_as_float(0x7f000000u - __float_as_uint(rsc[i])) * cscale;  // 1 / (a power of two), exactly: exponent 254 - e; x the constant scales
       if (lc4 == 0) rsl[lrow + i * RSTEP] = r;
     }
     __syncthreads();
     rs = rsl;
   }
-  gemm_store_tile<WM, WN, TM, TN, EPI, OUT>(g, reinterpret_cast<float*>(smem4), acc, biasv, m0, n0, &ext, rs);
+  gemm_store_tile<WM, WN, TM, TN, EPI, OUT>(g, reinterpret_cast<float*>(smem4), acc, biasv, m0, n0, &ext, rs, cscale);
   if (dbg && tid == 0) dbg[3] = clock64();
 }
 

@@ -16,14 +16,15 @@
 // to g.C; 8 = C as bf16 to g.C AND ELU(C) as bf16 to ext.C2.  g.C / ext.C2 / g.R (the skip operand of EPI_RES) point at bf16
 // elements and their strides count elements; host guarantees N % 4 == 0 and 8-byte aligned rows.
 // rs (optional, LDS): one scale per tile row applied to the accumulator before the bias: the RMSNorm of the operand row
-// when its weight vector has been folded into W (out = rs * (x W'^T) + b).
+// when its weight vector has been folded into W (out = rs * (x W'^T) + b).  cscale: a constant factor on the accumulators when
+// there is no rs (the f16 forms' operand scales; with rs the caller has multiplied it into the row scales).
 // (internal epilogue id, not part of the ABI: GELU with gelu_fast - what the three-pass / one-pass launchers instantiate for EPI_GELU)
 constexpr int SOPRO_EPI_GELU_FAST = 100;
 template <int WM, int WN, int TM, int TN, int EPI, int OUT = 0>
 __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float* __restrict__ Cs, f32x16 (&acc)[TM][TN],
                                                 const float (&biasv)[TN], int m0, int n0,
                                                 const sopro_gemm_split_ext* __restrict__ ext = nullptr,
-                                                const float* __restrict__ rs = nullptr) {
+                                                const float* __restrict__ rs = nullptr, float cscale = 1.0f) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -46,11 +47,22 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
   constexpr bool RES_AHEAD = EPI == SOPRO_EPI_RES && OUT < 5;
   constexpr int RA_TPR = BN / 4, RA_RPP = NT / RA_TPR, RA_NPASS = BM / RA_RPP;
   float4 rahead[RES_AHEAD ? RA_NPASS : 1];
+  // A tile that lies wholly inside M x N and inside one segment (all but the last row / column of tiles, and the few tiles that
+  // straddle two utterances of a row-window problem): every row pointer is (first row) + q x (rows per pass x leading dimension) -
+  // no per-piece bounds tests, segment wraps or null checks, i.e. no divergent branches (round 6: the general walk's compare /
+  // exec-mask / branch / 64-bit multiply per piece was a third of a plain epilogue).  Workgroup-uniform.
+  const bool whole_tile = m0 + BM <= g.M && n0 + BN <= g.N && (m0 / rps) == ((m0 + BM - 1) / rps);
   if constexpr (RES_AHEAD) {
     const int prow = tid / RA_TPR, ocol = n0 + (tid % RA_TPR) * 4;
     const bool rvec = ((g.N & 3) == 0) && ((g.ldr & 3) == 0) && ((g.r_seg_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.R) & 15u) == 0);
     int m = m0 + prow;
     int seg = m / rps, rr = m - seg * rps;
+    if (whole_tile && rvec) {
+      const float* rptr = g.R + (int64_t)seg * g.r_seg_stride + (int64_t)rr * g.ldr + ocol;
+      const int64_t rstep = (int64_t)RA_RPP * g.ldr;
+#pragma unroll
+      for (int q = 0; q < RA_NPASS; ++q) rahead[q] = *reinterpret_cast<const float4*>(rptr + q * rstep);
+    } else {
 #pragma unroll
     for (int q = 0; q < RA_NPASS; ++q) {
       rahead[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -68,18 +80,31 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
       m += RA_RPP; rr += RA_RPP;
       while (rr >= rps) { rr -= rps; ++seg; }
     }
+    }
   }
   {
     const int col = lane & 31;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          Cs[row * CLD + (wn * TN + j) * 32 + col] = (rs ? acc[i][j][r] * rs[row] : acc[i][j][r]) + biasv[j];
+      for (int k = 0; k < 4; ++k) {  // accumulator registers 4 k .. 4 k + 3 are four consecutive tile rows: their row scales are ONE 16-byte LDS read
+        const int row0 = (wm * TM + i) * 32 + 8 * k + 4 * (lane >> 5);
+        float rs4[4] = {cscale, cscale, cscale, cscale};
+        if (rs) {
+          const float4 t = *reinterpret_cast<const float4*>(rs + row0);
+          rs4[0] = t.x; rs4[1] = t.y; rs4[2] = t.z; rs4[3] = t.w;
         }
+        // (the row-scaled product is rounded BEFORE the bias is added, as it always was - it used to sit inside a select, which kept it
+        // out of a fused multiply-add; with cscale alone the product is exact and either form gives the same sum)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float p = acc[i][j][4 * k + e] * rs4[e];
+            if (rs) asm("" : "+v"(p));  // (an opaque copy: the product cannot be contracted into the addition behind it)
+            Cs[(row0 + e) * CLD + (wn * TN + j) * 32 + col] = p + biasv[j];
+          }
+      }
   }
   __syncthreads();
 #ifdef SOPRO_DEV_SWITCHES
@@ -208,6 +233,83 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
   const float* csrc = Cs + prow * CLD + pc4 * 4;
   constexpr int BATCH = NPASS < 8 ? NPASS : 8;
   static_assert(!RES_AHEAD || (RA_NPASS == NPASS && RA_RPP == RPP), "the residual pieces requested ahead are the store loop's");
+  // one 16-byte piece of a row: pq = its pass (tile row prow + pq RPP), cpq / dpq = its destinations, rvq = its residual piece
+  auto emit = [&](int pq, float* cpq, char* dpq, const float4& rvq) {
+    {
+      float4 v = *reinterpret_cast<const float4*>(csrc + pq * RPP * CLD);
+      if (glu) {
+        const float4 gt = *reinterpret_cast<const float4*>(csrc + pq * RPP * CLD + 32);
+        v.x *= sigmoidf_(gt.x); v.y *= sigmoidf_(gt.y); v.z *= sigmoidf_(gt.z); v.w *= sigmoidf_(gt.w);
+      } else if (EPI == SOPRO_EPI_GELU) {
+        v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+      } else if (EPI == SOPRO_EPI_GELU_FAST) {
+        v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
+      } else if (EPI == SOPRO_EPI_TANH) {
+        v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+      } else if (res) {
+        v.x = rvq.x + sc4.x * v.x; v.y = rvq.y + sc4.y * v.y; v.z = rvq.z + sc4.z * v.z; v.w = rvq.w + sc4.w * v.w;
+        if (OUT == 0 && ext && ext->ln_stats_out) {
+          // LayerNorm statistics of the updated stream for the next contraction (sopro_gemm_split_ext.ln_stats): the 16 lanes that hold a
+          // 64-column group of the row reduce (mean, squared deviations) - row_stats_kernel's arithmetic (host guarantees N % 64 == 0:
+          // a group is entirely inside N or entirely outside, and rows >= M left through the `continue` above group-wise)
+          float s1 = (v.x + v.y) + (v.z + v.w);
+          s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64); s1 += __shfl_xor(s1, 8, 64);
+          const float mu = s1 * (1.0f / 64.0f);
+          const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+          float s2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+          s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64); s2 += __shfl_xor(s2, 8, 64);
+          if ((pc4 & 15) == 0) {
+            const int64_t mq = m0 + prow + pq * RPP;
+            *reinterpret_cast<float2*>(ext->ln_stats_out + (mq * (g.N >> 6) + (ncol >> 6)) * 2) = make_float2(mu, s2);
+          }
+        }
+      } else if (EPI == SOPRO_EPI_ROPE) {
+        // rotate-half RoPE of the q | k heads in the leading rope_cols columns: the partner column (+- dh / 2) is in the LDS tile, the
+        // position is the row's index within its utterance (sopro_rope_f32's arithmetic, without its pass over C)
+        if (ncol < ext->rope_cols) {
+          const int half = ext->rope_dh >> 1, e = ncol & (ext->rope_dh - 1);
+          const bool lowh = e < half;
+          const float4 pv = *reinterpret_cast<const float4*>(csrc + pq * RPP * CLD + (lowh ? half : -half));
+          const int mq = m0 + prow + pq * RPP;
+          const int64_t ti = (int64_t)(ext->rope_pos0 + mq % ext->rope_rows_per_seg) * half + (e & (half - 1));
+          const float4 c4 = *reinterpret_cast<const float4*>(ext->rope_cos + ti), s4 = *reinterpret_cast<const float4*>(ext->rope_sin + ti);
+          if (lowh) { v.x = v.x * c4.x - pv.x * s4.x; v.y = v.y * c4.y - pv.y * s4.y; v.z = v.z * c4.z - pv.z * s4.z; v.w = v.w * c4.w - pv.w * s4.w; }
+          else { v.x = v.x * c4.x + pv.x * s4.x; v.y = v.y * c4.y + pv.y * s4.y; v.z = v.z * c4.z + pv.z * s4.z; v.w = v.w * c4.w + pv.w * s4.w; }
+        }
+      }
+      if (split_out) {  // host guarantees N % 4 == 0 and 128-byte aligned rows
+        uint2 h, l;
+        split2_bf16(eluf_(v.x), eluf_(v.y), h.x, l.x);
+        split2_bf16(eluf_(v.z), eluf_(v.w), h.y, l.y);
+        *reinterpret_cast<uint2*>(dpq) = h;
+        *reinterpret_cast<uint2*>(dpq + 64) = l;
+        if (OUT == 1) return;
+      } else if (OUT != 0) {
+        bulk_store4(reinterpret_cast<float*>(dpq), make_float4(eluf_(v.x), eluf_(v.y), eluf_(v.z), eluf_(v.w)), big);
+        if (OUT == 3) return;
+      }
+      if (vec_ok) {
+        bulk_store4(cpq, v, big);
+      } else {
+        cpq[0] = v.x;
+        if (ocol + 1 < n_out_total) cpq[1] = v.y;
+        if (ocol + 2 < n_out_total) cpq[2] = v.z;
+        if (ocol + 3 < n_out_total) cpq[3] = v.w;
+      }
+    }
+  };
+  if (whole_tile && vec_ok) {  // straight-line: see whole_tile above
+    if (col_ok) {  // (GLU: the threads on gate columns have nothing to store; otherwise true for a whole tile)
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) {
+        emit(q, cptr + q * cstep, OUT != 0 ? dptr + q * dstep : nullptr, rahead[RES_AHEAD ? q : 0]);
+#ifdef SOPRO_DEV_SWITCHES
+        if (g.dbg && tid == 0 && q == BATCH - 1) g.dbg[(int64_t)blockIdx.x * 8 + 5] = clock64();
+#endif
+      }
+    }
+    return;
+  }
   auto batch = [&](int p0, const float4* rvb) {
     float* cp[BATCH];
     char* dp[BATCH];
@@ -229,66 +331,7 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
 #pragma unroll
     for (int q = 0; q < BATCH; ++q) {
       if (!cp[q]) continue;
-      float4 v = *reinterpret_cast<const float4*>(csrc + (p0 + q) * RPP * CLD);
-      if (glu) {
-        const float4 gt = *reinterpret_cast<const float4*>(csrc + (p0 + q) * RPP * CLD + 32);
-        v.x *= sigmoidf_(gt.x); v.y *= sigmoidf_(gt.y); v.z *= sigmoidf_(gt.z); v.w *= sigmoidf_(gt.w);
-      } else if (EPI == SOPRO_EPI_GELU) {
-        v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-      } else if (EPI == SOPRO_EPI_GELU_FAST) {
-        v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
-      } else if (EPI == SOPRO_EPI_TANH) {
-        v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
-      } else if (res) {
-        v.x = rv[q].x + sc4.x * v.x; v.y = rv[q].y + sc4.y * v.y; v.z = rv[q].z + sc4.z * v.z; v.w = rv[q].w + sc4.w * v.w;
-        if (OUT == 0 && ext && ext->ln_stats_out) {
-          // LayerNorm statistics of the updated stream for the next contraction (sopro_gemm_split_ext.ln_stats): the 16 lanes that hold a
-          // 64-column group of the row reduce (mean, squared deviations) - row_stats_kernel's arithmetic (host guarantees N % 64 == 0:
-          // a group is entirely inside N or entirely outside, and rows >= M left through the `continue` above group-wise)
-          float s1 = (v.x + v.y) + (v.z + v.w);
-          s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64); s1 += __shfl_xor(s1, 8, 64);
-          const float mu = s1 * (1.0f / 64.0f);
-          const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
-          float s2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-          s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64); s2 += __shfl_xor(s2, 8, 64);
-          if ((pc4 & 15) == 0) {
-            const int64_t mq = m0 + prow + (p0 + q) * RPP;
-            *reinterpret_cast<float2*>(ext->ln_stats_out + (mq * (g.N >> 6) + (ncol >> 6)) * 2) = make_float2(mu, s2);
-          }
-        }
-      } else if (EPI == SOPRO_EPI_ROPE) {
-        // rotate-half RoPE of the q | k heads in the leading rope_cols columns: the partner column (+- dh / 2) is in the LDS tile, the
-        // position is the row's index within its utterance (sopro_rope_f32's arithmetic, without its pass over C)
-        if (ncol < ext->rope_cols) {
-          const int half = ext->rope_dh >> 1, e = ncol & (ext->rope_dh - 1);
-          const bool lowh = e < half;
-          const float4 pv = *reinterpret_cast<const float4*>(csrc + (p0 + q) * RPP * CLD + (lowh ? half : -half));
-          const int mq = m0 + prow + (p0 + q) * RPP;
-          const int64_t ti = (int64_t)(ext->rope_pos0 + mq % ext->rope_rows_per_seg) * half + (e & (half - 1));
-          const float4 c4 = *reinterpret_cast<const float4*>(ext->rope_cos + ti), s4 = *reinterpret_cast<const float4*>(ext->rope_sin + ti);
-          if (lowh) { v.x = v.x * c4.x - pv.x * s4.x; v.y = v.y * c4.y - pv.y * s4.y; v.z = v.z * c4.z - pv.z * s4.z; v.w = v.w * c4.w - pv.w * s4.w; }
-          else { v.x = v.x * c4.x + pv.x * s4.x; v.y = v.y * c4.y + pv.y * s4.y; v.z = v.z * c4.z + pv.z * s4.z; v.w = v.w * c4.w + pv.w * s4.w; }
-        }
-      }
-      if (split_out) {  // host guarantees N % 4 == 0 and 128-byte aligned rows
-        uint2 h, l;
-        split2_bf16(eluf_(v.x), eluf_(v.y), h.x, l.x);
-        split2_bf16(eluf_(v.z), eluf_(v.w), h.y, l.y);
-        *reinterpret_cast<uint2*>(dp[q]) = h;
-        *reinterpret_cast<uint2*>(dp[q] + 64) = l;
-        if (OUT == 1) continue;
-      } else if (OUT != 0) {
-        bulk_store4(reinterpret_cast<float*>(dp[q]), make_float4(eluf_(v.x), eluf_(v.y), eluf_(v.z), eluf_(v.w)), big);
-        if (OUT == 3) continue;
-      }
-      if (vec_ok) {
-        bulk_store4(cp[q], v, big);
-      } else {
-        cp[q][0] = v.x;
-        if (ocol + 1 < n_out_total) cp[q][1] = v.y;
-        if (ocol + 2 < n_out_total) cp[q][2] = v.z;
-        if (ocol + 3 < n_out_total) cp[q][3] = v.w;
-      }
+      emit(p0 + q, cp[q], dp[q], rv[q]);
     }
   };
   if constexpr (RES_AHEAD) {  // (unrolled: the batches index the pieces requested ahead statically)

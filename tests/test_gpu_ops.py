@@ -349,6 +349,33 @@ def test_gemm_f16x3_is_fp32_class(M, N, K):
         assert torch.equal(got[:, 0].cpu().long(), C.cpu().argmax(-1))
 
 
+def test_fused_rmsnorm_forms_do_not_depend_on_the_tile_shape():
+    """Round 6: the f16 three-pass forms with a fused RMSNorm (plain, GELU, GLU) and the plain GLU on the three tile shapes the engine
+    picks by row count (override 1 = 128 x 128 for whole passes, 4 = 64 x 128, 5 = 64 x 64 / 64 x 128 for streaming chunks and small
+    batches): bit-identical.  They were not before round 6 - `acc * row_scale + bias` was contracted into a fused multiply-add in some
+    instantiations and not in others (1 ulp apart), so a refinement over a whole pass and the same rows in a small batch could differ;
+    the epilogue now rounds the row-scaled product explicitly (gemm_epilogue.h).  The six-pass form (the refinement's fallback) likewise."""
+    M, K = 1100, 384  # ragged last row tile on every shape
+    lib = hip.load()
+    for name, N, kw, pack in (("rms plain", 256, {}, hip.pack_w_f16x3), ("rms gelu", 640, dict(epilogue=hip.EPI_GELU), hip.pack_w_f16x3),
+                              ("rms glu", 768, dict(epilogue=hip.EPI_GLU), hip.pack_w_f16x3), ("glu", 768, dict(epilogue=hip.EPI_GLU, rms_eps=0.0), hip.pack_w_f16x3),
+                              ("six-pass rms gelu", 512, dict(epilogue=hip.EPI_GELU), hip.pack_w_bf16x6)):
+        A, W, b = rnd(M, K, seed=171), rnd(N, K, seed=172, scale=K ** -0.5), rnd(N, seed=173)
+        Ad, bd, Wp = dev(A), dev(b), pack(dev(W))
+        outs = []
+        try:
+            for cfg in (1, 4, 5):
+                lib.sopro_gemm_bf16_set_tile_override(cfg)
+                C = torch.full((M, N // 2 if kw.get("epilogue") == hip.EPI_GLU else N), float("nan"), device=DEV)
+                hip.gemm(Ad, Wp, C, M=M, N=N, K=K, bias=bd, **dict(dict(rms_eps=1e-6), **kw))
+                torch.cuda.synchronize()
+                outs.append(C.cpu())
+        finally:
+            lib.sopro_gemm_bf16_set_tile_override(0)
+        assert bool(torch.isfinite(outs[0]).all()), name
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), name
+
+
 def test_gemm_eight_wave_tiles_are_the_same_function():
     """128x128 tiles on eight waves (round 4 developer form of the three-pass decoder contraction, tile override 7: four waves per
     SIMD; measured faster alone, not in the pipeline - profiles/r04_experiments.md) against the four-wave form: every output element
