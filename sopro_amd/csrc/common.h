@@ -87,6 +87,12 @@ __device__ __forceinline__ float gelu_fast(float v) {
   return fmaf(h, copysignf(y, v), h);
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// Round 6: the GLU gate of the f16 three-pass / one-pass contraction epilogues (the refinement's GLU projection, 24 launches per pass): the
+// hardware exponential and reciprocal (1 ulp each; <= ~3 ulp relative against the precise form's <= 1) - 5 issue slots per element
+// instead of ~27 (software expf + IEEE division), whose dependency chains were 8.3 k of the GLU launch's 44.5 k cycles per tile
+// (profiles/r06_tile_life_*.txt).  Large |v| end where the precise form does: exp2 -> inf / 0, rcp -> 0 / 1.  The six-pass kernel (the
+// refinement's fallback, the conditioning) and the exact-fp32 kernels (the AR frame) keep sigmoidf_.
+__device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * v)); }
 // ELU(alpha=1).  exp(v)-1 with the hardware exponential: absolute error <= ~2e-7 on v <= 0 (fp32 round-off of the
 // surrounding contractions is larger); expm1f's software expansion was the dominant VALU cost of the SEANet tail.
 // Round 6: the selection is ONE v_med3_f32 instead of a compare + select: w = exp(v) - 1 >= v everywhere (convexity), so for v > 0 the

@@ -649,8 +649,10 @@ int launch_cfg6(const sopro_gemm_args& g, const uint4* wp, int ksubs, const sopr
   }
 #undef SOPRO_CASE
   if constexpr (WN * TN * 32 >= 64) {
-    if (key == SOPRO_EPI_GLU * 10) return launch_one<NPL, WM, WN, TM, TN, SOPRO_EPI_GLU, 0, 0, F16>(g, wp, ksubs, ext, s);
-    if (key == SOPRO_EPI_GLU * 10 + 4) return launch_one<NPL, WM, WN, TM, TN, SOPRO_EPI_GLU, 4, 0, F16>(g, wp, ksubs, ext, s);  // RMSNorm -> GLU
+    // (EPI_GLU: the hardware-exponential sigmoid for the f16 three-pass and one-pass kernels, the precise one for the six-pass kernel - as for GELU)
+    constexpr int GLU_ = (F16 || NPL != 3) ? SOPRO_EPI_GLU_FAST : SOPRO_EPI_GLU;
+    if (key == SOPRO_EPI_GLU * 10) return launch_one<NPL, WM, WN, TM, TN, GLU_, 0, 0, F16>(g, wp, ksubs, ext, s);
+    if (key == SOPRO_EPI_GLU * 10 + 4) return launch_one<NPL, WM, WN, TM, TN, GLU_, 4, 0, F16>(g, wp, ksubs, ext, s);  // RMSNorm -> GLU
   }
   sopro_set_error("sopro_gemm_%s: (epilogue %d, prologue %d) is not an available combination", F16 ? "f16x3" : (NPL == 3 ? "bf16x6" : "bf16x1"), g.epilogue, g.prologue);
   return -2;

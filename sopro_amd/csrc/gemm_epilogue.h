@@ -20,6 +20,7 @@
 // there is no rs (the f16 forms' operand scales; with rs the caller has multiplied it into the row scales).
 // (internal epilogue id, not part of the ABI: GELU with gelu_fast - what the three-pass / one-pass launchers instantiate for EPI_GELU)
 constexpr int SOPRO_EPI_GELU_FAST = 100;
+constexpr int SOPRO_EPI_GLU_FAST = 101;  // GLU with sigmoid_fast (common.h): what the f16 three-pass / one-pass launchers instantiate for EPI_GLU
 template <int WM, int WN, int TM, int TN, int EPI, int OUT = 0>
 __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float* __restrict__ Cs, f32x16 (&acc)[TM][TN],
                                                 const float (&biasv)[TN], int m0, int n0,
@@ -197,8 +198,53 @@ __device__ __forceinline__ void gemm_store_tile(const sopro_gemm_args& g, float*
     }
     return;
   }
-  constexpr bool glu = EPI == SOPRO_EPI_GLU;
+  constexpr bool glu = EPI == SOPRO_EPI_GLU || EPI == SOPRO_EPI_GLU_FAST;
   constexpr bool res = EPI == SOPRO_EPI_RES;
+  if constexpr (glu && OUT == 0) {
+    // GLU (round 6): EVERY thread of a tile row works - thread t takes the two value columns 64 (t / 16) + 2 (t % 16) .. + 1 of its
+    // 64-column group [32 value | 32 gate] and their gates 32 columns further, and writes 8 bytes.  The general path below gives a
+    // thread four consecutive tile columns: the threads on gate columns idle, and the waves issue the sigmoids' ~27 instructions per
+    // element at half their lanes (stamps: 10.8 k of the GLU launch's 49 k cycles per tile).  Same arithmetic per element.
+    constexpr int GT = BN / 4, GRPP = NT / GT, GNP = BM / GRPP;
+    const int prow = tid / GT, t = tid % GT;
+    const int grp = t >> 4, u = t & 15;
+    const int ocol = ((n0 + grp * 64) >> 6) * 32 + 2 * u;
+    const bool col_ok = n0 + grp * 64 < g.N;  // (N % 64 == 0: a group lies wholly inside or outside)
+    const bool st2 = ((g.ldc & 1) == 0) && ((g.c_seg_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7u) == 0);
+    const float* csrc = Cs + prow * CLD + grp * 64 + 2 * u;
+    auto piece = [&](int q, float* cp) {
+      const float2 v = *reinterpret_cast<const float2*>(csrc + q * GRPP * CLD), gt = *reinterpret_cast<const float2*>(csrc + q * GRPP * CLD + 32);
+      const float ox = v.x * (EPI == SOPRO_EPI_GLU_FAST ? sigmoid_fast(gt.x) : sigmoidf_(gt.x)), oy = v.y * (EPI == SOPRO_EPI_GLU_FAST ? sigmoid_fast(gt.y) : sigmoidf_(gt.y));
+      if (st2) {
+        bulk_store_u2(cp, make_uint2(__float_as_uint(ox), __float_as_uint(oy)), big);
+      } else {
+        cp[0] = ox;
+        cp[1] = oy;
+      }
+    };
+    if (!col_ok) return;
+    if (m0 + BM <= g.M && (m0 / rps) == ((m0 + BM - 1) / rps)) {  // whole rows inside one segment: straight-line
+      const int m = m0 + prow, seg = m / rps, rr = m - seg * rps;
+      float* cptr = g.C + (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc + ocol;
+      const int64_t cstep = (int64_t)GRPP * g.ldc;
+#pragma unroll
+      for (int q = 0; q < GNP; ++q) {
+        piece(q, cptr + q * cstep);
+#ifdef SOPRO_DEV_SWITCHES
+        if (g.dbg && tid == 0 && q == GNP / 2 - 1) g.dbg[(int64_t)blockIdx.x * 8 + 5] = clock64();
+#endif
+      }
+    } else {
+#pragma unroll 1
+      for (int q = 0; q < GNP; ++q) {
+        const int m = m0 + prow + q * GRPP;
+        if (m >= g.M) break;
+        const int seg = m / rps, rr = m - seg * rps;
+        piece(q, g.C + (int64_t)seg * g.c_seg_stride + (int64_t)rr * g.ldc + ocol);
+      }
+    }
+    return;
+  }
   constexpr int TPR = BN / 4;          // threads per tile row (one float4 each)
   constexpr int RPP = NT / TPR;        // rows per pass
   constexpr int NPASS = BM / RPP;

@@ -16,15 +16,18 @@ torch.cuda.set_device(0)
 st = hip.cu_range_stream(64, 192, DEV)
 g = torch.Generator(device=DEV).manual_seed(1)
 rn = lambda *s, scale=1.0: torch.randn(*s, device=DEV, generator=g) * scale  # noqa: E731
-SHAPES = (("nar ff1 rms+gelu", 25600, 1536, 384, "f16x3", dict(epilogue=hip.EPI_GELU, rms_eps=1e-6)), ("nar ff2 res", 25600, 384, 1536, "f16x3", dict(epilogue=hip.EPI_RES)),
+SHAPES = (("nar glu rms", 25600, 768, 384, "f16x3", dict(epilogue=hip.EPI_GLU, rms_eps=1e-6)), ("nar heads argmax", 25600, 8192, 256, "f16x3", dict(c_mode=5)),
+          ("nar ff1 rms+gelu", 25600, 1536, 384, "f16x3", dict(epilogue=hip.EPI_GELU, rms_eps=1e-6)), ("nar ff2 res", 25600, 384, 1536, "f16x3", dict(epilogue=hip.EPI_RES)),
           ("mimi qkv", 25600, 1536, 512, "bf16x3", {}), ("mimi o res", 25600, 512, 512, "bf16x3", dict(epilogue=hip.EPI_RES)),
           ("mimi fc1 gelu", 25600, 2048, 512, "bf16x3", dict(epilogue=hip.EPI_GELU)), ("mimi fc2 res", 25600, 512, 2048, "bf16x3", dict(epilogue=hip.EPI_RES)),
           ("up2", 307200, 640, 512, "bf16x3", {}))
 for name, M, N, K, kind, kw in SHAPES:
     A, W, b, Rr = rn(M, K), rn(N, K, scale=K ** -0.5), rn(N, scale=0.1), rn(M, N)
     Wp = hip.pack_w_f16x3(W) if kind == "f16x3" else hip.pack_w_bf16x3(W)
-    Cc = torch.empty(M, N, device=DEV)
+    Cc = torch.empty(M, N // 2 if kw.get("epilogue") == hip.EPI_GLU else N, device=DEV) if kw.get("c_mode") != 5 else None
     kw = dict(kw, M=M, N=N, K=K, bias=b)
+    if kw.get("c_mode") == 5:
+        kw.update(C2=torch.zeros(M, N // 64, 2, device=DEV), ldc2=N // 64)
     if kw.get("epilogue") == hip.EPI_RES:
         kw["R"] = Rr
     nwg = ((M + 127) // 128) * ((N + 127) // 128)
