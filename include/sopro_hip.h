@@ -94,6 +94,9 @@ enum { SOPRO_EPI_NONE = 0, SOPRO_EPI_GELU = 1, SOPRO_EPI_GLU = 2, SOPRO_EPI_RES 
  *   EPI_RES : C = R + scale[n] * (acc + bias)  (scale NULL = 1) (residual adds, LayerScale
  *             HF:modeling_mimi.py:495-507, tanh(gate) of src/sopro/nn/text.py:131)
  *   EPI_GELU: erf form (torch nn.GELU default)
+ *   (sopro_gemm_f32 and sopro_gemm_bf16x6 evaluate GELU / the GLU gate with the library's erff / expf and an IEEE division; the f16
+ *   three-pass and the one- / three-pass bf16 entry points - the throughput phases - use an Abramowitz-Stegun erf (<= 4.7e-7 absolute)
+ *   and the hardware exponential / reciprocal for the gate (<= ~3 ulp): csrc/common.h gelu_fast, sigmoid_fast)
  * Replaces: every nn.Linear / F.linear of src/sopro/nn/{blocks,text,ref,nar,speaker}.py on the
  * full-sequence paths, HF MimiTransformer projections (HF:modeling_mimi.py:602-726) and,
  * through overlapping rows, MimiConv1d / MimiConvTranspose1d (HF:modeling_mimi.py:210-405). */
