@@ -257,6 +257,38 @@ def test_gemm_argmax_epilogue_equals_argmax_of_the_logits(pieces, M, heads, V, K
     assert torch.equal(got[:, 1:-1].cpu(), ref)
 
 
+@pytest.mark.parametrize("heads,per_head", [(1, 1), (3, 5), (4, 8), (2, 37), (31, 32)])
+def test_argmax_partials_order_free_reduction(heads, per_head):
+    """Round 6: sopro_argmax_partials_i32 reduces a head's (value, column) pairs with eight lanes per head (strided walk + three xor
+    exchanges) instead of one thread walking them in order: the winner - largest value, smallest column among equals - must not depend
+    on which lane saw which pair.  Synthetic pairs: ties between pairs of different lanes, heads shorter than eight pairs, rows whose
+    values are all -inf (every pair ties), padded rows (ldp > heads * per_head, ldo > heads)."""
+    import numpy as np
+    V, rows = 64 * per_head, 203
+    g = np.random.default_rng(7 + heads * 100 + per_head)
+    val = g.standard_normal((rows, heads, per_head)).astype(np.float32)
+    col = np.stack([np.stack([64 * j + g.integers(0, 64, rows) for j in range(per_head)], -1) + h * V for h in range(heads)], 1).astype(np.int32)
+    for r in range(0, rows, 3):  # exact ties: the maximum appears in two or three pairs (different lanes when per_head > 1)
+        for h in range(heads):
+            js = g.choice(per_head, size=min(per_head, 1 + (r % 3)), replace=False)
+            val[r, h, js] = 9.0
+    val[5] = -np.inf
+    ldp, ldo = heads * per_head + 3, heads + 2
+    part = torch.full((rows, ldp, 2), float("nan"))
+    part[:, :heads * per_head, 0] = torch.from_numpy(val.reshape(rows, -1))
+    part[:, :heads * per_head, 1] = torch.from_numpy(col.reshape(rows, -1)).view(torch.float32)
+    got = torch.full((rows, ldo), -1, dtype=torch.int32, device=DEV)
+    hip.argmax_partials(dev(part), got, rows=rows, heads=heads, per_head=per_head, V=V, ldp=ldp, ldo=ldo, o_off=1)
+    torch.cuda.synchronize()
+    want = np.zeros((rows, heads), np.int32)
+    for r in range(rows):
+        for h in range(heads):
+            m = val[r, h].max()
+            want[r, h] = col[r, h][val[r, h] == m].min() - h * V  # (a row of -inf: every pair ties - the smallest column)
+    assert np.array_equal(got[:, 1:-1].cpu().numpy(), want)
+    assert bool((got[:, 0] == -1).all()) and bool((got[:, -1] == -1).all())
+
+
 @pytest.mark.parametrize("M,K", [(6, 384), (200, 384), (1000, 384), (70, 64), (1, 32)])
 def test_gemm_bf16x6_fused_rmsnorm(M, K):
     """RMSNorm inside the GEMM (ext.rms_norm; reference: src/sopro/nn/blocks.py:26-37 followed by the block's GLU / FF1
